@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json by RUNNING THE REFERENCE ITSELF (oracle/_ref).
+
+TEST INFRASTRUCTURE.  Needs `make -C oracle ref` (i.e. /root/reference present); the
+fixtures it writes are committed so that the GPU box / CI never needs the reference.
+
+  maskgen.json : the reference's own query tables (Mask[256], Init[0], Init1, NO_ERR_MASK,
+                 endposition, D_endpos) for a list of (pattern, options) -- maskgen.c:218-266
+  scan.json    : for (text, pattern, k, options): the reference's -c count and, for the
+                 newline delimiter, the matched records it prints; both engines
+                 (sgrep.c:agrep() for plain k>0 queries, asearch.c for -i queries) and both
+                 I/O modes (file mode via the CLI, memory mode via memagrep()).
+  quirks.json  : small inputs on which the reference deviates from the Levenshtein
+                 semantic, with what it prints.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _oracle as O  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+AGREP = os.path.join(REF, "agrep")
+HARNESS = os.path.join(REF, "ref_harness")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def run(cmd, stdin=None):
+    p = subprocess.run(cmd, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return p.returncode, p.stdout, p.stderr
+
+
+def gen_maskgen():
+    cases = []
+    specs = [
+        # -n keeps a plain literal off the SGREP path (checksg.c:132) so maskgen runs
+        ("abcab", 1, ["-n"]), ("abcab", 1, ["-i"]),
+        ("approximatematch", 2, ["-n"]), ("approximatematch", 2, ["-i"]),
+        ("MiXed", 1, ["-n"]),
+        ("ApproXimateMatch", 2, ["-i"]),
+        ("homogenos", 2, ["-i"]), ("a", 0, ["-i"]), ("ab", 1, ["-i"]),
+        ("abcdefghijklmnopqrstuvwxyzabc", 3, ["-i"]),          # m = 29, the maximum
+        ("matching", 1, ["-i", "-d", "From "]),
+        ("matching", 2, ["-i", "-d", "$$"]),
+        ("hello world", 4, ["-i"]),
+        ("zzzyzzzy", 7, ["-i"]), ("abcdefghijkl", 8, ["-i"]),
+    ]
+    for pat, k, opts in specs:
+        if "-n" not in opts:
+            opts = opts + ["-n"]
+        args = [HARNESS, "tables"] + (["-%d" % k] if k else []) + opts + [pat]
+        rc, out, err = run(args)
+        assert rc == 0, (args, err)
+        t = json.loads(out)
+        # the reference runs maskgen only on the non-SGREP path (agrep.c:3181-3193)
+        assert t["SGREP"] == 0, (pat, opts)
+        cases.append({"pattern": pat, "k": k, "opts": opts, "tables": t})
+    # too long: m = 30 with newline delimiter is rejected (maskgen.c:201-208)
+    rc, out, err = run([HARNESS, "tables", "-2", "-i", "-n", "abcdefghijklmnopqrstuvwxyzabcd"])
+    cases.append({"pattern": "abcdefghijklmnopqrstuvwxyzabcd", "k": 2, "opts": ["-i"],
+                  "too_long": True, "stderr": err.decode("latin1")})
+    with open(os.path.join(OUT, "maskgen.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "cases": cases}, f, indent=0)
+    print("maskgen.json:", len(cases), "cases")
+
+
+def ref_scan(text, pat, k, opts, mode):
+    """-> (count, lines or None)"""
+    with tempfile.NamedTemporaryFile(suffix=".txt", delete=False) as tf:
+        tf.write(text)
+        path = tf.name
+    try:
+        kopt = ["-%d" % k] if k else []
+        if mode == "file":
+            rc, out, err = run([AGREP, "-V0"] + kopt + opts + ["-c", pat, path])
+            cnt = int(out.split()[0]) if out.strip() else 0
+            rc, out, err = run([AGREP, "-V0"] + kopt + opts + [pat, path])
+            lines = out.decode("latin1")
+        else:
+            rc, out, err = run([HARNESS, "count", path] + kopt + opts + [pat])
+            cnt = int(out.split()[0])
+            rc, out, err = run([HARNESS, "lines", path] + kopt + opts + [pat])
+            lines = out.decode("latin1")
+        return cnt, lines
+    finally:
+        os.unlink(path)
+
+
+def gen_scan():
+    cases = []
+    pat = O.PATTERN_C2
+    # (a) generator corpora, dense planting so every variant shows up
+    for pages, period, seed in [(16, 20, 12345), (64, 50, 7), (24, 3, 99)]:
+        text, planted = O.corpus(pages, seed=seed, variants=O.VARIANTS_C2, plant_period=period)
+        tb = text.tobytes()
+        for k in (0, 1, 2, 3):
+            for opts in ([], ["-i"]):
+                for mode in ("file", "mem"):
+                    if k == 0 and mode == "mem":
+                        continue
+                    cnt, lines = ref_scan(tb, pat.decode(), k, opts, mode)
+                    cases.append({"text": {"kind": "corpus", "pages": pages, "seed": seed,
+                                           "period": period},
+                                  "pattern": pat.decode(), "k": k, "opts": opts, "mode": mode,
+                                  "count": cnt, "lines": None, "n_lines": lines.count("\n"),
+                                  "lines_sha256": hashlib.sha256(lines.encode("latin1")).hexdigest()})
+    # (b) hand-written edge cases (newline delimiter)
+    lit = [
+        (b"", "abc", 1), (b"\n", "abc", 1), (b"\n\n\n", "abc", 1),
+        (b"abc", "abc", 0), (b"abc\n", "abc", 0), (b"xabcx", "abd", 1),
+        (b"hello world\nhomogeneous\nfoo\nhomogenos", "homogenos", 2),
+        (b"Massachusetts\nmassive\nMassechusets\n", "Massechusets", 2),
+        (b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaa\nbbbb\n", "aaaaaaaa", 3),
+        (b"ab\nabcdefgh\nabcdefg\nbcdefgh\nabcXefgh\nabcdeXXfgh\n", "abcdefgh", 1),
+        (b"x" * 5000 + b"needle" + b"y" * 5000 + b"\nshort\n", "needle", 1),
+        (b"first line has no newline at the end but matcZ", "match", 1),
+    ]
+    for text, p, k in lit:
+        for opts in ([], ["-i"]):
+            if k == 0 and not opts:
+                # plain k=0 goes to bm() which is always case-insensitive (Q6); the inputs
+                # here are lower-case only so it is still comparable
+                pass
+            for mode in ("file", "mem"):
+                if mode == "mem" and (not text.endswith(b"\n")):
+                    continue  # memory mode never closes an unterminated record (asearch.c:326-345)
+                cnt, lines = ref_scan(text, p, k, opts, mode)
+                cases.append({"text": {"kind": "literal", "latin1": text.decode("latin1")},
+                              "pattern": p, "k": k, "opts": opts, "mode": mode,
+                              "count": cnt, "lines": lines})
+    # (c) custom delimiters: counts only (the printed form depends on -t / OUTTAIL)
+    mbox = (b"From alice\nsubject: approximate matching\nbody\n"
+            b"From bob\nnothing here\n\nFrom carol\napproximatematch is here\n"
+            b"From dave\naproximatemach twice removed\n")
+    para = b"para one\nline\n\npara two approximatematch\n\n\npara three aproximatematc\nx\n\n"
+    for text, dl in ((mbox, "From "), (para, "$$")):
+        for k in (0, 1, 2):
+            for opts in ([], ["-i"]):
+                rc, out, err = run([AGREP, "-V0"] + (["-%d" % k] if k else []) + opts +
+                                   ["-d", dl, "-c", pat.decode(), "/dev/stdin"], stdin=text)
+                cnt = int(out.split()[0]) if out.strip() else 0
+                cases.append({"text": {"kind": "literal", "latin1": text.decode("latin1")},
+                              "pattern": pat.decode(), "k": k, "opts": opts, "mode": "file",
+                              "delim": dl, "count": cnt, "lines": None})
+    with open(os.path.join(OUT, "scan.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "cases": cases}, f, indent=0)
+    print("scan.json:", len(cases), "cases")
+
+
+def gen_quirks():
+    q = []
+    pat = "approximatematch"
+    # Q4: two occurrences far apart in one record: -c counts 2, one line printed (sgrep path)
+    rec = b"approxXmatematch" + b" filler" * 20 + b"appQoximRtematch\n"
+    cnt, lines = ref_scan(b"zzz\n" + rec + b"yyy\n", pat, 2, [], "file")
+    cnt_i, lines_i = ref_scan(b"zzz\n" + rec + b"yyy\n", pat, 2, ["-i"], "file")
+    q.append({"id": "Q4", "text": (b"zzz\n" + rec + b"yyy\n").decode("latin1"), "pattern": pat,
+              "k": 2, "sgrep_count": cnt, "sgrep_lines": lines, "asearch_count": cnt_i})
+    # Q2: record right after a matched record needs a leading deletion
+    text = b"xx approximatematch yy\npproximatematch trailing words here\nzz\n"
+    cnt, lines = ref_scan(text, pat, 1, [], "file")
+    cnt_i, lines_i = ref_scan(text, pat, 1, ["-i"], "file")
+    q.append({"id": "Q2", "text": text.decode("latin1"), "pattern": pat, "k": 1,
+              "sgrep_count": cnt, "sgrep_lines": lines, "asearch_count": cnt_i,
+              "asearch_lines": lines_i})
+    # Q6: plain k=0 (bm) is always case-insensitive
+    text = b"Hello World\nhello world\n"
+    cnt, lines = ref_scan(text, "hello", 0, [], "file")
+    q.append({"id": "Q6", "text": text.decode("latin1"), "pattern": "hello", "k": 0,
+              "sgrep_count": cnt, "sgrep_lines": lines})
+    with open(os.path.join(OUT, "quirks.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "cases": q}, f, indent=0)
+    print("quirks.json:", [(c["id"], c["sgrep_count"], c.get("asearch_count")) for c in q])
+
+
+if __name__ == "__main__":
+    assert O.have_ref(), "run `make -C oracle ref` first (needs /root/reference)"
+    os.makedirs(OUT, exist_ok=True)
+    gen_maskgen()
+    gen_scan()
+    gen_quirks()
