@@ -1,0 +1,14 @@
+"""agrep_amd -- MI355X-native approximate record scanner (the agrep k-error hot path).
+
+This package is a thin ctypes view of the C-ABI in include/agrep_hip.h (libagrep_hip.so,
+hand-written HIP for gfx950).  Python is used by the tests and by bench.py only; the host
+side of the product is C (agrep_amd/host).  There is deliberately no fallback: if the shared
+library is missing or no HIP device is usable, everything here raises.
+"""
+from ._ffi import (AghError, Match, Query, Result, corpus_fill_device, device_count, lib,  # noqa: F401
+                   probe_read_ms, set_device, ENGINE_FILTER, ENGINE_FULLSCAN, FORCE_FILTER,
+                   FORCE_FULLSCAN, COUNT, FILENAMEONLY)
+
+__all__ = ["AghError", "Match", "Query", "Result", "corpus_fill_device", "device_count", "lib",
+           "probe_read_ms", "set_device", "ENGINE_FILTER", "ENGINE_FULLSCAN", "FORCE_FILTER",
+           "FORCE_FULLSCAN", "COUNT", "FILENAMEONLY"]

@@ -1,0 +1,187 @@
+"""ctypes binding of include/agrep_hip.h.  Mirrors the C names one to one."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libagrep_hip.so")
+
+COUNT = 0x01
+FILENAMEONLY = 0x02
+FORCE_FULLSCAN = 0x10
+FORCE_FILTER = 0x20
+ENGINE_FULLSCAN = 1
+ENGINE_FILTER = 2
+
+
+class AghError(RuntimeError):
+    pass
+
+
+class Match(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("index", C.c_uint64)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_matched", C.c_uint64), ("n_records", C.c_uint64), ("n_bytes", C.c_uint64),
+                ("n_candidates", C.c_uint64), ("n_stored", C.c_uint64), ("engine", C.c_uint32),
+                ("truncated", C.c_uint32), ("device_ms", C.c_double)]
+
+
+_LIB = None
+
+
+def lib():
+    """Load libagrep_hip.so (built by __graft_entry__.build()); never falls back."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise AghError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u8p = C.c_void_p, C.c_char_p
+    L.agh_query_literal.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
+    L.agh_query_literal.restype = vp
+    L.agh_query_from_maskgen.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u8p,
+                                         C.c_int, C.c_int, C.c_int]
+    L.agh_query_from_maskgen.restype = vp
+    L.agh_query_free.argtypes = [vp]
+    L.agh_query_free.restype = None
+    L.agh_query_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
+    L.agh_query_info.restype = C.c_int
+    L.agh_scan_buffer.argtypes = [vp, vp, C.c_size_t, C.c_uint, C.POINTER(Result),
+                                  C.POINTER(Match), C.c_size_t]
+    L.agh_scan_buffer.restype = C.c_int
+    L.agh_scan_fd.argtypes = [vp, C.c_int, C.c_uint, C.POINTER(Result), C.POINTER(Match),
+                              C.c_size_t]
+    L.agh_scan_fd.restype = C.c_int
+    L.agh_scan_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint, C.POINTER(Result), vp,
+                                  C.c_size_t]
+    L.agh_scan_device.restype = C.c_int
+    L.agh_device_count.restype = C.c_int
+    L.agh_set_device.argtypes = [C.c_int]
+    L.agh_set_device.restype = C.c_int
+    L.agh_corpus_fill_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp,
+                                         C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.POINTER(C.c_uint64), vp]
+    L.agh_corpus_fill_device.restype = C.c_int
+    L.agh_probe_read_ms.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_double)]
+    L.agh_probe_read_ms.restype = C.c_int
+    L.agh_last_error.restype = C.c_char_p
+    L.agh_version.restype = C.c_char_p
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise AghError(lib().agh_last_error().decode("latin1"))
+
+
+def device_count():
+    return lib().agh_device_count()
+
+
+def set_device(i):
+    _check(lib().agh_set_device(i))
+
+
+class Query:
+    """A compiled pattern (agh_query_literal / agh_query_from_maskgen)."""
+
+    def __init__(self, pattern, k=0, nocase=False, delim=b"\n", _handle=None):
+        self._h = None
+        L = lib()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            pattern = bytes(pattern)
+            delim = bytes(delim)
+            self._h = L.agh_query_literal(pattern, len(pattern), k, int(nocase), delim, len(delim))
+        if not self._h:
+            raise AghError(L.agh_last_error().decode("latin1"))
+
+    @classmethod
+    def from_maskgen(cls, Mask, Init0, Init1, NO_ERR_MASK, endposition, D_endpos, M, old_D_pat,
+                     D, AND=0):
+        arr = (C.c_uint32 * 256)(*Mask)
+        old_D_pat = bytes(old_D_pat)
+        h = lib().agh_query_from_maskgen(arr, Init0, Init1, NO_ERR_MASK, endposition, D_endpos,
+                                         M, old_D_pat, len(old_D_pat), D, AND)
+        if not h:
+            raise AghError(lib().agh_last_error().decode("latin1"))
+        return cls(None, _handle=h)
+
+    def info(self):
+        m, d, fq, fh = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(lib().agh_query_info(self._h, C.byref(m), C.byref(d), C.byref(fq), C.byref(fh)))
+        return {"m": m.value, "k": d.value, "filter_q": fq.value, "filter_h": fh.value}
+
+    def scan_buffer(self, text, flags=0, cap=0):
+        """text: bytes or a contiguous numpy uint8 array -> (Result, [(start, end, index)])"""
+        import numpy as np
+        if isinstance(text, np.ndarray):
+            a = np.ascontiguousarray(text, dtype=np.uint8)
+            ptr, n, keep = a.ctypes.data, a.size, a
+        else:
+            b = bytes(text)
+            keep = C.create_string_buffer(b, len(b))
+            ptr, n = C.addressof(keep), len(b)
+        res = Result()
+        ms = (Match * max(cap, 1))()
+        _check(lib().agh_scan_buffer(self._h, ptr, n, flags, C.byref(res), ms if cap else None,
+                                     cap))
+        return res, [(ms[i].start, ms[i].end, ms[i].index) for i in range(int(res.n_stored))]
+
+    def scan_fd(self, fd, flags=0, cap=0):
+        res = Result()
+        ms = (Match * max(cap, 1))()
+        _check(lib().agh_scan_fd(self._h, fd, flags, C.byref(res), ms if cap else None, cap))
+        return res, [(ms[i].start, ms[i].end, ms[i].index) for i in range(int(res.n_stored))]
+
+    def scan_device(self, dev_ptr, n, stream=None, flags=0, match_pos_ptr=None, match_cap=0):
+        """dev_ptr: device address (e.g. torch tensor .data_ptr()), n bytes."""
+        res = Result()
+        _check(lib().agh_scan_device(self._h, dev_ptr, n, stream, flags, C.byref(res),
+                                     match_pos_ptr, match_cap))
+        return res
+
+    def close(self):
+        if self._h:
+            lib().agh_query_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def corpus_fill_device(dev_ptr, n_pages, first_page=0, seed=12345, variants=(), plant_period=500,
+                       upper_permille=0, stream=None):
+    """Fill n_pages*4096 bytes at dev_ptr with the synthetic corpus; -> planted counts."""
+    nv = len(variants)
+    vbuf = (C.c_uint8 * (80 * max(nv, 1)))()
+    vlen = (C.c_uint32 * 8)()
+    for i, v in enumerate(variants):
+        vlen[i] = len(v)
+        for j, ch in enumerate(v):
+            vbuf[i * 80 + j] = ch
+    planted = (C.c_uint64 * 8)()
+    _check(lib().agh_corpus_fill_device(dev_ptr, first_page, n_pages, seed, C.addressof(vbuf),
+                                        vlen, nv, plant_period, upper_permille, planted, stream))
+    return list(planted)[:max(nv, 1)]
+
+
+def probe_read_ms(dev_ptr, n, stream=None):
+    ms = C.c_double()
+    _check(lib().agh_probe_read_ms(dev_ptr, n, stream, C.byref(ms)))
+    return ms.value

@@ -1,0 +1,609 @@
+// agh_api.cpp -- the C-ABI of libagrep_hip.so (include/agrep_hip.h): query compilation,
+// workspace management, staging and kernel orchestration.  No CPU scan path exists here:
+// if HIP is unusable every entry point fails with -1 / errno = 123.
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/agrep_hip.h"
+#include "agh_device.h"
+#include "agh_launch.h"
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    errno = AGH_ERRNO;
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                        __LINE__);                                                        \
+    } while (0)
+
+extern "C" const char *agh_last_error(void) { return g_err; }
+extern "C" const char *agh_version(void) { return "agrep-hip 0.1 (gfx950)"; }
+
+extern "C" int agh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int agh_set_device(int ordinal)
+{
+    HIP_TRY(hipSetDevice(ordinal));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// query
+// ---------------------------------------------------------------------------------------
+struct dev_buf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 4096;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct agh_query {
+    int m = 0, k = 0, dlen = 1, wide = 0;
+    unsigned char delim[AGH_MAX_DELIM] = {'\n'};
+    uint64_t mask[256];                 // bit (p-1) set iff byte is in the class of position p
+    int fq = 0, fh = 0;                 // filter sample shape (0: no filter)
+    uint32_t qmask = 0, fold = 0;
+    // device-resident tables
+    void *d_mask = nullptr;             // 256 x uint32_t or uint64_t
+    uint8_t *d_ftab = nullptr;          // AGH_FT_SIZE bytes
+    // per-query workspace (grown lazily, reused across scans)
+    dev_buf strip_prefix, wave_totals, cand, bitmap, staging, match_pos, match_rec;
+    uint32_t *d_counters = nullptr;
+    uint32_t *h_counters = nullptr;     // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
+static bool is_lower(int c) { return c >= 'a' && c <= 'z'; }
+
+// Choose the q-gram sample shape: samples of q bytes at every multiple of h bytes.  Lossless
+// iff an occurrence (>= m-k text bytes) always contains >= k+1 whole samples, because k errors
+// can spoil at most k disjoint samples:  floor((m - k - q + 1) / h) >= k + 1.
+static void choose_filter(agh_query *q)
+{
+    q->fq = q->fh = 0;
+    q->qmask = q->fold = 0;
+    // every position must be a single byte or an ASCII case pair
+    bool any_pair = false;
+    for (int p = 0; p < q->m; ++p) {
+        int members = 0, lo = -1;
+        for (int c = 0; c < 256; ++c)
+            if ((q->mask[c] >> p) & 1) { ++members; if (lo < 0) lo = c; }
+        if (members == 1) continue;
+        if (members == 2 && is_upper(lo) && ((q->mask[lo + 32] >> p) & 1)) { any_pair = true; continue; }
+        return;
+    }
+    static const int hs[3] = {16, 8, 4};
+    for (int i = 0; i < 3; ++i) {
+        int h = hs[i];
+        int qmax = q->m - q->k + 1 - h * (q->k + 1);
+        if (qmax > 4) qmax = 4;
+        if (qmax > h) qmax = h;
+        if (qmax >= 3) {
+            q->fq = qmax;
+            q->fh = h;
+            break;
+        }
+    }
+    if (!q->fq) return;
+    q->qmask = q->fq == 4 ? 0xffffffffu : ((1u << (8 * q->fq)) - 1u);
+    q->fold = any_pair ? (0x20202020u & q->qmask) : 0u;
+}
+
+static int upload_tables(agh_query *q)
+{
+    if (q->wide) {
+        HIP_TRY(hipMalloc(&q->d_mask, 256 * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(q->d_mask, q->mask, 256 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    } else {
+        uint32_t m32[256];
+        for (int c = 0; c < 256; ++c) m32[c] = (uint32_t)q->mask[c];
+        HIP_TRY(hipMalloc(&q->d_mask, sizeof(m32)));
+        HIP_TRY(hipMemcpy(q->d_mask, m32, sizeof(m32), hipMemcpyHostToDevice));
+    }
+    if (q->fq) {
+        std::vector<uint8_t> tab(AGH_FT_SIZE, 0);
+        // one representative byte per position (lower-case member when folding)
+        unsigned char rep[AGH_MAX_PATTERN];
+        for (int p = 0; p < q->m; ++p) {
+            int lo = -1;
+            for (int c = 0; c < 256; ++c)
+                if ((q->mask[c] >> p) & 1) { lo = c; break; }
+            rep[p] = (unsigned char)lo;
+        }
+        for (int i = 0; i + q->fq <= q->m; ++i) {
+            uint32_t s = 0;
+            for (int t = 0; t < q->fq; ++t) s |= (uint32_t)rep[i + t] << (8 * t);
+            s = (s & q->qmask) | q->fold;
+            tab[agh_sample_hash(s)] = 1;
+        }
+        HIP_TRY(hipMalloc((void **)&q->d_ftab, AGH_FT_SIZE));
+        HIP_TRY(hipMemcpy(q->d_ftab, tab.data(), AGH_FT_SIZE, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void **)&q->d_counters, AGH_C_COUNT * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&q->h_counters, AGH_C_COUNT * sizeof(uint32_t)));
+    HIP_TRY(hipEventCreate(&q->ev0));
+    HIP_TRY(hipEventCreate(&q->ev1));
+    return 0;
+}
+
+static agh_query *finish_query(agh_query *q)
+{
+    q->wide = q->m > 32;
+    choose_filter(q);
+    if (agh_device_count() <= 0) {
+        fail("no usable HIP device: libagrep_hip has no CPU path");
+        delete q;
+        return nullptr;
+    }
+    if (upload_tables(q) != 0) {
+        agh_query_free(q);
+        return nullptr;
+    }
+    return q;
+}
+
+extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, int nocase,
+                                        const unsigned char *delim, int dlen)
+{
+    if (!pat || m < 1 || m > AGH_MAX_PATTERN) {
+        fail("pattern length %d outside 1..%d", m, AGH_MAX_PATTERN);
+        return nullptr;
+    }
+    if (D < 0 || D > AGH_MAX_ERRORS || D >= m) {   // checksg.c:34-41
+        fail("number of errors %d must be in 0..%d and smaller than the pattern length %d", D,
+             AGH_MAX_ERRORS, m);
+        return nullptr;
+    }
+    if (!delim || dlen < 1 || dlen > AGH_MAX_DELIM) {
+        fail("delimiter length %d outside 1..%d", dlen, AGH_MAX_DELIM);
+        return nullptr;
+    }
+    if (dlen != 1) {
+        fail("multi-byte delimiters are not implemented on the device path yet");
+        return nullptr;
+    }
+    agh_query *q = new agh_query();
+    q->m = m;
+    q->k = D;
+    q->dlen = dlen;
+    memcpy(q->delim, delim, (size_t)dlen);
+    memset(q->mask, 0, sizeof(q->mask));
+    for (int p = 0; p < m; ++p) {
+        int c = pat[p];
+        if (nocase && is_upper(c)) c += 32;             // maskgen.c:52-59
+        q->mask[c] |= (uint64_t)1 << p;
+        if (nocase && is_lower(c)) q->mask[c - 32] |= (uint64_t)1 << p;   // maskgen.c:259-266
+    }
+    return finish_query(q);
+}
+
+extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0,
+                                             uint32_t Init1, uint32_t NO_ERR_MASK,
+                                             uint32_t endposition, uint32_t D_endpos, int M,
+                                             const unsigned char *old_D_pat, int D_length,
+                                             int D, int AND)
+{
+    // reference layout (maskgen.c:218-257): positions 1..D_length = delimiter, D_length+1 =
+    // the AND separator, D_length+2..M = pattern; position p lives at bit (M - p).
+    if (!Mask || !old_D_pat || D_length < 1 || D_length > AGH_MAX_DELIM || M < D_length + 2 ||
+        M > 31) {
+        fail("malformed maskgen tables (M=%d, D_length=%d)", M, D_length);
+        return nullptr;
+    }
+    const int m = M - D_length - 1;
+    if (D < 0 || D > AGH_MAX_ERRORS || D >= m) {
+        fail("number of errors %d must be smaller than the pattern length %d", D, m);
+        return nullptr;
+    }
+    const uint32_t sep = 1u << (M - D_length - 1);
+    const uint32_t pad = M == 32 ? 0u : ~((1u << M) - 1u);
+    if (AND || endposition != 1u) {
+        fail("AND/OR patterns (endposition=0x%x) are outside the supported subset", endposition);
+        return nullptr;
+    }
+    if (Init0 != (pad | sep) || Init1 != (Init0 | 1u | D_endpos) ||
+        D_endpos != (1u << (M - D_length))) {
+        fail("wildcard / sticky positions are outside the supported subset");
+        return nullptr;
+    }
+    // NO_ERR_MASK must only forbid errors into the delimiter positions (no <exact> parts)
+    {
+        uint32_t pattern_bits = (1u << m) - 1u;
+        if ((NO_ERR_MASK & pattern_bits) != pattern_bits) {
+            fail("<exact> pattern segments are outside the supported subset");
+            return nullptr;
+        }
+    }
+    if (D_length != 1) {
+        fail("multi-byte delimiters are not implemented on the device path yet");
+        return nullptr;
+    }
+    agh_query *q = new agh_query();
+    q->m = m;
+    q->k = D;
+    q->dlen = D_length;
+    for (int i = 0; i < D_length; ++i) {
+        unsigned char c = old_D_pat[i];
+        q->delim[i] = (c == '^' || c == '$') ? '\n' : c;    // bitap.c:92-94
+    }
+    for (int c = 0; c < 256; ++c) {
+        uint64_t v = 0;
+        for (int p = 1; p <= m; ++p)
+            if ((Mask[c] >> (m - p)) & 1u) v |= (uint64_t)1 << (p - 1);
+        q->mask[c] = v;
+    }
+    return finish_query(q);
+}
+
+extern "C" void agh_query_free(agh_query *q)
+{
+    if (!q) return;
+    if (q->d_mask) (void)hipFree(q->d_mask);
+    if (q->d_ftab) (void)hipFree(q->d_ftab);
+    if (q->d_counters) (void)hipFree(q->d_counters);
+    if (q->h_counters) (void)hipHostFree(q->h_counters);
+    if (q->ev0) (void)hipEventDestroy(q->ev0);
+    if (q->ev1) (void)hipEventDestroy(q->ev1);
+    q->strip_prefix.release();
+    q->wave_totals.release();
+    q->cand.release();
+    q->bitmap.release();
+    q->staging.release();
+    q->match_pos.release();
+    q->match_rec.release();
+    delete q;
+}
+
+extern "C" int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q, int *filter_h)
+{
+    if (!q) return fail("null query");
+    if (m) *m = q->m;
+    if (D) *D = q->k;
+    if (filter_q) *filter_q = q->fq;
+    if (filter_h) *filter_h = q->fh;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// one segment (<= AGH_SEG_MAX bytes) resident in HBM
+// ---------------------------------------------------------------------------------------
+static const uint64_t AGH_SEG_MAX = (uint64_t)8 << 30;
+
+struct seg_result {
+    uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
+    uint32_t engine = 0, truncated = 0;
+    float ms = 0.f;
+};
+
+static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_t st,
+                        unsigned flags, uint32_t head_byte, int tail_virtual,
+                        uint64_t *d_match_pos, uint32_t *d_match_rec, uint32_t match_cap,
+                        seg_result *out)
+{
+    *out = seg_result();
+    if (n == 0) return 0;
+    if (((uintptr_t)d_text & 15u) != 0) return fail("device text must be 16-byte aligned");
+    const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
+    const uint64_t nw = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+    const bool want_filter = q->fq > 0 && !(flags & AGH_FORCE_FULLSCAN);
+    if (!want_filter && (flags & AGH_FORCE_FILTER))
+        return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
+    uint32_t cand_cap = 0;
+    if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
+    if (q->wave_totals.ensure((nw + 8) * sizeof(uint32_t))) return -1;
+    if (want_filter) {
+        uint64_t cap = n / 64 + 65536;
+        if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
+        if (q->cand.ensure(cap * sizeof(uint32_t))) return -1;
+        cand_cap = (uint32_t)cap;
+    }
+
+    agh_dev_query dq;
+    dq.m = q->m;
+    dq.k = q->k;
+    dq.delim = q->delim[0];
+    dq.fq = q->fq;
+    dq.fh = q->fh;
+    dq.qmask = q->qmask;
+    dq.fold = q->fold;
+    dq.head_byte = head_byte;
+    dq.tail_virtual = tail_virtual;
+
+    HIP_TRY(hipEventRecord(q->ev0, st));
+    HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+    agh_sweep_args sa;
+    sa.text = d_text;
+    sa.n = n;
+    sa.q = dq;
+    sa.ftab = q->d_ftab;
+    sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
+    sa.wave_totals = (uint32_t *)q->wave_totals.p;
+    sa.cand = (uint32_t *)q->cand.p;
+    sa.cand_cap = cand_cap;
+    sa.counters = q->d_counters;
+    agh_launch_sweep(sa, want_filter ? q->fh : 0, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+
+    const uint32_t n_delims = q->h_counters[AGH_C_NDELIM];
+    const uint32_t n_cand = q->h_counters[AGH_C_CAND];
+    bool use_filter = want_filter;
+    if (use_filter && (q->h_counters[AGH_C_OVERFLOW] || n_cand > cand_cap)) {
+        if (flags & AGH_FORCE_FILTER)
+            return fail("candidate buffer overflow (%u candidates)", n_cand);
+        use_filter = false;                     // not selective on this text: automaton everywhere
+    }
+    out->records = (uint64_t)n_delims + (q->h_counters[AGH_C_LASTBYTE] != q->delim[0] ? 1u : 0u);
+    out->candidates = use_filter ? n_cand : 0;
+    out->engine = use_filter ? AGH_ENGINE_FILTER : AGH_ENGINE_FULLSCAN;
+
+    const size_t bm_bytes = (((size_t)n_delims + 64 + 31) / 32) * sizeof(uint32_t);
+    if (q->bitmap.ensure(bm_bytes)) return -1;
+    HIP_TRY(hipMemsetAsync(q->bitmap.p, 0, bm_bytes, st));
+    if (q->h_counters[AGH_C_OVERFLOW])
+        HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_OVERFLOW, 0, sizeof(uint32_t), st));
+
+    agh_scan_args va;
+    va.text = d_text;
+    va.n = n;
+    va.q = dq;
+    va.mask = q->d_mask;
+    va.wide = q->wide;
+    va.cand = (const uint32_t *)q->cand.p;
+    va.n_cand = n_cand;
+    va.strip_prefix = (const uint32_t *)q->strip_prefix.p;
+    va.wave_prefix = (const uint32_t *)q->wave_totals.p;
+    va.n_strips = (uint32_t)n_strips;
+    va.mk.bitmap = (uint32_t *)q->bitmap.p;
+    va.mk.counters = q->d_counters;
+    va.mk.match_pos = d_match_pos;
+    va.mk.match_rec = d_match_rec;
+    va.mk.match_cap = match_cap;
+    if (use_filter) {
+        if (n_cand) agh_launch_verify(va, st);
+    } else {
+        agh_launch_fullscan(va, st);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(q->ev1, st));
+    HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
+    out->matched = q->h_counters[AGH_C_MATCHED];
+    out->stored = std::min<uint64_t>(q->h_counters[AGH_C_STORED], match_cap);
+    out->truncated = q->h_counters[AGH_C_STORED] > match_cap;
+    return 0;
+}
+
+// Largest cut <= want such that text[cut-1] is a delimiter (so segments hold whole records).
+static int find_cut(const agh_query *q, const unsigned char *d_text, uint64_t lo, uint64_t want,
+                    hipStream_t st, uint64_t *cut)
+{
+    std::vector<unsigned char> buf(1 << 20);
+    uint64_t hi = want;
+    while (hi > lo) {
+        uint64_t b = hi - lo > buf.size() ? hi - buf.size() : lo;
+        HIP_TRY(hipMemcpyAsync(buf.data(), d_text + b, hi - b, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint64_t i = hi; i > b; --i)
+            if (buf[i - 1 - b] == q->delim[0]) { *cut = i; return 0; }
+        hi = b;
+    }
+    return fail("a single record exceeds the %llu-byte segment limit",
+                (unsigned long long)AGH_SEG_MAX);
+}
+
+static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
+                            unsigned flags, agh_result *res, uint64_t *d_match_pos,
+                            uint32_t *d_match_rec, size_t match_cap)
+{
+    if (!q || !res) return fail("null argument");
+    memset(res, 0, sizeof(*res));
+    res->n_bytes = len;
+    const unsigned char *base = (const unsigned char *)dev_text;
+    uint64_t off = 0;
+    bool first = true;
+    while (off < len) {
+        uint64_t end = len;
+        if (end - off > AGH_SEG_MAX) {
+            uint64_t want = (off + AGH_SEG_MAX) & ~(uint64_t)15;
+            if (find_cut(q, base, off, want, st, &end)) return -1;
+            // keep the next segment 16-byte aligned: back off to an aligned delimiter-free cut
+            // is not possible in general, so require alignment of the cut instead
+            while (end > off && (end & 15u)) {
+                uint64_t c2;
+                if (find_cut(q, base, off, end - 1, st, &c2)) return -1;
+                end = c2;
+            }
+            if (end <= off) return fail("no 16-byte aligned record boundary inside a segment");
+        }
+        seg_result sr;
+        uint64_t stored = res->n_stored;
+        uint32_t cap_left = (uint32_t)std::min<uint64_t>(match_cap - stored, 0xffffffffu);
+        if (scan_segment(q, base + off, end - off, st, flags, first ? '\n' : q->delim[0],
+                         end == len, d_match_pos ? d_match_pos + stored : nullptr,
+                         d_match_rec ? d_match_rec + stored : nullptr,
+                         d_match_pos ? cap_left : 0, &sr))
+            return -1;
+        res->n_matched += sr.matched;
+        res->n_records += sr.records;
+        res->n_candidates += sr.candidates;
+        res->n_stored += sr.stored;
+        res->truncated |= sr.truncated;
+        res->device_ms += sr.ms;
+        res->engine = sr.engine;
+        off = end;
+        first = false;
+    }
+    return 0;
+}
+
+extern "C" int agh_scan_device(agh_query *q, const void *dev_text, size_t len, void *stream,
+                               unsigned flags, agh_result *res, void *dev_match_pos,
+                               size_t match_cap)
+{
+    return scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res,
+                            (uint64_t *)dev_match_pos, nullptr, dev_match_pos ? match_cap : 0);
+}
+
+extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t len,
+                               unsigned flags, agh_result *res, agh_match *matches, size_t cap)
+{
+    if (!q || !res || (!text && len)) return fail("null argument");
+    if (len > AGH_SEG_MAX) return fail("host buffers above 8 GiB must be scanned in pieces");
+    if (q->staging.ensure(((len + 15) & ~(size_t)15) + 16)) return -1;
+    if (len) HIP_TRY(hipMemcpy(q->staging.p, text, len, hipMemcpyHostToDevice));
+    uint64_t *d_pos = nullptr;
+    uint32_t *d_rec = nullptr;
+    if (matches && cap) {
+        if (q->match_pos.ensure(cap * sizeof(uint64_t))) return -1;
+        if (q->match_rec.ensure(cap * sizeof(uint32_t))) return -1;
+        d_pos = (uint64_t *)q->match_pos.p;
+        d_rec = (uint32_t *)q->match_rec.p;
+    }
+    if (scan_device_impl(q, q->staging.p, len, nullptr, flags, res, d_pos, d_rec, cap)) return -1;
+    if (d_pos && res->n_stored) {
+        const size_t ns = (size_t)res->n_stored;
+        std::vector<uint64_t> pos(ns);
+        std::vector<uint32_t> rec(ns);
+        HIP_TRY(hipMemcpy(pos.data(), d_pos, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rec.data(), d_rec, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<size_t> order(ns);
+        for (size_t i = 0; i < ns; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(),
+                  [&](size_t a, size_t b) { return pos[a] < pos[b]; });   // file order
+        const unsigned char d = q->delim[0];
+        for (size_t i = 0; i < ns; ++i) {
+            uint64_t e = pos[order[i]];
+            // record = (last delimiter before e, first delimiter at or after e)
+            uint64_t s = e > len ? len : e;
+            while (s > 0 && text[s - 1] != d) --s;
+            uint64_t en = e > len ? len : e;
+            const void *nx = en < len ? memchr(text + en, d, len - en) : nullptr;
+            en = nx ? (uint64_t)((const unsigned char *)nx - text) : len;
+            matches[i].start = s;
+            matches[i].end = en;
+            matches[i].index = rec[order[i]];
+        }
+    }
+    return 0;
+}
+
+extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res,
+                           agh_match *matches, size_t cap)
+{
+    if (fd < 0) return fail("agh_scan_fd needs fd >= 0 (memory mode is agh_scan_buffer)");
+    std::vector<unsigned char> buf;
+    size_t used = 0;
+    buf.resize(1 << 20);
+    for (;;) {                                   // bitap.c:450-477 fill_buf: read until EOF
+        if (used == buf.size()) buf.resize(buf.size() * 2);
+        ssize_t r = read(fd, buf.data() + used, buf.size() - used);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            return fail("read failed: %s", strerror(errno));
+        }
+        if (r == 0) break;
+        used += (size_t)r;
+    }
+    return agh_scan_buffer(q, buf.data(), used, flags, res, matches, cap);
+}
+
+// ---------------------------------------------------------------------------------------
+// bench / test support
+// ---------------------------------------------------------------------------------------
+extern "C" int agh_corpus_fill_device(void *dev_out, uint64_t first_page, uint64_t n_pages,
+                                      uint64_t seed, const unsigned char *variants,
+                                      const uint32_t *vlen, uint32_t n_variants,
+                                      uint32_t plant_period, uint32_t upper_permille,
+                                      uint64_t *planted, void *stream)
+{
+    if (n_variants > 8) return fail("at most 8 variants");
+    for (uint32_t i = 0; i < n_variants; ++i)
+        if (vlen[i] > 80) return fail("variant %u longer than 80 bytes", i);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d_planted = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_planted, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_planted, 0, 8 * sizeof(unsigned long long), st));
+    agh_launch_corpus(dev_out, first_page, n_pages, seed, variants, vlen, n_variants,
+                      plant_period, upper_permille, d_planted, st);
+    hipError_t e = hipGetLastError();
+    unsigned long long h[8] = {0};
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h, d_planted, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_planted);
+    if (e != hipSuccess) return fail("corpus generation failed: %s", hipGetErrorString(e));
+    if (planted)
+        for (int i = 0; i < 8; ++i) planted[i] = h[i];
+    return 0;
+}
+
+extern "C" int agh_probe_read_ms(const void *dev_text, size_t len, void *stream, double *ms)
+{
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *d_c = nullptr;
+    hipEvent_t a, b;
+    HIP_TRY(hipMalloc((void **)&d_c, AGH_C_COUNT * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(d_c, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, st));
+    agh_launch_read_probe(dev_text, len, d_c, st);
+    HIP_TRY(hipEventRecord(b, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float f = 0;
+    HIP_TRY(hipEventElapsedTime(&f, a, b));
+    if (ms) *ms = f;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(d_c);
+    return 0;
+}

@@ -1,0 +1,57 @@
+// agh_device.h -- structures and constants shared by the host side of libagrep_hip.so and
+// its gfx950 kernels.  Internal; the public boundary is include/agrep_hip.h.
+#pragma once
+#include <stdint.h>
+
+// A "strip" is 1 KiB of text = one coalesced wave-wide 16 B/lane load (64 lanes x 16 B).
+// The sweep kernel publishes, per strip, the number of record delimiters that precede it
+// inside its wave's range; that is what turns a match position into a record number.
+#define AGH_STRIP_SHIFT 10
+#define AGH_STRIP (1u << AGH_STRIP_SHIFT)
+// Contiguous strips owned by one wavefront of the sweep kernel (256 KiB of text).
+#define AGH_WAVE_STRIPS 256u
+// q-gram filter table: one byte per hash bucket, resident in LDS (32 KiB / workgroup).
+#define AGH_FT_BITS 15
+#define AGH_FT_SIZE (1u << AGH_FT_BITS)
+// Full-scan kernel: bytes per lane chunk and lanes per workgroup (tile = 64 KiB in LDS).
+#define AGH_FS_CHUNK 256u
+#define AGH_FS_THREADS 256u
+#define AGH_FS_SLOT (AGH_FS_CHUNK + 16u)   // LDS stride per chunk: +16 B keeps b128 reads conflict-free
+
+enum agh_counter {
+    AGH_C_CAND = 0,      // candidate windows emitted by the filter
+    AGH_C_OVERFLOW = 1,  // candidate / match buffer overflow flag
+    AGH_C_MATCHED = 2,   // distinct matched records
+    AGH_C_NDELIM = 3,    // delimiters in the text
+    AGH_C_STORED = 4,    // match positions stored
+    AGH_C_LASTBYTE = 5,  // text[n-1]
+    AGH_C_CHECK = 6,     // read-probe checksum sink
+    AGH_C_COUNT = 8
+};
+
+struct agh_dev_query {
+    int32_t m;          // pattern positions
+    int32_t k;          // errors
+    uint32_t delim;     // single-byte delimiter
+    int32_t fq;         // filter: sample length in bytes (1..4), 0 = no filter
+    int32_t fh;         // filter: sample stride in bytes (4, 8 or 16)
+    uint32_t qmask;     // low fq bytes
+    uint32_t fold;      // 0x20 in every sampled byte when the query folds ASCII case
+    uint32_t head_byte; // byte fed in front of the segment: '\n' for the first segment of a
+                        // file (asearch.c:69-78), the delimiter for later segments
+    int32_t tail_virtual; // 1: the delimiter is appended at the segment end (asearch.c:87-91)
+};
+
+// Hash of one text/pattern sample (already masked and folded) into the filter table.
+// Identical on host (table construction) and device (probe).  v_mul_u32_u24 is full rate.
+#if defined(__HIPCC__)
+#define AGH_HD __host__ __device__ __forceinline__
+#else
+#define AGH_HD static inline
+#endif
+AGH_HD uint32_t agh_sample_hash(uint32_t s)
+{
+    uint32_t t = (s ^ (s >> 11)) & 0xffffffu;
+    uint32_t p = t * 0x9E3779u;              // 24 x 24 -> low 32 bits (v_mul_u32_u24)
+    return (p >> 14) & (AGH_FT_SIZE - 1u);
+}

@@ -1,0 +1,50 @@
+// agh_launch.h -- internal C++ interface between the C-ABI layer (agh_api.cpp) and the
+// kernel translation unit (agh_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "agh_device.h"
+
+struct agh_marks {
+    uint32_t *bitmap;        // one bit per record
+    uint32_t *counters;
+    uint64_t *match_pos;     // optional: one byte offset per newly matched record
+    uint32_t *match_rec;     // optional: its record number
+    uint32_t match_cap;
+};
+
+struct agh_sweep_args {
+    const void *text;
+    uint64_t n;
+    agh_dev_query q;
+    const uint8_t *ftab;     // AGH_FT_SIZE bytes (device), may be NULL when H == 0
+    uint32_t *strip_prefix;  // ceil(n / 1024) + 4 entries
+    uint32_t *wave_totals;   // becomes wave_prefix after the sweep
+    uint32_t *cand;
+    uint32_t cand_cap;
+    uint32_t *counters;
+};
+
+struct agh_scan_args {
+    const void *text;
+    uint64_t n;
+    agh_dev_query q;
+    const void *mask;        // 256 x uint32_t or uint64_t (device)
+    int wide;                // 1: 64-bit state words
+    const uint32_t *cand;
+    uint32_t n_cand;
+    const uint32_t *strip_prefix;
+    const uint32_t *wave_prefix;
+    uint32_t n_strips;
+    agh_marks mk;
+};
+
+void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st);
+void agh_launch_verify(const agh_scan_args &a, hipStream_t st);
+void agh_launch_fullscan(const agh_scan_args &a, hipStream_t st);
+void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
+void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_t seed,
+                       const unsigned char *variants, const uint32_t *vlen,
+                       uint32_t n_variants, uint32_t plant_period, uint32_t upper_permille,
+                       unsigned long long *planted_dev, hipStream_t st);

