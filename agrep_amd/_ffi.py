@@ -24,7 +24,7 @@ class Match(C.Structure):
 class Result(C.Structure):
     _fields_ = [("n_matched", C.c_uint64), ("n_records", C.c_uint64), ("n_bytes", C.c_uint64),
                 ("n_candidates", C.c_uint64), ("n_stored", C.c_uint64), ("engine", C.c_uint32),
-                ("truncated", C.c_uint32), ("device_ms", C.c_double)]
+                ("truncated", C.c_uint32), ("device_ms", C.c_double), ("sweep_ms", C.c_double)]
 
 
 _LIB = None
@@ -35,6 +35,16 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (SONAME libamdhip64.so.7,
+    # found through torch/lib's RPATH).  If torch is going to be used in this process (device
+    # memory, torch.distributed) it must be loaded FIRST so that our NEEDED libamdhip64.so.7
+    # resolves to the already-loaded copy; a second runtime would see no GPUs.  Plain C users
+    # (agrep_amd/host) get /opt/rocm/lib through the library's RUNPATH.
+    if os.environ.get("AGH_NO_TORCH_PRELOAD", "") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise AghError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)

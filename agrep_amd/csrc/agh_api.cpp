@@ -90,10 +90,10 @@ struct agh_query {
     void *d_mask = nullptr;             // 256 x uint32_t or uint64_t
     uint8_t *d_ftab = nullptr;          // AGH_FT_SIZE bytes
     // per-query workspace (grown lazily, reused across scans)
-    dev_buf strip_prefix, wave_totals, cand, bitmap, staging, match_pos, match_rec;
+    dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, staging, match_pos, match_rec;
     uint32_t *d_counters = nullptr;
     uint32_t *h_counters = nullptr;     // pinned
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
 };
 
 static bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
@@ -167,6 +167,7 @@ static int upload_tables(agh_query *q)
     HIP_TRY(hipHostMalloc((void **)&q->h_counters, AGH_C_COUNT * sizeof(uint32_t)));
     HIP_TRY(hipEventCreate(&q->ev0));
     HIP_TRY(hipEventCreate(&q->ev1));
+    HIP_TRY(hipEventCreate(&q->ev2));
     return 0;
 }
 
@@ -288,9 +289,11 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->h_counters) (void)hipHostFree(q->h_counters);
     if (q->ev0) (void)hipEventDestroy(q->ev0);
     if (q->ev1) (void)hipEventDestroy(q->ev1);
+    if (q->ev2) (void)hipEventDestroy(q->ev2);
     q->strip_prefix.release();
     q->wave_totals.release();
     q->cand.release();
+    q->wave_cand.release();
     q->bitmap.release();
     q->staging.release();
     q->match_pos.release();
@@ -316,7 +319,7 @@ static const uint64_t AGH_SEG_MAX = (uint64_t)8 << 30;
 struct seg_result {
     uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
     uint32_t engine = 0, truncated = 0;
-    float ms = 0.f;
+    float ms = 0.f, sweep_ms = 0.f;
 };
 
 static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_t st,
@@ -332,14 +335,11 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const bool want_filter = q->fq > 0 && !(flags & AGH_FORCE_FULLSCAN);
     if (!want_filter && (flags & AGH_FORCE_FILTER))
         return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
-    uint32_t cand_cap = 0;
     if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
     if (q->wave_totals.ensure((nw + 8) * sizeof(uint32_t))) return -1;
     if (want_filter) {
-        uint64_t cap = n / 64 + 65536;
-        if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
-        if (q->cand.ensure(cap * sizeof(uint32_t))) return -1;
-        cand_cap = (uint32_t)cap;
+        if (q->cand.ensure(nw * AGH_SLICE_CAP * sizeof(uint64_t))) return -1;
+        if (q->wave_cand.ensure((nw + 8) * sizeof(uint32_t))) return -1;
     }
 
     agh_dev_query dq;
@@ -362,11 +362,12 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     sa.ftab = q->d_ftab;
     sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
     sa.wave_totals = (uint32_t *)q->wave_totals.p;
-    sa.cand = (uint32_t *)q->cand.p;
-    sa.cand_cap = cand_cap;
+    sa.cand = (uint64_t *)q->cand.p;
+    sa.wave_cand = (uint32_t *)q->wave_cand.p;
     sa.counters = q->d_counters;
     agh_launch_sweep(sa, want_filter ? q->fh : 0, st);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(q->ev2, st));
     HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -374,7 +375,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const uint32_t n_delims = q->h_counters[AGH_C_NDELIM];
     const uint32_t n_cand = q->h_counters[AGH_C_CAND];
     bool use_filter = want_filter;
-    if (use_filter && (q->h_counters[AGH_C_OVERFLOW] || n_cand > cand_cap)) {
+    if (use_filter && q->h_counters[AGH_C_OVERFLOW]) {
         if (flags & AGH_FORCE_FILTER)
             return fail("candidate buffer overflow (%u candidates)", n_cand);
         use_filter = false;                     // not selective on this text: automaton everywhere
@@ -395,7 +396,9 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     va.q = dq;
     va.mask = q->d_mask;
     va.wide = q->wide;
-    va.cand = (const uint32_t *)q->cand.p;
+    va.cand = (const uint64_t *)q->cand.p;
+    va.wave_cand = (const uint32_t *)q->wave_cand.p;
+    va.nw = (uint32_t)nw;
     va.n_cand = n_cand;
     va.strip_prefix = (const uint32_t *)q->strip_prefix.p;
     va.wave_prefix = (const uint32_t *)q->wave_totals.p;
@@ -410,12 +413,15 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     } else {
         agh_launch_fullscan(va, st);
     }
+    agh_launch_bitmap_count((const uint32_t *)q->bitmap.p, (uint32_t)(bm_bytes / 4), q->d_counters,
+                            st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(q->ev1, st));
     HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
+    HIP_TRY(hipEventElapsedTime(&out->sweep_ms, q->ev0, q->ev2));
     out->matched = q->h_counters[AGH_C_MATCHED];
     out->stored = std::min<uint64_t>(q->h_counters[AGH_C_STORED], match_cap);
     out->truncated = q->h_counters[AGH_C_STORED] > match_cap;
@@ -478,6 +484,7 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
         res->n_stored += sr.stored;
         res->truncated |= sr.truncated;
         res->device_ms += sr.ms;
+        res->sweep_ms += sr.sweep_ms;
         res->engine = sr.engine;
         off = end;
         first = false;

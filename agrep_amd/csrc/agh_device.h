@@ -10,6 +10,9 @@
 #define AGH_STRIP (1u << AGH_STRIP_SHIFT)
 // Contiguous strips owned by one wavefront of the sweep kernel (256 KiB of text).
 #define AGH_WAVE_STRIPS 256u
+// Candidate slots owned by one sweep wave (one per 64 text bytes; more means the filter is
+// not selective on this text and the scan falls back to the full automaton).
+#define AGH_SLICE_CAP (AGH_WAVE_STRIPS * 16u)
 // q-gram filter table: one byte per hash bucket, resident in LDS (32 KiB / workgroup).
 #define AGH_FT_BITS 15
 #define AGH_FT_SIZE (1u << AGH_FT_BITS)

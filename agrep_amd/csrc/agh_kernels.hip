@@ -104,10 +104,15 @@ __device__ __forceinline__ void sweep_chunk(uint4 v, uint32_t dd, const agh_dev_
     }
 }
 
-// Append the candidates of one wave.  hits: bit (4*u + d) of lane l = sample at dword d of
-// the lane's chunk in strip s+u.  Rare path (a few percent of samples at most).
-__device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, uint32_t *cand,
-                                                uint32_t cand_cap, uint32_t *counters)
+// Append the candidates of one wave to the wave's private slice of the candidate buffer (no
+// atomics: one hot global counter saturates at ~90 updates/us on this chip and would cap the
+// whole sweep).  hits: bit (4*u + d) of lane l = sample at dword d of the lane's chunk in
+// strip s+u.  rc[u] = delimiters (inside this wave's range) in front of the lane's chunk of
+// strip s+u -- stored with the candidate so that the verifier can number records without
+// re-reading any text.  cnt is wave-uniform.
+__device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, const uint32_t rc[4],
+                                                uint64_t *__restrict__ slice, uint32_t &cnt,
+                                                uint32_t *counters)
 {
     uint64_t hm = __ballot(hits != 0);
     const int lane = lane_id();
@@ -115,20 +120,24 @@ __device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, uint3
         int l = __ffsll((long long)hm) - 1;
         hm &= hm - 1;
         uint32_t hbits = (uint32_t)__builtin_amdgcn_readlane((int)hits, l);
-        int cnt = __popc(hbits);
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&counters[AGH_C_CAND], (uint32_t)cnt);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (lane < cnt) {
+        uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)rc[0], l);
+        uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)rc[1], l);
+        uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)rc[2], l);
+        uint32_t r3 = (uint32_t)__builtin_amdgcn_readlane((int)rc[3], l);
+        int c = __popc(hbits);
+        if (lane < c) {
             uint32_t t = hbits;
             for (int j = 0; j < lane; ++j) t &= t - 1;
             int b = __ffs((int)t) - 1;
-            uint32_t dw = (uint32_t)(((s + (uint64_t)(b >> 2)) * 64u + (uint64_t)l) * 4u +
+            int u = b >> 2;
+            uint32_t dw = (uint32_t)(((s + (uint64_t)u) * 64u + (uint64_t)l) * 4u +
                                      (uint64_t)(b & 3));
-            uint32_t idx = base + (uint32_t)lane;
-            if (idx < cand_cap) cand[idx] = dw;
+            uint32_t r = u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3));
+            uint32_t idx = cnt + (uint32_t)lane;
+            if (idx < AGH_SLICE_CAP) slice[idx] = ((uint64_t)r << 32) | dw;
             else counters[AGH_C_OVERFLOW] = 1u;
         }
+        cnt += (uint32_t)c;
     }
 }
 
@@ -140,7 +149,8 @@ __global__ __launch_bounds__(256) void k_sweep(const uint4 *__restrict__ text,
                                                const uint8_t *__restrict__ ftab_g,
                                                uint32_t *__restrict__ strip_prefix,
                                                uint32_t *__restrict__ wave_totals,
-                                               uint32_t *__restrict__ cand, uint32_t cand_cap,
+                                               uint64_t *__restrict__ cand,
+                                               uint32_t *__restrict__ wave_cand,
                                                uint32_t *__restrict__ counters)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ftab[H > 0 ? AGH_FT_SIZE : 16];
@@ -158,6 +168,8 @@ __global__ __launch_bounds__(256) void k_sweep(const uint4 *__restrict__ text,
     if (s1 > n_full_strips) s1 = n_full_strips;
     const uint32_t dd = q.delim * 0x01010101u;
     uint32_t run = 0;                           // delimiters before strip s inside this range
+    uint32_t ncand = 0;                         // candidates in this wave's slice
+    uint64_t *slice = cand + w * AGH_SLICE_CAP;
     uint64_t s = s0;
 
     for (; s + 4 <= s1; s += 4) {
@@ -168,30 +180,51 @@ __global__ __launch_bounds__(256) void k_sweep(const uint4 *__restrict__ text,
         sweep_chunk<H>(v1, dd, q, ftab, a1, hits, 4);
         sweep_chunk<H>(v2, dd, q, ftab, a2, hits, 8);
         sweep_chunk<H>(v3, dd, q, ftab, a3, hits, 12);
-        // per-strip delimiter totals: two packed 16-bit sums per DPP reduction
-        uint32_t p01 = wave_sum_to_lane63(a0 | (a1 << 16));
-        uint32_t p23 = wave_sum_to_lane63(a2 | (a3 << 16));
-        p01 = (uint32_t)__builtin_amdgcn_readlane((int)p01, 63);
-        p23 = (uint32_t)__builtin_amdgcn_readlane((int)p23, 63);
+        // per-strip delimiter totals: two packed 16-bit sums per DPP scan (the scan is a
+        // full inclusive prefix over the 64 lanes; lane 63 holds the totals)
+        const uint32_t own01 = a0 | (a1 << 16), own23 = a2 | (a3 << 16);
+        const uint32_t sc01 = wave_sum_to_lane63(own01);
+        const uint32_t sc23 = wave_sum_to_lane63(own23);
+        const uint32_t p01 = (uint32_t)__builtin_amdgcn_readlane((int)sc01, 63);
+        const uint32_t p23 = (uint32_t)__builtin_amdgcn_readlane((int)sc23, 63);
         uint32_t z0 = 8192u - (p01 & 0xffffu), z1 = 8192u - (p01 >> 16);
         uint32_t z2 = 8192u - (p23 & 0xffffu), z3 = 8192u - (p23 >> 16);
         if (lane == 0)
             *reinterpret_cast<uint4 *>(strip_prefix + s) =
                 make_uint4(run, run + z0, run + z0 + z1, run + z0 + z1 + z2);
+        if (H > 0 && __ballot(hits != 0)) {
+            // delimiters in front of my chunk: 128*lane minus the non-delimiter popcounts of
+            // the lanes before me (exclusive prefix = inclusive scan - own)
+            const uint32_t ex01 = sc01 - own01, ex23 = sc23 - own23;
+            const uint32_t lb = 128u * (uint32_t)lane;
+            uint32_t rc[4];
+            rc[0] = run + lb - (ex01 & 0xffffu);
+            rc[1] = run + z0 + lb - (ex01 >> 16);
+            rc[2] = run + z0 + z1 + lb - (ex23 & 0xffffu);
+            rc[3] = run + z0 + z1 + z2 + lb - (ex23 >> 16);
+            emit_candidates(hits, s, rc, slice, ncand, counters);
+        }
         run += z0 + z1 + z2 + z3;
-        if (H > 0 && __ballot(hits != 0)) emit_candidates(hits, s, cand, cand_cap, counters);
     }
     for (; s < s1; ++s) {                       // < 4 strips left in the range
         uint4 v0 = text[s * 64 + lane];
         uint32_t a0 = 0, hits = 0;
         sweep_chunk<H>(v0, dd, q, ftab, a0, hits, 0);
-        uint32_t p0 = wave_sum_to_lane63(a0);
-        p0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, 63);
+        const uint32_t sc0 = wave_sum_to_lane63(a0);
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)sc0, 63);
         if (lane == 0) strip_prefix[s] = run;
+        if (H > 0 && __ballot(hits != 0)) {
+            uint32_t rc[4];
+            rc[0] = run + 128u * (uint32_t)lane - (sc0 - a0);
+            rc[1] = rc[2] = rc[3] = 0;
+            emit_candidates(hits, s, rc, slice, ncand, counters);
+        }
         run += 8192u - p0;
-        if (H > 0 && __ballot(hits != 0)) emit_candidates(hits, s, cand, cand_cap, counters);
     }
-    if (lane == 0) wave_totals[w] = run;
+    if (lane == 0) {
+        wave_totals[w] = run;
+        if (H > 0) wave_cand[w] = ncand < AGH_SLICE_CAP ? ncand : AGH_SLICE_CAP;
+    }
 }
 
 // The last, partial strip (n % 1024 != 0): one wave, bytes >= n masked to a non-delimiter.
@@ -202,8 +235,8 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
                                                    const uint8_t *__restrict__ ftab_g,
                                                    uint32_t *__restrict__ strip_prefix,
                                                    uint32_t *__restrict__ wave_totals,
-                                                   uint32_t *__restrict__ cand,
-                                                   uint32_t cand_cap,
+                                                   uint64_t *__restrict__ cand,
+                                                   uint32_t *__restrict__ wave_cand,
                                                    uint32_t *__restrict__ counters)
 {
     const int lane = lane_id();
@@ -218,30 +251,44 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
     }
     uint32_t a0 = 0, hits = 0;
     sweep_chunk<H>(v, dd, q, ftab_g, a0, hits, 0);      // table straight from global/L2
-    uint32_t p0 = wave_sum_to_lane63(a0);
-    p0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, 63);
+    const uint32_t sc0 = wave_sum_to_lane63(a0);
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)sc0, 63);
     const uint32_t z = 8192u - p0;
     const uint64_t w = s / AGH_WAVE_STRIPS;
+    const bool fresh = (s % AGH_WAVE_STRIPS) == 0;      // k_sweep never touched this range
+    uint32_t before = fresh ? 0u : wave_totals[w];
+    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+    if (H > 0) {
+        uint32_t ncand = fresh ? 0u : wave_cand[w];
+        ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);
+        if (__ballot(hits != 0)) {
+            uint32_t rc[4];
+            rc[0] = before + 128u * (uint32_t)lane - (sc0 - a0);
+            rc[1] = rc[2] = rc[3] = 0;
+            emit_candidates(hits, s, rc, cand + w * AGH_SLICE_CAP, ncand, counters);
+        }
+        if (lane == 0) wave_cand[w] = ncand < AGH_SLICE_CAP ? ncand : AGH_SLICE_CAP;
+    }
     if (lane == 0) {
-        uint32_t before = (s % AGH_WAVE_STRIPS) ? wave_totals[w] : 0u;
         strip_prefix[s] = before;
         wave_totals[w] = before + z;
     }
-    if (H > 0 && __ballot(hits != 0)) emit_candidates(hits, s, cand, cand_cap, counters);
 }
 
-// Exclusive scan of wave_totals[0..nw) in place (one workgroup of 1024 threads); also records
-// the delimiter total and the last text byte.
-__global__ __launch_bounds__(1024) void k_wave_scan(uint32_t *__restrict__ wave_totals,
-                                                    uint32_t nw, const uint8_t *text,
-                                                    uint64_t n, uint32_t *__restrict__ counters)
+// Exclusive scans (one workgroup of 1024 threads, array staged in LDS so that the global
+// traffic is two coalesced passes): wave_totals[0..nw) in place -> delimiter prefix per wave
+// range; wave_cand[0..nw) -> total candidate count.  Also records the last text byte.
+#define AGH_SCAN_MAX 32768u   // 8 GiB segment / 256 KiB per wave range
+
+__device__ uint32_t block_exscan(const uint32_t *in, uint32_t *out, uint32_t nw, uint32_t *buf,
+                                 uint32_t *part)
 {
-    __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (nw + 1023u) / 1024u;
-    const uint32_t b = t * per;
+    for (uint32_t i = t; i < per * 1024u; i += 1024u) buf[i] = i < nw ? in[i] : 0u;
+    __syncthreads();
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < per && b + i < nw; ++i) sum += wave_totals[b + i];
+    for (uint32_t i = 0; i < per; ++i) sum += buf[t * per + i];
     part[t] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {           // Hillis-Steele inclusive scan
@@ -251,32 +298,70 @@ __global__ __launch_bounds__(1024) void k_wave_scan(uint32_t *__restrict__ wave_
         __syncthreads();
     }
     uint32_t run = part[t] - sum;
-    for (uint32_t i = 0; i < per && b + i < nw; ++i) {
-        uint32_t v = wave_totals[b + i];
-        wave_totals[b + i] = run;
+    for (uint32_t i = 0; i < per; ++i) {
+        uint32_t v = buf[t * per + i];
+        buf[t * per + i] = run;
         run += v;
     }
-    if (t == 1023) counters[AGH_C_NDELIM] = part[1023];
-    if (t == 0) counters[AGH_C_LASTBYTE] = n ? (uint32_t)text[n - 1] : 0xffffffffu;
+    const uint32_t total = part[1023];
+    __syncthreads();
+    if (out)
+        for (uint32_t i = t; i < nw; i += 1024u) out[i] = buf[i];
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void k_wave_scan(uint32_t *__restrict__ wave_totals,
+                                                    const uint32_t *__restrict__ wave_cand,
+                                                    uint32_t nw, const uint8_t *text,
+                                                    uint64_t n, uint32_t *__restrict__ counters)
+{
+    extern __shared__ uint32_t scan_lds[];
+    uint32_t *part = scan_lds;
+    uint32_t *buf = scan_lds + 1024;
+    uint32_t nd = block_exscan(wave_totals, wave_totals, nw, buf, part);
+    uint32_t nc = wave_cand ? block_exscan(wave_cand, nullptr, nw, buf, part) : 0u;
+    if (threadIdx.x == 0) {
+        counters[AGH_C_NDELIM] = nd;
+        counters[AGH_C_CAND] = nc;
+        counters[AGH_C_LASTBYTE] = n ? (uint32_t)text[n - 1] : 0xffffffffu;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
 // record bookkeeping shared by verify and fullscan
 // ---------------------------------------------------------------------------------------
-// Record r has a match whose last byte is at e: count it once.
+// Record r has a match whose last byte is at e: set its bit.  The number of matched records
+// is the population count of the bitmap (k_bitmap_count) -- a shared "matched" counter
+// would serialise on one L2 atomic unit (~90 updates/us) and dominate the scan.
 __device__ __forceinline__ void mark_record(const agh_marks &mk, uint32_t r, uint64_t e)
 {
     const uint32_t bit = 1u << (r & 31u);
     uint32_t old = atomicOr(&mk.bitmap[r >> 5], bit);
-    if (!(old & bit)) {
-        atomicAdd(&mk.counters[AGH_C_MATCHED], 1u);
-        if (mk.match_pos) {
-            uint32_t idx = atomicAdd(&mk.counters[AGH_C_STORED], 1u);
-            if (idx < mk.match_cap) {
-                mk.match_pos[idx] = e;
-                if (mk.match_rec) mk.match_rec[idx] = r;
-            }
+    if (mk.match_pos && !(old & bit)) {
+        uint32_t idx = atomicAdd(&mk.counters[AGH_C_STORED], 1u);
+        if (idx < mk.match_cap) {
+            mk.match_pos[idx] = e;
+            if (mk.match_rec) mk.match_rec[idx] = r;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bitmap_count(const uint32_t *__restrict__ bitmap,
+                                                      uint32_t n_words,
+                                                      uint32_t *__restrict__ counters)
+{
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
+         i += gridDim.x * blockDim.x)
+        acc += (uint32_t)__popc(bitmap[i]);
+    acc = wave_sum_to_lane63(acc);
+    __shared__ uint32_t part[4];
+    if (lane_id() == 63) part[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(&counters[AGH_C_MATCHED], t);
     }
 }
 
@@ -334,17 +419,54 @@ struct Automaton {
 };
 
 // ---------------------------------------------------------------------------------------
-// verify: one lane per candidate sample
+// verify: one hardware wave per sweep-wave slice, one lane per candidate sample
 // ---------------------------------------------------------------------------------------
+// The window [a0, we) around a sample is fetched with NCH aligned 16-byte loads issued
+// together (one memory round trip), then walked byte by byte out of registers.  Up to four
+// match events per window are kept in registers and resolved after the walk; a window with
+// more (records of a few bytes) is re-walked by the byte-wise slow path.
 template <typename WT, int K>
+__device__ __noinline__ void verify_window_slow(const uint8_t *__restrict__ text, uint64_t n,
+                                                const agh_dev_query &q, const WT *lmask,
+                                                uint64_t ws, uint64_t we, uint64_t anchor,
+                                                uint32_t rc_anchor, const agh_marks &mk,
+                                                uint32_t total_delims)
+{
+    const WT finalbit = (WT)1 << (q.m - 1);
+    // delimiters in [ws, anchor): the anchor's record number is known, ws's is derived
+    uint32_t back = 0;
+    for (uint64_t i = ws; i < anchor; ++i) back += (text[i] == q.delim);
+    uint32_t rec = rc_anchor - back;
+    Automaton<WT, K> A;
+    A.reset();
+    bool seen = false;
+    if (ws == 0) A.step(lmask[q.head_byte], finalbit);
+    for (uint64_t i = ws; i < we; ++i) {
+        const uint32_t c = text[i];
+        if (A.step(lmask[c], finalbit) && !seen) { seen = true; mark_record(mk, rec, i); }
+        if (c == q.delim) {
+            A.reset();
+            ++rec;
+            seen = false;
+            if (A.step(lmask[c], finalbit)) { seen = true; mark_record(mk, rec, i + 1); }
+        }
+    }
+    if (we == n && q.tail_virtual) {
+        if (A.step(lmask[q.delim], finalbit) && !seen) mark_record(mk, rec, n);
+        A.reset();
+        if (A.step(lmask[q.delim], finalbit)) mark_record(mk, rec + 1u, n);
+    }
+    (void)total_delims;
+}
+
+template <typename WT, int K, int NCH>
 __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text, uint64_t n,
                                                 agh_dev_query q,
                                                 const WT *__restrict__ mask_g,
-                                                const uint32_t *__restrict__ cand,
-                                                uint32_t n_cand,
-                                                const uint32_t *__restrict__ strip_prefix,
+                                                const uint64_t *__restrict__ cand,
+                                                const uint32_t *__restrict__ wave_cand,
                                                 const uint32_t *__restrict__ wave_prefix,
-                                                uint32_t n_strips, agh_marks mk)
+                                                uint32_t nw, agh_marks mk)
 {
     __shared__ WT lmask[256];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
@@ -352,43 +474,94 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
     const uint32_t total_delims = mk.counters[AGH_C_NDELIM];
     const WT finalbit = (WT)1 << (q.m - 1);
     const uint32_t L = (uint32_t)(q.m + q.k + 1);
+    const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
+    const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    const int lane = lane_id();
 
-    for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n_cand;
-         ci += gridDim.x * blockDim.x) {
-        const uint64_t j = (uint64_t)cand[ci] * 4u;
-        if (j >= n) continue;
-        uint64_t ws = j > L ? j - L : 0;
-        uint64_t we = j + (uint64_t)q.fq + (uint64_t)(q.m + q.k);
-        if (we > n) we = n;
-        Automaton<WT, K> A;
-        A.reset();
-        bool seen = false;                      // current record already reported by this lane
-        if (ws == 0) A.step(lmask[q.head_byte], finalbit);   // asearch.c:69-78: virtual byte in front
-        for (uint64_t i = ws; i < we; ++i) {
-            const uint32_t c = text[i];
-            bool hit = A.step(lmask[c], finalbit);
-            if (hit && !seen) {
-                seen = true;
-                mark_record(mk, record_of(text, n, i, strip_prefix, wave_prefix, n_strips,
-                                          total_delims, q.delim), i);
+    for (uint32_t w = blockIdx.x * 4 + threadIdx.x / WAVE; w < nw; w += gridDim.x * 4) {
+        const uint32_t cnt = wave_cand[w];
+        const uint64_t *slice = cand + (uint64_t)w * AGH_SLICE_CAP;
+        const uint32_t wp = wave_prefix[w];
+        for (uint32_t base = 0; base < cnt; base += WAVE) {
+            const uint32_t ci = base + (uint32_t)lane;
+            if (ci >= cnt) continue;
+            const uint64_t ent = slice[ci];
+            const uint64_t j = (ent & 0xffffffffull) * 4u;
+            if (j >= n) continue;
+            const uint32_t rc_anchor = wp + (uint32_t)(ent >> 32);   // record number at `anchor`
+            const uint64_t anchor = j & ~(uint64_t)15;               // the sample's chunk start
+            uint64_t ws = j > L ? j - L : 0;
+            if (anchor < ws) ws = anchor;
+            const uint64_t a0 = ws & ~(uint64_t)15;
+            uint64_t we = j + (uint64_t)q.fq + (uint64_t)(q.m + q.k);
+            if (we > n) we = n;
+
+            uint4 ch[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint64_t g = a0 + 16u * (uint64_t)c;
+                ch[c] = (g < n16 && g < we) ? *reinterpret_cast<const uint4 *>(text + g)
+                                            : make_uint4(fill4, fill4, fill4, fill4);
             }
-            if (c == q.delim) {                 // record boundary: reset, re-feed the byte
-                A.reset();
-                seen = false;
-                if (A.step(lmask[c], finalbit)) {
-                    seen = true;
-                    mark_record(mk, record_of(text, n, i + 1, strip_prefix, wave_prefix,
-                                              n_strips, total_delims, q.delim), i + 1);
+
+            Automaton<WT, K> A;
+            A.reset();
+            bool seen = false;
+            if (ws == 0) A.step(lmask[q.head_byte], finalbit);
+            uint32_t cd = 0;                    // delimiters seen in [ws, i)
+            uint32_t cd_anchor = 0;             // ... in [ws, anchor)
+            uint32_t ev0 = 0, ev1 = 0, ev2 = 0, ev3 = 0, nev = 0;   // events: cd-relative record
+            uint32_t ep0 = 0, ep1 = 0, ep2 = 0, ep3 = 0;            // and position (a0-relative)
+#define AGH_PUSH_EVENT(RELREC, RELPOS)                       \
+    do {                                                     \
+        ev3 = ev2; ev2 = ev1; ev1 = ev0; ev0 = (RELREC);     \
+        ep3 = ep2; ep2 = ep1; ep1 = ep0; ep0 = (RELPOS);     \
+        ++nev;                                               \
+    } while (0)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t dws[4] = {ch[c].x, ch[c].y, ch[c].z, ch[c].w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const uint32_t rel = (uint32_t)(16 * c + b);
+                    const uint64_t i = a0 + rel;
+                    if (i >= ws && i < we) {
+                        const uint32_t byte = (dws[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                        if (i == anchor) cd_anchor = cd;
+                        if (A.step(lmask[byte], finalbit) && !seen) {
+                            seen = true;
+                            AGH_PUSH_EVENT(cd, rel);
+                        }
+                        if (byte == q.delim) {
+                            A.reset();
+                            ++cd;
+                            seen = false;
+                            if (A.step(lmask[byte], finalbit)) {
+                                seen = true;
+                                AGH_PUSH_EVENT(cd, rel + 1u);
+                            }
+                        }
+                    }
                 }
             }
-        }
-        if (we == n && q.tail_virtual) {        // asearch.c:87-91: delimiter appended at EOF
-            if (A.step(lmask[q.delim], finalbit) && !seen)
-                mark_record(mk, record_of(text, n, n, strip_prefix, wave_prefix, n_strips,
-                                          total_delims, q.delim), n);
-            A.reset();
-            if (A.step(lmask[q.delim], finalbit))
-                mark_record(mk, total_delims + 1u, n);
+            if (anchor >= we) cd_anchor = cd;   // (cannot happen: the sample lies in the window)
+            if (we == n && q.tail_virtual) {    // asearch.c:87-91: delimiter appended at EOF
+                if (A.step(lmask[q.delim], finalbit) && !seen)
+                    AGH_PUSH_EVENT(cd, (uint32_t)(n - a0));
+                A.reset();
+                if (A.step(lmask[q.delim], finalbit)) AGH_PUSH_EVENT(cd + 1u, (uint32_t)(n - a0));
+            }
+#undef AGH_PUSH_EVENT
+            if (nev > 4) {
+                verify_window_slow<WT, K>(text, n, q, lmask, ws, we, anchor, rc_anchor, mk,
+                                          total_delims);
+            } else {
+                const uint32_t r0 = rc_anchor - cd_anchor;
+                if (nev > 0) mark_record(mk, r0 + ev0, a0 + ep0);
+                if (nev > 1) mark_record(mk, r0 + ev1, a0 + ep1);
+                if (nev > 2) mark_record(mk, r0 + ev2, a0 + ep2);
+                if (nev > 3) mark_record(mk, r0 + ev3, a0 + ep3);
+            }
         }
     }
 }
@@ -607,16 +780,18 @@ static void launch_sweep_t(const agh_sweep_args &a, hipStream_t st)
         const uint32_t blocks = (uint32_t)((n_waves + 3) / 4);
         hipLaunchKernelGGL(k_sweep<H>, dim3(blocks), dim3(256), 0, st,
                            (const uint4 *)a.text, n_full, a.q, a.ftab, a.strip_prefix,
-                           a.wave_totals, a.cand, a.cand_cap, a.counters);
+                           a.wave_totals, a.cand, a.wave_cand, a.counters);
     }
     if (a.n & (AGH_STRIP - 1))
         hipLaunchKernelGGL(k_sweep_tail<H>, dim3(1), dim3(64), 0, st, (const uint4 *)a.text,
                            a.n, a.q, a.ftab, a.strip_prefix, a.wave_totals, a.cand,
-                           a.cand_cap, a.counters);
+                           a.wave_cand, a.counters);
     const uint64_t n_strips = (a.n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint32_t nw = (uint32_t)((n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS);
-    hipLaunchKernelGGL(k_wave_scan, dim3(1), dim3(1024), 0, st, a.wave_totals, nw,
-                       (const uint8_t *)a.text, a.n, a.counters);
+    const size_t scan_lds = (1024 + ((nw + 1023u) / 1024u) * 1024u) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_wave_scan, dim3(1), dim3(1024), scan_lds, st, a.wave_totals,
+                       H > 0 ? (const uint32_t *)a.wave_cand : (const uint32_t *)nullptr,
+                       nw, (const uint8_t *)a.text, a.n, a.counters);
 }
 
 void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st)
@@ -629,15 +804,29 @@ void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st)
     }
 }
 
+template <typename WT, int K, int NCH>
+static void launch_verify_n(const agh_scan_args &a, hipStream_t st)
+{
+    uint32_t blocks = (a.nw + 3u) / 4u;
+    if (!blocks) return;
+    hipLaunchKernelGGL((k_verify<WT, K, NCH>), dim3(blocks), dim3(256), 0, st,
+                       (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
+                       a.wave_cand, a.wave_prefix, a.nw, a.mk);
+}
+
 template <typename WT, int K>
 static void launch_verify_t(const agh_scan_args &a, hipStream_t st)
 {
-    uint32_t blocks = (a.n_cand + 255u) / 256u;
-    if (blocks > 8192u) blocks = 8192u;
-    if (!blocks) return;
-    hipLaunchKernelGGL((k_verify<WT, K>), dim3(blocks), dim3(256), 0, st,
-                       (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand, a.n_cand,
-                       a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);
+    // window span: 2(m+k) + 1 + q plus up to 15 bytes of alignment slack in front
+    const int span = 2 * (a.q.m + a.q.k) + 1 + a.q.fq + 15;
+    const int nch = (span + 15) / 16;
+    if (sizeof(WT) == 4) {
+        if (nch <= 4) launch_verify_n<WT, K, 4>(a, st);
+        else launch_verify_n<WT, K, 8>(a, st);
+    } else {
+        if (nch <= 8) launch_verify_n<WT, K, 8>(a, st);
+        else launch_verify_n<WT, K, 12>(a, st);
+    }
 }
 
 template <typename WT, int K>
@@ -679,6 +868,15 @@ void agh_launch_fullscan(const agh_scan_args &a, hipStream_t st)
 {
     if (a.wide) dispatch_k<uint64_t>(a, true, st);
     else dispatch_k<uint32_t>(a, true, st);
+}
+
+void agh_launch_bitmap_count(const uint32_t *bitmap, uint32_t n_words, uint32_t *counters,
+                             hipStream_t st)
+{
+    uint32_t blocks = (n_words + 256u * 16u - 1u) / (256u * 16u);
+    if (blocks > 128u) blocks = 128u;
+    if (!blocks) blocks = 1u;
+    hipLaunchKernelGGL(k_bitmap_count, dim3(blocks), dim3(256), 0, st, bitmap, n_words, counters);
 }
 
 void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st)

@@ -21,8 +21,8 @@ struct agh_sweep_args {
     const uint8_t *ftab;     // AGH_FT_SIZE bytes (device), may be NULL when H == 0
     uint32_t *strip_prefix;  // ceil(n / 1024) + 4 entries
     uint32_t *wave_totals;   // becomes wave_prefix after the sweep
-    uint32_t *cand;
-    uint32_t cand_cap;
+    uint64_t *cand;          // nw slices of AGH_SLICE_CAP entries: (record count << 32) | dword
+    uint32_t *wave_cand;     // nw candidate counts
     uint32_t *counters;
 };
 
@@ -32,7 +32,9 @@ struct agh_scan_args {
     agh_dev_query q;
     const void *mask;        // 256 x uint32_t or uint64_t (device)
     int wide;                // 1: 64-bit state words
-    const uint32_t *cand;
+    const uint64_t *cand;
+    const uint32_t *wave_cand;
+    uint32_t nw;
     uint32_t n_cand;
     const uint32_t *strip_prefix;
     const uint32_t *wave_prefix;
@@ -43,6 +45,8 @@ struct agh_scan_args {
 void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st);
 void agh_launch_verify(const agh_scan_args &a, hipStream_t st);
 void agh_launch_fullscan(const agh_scan_args &a, hipStream_t st);
+void agh_launch_bitmap_count(const uint32_t *bitmap, uint32_t n_words, uint32_t *counters,
+                             hipStream_t st);
 void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
 void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_t seed,
                        const unsigned char *variants, const uint32_t *vlen,

@@ -70,7 +70,8 @@ typedef struct {
     uint64_t n_stored;      /* matches written to the caller's agh_match array */
     uint32_t engine;        /* AGH_ENGINE_* */
     uint32_t truncated;     /* 1: more matches than the agh_match array could hold */
-    double   device_ms;     /* GPU time of the scan kernels (hipEvent), excluding staging */
+    double   device_ms;     /* GPU time of the whole scan (hipEvent), excluding staging */
+    double   sweep_ms;      /* of which: the streaming sweep kernel(s) that read every byte */
 } agh_result;
 
 /* ---- query construction ------------------------------------------------------------- */

@@ -1,0 +1,19 @@
+"""Small driver for rocprofv3: N scans of the C2 workload (m=16, k from argv) resident in HBM."""
+import sys
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
+import torch
+import agrep_amd as A
+import _oracle as O
+
+gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+flags = A.FORCE_FULLSCAN if (len(sys.argv) > 3 and sys.argv[3] == "full") else 0
+n = int(gib * (1 << 30))
+t = torch.empty(n, dtype=torch.uint8, device='cuda')
+A.corpus_fill_device(t.data_ptr(), n // 4096, seed=12345, variants=O.VARIANTS_C2, plant_period=500)
+q = A.Query(O.PATTERN_C2, k)
+for it in range(6):
+    r = q.scan_device(t.data_ptr(), n, flags=flags)
+print("k", k, "matched", r.n_matched, "cand", r.n_candidates, "dev_ms %.3f sweep_ms %.3f" % (r.device_ms, r.sweep_ms))
