@@ -92,8 +92,11 @@ struct agh_query {
     // per-query workspace (grown lazily, reused across scans)
     dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, staging, match_pos, match_rec;
     uint32_t *d_counters = nullptr;
+    uint32_t *d_chunk_totals = nullptr; // scratch of the prefix scan
     uint32_t *h_counters = nullptr;     // pinned
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    uint64_t bitmap_bits_hint = 0;      // records seen by the previous scan (+25 %)
+    bool bitmap_dirty = false;          // a scan was queued but its count-and-clear did not finish
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };
 
 static bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
@@ -158,16 +161,18 @@ static int upload_tables(agh_query *q)
             uint32_t s = 0;
             for (int t = 0; t < q->fq; ++t) s |= (uint32_t)rep[i + t] << (8 * t);
             s = (s & q->qmask) | q->fold;
-            tab[agh_sample_hash(s)] = 1;
+            tab[q->fq == 4 ? agh_sample_hash_q4(s) : agh_sample_hash_q3(s)] = 1;
         }
         HIP_TRY(hipMalloc((void **)&q->d_ftab, AGH_FT_SIZE));
         HIP_TRY(hipMemcpy(q->d_ftab, tab.data(), AGH_FT_SIZE, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc((void **)&q->d_counters, AGH_C_COUNT * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&q->d_chunk_totals, 128 * sizeof(uint32_t)));
     HIP_TRY(hipHostMalloc((void **)&q->h_counters, AGH_C_COUNT * sizeof(uint32_t)));
     HIP_TRY(hipEventCreate(&q->ev0));
     HIP_TRY(hipEventCreate(&q->ev1));
     HIP_TRY(hipEventCreate(&q->ev2));
+    HIP_TRY(hipEventCreate(&q->ev3));
     return 0;
 }
 
@@ -286,10 +291,12 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_mask) (void)hipFree(q->d_mask);
     if (q->d_ftab) (void)hipFree(q->d_ftab);
     if (q->d_counters) (void)hipFree(q->d_counters);
+    if (q->d_chunk_totals) (void)hipFree(q->d_chunk_totals);
     if (q->h_counters) (void)hipHostFree(q->h_counters);
     if (q->ev0) (void)hipEventDestroy(q->ev0);
     if (q->ev1) (void)hipEventDestroy(q->ev1);
     if (q->ev2) (void)hipEventDestroy(q->ev2);
+    if (q->ev3) (void)hipEventDestroy(q->ev3);
     q->strip_prefix.release();
     q->wave_totals.release();
     q->cand.release();
@@ -353,79 +360,113 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     dq.head_byte = head_byte;
     dq.tail_virtual = tail_virtual;
 
-    HIP_TRY(hipEventRecord(q->ev0, st));
-    HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
-    agh_sweep_args sa;
-    sa.text = d_text;
-    sa.n = n;
-    sa.q = dq;
-    sa.ftab = q->d_ftab;
-    sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
-    sa.wave_totals = (uint32_t *)q->wave_totals.p;
-    sa.cand = (uint64_t *)q->cand.p;
-    sa.wave_cand = (uint32_t *)q->wave_cand.p;
-    sa.counters = q->d_counters;
-    agh_launch_sweep(sa, want_filter ? q->fh : 0, st);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(q->ev2, st));
-    HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-
-    const uint32_t n_delims = q->h_counters[AGH_C_NDELIM];
-    const uint32_t n_cand = q->h_counters[AGH_C_CAND];
+    // Optimistic single-sync pipeline: the record bitmap is sized from a hint (the previous
+    // scan of this query, or one record per 32 bytes) and everything -- census/filter sweep,
+    // prefix scan, verify or full scan, population count -- is queued back to back.  The host
+    // looks at the counters once at the end; only if a buffer turned out too small (candidate
+    // slices: the filter is not selective on this text; bitmap: more records than guessed)
+    // does it run the affected stage again.
     bool use_filter = want_filter;
-    if (use_filter && q->h_counters[AGH_C_OVERFLOW]) {
-        if (flags & AGH_FORCE_FILTER)
-            return fail("candidate buffer overflow (%u candidates)", n_cand);
-        use_filter = false;                     // not selective on this text: automaton everywhere
-    }
-    out->records = (uint64_t)n_delims + (q->h_counters[AGH_C_LASTBYTE] != q->delim[0] ? 1u : 0u);
-    out->candidates = use_filter ? n_cand : 0;
-    out->engine = use_filter ? AGH_ENGINE_FILTER : AGH_ENGINE_FULLSCAN;
+    uint64_t bits_hint = std::max<uint64_t>(q->bitmap_bits_hint, n / 64 + 1024);
+    bool swept = false;
+    float total_ms = 0.f;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const size_t bm_words = (size_t)(((bits_hint + 64 + 127) / 128) * 4);   // 16-byte units
+        {
+            const void *before = q->bitmap.p;
+            if (q->bitmap.ensure(bm_words * sizeof(uint32_t))) return -1;
+            if (q->bitmap.p != before || q->bitmap_dirty) {
+                // fresh allocation (or an aborted scan): zero everything once; afterwards
+                // k_bitmap_count leaves the bitmap clean
+                HIP_TRY(hipMemsetAsync(q->bitmap.p, 0, q->bitmap.cap, st));
+            }
+            q->bitmap_dirty = true;
+        }
 
-    const size_t bm_bytes = (((size_t)n_delims + 64 + 31) / 32) * sizeof(uint32_t);
-    if (q->bitmap.ensure(bm_bytes)) return -1;
-    HIP_TRY(hipMemsetAsync(q->bitmap.p, 0, bm_bytes, st));
-    if (q->h_counters[AGH_C_OVERFLOW])
-        HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_OVERFLOW, 0, sizeof(uint32_t), st));
+        HIP_TRY(hipEventRecord(q->ev0, st));
+        if (!swept) HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+        else {
+            // keep the census results (NDELIM, LASTBYTE, CAND), clear the rest
+            HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_OVERFLOW, 0, sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_MATCHED, 0, sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_STORED, 0, sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_BM_OVERFLOW, 0, sizeof(uint32_t), st));
+        }
+        if (!swept) {
+            agh_sweep_args sa;
+            sa.text = d_text;
+            sa.n = n;
+            sa.q = dq;
+            sa.ftab = q->d_ftab;
+            sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
+            sa.wave_totals = (uint32_t *)q->wave_totals.p;
+            sa.cand = (uint64_t *)q->cand.p;
+            sa.wave_cand = (uint32_t *)q->wave_cand.p;
+            sa.counters = q->d_counters;
+            sa.chunk_totals = q->d_chunk_totals;
+            sa.ev_begin = q->ev2;
+            sa.ev_end = q->ev3;
+            agh_launch_sweep(sa, use_filter ? q->fh : 0, st);
+            HIP_TRY(hipGetLastError());
+        }
+        agh_scan_args va;
+        va.text = d_text;
+        va.n = n;
+        va.q = dq;
+        va.mask = q->d_mask;
+        va.wide = q->wide;
+        va.cand = (const uint64_t *)q->cand.p;
+        va.wave_cand = (const uint32_t *)q->wave_cand.p;
+        va.nw = (uint32_t)nw;
+        va.strip_prefix = (const uint32_t *)q->strip_prefix.p;
+        va.wave_prefix = (const uint32_t *)q->wave_totals.p;
+        va.n_strips = (uint32_t)n_strips;
+        va.mk.bitmap = (uint32_t *)q->bitmap.p;
+        va.mk.bitmap_bits = (uint32_t)std::min<uint64_t>(bm_words * 32, 0xffffffffu);
+        va.mk.counters = q->d_counters;
+        va.mk.match_pos = d_match_pos;
+        va.mk.match_rec = d_match_rec;
+        va.mk.match_cap = match_cap;
+        if (use_filter) agh_launch_verify(va, st);
+        else agh_launch_fullscan(va, st);
+        agh_launch_bitmap_count((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), q->d_counters, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(q->ev1, st));
+        HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        q->bitmap_dirty = false;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, q->ev0, q->ev1));
+        total_ms += ms;
+        if (!swept) HIP_TRY(hipEventElapsedTime(&out->sweep_ms, q->ev2, q->ev3));
+        swept = true;
 
-    agh_scan_args va;
-    va.text = d_text;
-    va.n = n;
-    va.q = dq;
-    va.mask = q->d_mask;
-    va.wide = q->wide;
-    va.cand = (const uint64_t *)q->cand.p;
-    va.wave_cand = (const uint32_t *)q->wave_cand.p;
-    va.nw = (uint32_t)nw;
-    va.n_cand = n_cand;
-    va.strip_prefix = (const uint32_t *)q->strip_prefix.p;
-    va.wave_prefix = (const uint32_t *)q->wave_totals.p;
-    va.n_strips = (uint32_t)n_strips;
-    va.mk.bitmap = (uint32_t *)q->bitmap.p;
-    va.mk.counters = q->d_counters;
-    va.mk.match_pos = d_match_pos;
-    va.mk.match_rec = d_match_rec;
-    va.mk.match_cap = match_cap;
-    if (use_filter) {
-        if (n_cand) agh_launch_verify(va, st);
-    } else {
-        agh_launch_fullscan(va, st);
+        const uint32_t n_delims = q->h_counters[AGH_C_NDELIM];
+        q->bitmap_bits_hint = (uint64_t)n_delims + n_delims / 4 + 1024;
+        const bool slice_overflow = use_filter && q->h_counters[AGH_C_OVERFLOW];
+        const bool bm_overflow = q->h_counters[AGH_C_BM_OVERFLOW] != 0 ||
+                                 (uint64_t)n_delims + 2 > (uint64_t)bm_words * 32;
+        if (slice_overflow) {
+            if (flags & AGH_FORCE_FILTER)
+                return fail("candidate slices overflowed (%u candidates)", q->h_counters[AGH_C_CAND]);
+            use_filter = false;                 // not selective on this text: automaton everywhere
+            swept = false;                      // the full scan needs the H=0 sweep's strip prefix
+        }
+        if (slice_overflow || bm_overflow) {
+            bits_hint = (uint64_t)n_delims + 1024;
+            continue;
+        }
+        out->records = (uint64_t)n_delims + (q->h_counters[AGH_C_LASTBYTE] != q->delim[0] ? 1u : 0u);
+        out->candidates = use_filter ? q->h_counters[AGH_C_CAND] : 0;
+        out->engine = use_filter ? AGH_ENGINE_FILTER : AGH_ENGINE_FULLSCAN;
+        out->matched = q->h_counters[AGH_C_MATCHED];
+        out->stored = std::min<uint64_t>(q->h_counters[AGH_C_STORED], match_cap);
+        out->truncated = q->h_counters[AGH_C_STORED] > match_cap;
+        out->ms = total_ms;
+        return 0;
     }
-    agh_launch_bitmap_count((const uint32_t *)q->bitmap.p, (uint32_t)(bm_bytes / 4), q->d_counters,
-                            st);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(q->ev1, st));
-    HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
-    HIP_TRY(hipEventElapsedTime(&out->sweep_ms, q->ev0, q->ev2));
-    out->matched = q->h_counters[AGH_C_MATCHED];
-    out->stored = std::min<uint64_t>(q->h_counters[AGH_C_STORED], match_cap);
-    out->truncated = q->h_counters[AGH_C_STORED] > match_cap;
-    return 0;
+    return fail("internal error: scan did not converge");
 }
 
 // Largest cut <= want such that text[cut-1] is a delimiter (so segments hold whole records).

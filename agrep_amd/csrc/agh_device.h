@@ -29,6 +29,7 @@ enum agh_counter {
     AGH_C_STORED = 4,    // match positions stored
     AGH_C_LASTBYTE = 5,  // text[n-1]
     AGH_C_CHECK = 6,     // read-probe checksum sink
+    AGH_C_BM_OVERFLOW = 7, // a record number did not fit the record bitmap
     AGH_C_COUNT = 8
 };
 
@@ -52,9 +53,16 @@ struct agh_dev_query {
 #else
 #define AGH_HD static inline
 #endif
-AGH_HD uint32_t agh_sample_hash(uint32_t s)
+// q == 4: the sample has 32 significant bits, fold the top byte down first.
+AGH_HD uint32_t agh_sample_hash_q4(uint32_t s)
 {
     uint32_t t = (s ^ (s >> 11)) & 0xffffffu;
     uint32_t p = t * 0x9E3779u;              // 24 x 24 -> low 32 bits (v_mul_u32_u24)
     return (p >> 14) & (AGH_FT_SIZE - 1u);
+}
+// q <= 3: the sample already fits 24 bits.
+AGH_HD uint32_t agh_sample_hash_q3(uint32_t s)
+{
+    uint32_t p = (s & 0xffffffu) * 0x85EBCAu;
+    return (p >> 13) & (AGH_FT_SIZE - 1u);
 }

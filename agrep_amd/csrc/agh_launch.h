@@ -8,6 +8,7 @@
 
 struct agh_marks {
     uint32_t *bitmap;        // one bit per record
+    uint32_t bitmap_bits;    // capacity; larger record numbers raise AGH_C_BM_OVERFLOW
     uint32_t *counters;
     uint64_t *match_pos;     // optional: one byte offset per newly matched record
     uint32_t *match_rec;     // optional: its record number
@@ -23,7 +24,10 @@ struct agh_sweep_args {
     uint32_t *wave_totals;   // becomes wave_prefix after the sweep
     uint64_t *cand;          // nw slices of AGH_SLICE_CAP entries: (record count << 32) | dword
     uint32_t *wave_cand;     // nw candidate counts
+    uint32_t *chunk_totals;  // 2 * 64 scratch words of the prefix scan
     uint32_t *counters;
+    hipEvent_t ev_begin;     // optional: recorded right before / after the k_sweep launch
+    hipEvent_t ev_end;
 };
 
 struct agh_scan_args {
@@ -35,7 +39,6 @@ struct agh_scan_args {
     const uint64_t *cand;
     const uint32_t *wave_cand;
     uint32_t nw;
-    uint32_t n_cand;
     const uint32_t *strip_prefix;
     const uint32_t *wave_prefix;
     uint32_t n_strips;
@@ -45,7 +48,7 @@ struct agh_scan_args {
 void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st);
 void agh_launch_verify(const agh_scan_args &a, hipStream_t st);
 void agh_launch_fullscan(const agh_scan_args &a, hipStream_t st);
-void agh_launch_bitmap_count(const uint32_t *bitmap, uint32_t n_words, uint32_t *counters,
+void agh_launch_bitmap_count(uint32_t *bitmap, uint32_t n_words, uint32_t *counters,
                              hipStream_t st);
 void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
 void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_t seed,

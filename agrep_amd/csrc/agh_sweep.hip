@@ -1,0 +1,578 @@
+// agh_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the agrep record scanner.
+//
+// Data flow of one scan (all buffers in HBM, text read with 16 B/lane coalesced loads):
+//
+//   k_sweep<H>      streams every text byte once.  Per 1 KiB strip it counts the record
+//                   delimiters (SWAR zero-byte test + v_bcnt) and, when the query admits the
+//                   q-gram sample filter, probes one q-byte sample every H bytes against a
+//                   32 KiB hash table held in LDS; samples that hit are appended to the
+//                   candidate list (wave-aggregated atomics).  HBM-bound: this is the
+//                   kernel the roofline is quoted on.
+//   k_scan_local /  exclusive scan of the per-wave delimiter totals (two tiny multi-block
+//   k_scan_fixup    kernels).
+//   k_verify<W,K>   one lane per candidate: the Wu-Manber k-error shift-AND automaton
+//                   (asearch.c:94-116 restated with left shifts, delimiter out of band) over
+//                   the <= 2(m+k)+q bytes around the sample; every match is turned into a
+//                   record number and marked in a one-bit-per-record bitmap, so a record is
+//                   counted once however many windows or occurrences hit it.
+//   k_fullscan<W,K> the same automaton over every byte (the asearch.c shape), for queries the
+//                   filter cannot serve.  Text is staged through LDS so that each lane walks
+//                   a contiguous 256 B chunk while global loads stay coalesced; a lane starts
+//                   m+k+1 bytes early to rebuild the automaton state (bounded memory,
+//                   SURVEY.md B.5).
+//
+// No MFMA anywhere: the work is byte/bitwise integer and the bound is HBM read bandwidth.
+#include <stdlib.h>
+#include <string.h>
+
+#include "agh_device_inl.h"
+
+
+// ---------------------------------------------------------------------------------------
+// sweep: delimiter census + q-gram sample filter
+// ---------------------------------------------------------------------------------------
+// MODE bit 0: the query folds ASCII case (OR 0x20 into every sampled byte);
+// MODE bit 1: 4-byte samples (no mask needed, 32-bit hash) instead of <= 3-byte samples.
+template <int MODE>
+__device__ __forceinline__ uint32_t probe(uint32_t w, const agh_dev_query &q,
+                                          const uint8_t *ftab)
+{
+    if (MODE & 2) {
+        const uint32_t s = (MODE & 1) ? (w | q.fold) : w;
+        return ftab[agh_sample_hash_q4(s)];
+    } else {
+        const uint32_t s = (MODE & 1) ? ((w & q.qmask) | q.fold) : (w & q.qmask);
+        return ftab[agh_sample_hash_q3(s)];
+    }
+}
+
+// One 16-byte chunk: accumulate the non-delimiter popcount and the sample hit bits.
+template <int H, int MODE>
+__device__ __forceinline__ void sweep_chunk(uint4 v, uint32_t dd, const agh_dev_query &q,
+                                            const uint8_t *ftab, uint32_t &acc,
+                                            uint32_t &hits, int bitbase)
+{
+    acc += nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
+    if (H > 0) {
+        hits |= probe<MODE>(v.x, q, ftab) << bitbase;
+        if (H <= 8) hits |= probe<MODE>(v.z, q, ftab) << (bitbase + 2);
+        if (H <= 4) {
+            hits |= probe<MODE>(v.y, q, ftab) << (bitbase + 1);
+            hits |= probe<MODE>(v.w, q, ftab) << (bitbase + 3);
+        }
+    }
+}
+
+// Append the candidates of one wave to the wave's private slice of the candidate buffer (no
+// atomics: one hot global counter saturates at ~90 updates/us on this chip and would cap the
+// whole sweep).  hits: bit (4*u + d) of lane l = sample at dword d of the lane's chunk in
+// strip s+u.  rc[u] = delimiters (inside this wave's range) in front of the lane's chunk of
+// strip s+u -- stored with the candidate so that the verifier can number records without
+// re-reading any text.  cnt is wave-uniform.
+__device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, const uint32_t rc[4],
+                                                uint64_t *__restrict__ slice, uint32_t &cnt,
+                                                uint32_t *counters)
+{
+    uint64_t hm = __ballot(hits != 0);
+    const int lane = lane_id();
+    while (hm) {
+        int l = __ffsll((long long)hm) - 1;
+        hm &= hm - 1;
+        uint32_t hbits = (uint32_t)__builtin_amdgcn_readlane((int)hits, l);
+        uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)rc[0], l);
+        uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)rc[1], l);
+        uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)rc[2], l);
+        uint32_t r3 = (uint32_t)__builtin_amdgcn_readlane((int)rc[3], l);
+        int c = __popc(hbits);
+        if (lane < c) {
+            uint32_t t = hbits;
+            for (int j = 0; j < lane; ++j) t &= t - 1;
+            int b = __ffs((int)t) - 1;
+            int u = b >> 2;
+            uint32_t dw = (uint32_t)(((s + (uint64_t)u) * 64u + (uint64_t)l) * 4u +
+                                     (uint64_t)(b & 3));
+            uint32_t r = u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3));
+            uint32_t idx = cnt + (uint32_t)lane;
+            if (idx < AGH_SLICE_CAP) slice[idx] = ((uint64_t)r << 32) | dw;
+            else counters[AGH_C_OVERFLOW] = 1u;
+        }
+        cnt += (uint32_t)c;
+    }
+}
+
+// One supertile = 4 consecutive strips (4 KiB) of one wave: census, probes, prefix, emit.
+template <int H, int MODE>
+__device__ __forceinline__ void sweep_supertile(uint4 v0, uint4 v1, uint4 v2, uint4 v3,
+                                                uint64_t s, int lane, uint32_t dd,
+                                                const agh_dev_query &q, const uint8_t *ftab,
+                                                uint32_t *__restrict__ strip_prefix,
+                                                uint64_t *__restrict__ slice, uint32_t &run,
+                                                uint32_t &ncand, uint32_t *counters)
+{
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, hits = 0;
+    sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0);
+    sweep_chunk<H, MODE>(v1, dd, q, ftab, a1, hits, 4);
+    sweep_chunk<H, MODE>(v2, dd, q, ftab, a2, hits, 8);
+    sweep_chunk<H, MODE>(v3, dd, q, ftab, a3, hits, 12);
+    // per-strip delimiter totals: two packed 16-bit sums per DPP scan (the scan is a full
+    // inclusive prefix over the 64 lanes; lane 63 holds the totals)
+    const uint32_t own01 = a0 | (a1 << 16), own23 = a2 | (a3 << 16);
+    const uint32_t sc01 = wave_sum_to_lane63(own01);
+    const uint32_t sc23 = wave_sum_to_lane63(own23);
+    const uint32_t p01 = (uint32_t)__builtin_amdgcn_readlane((int)sc01, 63);
+    const uint32_t p23 = (uint32_t)__builtin_amdgcn_readlane((int)sc23, 63);
+    const uint32_t z0 = 8192u - (p01 & 0xffffu), z1 = 8192u - (p01 >> 16);
+    const uint32_t z2 = 8192u - (p23 & 0xffffu), z3 = 8192u - (p23 >> 16);
+    if (H == 0 && lane == 0)                    // only the full-scan kernel reads strip_prefix
+        *reinterpret_cast<uint4 *>(strip_prefix + s) =
+            make_uint4(run, run + z0, run + z0 + z1, run + z0 + z1 + z2);
+    if (H > 0 && __ballot(hits != 0)) {
+        // delimiters in front of my chunk: 128*lane minus the non-delimiter popcounts of the
+        // lanes before me (exclusive prefix = inclusive scan - own)
+        const uint32_t ex01 = sc01 - own01, ex23 = sc23 - own23;
+        const uint32_t lb = 128u * (uint32_t)lane;
+        uint32_t rc[4];
+        rc[0] = run + lb - (ex01 & 0xffffu);
+        rc[1] = run + z0 + lb - (ex01 >> 16);
+        rc[2] = run + z0 + z1 + lb - (ex23 & 0xffffu);
+        rc[3] = run + z0 + z1 + z2 + lb - (ex23 >> 16);
+        emit_candidates(hits, s, rc, slice, ncand, counters);
+    }
+    run += z0 + z1 + z2 + z3;
+}
+
+// grid: ceil(n_waves / (BLOCK/64)) workgroups of BLOCK threads sharing one LDS copy of the
+// filter table; wave w owns strips [w*AGH_WAVE_STRIPS, min((w+1)*AGH_WAVE_STRIPS, n_full)).
+// PREFETCH: the loads of supertile i+1 are issued before supertile i is processed, so every
+// wave keeps 4-8 KiB of HBM reads in flight while its VALU work runs.
+template <int H, int MODE, int BLOCK, bool PREFETCH>
+__global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
+                                                 uint64_t n_full_strips, agh_dev_query q,
+                                                 const uint8_t *__restrict__ ftab_g,
+                                                 uint32_t *__restrict__ strip_prefix,
+                                                 uint32_t *__restrict__ wave_totals,
+                                                 uint64_t *__restrict__ cand,
+                                                 uint32_t *__restrict__ wave_cand,
+                                                 uint32_t *__restrict__ counters)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ftab[H > 0 ? AGH_FT_SIZE : 16];
+    if (H > 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(ftab_g);
+        uint4 *dst = reinterpret_cast<uint4 *>(ftab);
+        constexpr int PER = AGH_FT_SIZE / 16 / BLOCK;        // 16-byte pieces per thread
+        uint4 tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) tmp[i] = src[threadIdx.x + i * BLOCK];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) dst[threadIdx.x + i * BLOCK] = tmp[i];
+        __syncthreads();
+    }
+    const int lane = lane_id();
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const uint64_t w = (uint64_t)blockIdx.x * (BLOCK / WAVE) + wib;
+    const uint64_t s0 = w * AGH_WAVE_STRIPS;
+    if (s0 >= n_full_strips) return;
+    uint64_t s1 = s0 + AGH_WAVE_STRIPS;
+    if (s1 > n_full_strips) s1 = n_full_strips;
+    const uint32_t dd = q.delim * 0x01010101u;
+    uint32_t run = 0;                           // delimiters before strip s inside this range
+    uint32_t ncand = 0;                         // candidates in this wave's slice
+    uint64_t *slice = cand + w * AGH_SLICE_CAP;
+    uint64_t s = s0;
+
+    if (PREFETCH) {
+        if (s + 4 <= s1) {
+            const uint4 *p = text + s * 64 + lane;
+            uint4 c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192];
+            for (; s + 8 <= s1; s += 4) {
+                const uint4 *pn = text + (s + 4) * 64 + lane;
+                uint4 n0 = pn[0], n1 = pn[64], n2 = pn[128], n3 = pn[192];
+                sweep_supertile<H, MODE>(c0, c1, c2, c3, s, lane, dd, q, ftab, strip_prefix, slice,
+                                   run, ncand, counters);
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            }
+            sweep_supertile<H, MODE>(c0, c1, c2, c3, s, lane, dd, q, ftab, strip_prefix, slice, run,
+                               ncand, counters);
+            s += 4;
+        }
+    } else {
+        for (; s + 4 <= s1; s += 4) {
+            const uint4 *p = text + s * 64 + lane;
+            uint4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];   // 4 x 1 KiB in flight
+            sweep_supertile<H, MODE>(v0, v1, v2, v3, s, lane, dd, q, ftab, strip_prefix, slice, run,
+                               ncand, counters);
+        }
+    }
+    for (; s < s1; ++s) {                       // < 4 strips left in the range
+        uint4 v0 = text[s * 64 + lane];
+        uint32_t a0 = 0, hits = 0;
+        sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0);
+        const uint32_t sc0 = wave_sum_to_lane63(a0);
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)sc0, 63);
+        if (H == 0 && lane == 0) strip_prefix[s] = run;
+        if (H > 0 && __ballot(hits != 0)) {
+            uint32_t rc[4];
+            rc[0] = run + 128u * (uint32_t)lane - (sc0 - a0);
+            rc[1] = rc[2] = rc[3] = 0;
+            emit_candidates(hits, s, rc, slice, ncand, counters);
+        }
+        run += 8192u - p0;
+    }
+    if (lane == 0) {
+        wave_totals[w] = run;
+        if (H > 0) wave_cand[w] = ncand < AGH_SLICE_CAP ? ncand : AGH_SLICE_CAP;
+    }
+}
+
+// The last, partial strip (n % 1024 != 0): one wave, bytes >= n masked to a non-delimiter.
+// Runs after k_sweep on the same stream.
+template <int H, int MODE>
+__global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ text, uint64_t n,
+                                                   agh_dev_query q,
+                                                   const uint8_t *__restrict__ ftab_g,
+                                                   uint32_t *__restrict__ strip_prefix,
+                                                   uint32_t *__restrict__ wave_totals,
+                                                   uint64_t *__restrict__ cand,
+                                                   uint32_t *__restrict__ wave_cand,
+                                                   uint32_t *__restrict__ counters)
+{
+    const int lane = lane_id();
+    const uint64_t s = n >> AGH_STRIP_SHIFT;            // index of the partial strip
+    const uint64_t off = (s << AGH_STRIP_SHIFT) + (uint64_t)lane * 16u;
+    const uint32_t dd = q.delim * 0x01010101u;
+    const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
+    uint4 v = make_uint4(fill4, fill4, fill4, fill4);
+    if (off < n) {
+        v = text[off >> 4];
+        if (off + 16 > n) v = mask_tail(v, (int)(n - off), fill4);
+    }
+    uint32_t a0 = 0, hits = 0;
+    sweep_chunk<H, MODE>(v, dd, q, ftab_g, a0, hits, 0);      // table straight from global/L2
+    const uint32_t sc0 = wave_sum_to_lane63(a0);
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)sc0, 63);
+    const uint32_t z = 8192u - p0;
+    const uint64_t w = s / AGH_WAVE_STRIPS;
+    const bool fresh = (s % AGH_WAVE_STRIPS) == 0;      // k_sweep never touched this range
+    uint32_t before = fresh ? 0u : wave_totals[w];
+    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+    if (H > 0) {
+        uint32_t ncand = fresh ? 0u : wave_cand[w];
+        ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);
+        if (__ballot(hits != 0)) {
+            uint32_t rc[4];
+            rc[0] = before + 128u * (uint32_t)lane - (sc0 - a0);
+            rc[1] = rc[2] = rc[3] = 0;
+            emit_candidates(hits, s, rc, cand + w * AGH_SLICE_CAP, ncand, counters);
+        }
+        if (lane == 0) wave_cand[w] = ncand < AGH_SLICE_CAP ? ncand : AGH_SLICE_CAP;
+    }
+    if (lane == 0) {
+        if (H == 0) strip_prefix[s] = before;
+        wave_totals[w] = before + z;
+    }
+}
+
+// Exclusive scan of the per-wave delimiter totals, two small multi-block kernels:
+//   k_scan_local: every workgroup scans 1024 consecutive entries in place (4 per thread,
+//                 wave DPP scan, 4 wave totals through LDS) and publishes its chunk total;
+//                 it also reduces its 1024 candidate counts.
+//   k_scan_fixup: every workgroup adds the totals of the chunks before it (<= 32 values) to
+//                 its entries; workgroup 0 writes the grand totals and the last text byte.
+#define AGH_SCAN_CHUNK 1024u
+#define AGH_SCAN_MAXCHUNKS 64u   // 64 * 1024 wave ranges * 256 KiB = 16 GiB >= one segment
+
+__global__ __launch_bounds__(256) void k_scan_local(uint32_t *__restrict__ wave_totals,
+                                                    const uint32_t *__restrict__ wave_cand,
+                                                    uint32_t nw,
+                                                    uint32_t *__restrict__ chunk_totals)
+{
+    __shared__ uint32_t wsum[4], csum[4];
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    const uint32_t base = blockIdx.x * AGH_SCAN_CHUNK + threadIdx.x * 4u;
+    uint32_t v[4], c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = base + i < nw ? wave_totals[base + i] : 0u;
+        if (wave_cand) c += base + i < nw ? wave_cand[base + i] : 0u;
+    }
+    const uint32_t own = v[0] + v[1] + v[2] + v[3];
+    const uint32_t inc = wave_sum_to_lane63(own);       // inclusive scan over the wave
+    const uint32_t csc = wave_sum_to_lane63(c);
+    if (lane == 63) { wsum[wv] = inc; csum[wv] = csc; }
+    __syncthreads();
+    uint32_t before = inc - own;
+    for (uint32_t i = 0; i < wv; ++i) before += wsum[i];
+    if (base < nw) wave_totals[base] = before;
+    if (base + 1 < nw) wave_totals[base + 1] = before + v[0];
+    if (base + 2 < nw) wave_totals[base + 2] = before + v[0] + v[1];
+    if (base + 3 < nw) wave_totals[base + 3] = before + v[0] + v[1] + v[2];
+    if (threadIdx.x == 0) {
+        chunk_totals[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        chunk_totals[AGH_SCAN_MAXCHUNKS + blockIdx.x] = csum[0] + csum[1] + csum[2] + csum[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_fixup(uint32_t *__restrict__ wave_totals,
+                                                    uint32_t nw,
+                                                    const uint32_t *__restrict__ chunk_totals,
+                                                    uint32_t n_chunks, const uint8_t *text,
+                                                    uint64_t n, uint32_t *__restrict__ counters)
+{
+    __shared__ uint32_t sh_before;
+    if (threadIdx.x < WAVE) {
+        const uint32_t i = threadIdx.x;
+        uint32_t d = i < n_chunks ? chunk_totals[i] : 0u;
+        uint32_t c = i < n_chunks ? chunk_totals[AGH_SCAN_MAXCHUNKS + i] : 0u;
+        const uint32_t dpre = wave_sum_to_lane63(i < blockIdx.x ? d : 0u);
+        const uint32_t dall = wave_sum_to_lane63(d);
+        const uint32_t call = wave_sum_to_lane63(c);
+        if (i == 63) {
+            sh_before = dpre;
+            if (blockIdx.x == 0) {
+                counters[AGH_C_NDELIM] = dall;
+                counters[AGH_C_CAND] = call;
+                counters[AGH_C_LASTBYTE] = n ? (uint32_t)text[n - 1] : 0xffffffffu;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t before = sh_before;
+    if (before) {
+        const uint32_t base = blockIdx.x * AGH_SCAN_CHUNK + threadIdx.x * 4u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (base + i < nw) wave_totals[base + i] += before;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// matched-record count = population count of the record bitmap
+// ---------------------------------------------------------------------------------------
+// Counts the set bits of the record bitmap and leaves it zeroed for the next scan (so a scan
+// never pays a separate memset for a bitmap that is almost entirely zero already).
+__global__ __launch_bounds__(256) void k_bitmap_count(uint4 *__restrict__ bitmap,
+                                                      uint32_t n_vec,
+                                                      uint32_t *__restrict__ counters)
+{
+    // few, fat workgroups: the matched counter gets one atomic per workgroup (a hot counter
+    // takes only ~90 updates/us)
+    uint32_t acc = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n_vec; i += 4 * stride) {
+        uint4 b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = bitmap[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (b[u].x | b[u].y | b[u].z | b[u].w) {
+                acc += (uint32_t)(__popc(b[u].x) + __popc(b[u].y) + __popc(b[u].z) + __popc(b[u].w));
+                bitmap[i + u * stride] = make_uint4(0, 0, 0, 0);
+            }
+    }
+    for (; i < n_vec; i += stride) {
+        const uint4 b = bitmap[i];
+        if (b.x | b.y | b.z | b.w) {
+            acc += (uint32_t)(__popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w));
+            bitmap[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    acc = wave_sum_to_lane63(acc);
+    __shared__ uint32_t part[4];
+    if (lane_id() == 63) part[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(&counters[AGH_C_MATCHED], t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// bench support: read probe and synthetic corpus
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_read_probe(const uint4 *__restrict__ text,
+                                                    uint64_t n_strips,
+                                                    uint32_t *__restrict__ counters)
+{
+    const int lane = lane_id();
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x / WAVE);
+    const uint64_t s0 = w * AGH_WAVE_STRIPS;
+    if (s0 >= n_strips) return;
+    uint64_t s1 = s0 + AGH_WAVE_STRIPS;
+    if (s1 > n_strips) s1 = n_strips;
+    uint32_t acc = 0;
+    uint64_t s = s0;
+    for (; s + 4 <= s1; s += 4) {
+        const uint4 *p = text + s * 64 + lane;
+        uint4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];
+        acc ^= v0.x ^ v0.y ^ v0.z ^ v0.w ^ v1.x ^ v1.y ^ v1.z ^ v1.w;
+        acc ^= v2.x ^ v2.y ^ v2.z ^ v2.w ^ v3.x ^ v3.y ^ v3.z ^ v3.w;
+    }
+    for (; s < s1; ++s) {
+        uint4 v0 = text[s * 64 + lane];
+        acc ^= v0.x ^ v0.y ^ v0.z ^ v0.w;
+    }
+    if (acc == 0x9e3779b9u) counters[AGH_C_CHECK] = acc;   // keeps the loads alive
+}
+
+struct agh_corpus_params {
+    uint64_t seed;
+    uint32_t n_variants, plant_period, upper_permille;
+    uint32_t vlen[8];
+    uint8_t variants[8][80];
+};
+
+__device__ __forceinline__ uint64_t cg_next(uint64_t &s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// One thread per 4096-byte page; bytes are produced strictly in order and stored 8 at a time.
+// Twin of oracle/corpus_gen.c:cg_page (tests assert byte equality).
+__global__ __launch_bounds__(64) void k_corpus(uint64_t *__restrict__ out, uint64_t first_page,
+                                               uint64_t n_pages, agh_corpus_params p,
+                                               unsigned long long *__restrict__ planted)
+{
+    const uint64_t pg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pg >= n_pages) return;
+    const char alpha[42] = "abcdefghijklmnopqrstuvwxyz      etaoinshr";
+    const uint64_t page = first_page + pg;
+    uint64_t s = p.seed ^ (page * 0x9E3779B97F4A7C15ull) ^ 0xA5A5A5A55A5A5A5Aull;
+    uint64_t *dst = out + pg * 512;
+    uint32_t pos = 0;
+    uint64_t acc = 0;
+    bool prev_planted = true;
+    (void)cg_next(s);
+    while (pos < 4096u) {
+        uint64_t r = cg_next(s);
+        uint32_t len = 40u + (uint32_t)((r & 0xffff) % 81u);
+        uint32_t rem = 4096u - pos;
+        uint32_t draw = (uint32_t)((r >> 16) & 0xffffff);
+        uint32_t v = p.n_variants ? (uint32_t)((r >> 40) % p.n_variants) : 0u;
+        if (rem < len + 1u + 41u) len = rem - 1u;
+        bool plant = !prev_planted && p.n_variants && p.plant_period &&
+                     (draw % p.plant_period == 0) && len >= 5u + p.vlen[v] + 5u;
+        uint64_t x = 0, u = 0;
+        for (uint32_t i = 0; i <= len; ++i) {
+            uint32_t c;
+            if (i == len) {
+                c = '\n';
+            } else {
+                if ((i & 7u) == 0) { x = cg_next(s); u = cg_next(s); }
+                c = (uint8_t)alpha[(((uint32_t)(x >> (8 * (i & 7u))) & 0xffu) * 41u) >> 8];
+                if (plant && i >= 5u && i < 5u + p.vlen[v]) c = p.variants[v][i - 5u];
+                if (p.upper_permille && c >= 'a' && c <= 'z' &&
+                    ((((uint32_t)(u >> (8 * (i & 7u))) & 0xffu) * 1000u) >> 8) < p.upper_permille)
+                    c -= 32u;
+            }
+            acc |= (uint64_t)c << (8 * (pos & 7u));
+            if ((pos & 7u) == 7u) { dst[pos >> 3] = acc; acc = 0; }
+            ++pos;
+        }
+        if (plant && planted) atomicAdd(&planted[v], 1ull);
+        prev_planted = plant;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------------------
+// Launch geometry chosen from within-process A/B rounds on MI355X (scripts/sweep_variants.py,
+// DESIGN.md): 256-thread workgroups, next supertile prefetched.
+#define AGH_SWEEP_BLOCK 256
+
+template <int H, int MODE>
+static void launch_sweep_hm(const agh_sweep_args &a, hipStream_t st)
+{
+    const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
+    const uint64_t n_waves = (n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+    if (a.ev_begin) (void)hipEventRecord(a.ev_begin, st);
+    if (n_waves) {
+        const uint32_t wpb = AGH_SWEEP_BLOCK / 64;
+        const uint32_t blocks = (uint32_t)((n_waves + wpb - 1) / wpb);
+        hipLaunchKernelGGL((k_sweep<H, MODE, AGH_SWEEP_BLOCK, true>), dim3(blocks),
+                           dim3(AGH_SWEEP_BLOCK), 0, st, (const uint4 *)a.text, n_full, a.q,
+                           a.ftab, a.strip_prefix, a.wave_totals, a.cand, a.wave_cand,
+                           a.counters);
+    }
+    if (a.ev_end) (void)hipEventRecord(a.ev_end, st);
+    if (a.n & (AGH_STRIP - 1))
+        hipLaunchKernelGGL((k_sweep_tail<H, MODE>), dim3(1), dim3(64), 0, st,
+                           (const uint4 *)a.text, a.n, a.q, a.ftab, a.strip_prefix,
+                           a.wave_totals, a.cand, a.wave_cand, a.counters);
+    const uint64_t n_strips = (a.n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
+    const uint32_t nw = (uint32_t)((n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS);
+    const uint32_t n_chunks = (nw + AGH_SCAN_CHUNK - 1) / AGH_SCAN_CHUNK;
+    hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, st, a.wave_totals,
+                       H > 0 ? (const uint32_t *)a.wave_cand : (const uint32_t *)nullptr, nw,
+                       a.chunk_totals);
+    hipLaunchKernelGGL(k_scan_fixup, dim3(n_chunks), dim3(256), 0, st, a.wave_totals, nw,
+                       (const uint32_t *)a.chunk_totals, n_chunks, (const uint8_t *)a.text, a.n,
+                       a.counters);
+}
+
+template <int H>
+static void launch_sweep_t(const agh_sweep_args &a, hipStream_t st)
+{
+    const int mode = (a.q.fold ? 1 : 0) | (a.q.fq == 4 ? 2 : 0);
+    switch (mode) {
+    case 0: launch_sweep_hm<H, 0>(a, st); break;
+    case 1: launch_sweep_hm<H, 1>(a, st); break;
+    case 2: launch_sweep_hm<H, 2>(a, st); break;
+    default: launch_sweep_hm<H, 3>(a, st); break;
+    }
+}
+
+void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st)
+{
+    switch (H) {
+    case 0: launch_sweep_hm<0, 0>(a, st); break;
+    case 4: launch_sweep_t<4>(a, st); break;
+    case 8: launch_sweep_t<8>(a, st); break;
+    default: launch_sweep_t<16>(a, st); break;
+    }
+}
+
+void agh_launch_bitmap_count(uint32_t *bitmap, uint32_t n_words, uint32_t *counters,
+                             hipStream_t st)
+{
+    const uint32_t n_vec = n_words / 4;          // the bitmap is allocated in 16-byte units
+    if (!n_vec) return;
+    uint32_t blocks = (n_vec + 256u * 8u - 1u) / (256u * 8u);
+    if (blocks > 256u) blocks = 256u;
+    hipLaunchKernelGGL(k_bitmap_count, dim3(blocks), dim3(256), 0, st, (uint4 *)bitmap, n_vec,
+                       counters);
+}
+
+void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st)
+{
+    const uint64_t n_strips = n >> AGH_STRIP_SHIFT;
+    const uint64_t n_waves = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+    if (!n_waves) return;
+    hipLaunchKernelGGL(k_read_probe, dim3((uint32_t)((n_waves + 3) / 4)), dim3(256), 0, st,
+                       (const uint4 *)text, n_strips, counters);
+}
+
+void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_t seed,
+                       const unsigned char *variants, const uint32_t *vlen,
+                       uint32_t n_variants, uint32_t plant_period, uint32_t upper_permille,
+                       unsigned long long *planted_dev, hipStream_t st)
+{
+    agh_corpus_params p;
+    p.seed = seed;
+    p.n_variants = n_variants;
+    p.plant_period = plant_period;
+    p.upper_permille = upper_permille;
+    for (uint32_t i = 0; i < 8; ++i) {
+        p.vlen[i] = i < n_variants ? vlen[i] : 0;
+        for (uint32_t j = 0; j < 80; ++j)
+            p.variants[i][j] = (i < n_variants && j < p.vlen[i]) ? variants[i * 80 + j] : 0;
+    }
+    if (!n_pages) return;
+    hipLaunchKernelGGL(k_corpus, dim3((uint32_t)((n_pages + 63) / 64)), dim3(64), 0, st,
+                       (uint64_t *)out, first_page, n_pages, p, planted_dev);
+}

@@ -71,7 +71,8 @@ typedef struct {
     uint32_t engine;        /* AGH_ENGINE_* */
     uint32_t truncated;     /* 1: more matches than the agh_match array could hold */
     double   device_ms;     /* GPU time of the whole scan (hipEvent), excluding staging */
-    double   sweep_ms;      /* of which: the streaming sweep kernel(s) that read every byte */
+    double   sweep_ms;      /* of which: the k_sweep kernel launches (the kernel that reads every
+                               byte), hipEvents recorded right around them on the scan stream */
 } agh_result;
 
 /* ---- query construction ------------------------------------------------------------- */
