@@ -1,0 +1,382 @@
+/*
+ * agrep_hip.c -- C host side of the MI355X agrep scanner: the command-line surface of the
+ * reference for the k-error hot path ( -# -c -l -i -d -B -y -n -h -s -e -k -V0 ), driving the
+ * HIP C-ABI of include/agrep_hip.h.  It mirrors, for literal patterns,
+ *
+ *   option parsing      agrep.c:2121-2739  (grouped flags, a digit run ends its group)
+ *   engine dispatch     agrep.c:3357-3361 / 3428-3432  -> agh_query_literal + agh_scan_fd
+ *   -c / -l / prefixes  agrep.c:3444-3558, asearch.c:130-161, agrep.c:3845-3875
+ *   -B best match       agrep.c:3582-3728
+ *   Grand Total, exit   agrep.c:3229-3231, main.c:78-96
+ *
+ * Everything outside the hot path (regular expressions, boolean patterns, character classes,
+ * -r, -f, -v, weighted costs ...) is rejected with exit status 2: this binary is the
+ * hot-path driver, not a re-implementation of agrep's control plane.  There is no CPU scan
+ * engine here; without a HIP device the library calls fail and so does this program.
+ */
+#include <errno.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "../../include/agrep_hip.h"
+
+#define MAX_FILES 4096
+
+static const char *Progname = "agrep-hip";
+
+static struct {
+    int D;                 /* -#  */
+    int COUNT;             /* -c  */
+    int FILENAMEONLY;      /* -l  */
+    int NOUPPER;           /* -i  */
+    int LINENUM;           /* -n  */
+    int NOFILENAME;        /* -h  */
+    int SILENT;            /* -s  */
+    int BESTMATCH;         /* -B  */
+    int NOPROMPT;          /* -y  */
+    int VERBOSE;           /* -V# (default 1: print the Grand Total line) */
+    int APPROX;            /* a -# was given */
+    unsigned char delim[AGH_MAX_DELIM + 1];
+    int dlen;
+    const char *pattern;
+} opt;
+
+static void die_usage(const char *msg)
+{
+    fprintf(stderr, "%s: %s\n", Progname, msg);
+    fprintf(stderr,
+            "usage: %s [-#cilnhsyB] [-V0] [-d delim] [-e pattern | pattern] [file ...]\n",
+            Progname);
+    exit(2);
+}
+
+/* checksg.c:45-102: any of these makes the pattern non-simple (regex / boolean / class ...).
+ * -k (agrep.c, "pattern is a constant") switches the test off. */
+static int pattern_is_literal(const char *p)
+{
+    return strpbrk(p, ";,.*-[]()<>|#{}~^$\\") == NULL;
+}
+
+/* agrep.c:2265-2316 + preproce.c:181-213: '^' and '$' in a delimiter mean newline,
+ * a backslash quotes the next byte. */
+static void set_delimiter(const char *arg)
+{
+    int n = 0;
+    size_t i, len = strlen(arg);
+    if (len == 0) die_usage("the -d option must have a delimiter argument");
+    for (i = 0; i < len; i++) {
+        unsigned char c = (unsigned char)arg[i];
+        if (c == '\\' && i + 1 < len) c = (unsigned char)arg[++i];
+        else if (c == '^' || c == '$') c = '\n';
+        if (n >= AGH_MAX_DELIM) {
+            fprintf(stderr, "%s: delimiter pattern too long (has > %d chars)\n", Progname,
+                    AGH_MAX_DELIM);
+            exit(2);
+        }
+        opt.delim[n++] = c;
+    }
+    opt.dlen = n;
+}
+
+static int parse_options(int argc, char **argv, char **files)
+{
+    int nfiles = 0, i, literal_only = 0;
+    opt.VERBOSE = 1;
+    opt.delim[0] = '\n';
+    opt.dlen = 1;
+    for (i = 1; i < argc; i++) {
+        char *a = argv[i];
+        if (a[0] == '-' && a[1] != '\0' && (opt.pattern == NULL || 1)) {
+            char *p = a + 1;
+            if (opt.pattern != NULL) {           /* after the pattern everything is a file */
+                files[nfiles++] = a;
+                continue;
+            }
+            while (*p) {                        /* grouped single-letter options */
+                char c = *p++;
+                if (c >= '0' && c <= '9') {     /* agrep.c:2716-2728: a number ends the group */
+                    opt.D = atoi(p - 1);
+                    opt.APPROX = 1;
+                    if (opt.D > AGH_MAX_ERRORS) {
+                        fprintf(stderr, "%s: the maximum number of errors is %d\n", Progname,
+                                AGH_MAX_ERRORS);
+                        exit(2);
+                    }
+                    break;
+                }
+                switch (c) {
+                case 'c': opt.COUNT = 1; break;
+                case 'l': opt.FILENAMEONLY = 1; break;
+                case 'i': opt.NOUPPER = 1; break;
+                case 'n': opt.LINENUM = 1; break;
+                case 'h': opt.NOFILENAME = 1; break;
+                case 's': opt.SILENT = 1; break;
+                case 'y': opt.NOPROMPT = 1; break;
+                case 'B': opt.BESTMATCH = 1; break;
+                case 'k': literal_only = 1; break;
+                case 'V':
+                    opt.VERBOSE = (*p >= '0' && *p <= '9') ? atoi(p) : 1;
+                    while (*p >= '0' && *p <= '9') p++;
+                    break;
+                case 'd':
+                    if (*p) set_delimiter(p);
+                    else if (i + 1 < argc) set_delimiter(argv[++i]);
+                    else die_usage("the -d option must have a delimiter argument");
+                    p = (char *)"";
+                    break;
+                case 'e':
+                    if (i + 1 >= argc) die_usage("the -e option must have a pattern argument");
+                    opt.pattern = argv[++i];
+                    p = (char *)"";
+                    break;
+                default:
+                    fprintf(stderr, "%s: option -%c is outside the GPU hot path of this build\n",
+                            Progname, c);
+                    exit(2);
+                }
+            }
+        } else if (opt.pattern == NULL) {
+            opt.pattern = a;
+        } else {
+            if (nfiles >= MAX_FILES) die_usage("too many files");
+            files[nfiles++] = a;
+        }
+    }
+    if (opt.pattern == NULL) die_usage("no pattern");
+    if (!literal_only && !pattern_is_literal(opt.pattern)) {
+        fprintf(stderr,
+                "%s: pattern '%s' uses regular-expression / boolean / class syntax, which is "
+                "outside the GPU hot path (use -k for a literal pattern)\n",
+                Progname, opt.pattern);
+        exit(2);
+    }
+    /* compat.c:26-29: -B is ignored together with -c, -l or -# */
+    if (opt.BESTMATCH && (opt.COUNT || opt.FILENAMEONLY || opt.APPROX)) opt.BESTMATCH = 0;
+    if (opt.COUNT && opt.FILENAMEONLY) opt.FILENAMEONLY = 0;     /* agrep.c:2896-2899 */
+    return nfiles;
+}
+
+struct filehit {
+    agh_result res;
+    agh_match *matches;
+    unsigned char *text;   /* only kept when records must be printed */
+    size_t len;
+};
+
+static unsigned char *slurp(int fd, size_t *len)
+{
+    size_t cap = 1 << 20, used = 0;
+    unsigned char *buf = (unsigned char *)malloc(cap);
+    if (!buf) return NULL;
+    for (;;) {
+        ssize_t r;
+        if (used == cap) {
+            unsigned char *nb = (unsigned char *)realloc(buf, cap * 2);
+            if (!nb) { free(buf); return NULL; }
+            buf = nb;
+            cap *= 2;
+        }
+        r = read(fd, buf + used, cap - used);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            free(buf);
+            return NULL;
+        }
+        if (r == 0) break;
+        used += (size_t)r;
+    }
+    *len = used;
+    return buf;
+}
+
+/* One file through the device engines; count-only unless records have to be printed. */
+static int scan_one(agh_query *q, int fd, int want_records, struct filehit *out)
+{
+    memset(out, 0, sizeof(*out));
+    if (!want_records) {
+        unsigned flags = opt.FILENAMEONLY ? AGH_FILENAMEONLY : AGH_COUNT;
+        return agh_scan_fd(q, fd, flags, &out->res, NULL, 0);
+    }
+    out->text = slurp(fd, &out->len);
+    if (!out->text) return -1;
+    {
+        size_t cap = 1024;
+        for (;;) {
+            out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
+            if (!out->matches) return -1;
+            if (agh_scan_buffer(q, out->text, out->len, 0, &out->res, out->matches, cap)) return -1;
+            if (!out->res.truncated) break;
+            free(out->matches);
+            cap = (size_t)out->res.n_matched + 16;
+        }
+    }
+    return 0;
+}
+
+/* agrep.c:3805-3956 output(): [file: ][N: ]record\n */
+static void print_records(const struct filehit *h, const char *name, int with_name)
+{
+    uint64_t i;
+    for (i = 0; i < h->res.n_stored; i++) {
+        const agh_match *m = &h->matches[i];
+        if (with_name) printf("%s: ", name);
+        if (opt.LINENUM) printf("%llu: ", (unsigned long long)(m->index + 1));
+        fwrite(h->text + m->start, 1, (size_t)(m->end - m->start), stdout);
+        fputc('\n', stdout);
+    }
+}
+
+static long run_pass(agh_query *q, char **files, int nfiles, int print, int count_only,
+                     long *files_matched)
+{
+    long total = 0;
+    int i;
+    for (i = 0; i < (nfiles ? nfiles : 1); i++) {
+        const char *name = nfiles ? files[i] : "stdin";
+        int fd = nfiles ? open(files[i], O_RDONLY) : 0;
+        struct filehit h;
+        int want_records = print && !count_only && !opt.COUNT && !opt.FILENAMEONLY && !opt.SILENT;
+        if (fd < 0) {                           /* agrep.c:2952-2958 */
+            fprintf(stderr, "%s: '%s' no such file or directory\n", Progname, name);
+            continue;
+        }
+        if (scan_one(q, fd, want_records, &h)) {
+            fprintf(stderr, "%s: %s: %s\n", Progname, name, agh_last_error());
+            exit(2);
+        }
+        if (nfiles) close(fd);
+        if (print && !opt.SILENT) {
+            if (opt.COUNT) {                    /* agrep.c:3501-3556 */
+                if (nfiles > 1 && !opt.NOFILENAME)
+                    printf("%s: %llu\n", name, (unsigned long long)h.res.n_matched);
+                else
+                    printf("%llu\n", (unsigned long long)h.res.n_matched);
+            } else if (opt.FILENAMEONLY) {      /* asearch.c:130-161 */
+                if (h.res.n_matched) printf("%s\n", name);
+            } else if (want_records) {
+                print_records(&h, name, nfiles > 1 && !opt.NOFILENAME);
+            }
+        }
+        if (h.res.n_matched) (*files_matched)++;
+        /* -l counts files, everything else counts records (sgrep.c:1188, Appendix A) */
+        total += opt.FILENAMEONLY ? (h.res.n_matched ? 1 : 0) : (long)h.res.n_matched;
+        free(h.matches);
+        free(h.text);
+    }
+    return total;
+}
+
+int main(int argc, char **argv)
+{
+    static char *files[MAX_FILES];
+    int nfiles, m;
+    long total = 0, files_matched = 0;
+    agh_query *q;
+
+    nfiles = parse_options(argc, argv, files);
+    m = (int)strlen(opt.pattern);
+    if (opt.D >= m) {                           /* checksg.c:34-41 */
+        fprintf(stderr, "%s: size of pattern must be greater than number of errors\n", Progname);
+        exit(2);
+    }
+    if (agh_device_count() <= 0) {
+        fprintf(stderr, "%s: no usable HIP device (this build has no CPU scan engine)\n", Progname);
+        exit(2);
+    }
+
+    if (!opt.BESTMATCH) {
+        q = agh_query_literal((const unsigned char *)opt.pattern, m, opt.D, opt.NOUPPER,
+                              opt.delim, opt.dlen);
+        if (!q) { fprintf(stderr, "%s: %s\n", Progname, agh_last_error()); exit(2); }
+        total = run_pass(q, files, nfiles, 1, 0, &files_matched);
+        agh_query_free(q);
+    } else {
+        /* agrep.c:3582-3728: exact first; then the smallest D in 1..min(M-1, 8) with a match,
+         * where M = m + 2 counts the delimiter slots (maskgen.c), so D may reach m: at that
+         * point every non-empty record is within D errors and the whole file is printed. */
+        int D = 0, maxD = m + 1 < AGH_MAX_ERRORS ? m + 1 : AGH_MAX_ERRORS;
+        long found = 0;
+        if (nfiles == 0) die_usage("-B needs file arguments (stdin cannot be re-read)");
+        q = NULL;
+        for (D = 0; D <= maxD && D < m; D++) {
+            long fm = 0;
+            q = agh_query_literal((const unsigned char *)opt.pattern, m, D, opt.NOUPPER,
+                                  opt.delim, opt.dlen);
+            if (!q) { fprintf(stderr, "%s: %s\n", Progname, agh_last_error()); exit(2); }
+            found = run_pass(q, files, nfiles, 0, 1, &fm);
+            if (found > 0) break;
+            agh_query_free(q);
+            q = NULL;
+        }
+        if (found == 0 && D <= maxD) {
+            /* D == m: count the non-empty records with a plain delimiter census */
+            int i;
+            for (i = 0; i < nfiles; i++) {
+                size_t len = 0, j, start = 0;
+                int fd = open(files[i], O_RDONLY);
+                unsigned char *t;
+                if (fd < 0) continue;
+                t = slurp(fd, &len);
+                close(fd);
+                if (!t) continue;
+                for (j = 0; j <= len; j++)
+                    if (j == len || t[j] == opt.delim[0]) {
+                        if (j > start) found++;
+                        start = j + 1;
+                    }
+                free(t);
+            }
+        }
+        if (found > 0) {
+            int go = 1;
+            if (D > 0) {
+                char c[8] = "y";
+                if (found == 1) fprintf(stderr, "%s: 1 word matches within ", Progname);
+                else fprintf(stderr, "%s: %ld words match within ", Progname, found);
+                if (D == 1) fprintf(stderr, "1 error");
+                else fprintf(stderr, "%d errors", D);
+                fflush(stderr);
+                if (opt.NOPROMPT) fprintf(stderr, "\n");
+                else {
+                    fprintf(stderr, found == 1 ? "; search for it? (y/n)" : "; search for them? (y/n)");
+                    if (fgets(c, 4, stdin) == NULL || c[0] != 'y') go = 0;
+                }
+            }
+            if (go && q) total = run_pass(q, files, nfiles, 1, 0, &files_matched);
+            else if (go) {                      /* D == m: every non-empty record */
+                int i;
+                for (i = 0; i < nfiles; i++) {
+                    size_t len = 0, j, start = 0;
+                    int fd = open(files[i], O_RDONLY);
+                    unsigned char *t;
+                    if (fd < 0) continue;
+                    t = slurp(fd, &len);
+                    close(fd);
+                    if (!t) continue;
+                    for (j = 0; j <= len; j++)
+                        if (j == len || t[j] == opt.delim[0]) {
+                            if (j > start) {
+                                if (!opt.SILENT) {
+                                    if (nfiles > 1 && !opt.NOFILENAME) printf("%s: ", files[i]);
+                                    fwrite(t + start, 1, j - start, stdout);
+                                    fputc('\n', stdout);
+                                }
+                                total++;
+                            }
+                            start = j + 1;
+                        }
+                    free(t);
+                }
+            }
+            errno = D;
+        }
+        if (q) agh_query_free(q);
+    }
+
+    if (opt.VERBOSE > 0 && !opt.SILENT)          /* agrep.c:3229-3231 */
+        printf("Grand Total: %ld match(es) found.\n", total);
+    return (int)total;                          /* main.c:79,96: exit status = matches (mod 256) */
+}

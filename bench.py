@@ -86,6 +86,7 @@ def main():
     import torch
     import torch.distributed as dist
     import agrep_amd as A
+    from agrep_amd import shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -100,18 +101,19 @@ def main():
     n_pages = int(args.gib * (1 << 30)) // 4096
     n = n_pages * 4096
     text = torch.empty(n, dtype=torch.uint8, device="cuda")
-    planted = A.corpus_fill_device(text.data_ptr(), n_pages, first_page=rank * n_pages, seed=SEED,
+    first_page, my_pages = shard.shard_pages(n_pages * world, world, rank)
+    assert my_pages == n_pages
+    planted = A.corpus_fill_device(text.data_ptr(), n_pages, first_page=first_page, seed=SEED,
                                    variants=VARIANTS, plant_period=500)
     torch.cuda.synchronize()
     q = A.Query(PATTERN, args.k)
     info = q.info()
-    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    agg = [0, 0]
 
     def step():
         res = q.scan_device(text.data_ptr(), n, flags=A.COUNT)
-        if world > 1:
-            total.fill_(int(res.n_matched))
-            dist.all_reduce(total, op=dist.ReduceOp.SUM)     # RCCL: the -c aggregate
+        if world > 1:                                        # RCCL: the -c aggregate
+            agg[0], agg[1] = shard.reduce_counts(res.n_matched, res.n_records, device="cuda")
         return res
 
     def fence():
@@ -136,7 +138,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        matched_all = int(total.item())
+        matched_all = int(agg[0])
     else:
         matched_all = int(res.n_matched)
 

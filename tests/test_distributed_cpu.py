@@ -1,0 +1,97 @@
+"""N > 1 path on CPU: two gloo ranks shard a corpus, scan their shards (the oracle stands in
+for the device scan here -- no GPU in this test) and reduce the counts; the result must equal
+the single-process answer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import _oracle as O  # noqa: E402
+from agrep_amd import shard  # noqa: E402
+
+
+def _worker(rank, world, port, total_pages, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # (1) page-sharded synthetic corpus, as bench.py does it
+        first, count = shard.shard_pages(total_pages, world, rank)
+        text, _ = O.corpus(count, first_page=first, seed=12345, variants=O.VARIANTS_C2,
+                           plant_period=17)
+        n, recs = O.asearch(O.PATTERN_C2, 2, text)[0], int((text == 10).sum())
+        tot, trec = shard.reduce_counts(n, recs)
+        # (2) a ragged host buffer cut at record boundaries
+        rng = np.random.default_rng(5)
+        buf, _ = O.corpus(9, seed=77, variants=O.VARIANTS_C2, plant_period=3)
+        buf = buf[: buf.size - int(rng.integers(1, 300))].copy()      # no trailing newline
+        cuts = shard.record_cuts(buf, world)
+        piece = buf[cuts[rank]:cuts[rank + 1]]
+        tot2, _ = shard.reduce_counts(O.asearch(O.PATTERN_C2, 2, piece)[0])
+        hits = shard.reduce_file_hits([rank == 0, False, rank == 1])
+        q.put((rank, tot, trec, tot2, hits, cuts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_reduce():
+    world, total_pages = 2, 23
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total_pages, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole, _ = O.corpus(total_pages, seed=12345, variants=O.VARIANTS_C2, plant_period=17)
+    want = O.asearch(O.PATTERN_C2, 2, whole)[0]
+    buf, _ = O.corpus(9, seed=77, variants=O.VARIANTS_C2, plant_period=3)
+    rng = np.random.default_rng(5)
+    buf = buf[: buf.size - int(rng.integers(1, 300))].copy()
+    want2 = O.asearch(O.PATTERN_C2, 2, buf)[0]
+    assert want > 0 and want2 > 0
+    for rank, tot, trec, tot2, hits, cuts in outs:
+        assert tot == want
+        assert trec == int((whole == 10).sum())
+        assert tot2 == want2
+        assert hits == [True, False, True]
+        assert cuts[0] == 0 and cuts[-1] == buf.size
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_record_cuts_partition_records(world):
+    rng = np.random.default_rng(world)
+    for trial in range(20):
+        n = int(rng.integers(0, 5000))
+        a = rng.integers(97, 100, size=n).astype(np.uint8)
+        a[rng.random(n) < 0.03] = 10
+        cuts = shard.record_cuts(a, world)
+        assert cuts[0] == 0 and cuts[-1] == n and all(x <= y for x, y in zip(cuts, cuts[1:]))
+        for c in cuts[1:-1]:
+            assert c == n or c == 0 or a[c - 1] == 10
+        pieces = [a[cuts[r]:cuts[r + 1]].tobytes() for r in range(world)]
+        assert b"".join(pieces) == a.tobytes()
+        # every record is whole inside one piece: per-piece counts add up
+        pat = b"abca"
+        total = sum(O.dp_count(pat, 1, p)[0] for p in pieces)
+        assert total == O.dp_count(pat, 1, a.tobytes())[0]
+
+
+def test_shard_pages_cover_everything():
+    for total in (0, 1, 7, 64, 1048576):
+        for world in (1, 2, 3, 8):
+            got = [shard.shard_pages(total, world, r) for r in range(world)]
+            assert got[0][0] == 0
+            assert sum(c for _, c in got) == total
+            for (f0, c0), (f1, _) in zip(got, got[1:]):
+                assert f0 + c0 == f1

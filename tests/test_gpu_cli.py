@@ -1,0 +1,101 @@
+"""The C host CLI (agrep_amd/agrep-hip) against the reference CLI (oracle/_ref/agrep) on the
+same files: stdout, stderr shape and exit status for the hot-path option surface
+(-# -c -l -i -n -h -s -d -B -y -V0), SURVEY.md Appendix A."""
+import os
+import subprocess
+
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "agrep_amd", "agrep-hip")
+REF = os.path.join(O.REF_DIR, "agrep")
+
+
+def _run(exe, args, stdin=None):
+    p = subprocess.run([exe] + args, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return p.returncode, p.stdout, p.stderr
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    if not os.path.exists(CLI):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "agrep_amd", "host")])
+    d = tmp_path_factory.mktemp("cli")
+    out = []
+    for i, (pages, period) in enumerate(((24, 30), (8, 11), (4, 1000000))):
+        text, _ = O.corpus(pages, seed=100 + i, variants=O.VARIANTS_C2, plant_period=period)
+        p = d / ("f%d.txt" % i)
+        p.write_bytes(text.tobytes())
+        out.append(str(p))
+    return out
+
+
+needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/agrep not built")
+
+
+@needs_ref
+@pytest.mark.parametrize("args", [
+    ["-V0", "-2", "-c"], ["-2", "-c"], ["-V0", "-2"], ["-2"], ["-V0", "-i", "-2"],
+    ["-V0", "-1", "-l"], ["-2", "-l"], ["-V0", "-2", "-h"], ["-V0", "-i", "-n", "-2"],
+    ["-V0", "-c"], ["-V0", "-s", "-2"], ["-V0", "-3", "-ci"], ["-V0", "-ic", "-2"],
+])
+def test_cli_matches_reference(files, args):
+    for fl in (files[:1], files):
+        a = args + ["approximatematch"] + fl
+        rc_r, out_r, err_r = _run(REF, a)
+        rc_g, out_g, err_g = _run(CLI, a)
+        assert out_g == out_r, (a, out_g[:300], out_r[:300])
+        assert rc_g == rc_r, a
+        assert err_g == b""
+
+
+@needs_ref
+def test_cli_stdin_and_missing_file(files):
+    data = open(files[1], "rb").read()
+    rc_r, out_r, _ = _run(REF, ["-V0", "-2", "-c", "approximatematch", "/dev/stdin"], stdin=data)
+    rc_g, out_g, _ = _run(CLI, ["-V0", "-2", "-c", "approximatematch", "/dev/stdin"], stdin=data)
+    assert (rc_g, out_g) == (rc_r, out_r)
+    rc_g, out_g, _ = _run(CLI, ["-V0", "-2", "-c", "approximatematch"], stdin=data)   # plain stdin
+    assert (rc_g, out_g) == (rc_r, out_r)
+    a = ["-V0", "-2", "-c", "approximatematch", files[0], "/nonexistent/x", files[1]]
+    rc_r, out_r, err_r = _run(REF, a)
+    rc_g, out_g, err_g = _run(CLI, a)
+    assert out_g == out_r and rc_g == rc_r
+    assert b"no such file or directory" in err_g and b"no such file or directory" in err_r
+
+
+@needs_ref
+def test_cli_best_match(files, tmp_path):
+    p = tmp_path / "words.txt"
+    p.write_bytes(b"alpha\nhomogeneous\nbeta\nhomogenous\ngamma\n")
+    for pat in ("homogenoss", "homogeneous", "zzzzqqqq"):
+        a = ["-V0", "-B", "-y", pat, str(p)]
+        rc_r, out_r, err_r = _run(REF, a)
+        rc_g, out_g, err_g = _run(CLI, a)
+        assert out_g == out_r, (pat, out_g, out_r)
+        # stderr: "<prog>: N word(s) match(es) within D error(s)" -- program names differ
+        assert err_g.split(b":", 1)[-1] == err_r.split(b":", 1)[-1], (err_g, err_r)
+        assert rc_g == rc_r
+
+
+@needs_ref
+def test_cli_single_byte_delimiter_counts(tmp_path):
+    p = tmp_path / "semi.txt"
+    p.write_bytes(b"one approximatematch;two;three aproximatematch;four apprximatemtch;five")
+    for k in (0, 1, 2):
+        a = ["-V0", "-i", "-%d" % k, "-c", "-d", ";", "approximatematch", str(p)] if k else \
+            ["-V0", "-i", "-c", "-d", ";", "approximatematch", str(p)]
+        rc_r, out_r, _ = _run(REF, a)
+        rc_g, out_g, _ = _run(CLI, a)
+        assert (rc_g, out_g) == (rc_r, out_r), (k, out_g, out_r)
+
+
+def test_cli_rejects_what_is_outside_the_hot_path(files):
+    for a in (["-2", "a|b", files[0]], ["-2", "[ab]cdefgh", files[0]], ["-v", "x", files[0]],
+              ["-9", "approximatematch", files[0]], ["-2", "ab", files[0]]):
+        rc, out, err = _run(CLI, a)
+        assert rc == 2 and err
