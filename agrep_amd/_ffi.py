@@ -9,6 +9,7 @@ COUNT = 0x01
 FILENAMEONLY = 0x02
 FORCE_FULLSCAN = 0x10
 FORCE_FILTER = 0x20
+FORCE_NUMBERED = 0x40
 ENGINE_FULLSCAN = 1
 ENGINE_FILTER = 2
 
@@ -78,6 +79,8 @@ def lib():
     L.agh_corpus_fill_device.restype = C.c_int
     L.agh_probe_read_ms.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_double)]
     L.agh_probe_read_ms.restype = C.c_int
+    L.agh_probe_variant_ms.argtypes = [vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_double)]
+    L.agh_probe_variant_ms.restype = C.c_int
     L.agh_last_error.restype = C.c_char_p
     L.agh_version.restype = C.c_char_p
     _LIB = L
@@ -194,4 +197,10 @@ def corpus_fill_device(dev_ptr, n_pages, first_page=0, seed=12345, variants=(), 
 def probe_read_ms(dev_ptr, n, stream=None):
     ms = C.c_double()
     _check(lib().agh_probe_read_ms(dev_ptr, n, stream, C.byref(ms)))
+    return ms.value
+
+
+def probe_variant_ms(dev_ptr, n, exp, stream=None):
+    ms = C.c_double()
+    _check(lib().agh_probe_variant_ms(dev_ptr, n, stream, exp, C.byref(ms)))
     return ms.value

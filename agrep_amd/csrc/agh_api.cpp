@@ -90,12 +90,15 @@ struct agh_query {
     void *d_mask = nullptr;             // 256 x uint32_t or uint64_t
     uint8_t *d_ftab = nullptr;          // AGH_FT_SIZE bytes
     // per-query workspace (grown lazily, reused across scans)
-    dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, staging, match_pos, match_rec;
+    dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, hashset, staging, match_pos,
+        match_rec;
     uint32_t *d_counters = nullptr;
     uint32_t *d_chunk_totals = nullptr; // scratch of the prefix scan
     uint32_t *h_counters = nullptr;     // pinned
     uint64_t bitmap_bits_hint = 0;      // records seen by the previous scan (+25 %)
     bool bitmap_dirty = false;          // a scan was queued but its count-and-clear did not finish
+    uint64_t hashset_slots_hint = 0;    // lean scans: slots wanted by the previous scan
+    bool hashset_dirty = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };
 
@@ -302,6 +305,7 @@ extern "C" void agh_query_free(agh_query *q)
     q->cand.release();
     q->wave_cand.release();
     q->bitmap.release();
+    q->hashset.release();
     q->staging.release();
     q->match_pos.release();
     q->match_rec.release();
@@ -360,6 +364,79 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     dq.head_byte = head_byte;
     dq.tail_virtual = tail_virtual;
 
+    // ---- lean pipeline: count-only scans (-c, -l) of a filterable query -------------------
+    // No delimiter census, no record numbers: the verifier identifies a matched record by the
+    // offset of its first byte and de-duplicates through a hash set; the count is the number
+    // of occupied slots.  Gives up (-> numbered pipeline below) when a record start lies more
+    // than AGH_LEAN_BACK_CAP bytes in front of a match, the set fills up, or slices overflow.
+    const bool lean_ok = want_filter && !d_match_pos && (flags & (AGH_COUNT | AGH_FILENAMEONLY)) &&
+                         !(flags & AGH_FORCE_NUMBERED);
+    if (lean_ok) {
+        uint64_t slots = 1u << 20;
+        while (slots < q->hashset_slots_hint) slots <<= 1;
+        {
+            const void *before = q->hashset.p;
+            if (q->hashset.ensure(slots * sizeof(uint64_t))) return -1;
+            if (q->hashset.p != before || q->hashset_dirty)
+                HIP_TRY(hipMemsetAsync(q->hashset.p, 0, q->hashset.cap, st));
+            q->hashset_dirty = true;
+        }
+        dq.tail_virtual = tail_virtual;
+        HIP_TRY(hipEventRecord(q->ev0, st));
+        HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+        agh_sweep_args sa;
+        sa.text = d_text;
+        sa.n = n;
+        sa.q = dq;
+        sa.ftab = q->d_ftab;
+        sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
+        sa.wave_totals = (uint32_t *)q->wave_totals.p;
+        sa.cand = (uint64_t *)q->cand.p;
+        sa.wave_cand = (uint32_t *)q->wave_cand.p;
+        sa.counters = q->d_counters;
+        sa.chunk_totals = q->d_chunk_totals;
+        sa.lean = 1;
+        sa.ev_begin = q->ev2;
+        sa.ev_end = q->ev3;
+        agh_launch_sweep(sa, q->fh, st);
+        agh_scan_args va;
+        memset(&va, 0, sizeof(va));
+        va.text = d_text;
+        va.n = n;
+        va.q = dq;
+        va.mask = q->d_mask;
+        va.wide = q->wide;
+        va.cand = (const uint64_t *)q->cand.p;
+        va.wave_cand = (const uint32_t *)q->wave_cand.p;
+        va.nw = (uint32_t)nw;
+        va.wave_prefix = (const uint32_t *)q->wave_totals.p;
+        va.mk.counters = q->d_counters;
+        va.mk.hashset = (uint64_t *)q->hashset.p;
+        va.mk.hashset_mask = (uint32_t)(slots - 1);
+        agh_launch_verify_lean(va, st);
+        agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
+                                 (const uint32_t *)q->wave_cand.p, (uint32_t)nw, q->d_counters, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(q->ev1, st));
+        HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        q->hashset_dirty = false;
+        const bool gave_up = q->h_counters[AGH_C_LEAN_FALLBACK] || q->h_counters[AGH_C_OVERFLOW];
+        if (!gave_up) {
+            HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
+            HIP_TRY(hipEventElapsedTime(&out->sweep_ms, q->ev2, q->ev3));
+            out->matched = q->h_counters[AGH_C_MATCHED];
+            out->candidates = q->h_counters[AGH_C_CAND];
+            out->records = 0;                   // not computed by a lean scan
+            out->engine = AGH_ENGINE_FILTER;
+            q->hashset_slots_hint = 4ull * out->matched;
+            return 0;
+        }
+        q->hashset_slots_hint = 8ull * (q->h_counters[AGH_C_MATCHED] + 1024);
+        // fall through: the numbered pipeline is exact for every input
+    }
+
     // Optimistic single-sync pipeline: the record bitmap is sized from a hint (the previous
     // scan of this query, or one record per 32 bytes) and everything -- census/filter sweep,
     // prefix scan, verify or full scan, population count -- is queued back to back.  The host
@@ -404,6 +481,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.wave_cand = (uint32_t *)q->wave_cand.p;
             sa.counters = q->d_counters;
             sa.chunk_totals = q->d_chunk_totals;
+            sa.lean = 0;
             sa.ev_begin = q->ev2;
             sa.ev_end = q->ev3;
             agh_launch_sweep(sa, use_filter ? q->fh : 0, st);
@@ -427,6 +505,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.match_pos = d_match_pos;
         va.mk.match_rec = d_match_rec;
         va.mk.match_cap = match_cap;
+        va.mk.hashset = nullptr;
+        va.mk.hashset_mask = 0;
         if (use_filter) agh_launch_verify(va, st);
         else agh_launch_fullscan(va, st);
         agh_launch_bitmap_count((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), q->d_counters, st);
@@ -634,7 +714,17 @@ extern "C" int agh_corpus_fill_device(void *dev_out, uint64_t first_page, uint64
     return 0;
 }
 
+// Diagnostics: time one structural variant of the sweep (agh_exp.hip); exp < 0 = read probe.
+extern "C" int agh_probe_variant_ms(const void *dev_text, size_t len, void *stream, int exp,
+                                    double *ms);
+
 extern "C" int agh_probe_read_ms(const void *dev_text, size_t len, void *stream, double *ms)
+{
+    return agh_probe_variant_ms(dev_text, len, stream, -1, ms);
+}
+
+extern "C" int agh_probe_variant_ms(const void *dev_text, size_t len, void *stream, int exp,
+                                    double *ms)
 {
     hipStream_t st = (hipStream_t)stream;
     uint32_t *d_c = nullptr;
@@ -644,7 +734,8 @@ extern "C" int agh_probe_read_ms(const void *dev_text, size_t len, void *stream,
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     HIP_TRY(hipEventRecord(a, st));
-    agh_launch_read_probe(dev_text, len, d_c, st);
+    if (exp < 0) agh_launch_read_probe(dev_text, len, d_c, st);
+    else agh_launch_exp(exp, dev_text, len, d_c, st);
     HIP_TRY(hipEventRecord(b, st));
     HIP_TRY(hipStreamSynchronize(st));
     float f = 0;

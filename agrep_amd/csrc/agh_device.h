@@ -13,6 +13,9 @@
 // Candidate slots owned by one sweep wave (one per 64 text bytes; more means the filter is
 // not selective on this text and the scan falls back to the full automaton).
 #define AGH_SLICE_CAP (AGH_WAVE_STRIPS * 16u)
+// Lean scans: how far back the verifier looks for the start of a matched record before the
+// scan falls back to the numbered (census) mode.
+#define AGH_LEAN_BACK_CAP (64u * 1024u)
 // q-gram filter table: one byte per hash bucket, resident in LDS (32 KiB / workgroup).
 #define AGH_FT_BITS 15
 #define AGH_FT_SIZE (1u << AGH_FT_BITS)
@@ -30,7 +33,8 @@ enum agh_counter {
     AGH_C_LASTBYTE = 5,  // text[n-1]
     AGH_C_CHECK = 6,     // read-probe checksum sink
     AGH_C_BM_OVERFLOW = 7, // a record number did not fit the record bitmap
-    AGH_C_COUNT = 8
+    AGH_C_LEAN_FALLBACK = 8, // lean scan gave up (record start too far back / hash set full)
+    AGH_C_COUNT = 12
 };
 
 struct agh_dev_query {

@@ -13,6 +13,8 @@ struct agh_marks {
     uint64_t *match_pos;     // optional: one byte offset per newly matched record
     uint32_t *match_rec;     // optional: its record number
     uint32_t match_cap;
+    uint64_t *hashset;       // lean scans: open-addressing set of (record start + 1)
+    uint32_t hashset_mask;   // slots - 1 (power of two)
 };
 
 struct agh_sweep_args {
@@ -26,6 +28,7 @@ struct agh_sweep_args {
     uint32_t *wave_cand;     // nw candidate counts
     uint32_t *chunk_totals;  // 2 * 64 scratch words of the prefix scan
     uint32_t *counters;
+    int lean;                // 1: no delimiter census (count-only scans)
     hipEvent_t ev_begin;     // optional: recorded right before / after the k_sweep launch
     hipEvent_t ev_end;
 };
@@ -50,8 +53,12 @@ void agh_launch_verify(const agh_scan_args &a, hipStream_t st);
 void agh_launch_fullscan(const agh_scan_args &a, hipStream_t st);
 void agh_launch_bitmap_count(uint32_t *bitmap, uint32_t n_words, uint32_t *counters,
                              hipStream_t st);
+void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *wave_cand,
+                              uint32_t nw, uint32_t *counters, hipStream_t st);
+void agh_launch_verify_lean(const agh_scan_args &a, hipStream_t st);
 void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
 void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_t seed,
                        const unsigned char *variants, const uint32_t *vlen,
                        uint32_t n_variants, uint32_t plant_period, uint32_t upper_permille,
                        unsigned long long *planted_dev, hipStream_t st);
+void agh_launch_exp(int exp, const void *text, uint64_t n, uint32_t *counters, hipStream_t st);

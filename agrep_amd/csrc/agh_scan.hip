@@ -25,6 +25,48 @@ __device__ __forceinline__ void mark_record(const agh_marks &mk, uint32_t r, uin
     }
 }
 
+// ---- lean scans: a record is identified by the offset of its first byte ---------------------
+__device__ __forceinline__ void lean_insert(const agh_marks &mk, uint64_t rec_start)
+{
+    const uint64_t key = rec_start + 1;         // 0 = empty slot
+    uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & mk.hashset_mask;
+    for (int probe = 0; probe < 64; ++probe) {
+        const uint64_t old = atomicCAS((unsigned long long *)&mk.hashset[slot], 0ull,
+                                       (unsigned long long)key);
+        if (old == 0 || old == key) return;
+        slot = (slot + 1) & mk.hashset_mask;
+    }
+    mk.counters[AGH_C_LEAN_FALLBACK] = 1u;      // table too full: the host re-runs numbered
+}
+
+// 1 + position of the last delimiter at a byte offset < pos (0 if there is none), looking
+// back at most AGH_LEAN_BACK_CAP bytes; ~0 and the fallback flag if it is further away.
+__device__ uint64_t lean_record_start(const uint8_t *__restrict__ text, uint64_t pos,
+                                      uint32_t delim, const agh_marks &mk)
+{
+    typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+    const uint32_t dd = delim * 0x01010101u;
+    const uint64_t stop = pos > AGH_LEAN_BACK_CAP ? pos - AGH_LEAN_BACK_CAP : 0;
+    while (pos >= stop + 16) {
+        const u32x4_a1 v = *reinterpret_cast<const u32x4_a1 *>(text + pos - 16);
+#pragma unroll
+        for (int d = 3; d >= 0; --d) {
+            const uint32_t x = v[d] ^ dd;
+            // bit 7 of every byte that equals the delimiter
+            const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+            if (z) return pos - 16 + 4u * d + (uint32_t)((31 - __clz((int)z)) >> 3) + 1;
+        }
+        pos -= 16;
+    }
+    while (pos > stop) {
+        if (text[pos - 1] == delim) return pos;
+        --pos;
+    }
+    if (stop == 0) return 0;
+    mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
+    return ~0ull;
+}
+
 // Number of delimiters at byte positions < e (= 0-based record number of position e).
 __device__ uint32_t record_of(const uint8_t *__restrict__ text, uint64_t n, uint64_t e,
                               const uint32_t *__restrict__ strip_prefix,
@@ -83,38 +125,54 @@ struct Automaton {
 // ---------------------------------------------------------------------------------------
 // Byte-wise reference walk of one window: used for windows at the head / tail of the text
 // (virtual head byte, appended delimiter) where the register fast path does not apply.
-template <typename WT, int K>
+template <typename WT, int K, bool LEAN>
 __device__ __noinline__ void verify_window_slow(const uint8_t *__restrict__ text, uint64_t n,
                                                 const agh_dev_query &q, const WT *lmask,
                                                 uint64_t ws, uint64_t we, uint64_t anchor,
-                                                uint32_t rc_anchor, const agh_marks &mk,
-                                                uint32_t total_delims)
+                                                uint32_t rc_anchor, const agh_marks &mk)
 {
     const WT finalbit = (WT)1 << (q.m - 1);
-    // delimiters in [ws, anchor): the anchor's record number is known, ws's is derived
-    uint32_t back = 0;
-    for (uint64_t i = ws; i < anchor; ++i) back += (text[i] == q.delim);
-    uint32_t rec = rc_anchor - back;
+    uint32_t rec = 0;
+    uint64_t rstart = 0;                        // LEAN: first byte of the current record
+    if (LEAN) {
+        rstart = lean_record_start(text, ws, q.delim, mk);
+        if (rstart == ~0ull) return;
+    } else {
+        // delimiters in [ws, anchor): the anchor's record number is known, ws's is derived
+        uint32_t back = 0;
+        for (uint64_t i = ws; i < anchor; ++i) back += (text[i] == q.delim);
+        rec = rc_anchor - back;
+    }
     Automaton<WT, K> A;
     A.reset();
     bool seen = false;
     if (ws == 0) A.step(lmask[q.head_byte], finalbit);
     for (uint64_t i = ws; i < we; ++i) {
         const uint32_t c = text[i];
-        if (A.step(lmask[c], finalbit) && !seen) { seen = true; mark_record(mk, rec, i); }
+        if (A.step(lmask[c], finalbit) && !seen) {
+            seen = true;
+            if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, i);
+        }
         if (c == q.delim) {
             A.reset();
             ++rec;
+            rstart = i + 1;
             seen = false;
-            if (A.step(lmask[c], finalbit)) { seen = true; mark_record(mk, rec, i + 1); }
+            if (A.step(lmask[c], finalbit)) {
+                seen = true;
+                if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, i + 1);
+            }
         }
     }
     if (we == n && q.tail_virtual) {
-        if (A.step(lmask[q.delim], finalbit) && !seen) mark_record(mk, rec, n);
+        if (A.step(lmask[q.delim], finalbit) && !seen) {
+            if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
+        }
         A.reset();
-        if (A.step(lmask[q.delim], finalbit)) mark_record(mk, rec + 1u, n);
+        if (A.step(lmask[q.delim], finalbit)) {
+            if (LEAN) lean_insert(mk, n + 1); else mark_record(mk, rec + 1u, n);
+        }
     }
-    (void)total_delims;
 }
 
 // Unaligned 16-byte view of the text (gfx9+ global loads accept any byte address).
@@ -127,7 +185,7 @@ typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
 // loads issued together and walked branch-free out of registers.  Match positions and
 // delimiter positions are collected as bit masks; record numbers are derived from them after
 // the walk.  Windows that touch the head or the tail of the text take the byte-wise path.
-template <typename WT, int K, int NCH>
+template <typename WT, int K, int NCH, bool LEAN>
 __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text, uint64_t n,
                                                 agh_dev_query q,
                                                 const WT *__restrict__ mask_g,
@@ -152,7 +210,6 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
     __syncthreads();
     const uint32_t total = pre[AGH_VGROUP];
     if (total == 0) return;
-    const uint32_t total_delims = mk.counters[AGH_C_NDELIM];
     const WT finalbit = (WT)1 << (q.m - 1);
     const uint32_t Lw = (uint32_t)(q.m + q.k + 1) > 16u ? (uint32_t)(q.m + q.k + 1) : 16u;
     const uint32_t tailw = (uint32_t)(q.fq + q.m + q.k);
@@ -172,7 +229,7 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
         const uint64_t ent = cand[(uint64_t)w * AGH_SLICE_CAP + (ci - pre[sl])];
         const uint64_t j = (ent & 0xffffffffull) * 4u;
         if (j >= n) continue;
-        const uint32_t rc_anchor = wave_prefix[w] + (uint32_t)(ent >> 32);   // record no. at anchor
+        const uint32_t rc_anchor = LEAN ? 0u : wave_prefix[w] + (uint32_t)(ent >> 32);  // record no. at anchor
         const uint64_t anchor = j & ~(uint64_t)15;                           // sample's chunk start
 
         const bool fast = j >= Lw && j + tailw < n && (j - Lw) + 16u * NCH <= n16;
@@ -180,8 +237,7 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
             const uint64_t ws = j > Lw ? j - Lw : 0;
             uint64_t we = j + tailw;
             if (we > n) we = n;
-            verify_window_slow<WT, K>(text, n, q, lmask, ws, we, anchor, rc_anchor, mk,
-                                      total_delims);
+            verify_window_slow<WT, K, LEAN>(text, n, q, lmask, ws, we, anchor, rc_anchor, mk);
             continue;
         }
         const uint64_t ws = j - Lw;
@@ -219,7 +275,44 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
         bool any = false;
 #pragma unroll
         for (int i = 0; i < NMW; ++i) any |= (hitm[i] | hit2m[i]) != 0;
-        if (any) {
+        if (any && LEAN) {
+            // record start = 1 + last delimiter in front of the event: taken from the window's
+            // delimiter mask when it is there, else found by looking back from the window
+            auto last_delim_below = [&](uint32_t x) -> int {   // relative index or -1
+                int best = -1;
+#pragma unroll
+                for (int i = 0; i < NMW; ++i) {
+                    const int lo = i * 64;
+                    uint64_t m = dm[i];
+                    if ((int)x < lo + 64) m &= (int)x > lo ? ((1ull << (x - lo)) - 1ull) : 0ull;
+                    if (m) best = lo + 63 - __clzll((long long)m);
+                }
+                return best;
+            };
+            uint64_t before_ws = ~1ull;                         // lazily computed
+            auto start_of = [&](uint32_t x) -> uint64_t {
+                const int d = last_delim_below(x);
+                if (d >= 0) return ws + (uint64_t)d + 1;
+                if (before_ws == ~1ull) before_ws = lean_record_start(text, ws, q.delim, mk);
+                return before_ws;
+            };
+#pragma unroll
+            for (int i = 0; i < NMW; ++i) {
+                uint64_t hm = hitm[i];
+                while (hm) {
+                    const uint32_t p = (uint32_t)(i * 64 + __ffsll((long long)hm) - 1);
+                    hm &= hm - 1;
+                    const uint64_t st = start_of(p);
+                    if (st != ~0ull) lean_insert(mk, st);
+                }
+                uint64_t h2 = hit2m[i];
+                while (h2) {
+                    const uint32_t p = (uint32_t)(i * 64 + __ffsll((long long)h2) - 1);
+                    h2 &= h2 - 1;
+                    lean_insert(mk, ws + p + 1);                // the record right after delimiter p
+                }
+            }
+        } else if (any) {
             // delimiters in [ws, x) from the delimiter mask
             auto delims_before = [&](uint32_t x) {
                 uint32_t c = 0;
@@ -366,28 +459,28 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
 // ---------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------
-template <typename WT, int K, int NCH>
+template <typename WT, int K, int NCH, bool LEAN>
 static void launch_verify_n(const agh_scan_args &a, hipStream_t st)
 {
     uint32_t blocks = (a.nw + AGH_VGROUP - 1u) / AGH_VGROUP;
     if (!blocks) return;
-    hipLaunchKernelGGL((k_verify<WT, K, NCH>), dim3(blocks), dim3(256), 0, st,
+    hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN>), dim3(blocks), dim3(256), 0, st,
                        (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
                        a.wave_cand, a.wave_prefix, a.nw, a.mk);
 }
 
-template <typename WT, int K>
+template <typename WT, int K, bool LEAN>
 static void launch_verify_t(const agh_scan_args &a, hipStream_t st)
 {
     // window span = max(m+k+1, 16) + q + m + k bytes, fetched as ceil(span/16) pieces
     const int lw = a.q.m + a.q.k + 1 > 16 ? a.q.m + a.q.k + 1 : 16;
     const int nch = (lw + a.q.fq + a.q.m + a.q.k + 15) / 16;
     if (sizeof(WT) == 4) {                  // m <= 32: span <= 85
-        if (nch <= 3) launch_verify_n<WT, K, 3>(a, st);
-        else launch_verify_n<WT, K, 6>(a, st);
+        if (nch <= 3) launch_verify_n<WT, K, 3, LEAN>(a, st);
+        else launch_verify_n<WT, K, 6, LEAN>(a, st);
     } else {                                // m <= 64: span <= 149
-        if (nch <= 7) launch_verify_n<WT, K, 7>(a, st);
-        else launch_verify_n<WT, K, 10>(a, st);
+        if (nch <= 7) launch_verify_n<WT, K, 7, LEAN>(a, st);
+        else launch_verify_n<WT, K, 10, LEAN>(a, st);
     }
 }
 
@@ -405,12 +498,13 @@ static void launch_fullscan_t(const agh_scan_args &a, hipStream_t st)
 }
 
 template <typename WT>
-static void dispatch_k(const agh_scan_args &a, bool full, hipStream_t st)
+static void dispatch_k(const agh_scan_args &a, int what, hipStream_t st)
 {
 #define AGH_CASE(KK)                                            \
     case KK:                                                    \
-        if (full) launch_fullscan_t<WT, KK>(a, st);             \
-        else launch_verify_t<WT, KK>(a, st);                    \
+        if (what == 0) launch_verify_t<WT, KK, false>(a, st);   \
+        else if (what == 1) launch_fullscan_t<WT, KK>(a, st);   \
+        else launch_verify_t<WT, KK, true>(a, st);              \
         break;
     switch (a.q.k) {
         AGH_CASE(0) AGH_CASE(1) AGH_CASE(2) AGH_CASE(3) AGH_CASE(4)
@@ -422,13 +516,19 @@ static void dispatch_k(const agh_scan_args &a, bool full, hipStream_t st)
 
 void agh_launch_verify(const agh_scan_args &a, hipStream_t st)
 {
-    if (a.wide) dispatch_k<uint64_t>(a, false, st);
-    else dispatch_k<uint32_t>(a, false, st);
+    if (a.wide) dispatch_k<uint64_t>(a, 0, st);
+    else dispatch_k<uint32_t>(a, 0, st);
 }
 
 void agh_launch_fullscan(const agh_scan_args &a, hipStream_t st)
 {
-    if (a.wide) dispatch_k<uint64_t>(a, true, st);
-    else dispatch_k<uint32_t>(a, true, st);
+    if (a.wide) dispatch_k<uint64_t>(a, 1, st);
+    else dispatch_k<uint32_t>(a, 1, st);
+}
+
+void agh_launch_verify_lean(const agh_scan_args &a, hipStream_t st)
+{
+    if (a.wide) dispatch_k<uint64_t>(a, 2, st);
+    else dispatch_k<uint32_t>(a, 2, st);
 }
 

@@ -32,7 +32,9 @@
 // sweep: delimiter census + q-gram sample filter
 // ---------------------------------------------------------------------------------------
 // MODE bit 0: the query folds ASCII case (OR 0x20 into every sampled byte);
-// MODE bit 1: 4-byte samples (no mask needed, 32-bit hash) instead of <= 3-byte samples.
+// MODE bit 1: 4-byte samples (no mask needed, 32-bit hash) instead of <= 3-byte samples;
+// MODE bit 2: lean sweep -- no delimiter census (count-only scans identify a record by the
+//             offset of its first byte, found by the verifier, instead of by its number).
 template <int MODE>
 __device__ __forceinline__ uint32_t probe(uint32_t w, const agh_dev_query &q,
                                           const uint8_t *ftab)
@@ -52,7 +54,7 @@ __device__ __forceinline__ void sweep_chunk(uint4 v, uint32_t dd, const agh_dev_
                                             const uint8_t *ftab, uint32_t &acc,
                                             uint32_t &hits, int bitbase)
 {
-    acc += nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
+    if (!(MODE & 4)) acc += nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
     if (H > 0) {
         hits |= probe<MODE>(v.x, q, ftab) << bitbase;
         if (H <= 8) hits |= probe<MODE>(v.z, q, ftab) << (bitbase + 2);
@@ -63,13 +65,39 @@ __device__ __forceinline__ void sweep_chunk(uint4 v, uint32_t dd, const agh_dev_
     }
 }
 
-// Append the candidates of one wave to the wave's private slice of the candidate buffer (no
-// atomics: one hot global counter saturates at ~90 updates/us on this chip and would cap the
-// whole sweep).  hits: bit (4*u + d) of lane l = sample at dword d of the lane's chunk in
-// strip s+u.  rc[u] = delimiters (inside this wave's range) in front of the lane's chunk of
-// strip s+u -- stored with the candidate so that the verifier can number records without
-// re-reading any text.  cnt is wave-uniform.
+// Candidates of one wave.  They are queued in LDS (cq, private to the wave) and written to the
+// wave's private slice of the candidate buffer 64 at a time with one coalesced store:
+//   * no atomics -- one hot global counter saturates at ~90 updates/us on this chip and would
+//     cap the whole sweep;
+//   * no global store per hit -- vmcnt also counts stores, so a store issued between the
+//     prefetch and its use stalls the wave until that store has completed (measured: ~7 % of
+//     the sweep).
+// hits: bit (4*u + d) of lane l = sample at dword d of the lane's chunk in strip s+u.
+// rc[u] = delimiters (inside this wave's range) in front of the lane's chunk of strip s+u --
+// stored with the candidate so that the verifier can number records without re-reading text.
+// qn (queued) and cnt (already in the slice) are wave-uniform.
+#define AGH_CQ_LEN 96
+
+__device__ __forceinline__ void flush_candidates(uint64_t *cq, uint32_t &qn, uint32_t take,
+                                                 uint64_t *__restrict__ slice, uint32_t &cnt,
+                                                 uint32_t *counters)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    if (lane < take) {
+        const uint32_t idx = cnt + lane;
+        if (idx < AGH_SLICE_CAP) slice[idx] = cq[lane];
+        else counters[AGH_C_OVERFLOW] = 1u;
+    }
+    cnt += take;
+    const uint32_t rest = qn - take;            // < 32: move it to the front
+    uint64_t keep = 0;
+    if (lane < rest) keep = cq[take + lane];
+    if (lane < rest) cq[lane] = keep;
+    qn = rest;
+}
+
 __device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, const uint32_t rc[4],
+                                                uint64_t *cq, uint32_t &qn,
                                                 uint64_t *__restrict__ slice, uint32_t &cnt,
                                                 uint32_t *counters)
 {
@@ -92,11 +120,10 @@ __device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, const
             uint32_t dw = (uint32_t)(((s + (uint64_t)u) * 64u + (uint64_t)l) * 4u +
                                      (uint64_t)(b & 3));
             uint32_t r = u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3));
-            uint32_t idx = cnt + (uint32_t)lane;
-            if (idx < AGH_SLICE_CAP) slice[idx] = ((uint64_t)r << 32) | dw;
-            else counters[AGH_C_OVERFLOW] = 1u;
+            cq[qn + (uint32_t)lane] = ((uint64_t)r << 32) | dw;
         }
-        cnt += (uint32_t)c;
+        qn += (uint32_t)c;
+        if (qn >= 64u) flush_candidates(cq, qn, 64u, slice, cnt, counters);
     }
 }
 
@@ -106,6 +133,7 @@ __device__ __forceinline__ void sweep_supertile(uint4 v0, uint4 v1, uint4 v2, ui
                                                 uint64_t s, int lane, uint32_t dd,
                                                 const agh_dev_query &q, const uint8_t *ftab,
                                                 uint32_t *__restrict__ strip_prefix,
+                                                uint64_t *cq, uint32_t &qn,
                                                 uint64_t *__restrict__ slice, uint32_t &run,
                                                 uint32_t &ncand, uint32_t *counters)
 {
@@ -114,6 +142,13 @@ __device__ __forceinline__ void sweep_supertile(uint4 v0, uint4 v1, uint4 v2, ui
     sweep_chunk<H, MODE>(v1, dd, q, ftab, a1, hits, 4);
     sweep_chunk<H, MODE>(v2, dd, q, ftab, a2, hits, 8);
     sweep_chunk<H, MODE>(v3, dd, q, ftab, a3, hits, 12);
+    if (MODE & 4) {
+        if (__ballot(hits != 0)) {
+            const uint32_t rc[4] = {0u, 0u, 0u, 0u};
+            emit_candidates(hits, s, rc, cq, qn, slice, ncand, counters);
+        }
+        return;
+    }
     // per-strip delimiter totals: two packed 16-bit sums per DPP scan (the scan is a full
     // inclusive prefix over the 64 lanes; lane 63 holds the totals)
     const uint32_t own01 = a0 | (a1 << 16), own23 = a2 | (a3 << 16);
@@ -136,7 +171,7 @@ __device__ __forceinline__ void sweep_supertile(uint4 v0, uint4 v1, uint4 v2, ui
         rc[1] = run + z0 + lb - (ex01 >> 16);
         rc[2] = run + z0 + z1 + lb - (ex23 & 0xffffu);
         rc[3] = run + z0 + z1 + z2 + lb - (ex23 >> 16);
-        emit_candidates(hits, s, rc, slice, ncand, counters);
+        emit_candidates(hits, s, rc, cq, qn, slice, ncand, counters);
     }
     run += z0 + z1 + z2 + z3;
 }
@@ -156,6 +191,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
                                                  uint32_t *__restrict__ counters)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ftab[H > 0 ? AGH_FT_SIZE : 16];
+    __shared__ uint64_t cq_all[H > 0 ? (BLOCK / WAVE) * AGH_CQ_LEN : 1];
     if (H > 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(ftab_g);
         uint4 *dst = reinterpret_cast<uint4 *>(ftab);
@@ -176,7 +212,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
     if (s1 > n_full_strips) s1 = n_full_strips;
     const uint32_t dd = q.delim * 0x01010101u;
     uint32_t run = 0;                           // delimiters before strip s inside this range
-    uint32_t ncand = 0;                         // candidates in this wave's slice
+    uint32_t ncand = 0;                         // candidates already in this wave's slice
+    uint32_t qn = 0;                            // candidates queued in LDS
+    uint64_t *cq = cq_all + (H > 0 ? wib * AGH_CQ_LEN : 0);
     uint64_t *slice = cand + w * AGH_SLICE_CAP;
     uint64_t s = s0;
 
@@ -187,26 +225,33 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
             for (; s + 8 <= s1; s += 4) {
                 const uint4 *pn = text + (s + 4) * 64 + lane;
                 uint4 n0 = pn[0], n1 = pn[64], n2 = pn[128], n3 = pn[192];
-                sweep_supertile<H, MODE>(c0, c1, c2, c3, s, lane, dd, q, ftab, strip_prefix, slice,
-                                   run, ncand, counters);
+                sweep_supertile<H, MODE>(c0, c1, c2, c3, s, lane, dd, q, ftab, strip_prefix, cq, qn,
+                                   slice, run, ncand, counters);
                 c0 = n0; c1 = n1; c2 = n2; c3 = n3;
             }
-            sweep_supertile<H, MODE>(c0, c1, c2, c3, s, lane, dd, q, ftab, strip_prefix, slice, run,
-                               ncand, counters);
+            sweep_supertile<H, MODE>(c0, c1, c2, c3, s, lane, dd, q, ftab, strip_prefix, cq, qn, slice,
+                               run, ncand, counters);
             s += 4;
         }
     } else {
         for (; s + 4 <= s1; s += 4) {
             const uint4 *p = text + s * 64 + lane;
             uint4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];   // 4 x 1 KiB in flight
-            sweep_supertile<H, MODE>(v0, v1, v2, v3, s, lane, dd, q, ftab, strip_prefix, slice, run,
-                               ncand, counters);
+            sweep_supertile<H, MODE>(v0, v1, v2, v3, s, lane, dd, q, ftab, strip_prefix, cq, qn, slice,
+                               run, ncand, counters);
         }
     }
     for (; s < s1; ++s) {                       // < 4 strips left in the range
         uint4 v0 = text[s * 64 + lane];
         uint32_t a0 = 0, hits = 0;
         sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0);
+        if (MODE & 4) {
+            if (__ballot(hits != 0)) {
+                const uint32_t rc[4] = {0u, 0u, 0u, 0u};
+                emit_candidates(hits, s, rc, cq, qn, slice, ncand, counters);
+            }
+            continue;
+        }
         const uint32_t sc0 = wave_sum_to_lane63(a0);
         const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)sc0, 63);
         if (H == 0 && lane == 0) strip_prefix[s] = run;
@@ -214,10 +259,11 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
             uint32_t rc[4];
             rc[0] = run + 128u * (uint32_t)lane - (sc0 - a0);
             rc[1] = rc[2] = rc[3] = 0;
-            emit_candidates(hits, s, rc, slice, ncand, counters);
+            emit_candidates(hits, s, rc, cq, qn, slice, ncand, counters);
         }
         run += 8192u - p0;
     }
+    if (H > 0 && qn) flush_candidates(cq, qn, qn, slice, ncand, counters);
     if (lane == 0) {
         wave_totals[w] = run;
         if (H > 0) wave_cand[w] = ncand < AGH_SLICE_CAP ? ncand : AGH_SLICE_CAP;
@@ -236,6 +282,8 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
                                                    uint32_t *__restrict__ wave_cand,
                                                    uint32_t *__restrict__ counters)
 {
+    __shared__ uint64_t cq[AGH_CQ_LEN];
+    uint32_t qn = 0;
     const int lane = lane_id();
     const uint64_t s = n >> AGH_STRIP_SHIFT;            // index of the partial strip
     const uint64_t off = (s << AGH_STRIP_SHIFT) + (uint64_t)lane * 16u;
@@ -248,9 +296,9 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
     }
     uint32_t a0 = 0, hits = 0;
     sweep_chunk<H, MODE>(v, dd, q, ftab_g, a0, hits, 0);      // table straight from global/L2
-    const uint32_t sc0 = wave_sum_to_lane63(a0);
+    const uint32_t sc0 = (MODE & 4) ? 0u : wave_sum_to_lane63(a0);
     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)sc0, 63);
-    const uint32_t z = 8192u - p0;
+    const uint32_t z = (MODE & 4) ? 0u : 8192u - p0;
     const uint64_t w = s / AGH_WAVE_STRIPS;
     const bool fresh = (s % AGH_WAVE_STRIPS) == 0;      // k_sweep never touched this range
     uint32_t before = fresh ? 0u : wave_totals[w];
@@ -262,7 +310,8 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
             uint32_t rc[4];
             rc[0] = before + 128u * (uint32_t)lane - (sc0 - a0);
             rc[1] = rc[2] = rc[3] = 0;
-            emit_candidates(hits, s, rc, cand + w * AGH_SLICE_CAP, ncand, counters);
+            emit_candidates(hits, s, rc, cq, qn, cand + w * AGH_SLICE_CAP, ncand, counters);
+            if (qn) flush_candidates(cq, qn, qn, cand + w * AGH_SLICE_CAP, ncand, counters);
         }
         if (lane == 0) wave_cand[w] = ncand < AGH_SLICE_CAP ? ncand : AGH_SLICE_CAP;
     }
@@ -388,6 +437,39 @@ __global__ __launch_bounds__(256) void k_bitmap_count(uint4 *__restrict__ bitmap
     }
 }
 
+// Lean scans: the set of matched records is a hash set of record-start offsets (+1); count the
+// occupied slots, clear them, and total the candidate counters while at it.
+__global__ __launch_bounds__(256) void k_hashset_count(uint64_t *__restrict__ tab,
+                                                       uint32_t n_slots,
+                                                       const uint32_t *__restrict__ wave_cand,
+                                                       uint32_t nw,
+                                                       uint32_t *__restrict__ counters)
+{
+    uint32_t acc = 0, cacc = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n2 = n_slots / 2;            // two slots per 16-byte access
+    uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const uint4 b = t4[i];
+        if (b.x | b.y | b.z | b.w) {
+            acc += ((b.x | b.y) ? 1u : 0u) + ((b.z | b.w) ? 1u : 0u);
+            t4[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) cacc += wave_cand[i];
+    acc = wave_sum_to_lane63(acc);
+    cacc = wave_sum_to_lane63(cacc);
+    __shared__ uint32_t part[8];
+    if (lane_id() == 63) { part[threadIdx.x / WAVE] = acc; part[4 + threadIdx.x / WAVE] = cacc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = part[0] + part[1] + part[2] + part[3];
+        const uint32_t c = part[4] + part[5] + part[6] + part[7];
+        if (t) atomicAdd(&counters[AGH_C_MATCHED], t);
+        if (c) atomicAdd(&counters[AGH_C_CAND], c);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // bench support: read probe and synthetic corpus
 // ---------------------------------------------------------------------------------------
@@ -504,6 +586,7 @@ static void launch_sweep_hm(const agh_sweep_args &a, hipStream_t st)
         hipLaunchKernelGGL((k_sweep_tail<H, MODE>), dim3(1), dim3(64), 0, st,
                            (const uint4 *)a.text, a.n, a.q, a.ftab, a.strip_prefix,
                            a.wave_totals, a.cand, a.wave_cand, a.counters);
+    if (MODE & 4) return;                       // lean: no record numbering, nothing to scan
     const uint64_t n_strips = (a.n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint32_t nw = (uint32_t)((n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS);
     const uint32_t n_chunks = (nw + AGH_SCAN_CHUNK - 1) / AGH_SCAN_CHUNK;
@@ -518,12 +601,16 @@ static void launch_sweep_hm(const agh_sweep_args &a, hipStream_t st)
 template <int H>
 static void launch_sweep_t(const agh_sweep_args &a, hipStream_t st)
 {
-    const int mode = (a.q.fold ? 1 : 0) | (a.q.fq == 4 ? 2 : 0);
+    const int mode = (a.q.fold ? 1 : 0) | (a.q.fq == 4 ? 2 : 0) | (a.lean ? 4 : 0);
     switch (mode) {
     case 0: launch_sweep_hm<H, 0>(a, st); break;
     case 1: launch_sweep_hm<H, 1>(a, st); break;
     case 2: launch_sweep_hm<H, 2>(a, st); break;
-    default: launch_sweep_hm<H, 3>(a, st); break;
+    case 3: launch_sweep_hm<H, 3>(a, st); break;
+    case 4: launch_sweep_hm<H, 4>(a, st); break;
+    case 5: launch_sweep_hm<H, 5>(a, st); break;
+    case 6: launch_sweep_hm<H, 6>(a, st); break;
+    default: launch_sweep_hm<H, 7>(a, st); break;
     }
 }
 
@@ -546,6 +633,16 @@ void agh_launch_bitmap_count(uint32_t *bitmap, uint32_t n_words, uint32_t *count
     if (blocks > 256u) blocks = 256u;
     hipLaunchKernelGGL(k_bitmap_count, dim3(blocks), dim3(256), 0, st, (uint4 *)bitmap, n_vec,
                        counters);
+}
+
+void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *wave_cand,
+                              uint32_t nw, uint32_t *counters, hipStream_t st)
+{
+    uint32_t blocks = (n_slots / 2 + 256u * 8u - 1u) / (256u * 8u);
+    if (blocks > 256u) blocks = 256u;
+    if (!blocks) blocks = 1u;
+    hipLaunchKernelGGL(k_hashset_count, dim3(blocks), dim3(256), 0, st, tab, n_slots, wave_cand,
+                       nw, counters);
 }
 
 void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st)

@@ -47,6 +47,7 @@ extern "C" {
 #define AGH_FORCE_FULLSCAN 0x10u  /* diagnostics: skip the q-gram filter, run the automaton
                                      over every byte (the asearch.c shape) */
 #define AGH_FORCE_FILTER   0x20u  /* diagnostics: fail instead of falling back to full scan */
+#define AGH_FORCE_NUMBERED 0x40u  /* diagnostics: compute record numbers even for -c / -l scans */
 
 /* engine that produced a result */
 #define AGH_ENGINE_FULLSCAN 1u    /* k-error automaton over every byte (asearch.c:94-116) */
@@ -64,7 +65,8 @@ typedef struct {
 
 typedef struct {
     uint64_t n_matched;     /* what the engines add to num_of_matched (agrep.c:148) */
-    uint64_t n_records;     /* records in the scanned text */
+    uint64_t n_records;     /* records in the scanned text; 0 when a count-only scan (AGH_COUNT /
+                               AGH_FILENAMEONLY) took the lean path that never numbers records */
     uint64_t n_bytes;       /* bytes scanned */
     uint64_t n_candidates;  /* filter engine: candidate windows verified */
     uint64_t n_stored;      /* matches written to the caller's agh_match array */
@@ -141,6 +143,8 @@ int agh_corpus_fill_device(void *dev_out, uint64_t first_page, uint64_t n_pages,
 /* Streaming-read ceiling probe: reads len bytes with the same 16 B/lane access pattern as
  * the sweep kernel and no arithmetic beyond a checksum; returns the kernel time in ms. */
 int agh_probe_read_ms(const void *dev_text, size_t len, void *stream, double *ms);
+/* Diagnostics: the same for one structural variant of the sweep (csrc/agh_exp.hip). */
+int agh_probe_variant_ms(const void *dev_text, size_t len, void *stream, int exp, double *ms);
 
 const char *agh_last_error(void);
 const char *agh_version(void);

@@ -42,6 +42,12 @@ def _check(agh, pat, k, text, nocase=False):
     res, recs, idx = _gpu(agh, pat, k, text, nocase)
     assert (res.n_matched, recs) == want, ("default", pat, k, nocase, res.engine)
     assert idx == idx_f
+    # count-only scans take the lean path (record = offset of its first byte, no census)
+    with agh.Query(pat, k, nocase=nocase) as q:
+        res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+        res_n, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
+    assert res_c.n_matched == want[0], ("lean", pat, k, nocase)
+    assert res_n.n_matched == want[0] and res_n.n_records == res.n_records
     # record numbers are consistent with the record starts
     nl = np.frombuffer(tb, dtype=np.uint8) == 10
     for (s, e), i in zip(recs[:50], idx[:50]):
@@ -219,6 +225,8 @@ def test_resident_corpus_properties_at_scale(agh):
         with agh.Query(O.PATTERN_C2, k) as q:
             r1 = q.scan_device(t.data_ptr(), t.numel())
             r2 = q.scan_device(t.data_ptr(), t.numel(), flags=agh.FORCE_FULLSCAN)
+            r3 = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+        assert r3.n_matched == r1.n_matched
         assert r1.engine == (agh.ENGINE_FILTER if k <= 2 else agh.ENGINE_FULLSCAN)
         assert r2.engine == agh.ENGINE_FULLSCAN
         assert r1.n_matched == r2.n_matched and r1.n_records == r2.n_records
