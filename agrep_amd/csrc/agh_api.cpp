@@ -325,7 +325,20 @@ extern "C" int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q,
 // ---------------------------------------------------------------------------------------
 // one segment (<= AGH_SEG_MAX bytes) resident in HBM
 // ---------------------------------------------------------------------------------------
-static const uint64_t AGH_SEG_MAX = (uint64_t)8 << 30;
+static const uint64_t AGH_SEG_MAX_DEFAULT = (uint64_t)8 << 30;
+
+// Largest piece scanned by one kernel sequence (dword indices are 32-bit).  AGH_SEG_MAX_MB
+// lowers it (tests exercise the record-aligned cutting with small inputs).
+static uint64_t seg_max()
+{
+    const char *e = getenv("AGH_SEG_MAX_MB");
+    if (e && *e) {
+        uint64_t mb = strtoull(e, nullptr, 10);
+        if (mb >= 1 && mb <= 8192) return mb << 20;
+    }
+    return AGH_SEG_MAX_DEFAULT;
+}
+#define AGH_SEG_MAX (seg_max())
 
 struct seg_result {
     uint64_t matched = 0, records = 0, candidates = 0, stored = 0;

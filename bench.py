@@ -166,7 +166,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: pattern 'approximatematch' (m=16), k=%d, "
                                    "%.2f GiB of newline-delimited records per GPU resident in HBM, "
                                    "count-only (-c)" % (args.k, args.gib),
-                       "bytes_per_gpu": n, "records_per_gpu": int(res.n_records),
+                       "bytes_per_gpu": n,
+                       "records_per_gpu": int(q.scan_device(text.data_ptr(), n).n_records),
                        "sharding": "disjoint page ranges per rank, RCCL all-reduce of the counts",
                        "engine": {1: "fullscan", 2: "q-gram sample filter + verify"}[res.engine],
                        "filter_sample": "q=%d bytes every h=%d bytes" % (info["filter_q"], info["filter_h"]),
@@ -185,10 +186,10 @@ def main():
         # secondary points of the metric: k = 0 and the streaming-read ceiling of this access pattern
         q0 = A.Query(PATTERN, 0)
         for _ in range(2):
-            q0.scan_device(text.data_ptr(), n)
+            q0.scan_device(text.data_ptr(), n, flags=A.COUNT)
         t1 = time.perf_counter()
         for _ in range(5):
-            r0 = q0.scan_device(text.data_ptr(), n)
+            r0 = q0.scan_device(text.data_ptr(), n, flags=A.COUNT)
         torch.cuda.synchronize()
         out["k0"] = {"value": round(n / 1e9 / ((time.perf_counter() - t1) / 5), 2), "unit": "GB/s",
                      "matched_records_rank0": int(r0.n_matched)}

@@ -237,3 +237,63 @@ def test_resident_corpus_properties_at_scale(agh):
     with agh.Query(O.PATTERN_C2, 2) as q:
         r = q.scan_device(t.data_ptr(), 16 << 20)
     assert r.n_matched == O.asearch(O.PATTERN_C2, 2, sl)[0]
+
+
+def _c3_pattern_and_variants():
+    rng = random.Random(48)
+    pat = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(48))
+    vs = [pat]
+    for edits in (1, 2, 3, 4):
+        v = bytearray(pat)
+        for _ in range(edits):
+            op, pos = rng.randint(0, 2), rng.randrange(4, len(v) - 4)
+            if op == 0:
+                v[pos] = ord("Q")
+            elif op == 1:
+                del v[pos]
+            else:
+                v.insert(pos, ord("Z"))
+        vs.append(bytes(v))
+    return pat, tuple(vs)
+
+
+def test_config_c3_shape_long_pattern_nocase(agh):
+    """BASELINE config 3 shape: m=48 (64-bit state words), k=3, -i, mixed-case text.
+    The reference rejects m > 29, so the anchor is the multi-word oracle / DP."""
+    import torch
+    pat, vs = _c3_pattern_and_variants()
+    text, planted = O.corpus(768, seed=3, variants=vs, plant_period=25, upper_permille=500)
+    res = _check(agh, pat, 3, text, nocase=True)
+    assert res.engine == agh.ENGINE_FILTER
+    assert res.n_matched >= sum(planted[:4])          # 0..3 edits must be found
+    # at scale: engines agree and lean == numbered
+    pages = (1 << 30) // 4096
+    t = torch.empty(pages * 4096, dtype=torch.uint8, device="cuda")
+    planted = agh.corpus_fill_device(t.data_ptr(), pages, seed=9, variants=vs, plant_period=500,
+                                     upper_permille=500)
+    with agh.Query(pat, 3, nocase=True) as q:
+        a = q.scan_device(t.data_ptr(), t.numel())
+        b = q.scan_device(t.data_ptr(), t.numel(), flags=agh.FORCE_FULLSCAN)
+        c = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+    assert a.n_matched == b.n_matched == c.n_matched >= sum(planted[:4])
+    assert a.n_records == b.n_records
+
+
+def test_segmented_scan_cuts_at_record_boundaries(agh, monkeypatch):
+    """Inputs above the segment limit are cut at (16-byte aligned) record boundaries and the
+    per-segment results add up to the single-segment answer."""
+    import torch
+    pages = (96 << 20) // 4096
+    t = torch.empty(pages * 4096, dtype=torch.uint8, device="cuda")
+    agh.corpus_fill_device(t.data_ptr(), pages, seed=21, variants=O.VARIANTS_C2, plant_period=60)
+    with agh.Query(O.PATTERN_C2, 2) as q:
+        whole = q.scan_device(t.data_ptr(), t.numel())
+        whole_lean = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+    monkeypatch.setenv("AGH_SEG_MAX_MB", "20")
+    with agh.Query(O.PATTERN_C2, 2) as q:
+        parts = q.scan_device(t.data_ptr(), t.numel())
+        parts_lean = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+        parts_full = q.scan_device(t.data_ptr(), t.numel(), flags=agh.FORCE_FULLSCAN)
+    assert parts.n_matched == whole.n_matched == whole_lean.n_matched == parts_lean.n_matched
+    assert parts_full.n_matched == whole.n_matched
+    assert parts.n_records == whole.n_records == parts_full.n_records
