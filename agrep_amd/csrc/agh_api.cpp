@@ -411,9 +411,12 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         sa.lean = 1;
         sa.ev_begin = q->ev2;
         sa.ev_end = q->ev3;
-        agh_launch_sweep(sa, q->fh, st);
         agh_scan_args va;
         memset(&va, 0, sizeof(va));
+        va.mk.counters = q->d_counters;
+        va.mk.hashset = (uint64_t *)q->hashset.p;
+        va.mk.hashset_mask = (uint32_t)(slots - 1);
+        agh_launch_sweep(sa, q->fh, st);
         va.text = d_text;
         va.n = n;
         va.q = dq;
@@ -423,9 +426,6 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.wave_cand = (const uint32_t *)q->wave_cand.p;
         va.nw = (uint32_t)nw;
         va.wave_prefix = (const uint32_t *)q->wave_totals.p;
-        va.mk.counters = q->d_counters;
-        va.mk.hashset = (uint64_t *)q->hashset.p;
-        va.mk.hashset_mask = (uint32_t)(slots - 1);
         agh_launch_verify_lean(va, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)q->wave_cand.p, (uint32_t)nw, q->d_counters, st);

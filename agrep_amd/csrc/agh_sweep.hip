@@ -96,10 +96,10 @@ __device__ __forceinline__ void flush_candidates(uint64_t *cq, uint32_t &qn, uin
     qn = rest;
 }
 
-__device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, const uint32_t rc[4],
-                                                uint64_t *cq, uint32_t &qn,
-                                                uint64_t *__restrict__ slice, uint32_t &cnt,
-                                                uint32_t *counters)
+template <typename OnFull>
+__device__ __forceinline__ void emit_candidates_to(uint32_t hits, uint64_t s,
+                                                   const uint32_t rc[4], uint64_t *cq,
+                                                   uint32_t &qn, OnFull on_full)
 {
     uint64_t hm = __ballot(hits != 0);
     const int lane = lane_id();
@@ -123,8 +123,17 @@ __device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, const
             cq[qn + (uint32_t)lane] = ((uint64_t)r << 32) | dw;
         }
         qn += (uint32_t)c;
-        if (qn >= 64u) flush_candidates(cq, qn, 64u, slice, cnt, counters);
+        if (qn >= 64u) on_full();
     }
+}
+
+__device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, const uint32_t rc[4],
+                                                uint64_t *cq, uint32_t &qn,
+                                                uint64_t *__restrict__ slice, uint32_t &cnt,
+                                                uint32_t *counters)
+{
+    emit_candidates_to(hits, s, rc, cq, qn,
+                       [&]() { flush_candidates(cq, qn, 64u, slice, cnt, counters); });
 }
 
 // One supertile = 4 consecutive strips (4 KiB) of one wave: census, probes, prefix, emit.
