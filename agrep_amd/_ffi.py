@@ -67,6 +67,11 @@ def lib():
     L.agh_scan_fd.argtypes = [vp, C.c_int, C.c_uint, C.POINTER(Result), C.POINTER(Match),
                               C.c_size_t]
     L.agh_scan_fd.restype = C.c_int
+    L.agh_rescan_staged.argtypes = [vp, C.c_uint, C.POINTER(Result), C.POINTER(Match), C.c_size_t]
+    L.agh_rescan_staged.restype = C.c_int
+    L.agh_fetch_records.argtypes = [vp, C.POINTER(Match), C.c_size_t, vp, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]
+    L.agh_fetch_records.restype = C.c_int
     L.agh_scan_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint, C.POINTER(Result), vp,
                                   C.c_size_t]
     L.agh_scan_device.restype = C.c_int
@@ -152,6 +157,22 @@ class Query:
         ms = (Match * max(cap, 1))()
         _check(lib().agh_scan_fd(self._h, fd, flags, C.byref(res), ms if cap else None, cap))
         return res, [(ms[i].start, ms[i].end, ms[i].index) for i in range(int(res.n_stored))]
+
+    def fetch_records(self, matches):
+        """matches: [(start, end, index)] from the last scan_fd / scan_buffer -> list of bytes"""
+        n = len(matches)
+        ms = (Match * max(n, 1))()
+        for i, (s, e, idx) in enumerate(matches):
+            ms[i].start, ms[i].end, ms[i].index = s, e, idx
+        total = sum(e - s for s, e, _ in matches)
+        buf = C.create_string_buffer(max(total, 1))
+        got = C.c_size_t()
+        _check(lib().agh_fetch_records(self._h, ms, n, C.addressof(buf), total, C.byref(got)))
+        raw, out, o = buf.raw[:total], [], 0
+        for s, e, _ in matches:
+            out.append(raw[o:o + (e - s)])
+            o += e - s
+        return out
 
     def scan_device(self, dev_ptr, n, stream=None, flags=0, match_pos_ptr=None, match_cap=0):
         """dev_ptr: device address (e.g. torch tensor .data_ptr()), n bytes."""

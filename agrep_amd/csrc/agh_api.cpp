@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -91,7 +92,11 @@ struct agh_query {
     uint8_t *d_ftab = nullptr;          // AGH_FT_SIZE bytes
     // per-query workspace (grown lazily, reused across scans)
     dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, hashset, staging, match_pos,
-        match_rec;
+        match_rec, match_start, match_end, match_off, gather;
+    uint64_t staged_len = 0;            // bytes of the text currently held in `staging`
+    hipStream_t stage_stream = nullptr; // H2D copies of agh_scan_fd
+    unsigned char *pinned[2] = {nullptr, nullptr};
+    hipEvent_t pinned_ev[2] = {nullptr, nullptr};
     uint32_t *d_counters = nullptr;
     uint32_t *d_chunk_totals = nullptr; // scratch of the prefix scan
     uint32_t *h_counters = nullptr;     // pinned
@@ -309,6 +314,15 @@ extern "C" void agh_query_free(agh_query *q)
     q->staging.release();
     q->match_pos.release();
     q->match_rec.release();
+    q->match_start.release();
+    q->match_end.release();
+    q->match_off.release();
+    q->gather.release();
+    for (int b = 0; b < 2; ++b) {
+        if (q->pinned[b]) (void)hipHostFree(q->pinned[b]);
+        if (q->pinned_ev[b]) (void)hipEventDestroy(q->pinned_ev[b]);
+    }
+    if (q->stage_stream) (void)hipStreamDestroy(q->stage_stream);
     delete q;
 }
 
@@ -634,13 +648,37 @@ extern "C" int agh_scan_device(agh_query *q, const void *dev_text, size_t len, v
                             (uint64_t *)dev_match_pos, nullptr, dev_match_pos ? match_cap : 0);
 }
 
-extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t len,
-                               unsigned flags, agh_result *res, agh_match *matches, size_t cap)
+// Matches of the text staged in q->staging: bounds computed on the device, sorted into file
+// order on the host.
+static int collect_matches(agh_query *q, uint64_t len, const agh_result *res, agh_match *matches)
 {
-    if (!q || !res || (!text && len)) return fail("null argument");
-    if (len > AGH_SEG_MAX) return fail("host buffers above 8 GiB must be scanned in pieces");
-    if (q->staging.ensure(((len + 15) & ~(size_t)15) + 16)) return -1;
-    if (len) HIP_TRY(hipMemcpy(q->staging.p, text, len, hipMemcpyHostToDevice));
+    const size_t ns = (size_t)res->n_stored;
+    if (!ns) return 0;
+    if (q->match_start.ensure(ns * sizeof(uint64_t))) return -1;
+    if (q->match_end.ensure(ns * sizeof(uint64_t))) return -1;
+    agh_launch_match_bounds(q->staging.p, len, q->delim[0], (const uint64_t *)q->match_pos.p,
+                            (uint32_t)ns, (uint64_t *)q->match_start.p,
+                            (uint64_t *)q->match_end.p, nullptr);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint64_t> st(ns), en(ns);
+    std::vector<uint32_t> rec(ns);
+    HIP_TRY(hipMemcpy(st.data(), q->match_start.p, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(en.data(), q->match_end.p, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rec.data(), q->match_rec.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<size_t> order(ns);
+    for (size_t i = 0; i < ns; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st[a] < st[b]; });
+    for (size_t i = 0; i < ns; ++i) {
+        matches[i].start = st[order[i]];
+        matches[i].end = en[order[i]];
+        matches[i].index = rec[order[i]];
+    }
+    return 0;
+}
+
+static int scan_staged(agh_query *q, uint64_t len, unsigned flags, agh_result *res,
+                       agh_match *matches, size_t cap)
+{
     uint64_t *d_pos = nullptr;
     uint32_t *d_rec = nullptr;
     if (matches && cap) {
@@ -649,52 +687,124 @@ extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t l
         d_pos = (uint64_t *)q->match_pos.p;
         d_rec = (uint32_t *)q->match_rec.p;
     }
+    q->staged_len = len;
     if (scan_device_impl(q, q->staging.p, len, nullptr, flags, res, d_pos, d_rec, cap)) return -1;
-    if (d_pos && res->n_stored) {
-        const size_t ns = (size_t)res->n_stored;
-        std::vector<uint64_t> pos(ns);
-        std::vector<uint32_t> rec(ns);
-        HIP_TRY(hipMemcpy(pos.data(), d_pos, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(rec.data(), d_rec, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        std::vector<size_t> order(ns);
-        for (size_t i = 0; i < ns; ++i) order[i] = i;
-        std::sort(order.begin(), order.end(),
-                  [&](size_t a, size_t b) { return pos[a] < pos[b]; });   // file order
-        const unsigned char d = q->delim[0];
-        for (size_t i = 0; i < ns; ++i) {
-            uint64_t e = pos[order[i]];
-            // record = (last delimiter before e, first delimiter at or after e)
-            uint64_t s = e > len ? len : e;
-            while (s > 0 && text[s - 1] != d) --s;
-            uint64_t en = e > len ? len : e;
-            const void *nx = en < len ? memchr(text + en, d, len - en) : nullptr;
-            en = nx ? (uint64_t)((const unsigned char *)nx - text) : len;
-            matches[i].start = s;
-            matches[i].end = en;
-            matches[i].index = rec[order[i]];
-        }
-    }
-    return 0;
+    return d_pos ? collect_matches(q, len, res, matches) : 0;
 }
+
+extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t len,
+                               unsigned flags, agh_result *res, agh_match *matches, size_t cap)
+{
+    if (!q || !res || (!text && len)) return fail("null argument");
+    if (q->staging.ensure(((len + 15) & ~(size_t)15) + 16)) return -1;
+    if (len) HIP_TRY(hipMemcpy(q->staging.p, text, len, hipMemcpyHostToDevice));
+    return scan_staged(q, len, flags, res, matches, cap);
+}
+
+// File mode: read() lands directly in pinned memory and is copied to HBM asynchronously while
+// the next chunk is being read (two chunks in flight) -- the staging role of fill_buf
+// (bitap.c:450-477), without an intermediate pageable copy.
+static const size_t AGH_STAGE_CHUNK = (size_t)32 << 20;
 
 extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res,
                            agh_match *matches, size_t cap)
 {
+    if (!q || !res) return fail("null argument");
     if (fd < 0) return fail("agh_scan_fd needs fd >= 0 (memory mode is agh_scan_buffer)");
-    std::vector<unsigned char> buf;
-    size_t used = 0;
-    buf.resize(1 << 20);
-    for (;;) {                                   // bitap.c:450-477 fill_buf: read until EOF
-        if (used == buf.size()) buf.resize(buf.size() * 2);
-        ssize_t r = read(fd, buf.data() + used, buf.size() - used);
-        if (r < 0) {
-            if (errno == EINTR) continue;
-            return fail("read failed: %s", strerror(errno));
+    if (!q->stage_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipHostMalloc((void **)&q->pinned[b], AGH_STAGE_CHUNK));
+            HIP_TRY(hipEventCreateWithFlags(&q->pinned_ev[b], hipEventDisableTiming));
         }
-        if (r == 0) break;
-        used += (size_t)r;
     }
-    return agh_scan_buffer(q, buf.data(), used, flags, res, matches, cap);
+    struct stat sb;
+    size_t want = AGH_STAGE_CHUNK * 2;
+    if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+        off_t cur = lseek(fd, 0, SEEK_CUR);
+        if (cur < 0) cur = 0;
+        want = (size_t)(sb.st_size - cur) + 64;
+    }
+    if (q->staging.ensure(want + 32)) return -1;
+    size_t used = 0;
+    int b = 0;
+    bool busy[2] = {false, false};
+    for (;;) {
+        if (busy[b]) HIP_TRY(hipEventSynchronize(q->pinned_ev[b]));   // its H2D copy finished
+        busy[b] = false;
+        size_t got = 0;
+        while (got < AGH_STAGE_CHUNK) {
+            ssize_t r = read(fd, q->pinned[b] + got, AGH_STAGE_CHUNK - got);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                return fail("read failed: %s", strerror(errno));
+            }
+            if (r == 0) break;
+            got += (size_t)r;
+        }
+        if (got == 0) break;
+        if (used + got + 32 > q->staging.cap) {     // unknown length (pipe): grow, keep contents
+            dev_buf bigger;
+            if (bigger.ensure((used + got) * 2 + 64)) return -1;
+            HIP_TRY(hipStreamSynchronize(q->stage_stream));
+            if (used) HIP_TRY(hipMemcpy(bigger.p, q->staging.p, used, hipMemcpyDeviceToDevice));
+            q->staging.release();
+            q->staging = bigger;
+        }
+        HIP_TRY(hipMemcpyAsync((unsigned char *)q->staging.p + used, q->pinned[b], got,
+                               hipMemcpyHostToDevice, q->stage_stream));
+        HIP_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
+        busy[b] = true;
+        used += got;
+        b ^= 1;
+        if (got < AGH_STAGE_CHUNK) break;            // EOF inside this chunk
+    }
+    HIP_TRY(hipStreamSynchronize(q->stage_stream));
+    return scan_staged(q, used, flags, res, matches, cap);
+}
+
+// Scan again what the last agh_scan_fd / agh_scan_buffer staged (e.g. with a larger match
+// array after `truncated`, or with other flags) without touching the input again.
+extern "C" int agh_rescan_staged(agh_query *q, unsigned flags, agh_result *res,
+                                 agh_match *matches, size_t cap)
+{
+    if (!q || !res) return fail("null argument");
+    return scan_staged(q, q->staged_len, flags, res, matches, cap);
+}
+
+// Bytes of matched records of the most recent agh_scan_fd / agh_scan_buffer, concatenated in
+// the order given (no delimiters in between): device-side gather + one D2H copy.
+extern "C" int agh_fetch_records(agh_query *q, const agh_match *m, size_t n_matches,
+                                 unsigned char *out, size_t out_cap, size_t *out_len)
+{
+    if (!q || (!m && n_matches) || (!out && out_cap)) return fail("null argument");
+    std::vector<uint64_t> st(n_matches), en(n_matches), off(n_matches);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_matches; ++i) {
+        if (m[i].end < m[i].start || m[i].end > q->staged_len)
+            return fail("match %zu lies outside the staged text", i);
+        st[i] = m[i].start;
+        en[i] = m[i].end;
+        off[i] = total;
+        total += m[i].end - m[i].start;
+    }
+    if (out_len) *out_len = (size_t)total;
+    if (total > out_cap) return fail("output buffer too small (%llu bytes needed)",
+                                     (unsigned long long)total);
+    if (!n_matches || !total) return 0;
+    const size_t bytes = n_matches * sizeof(uint64_t);
+    if (q->match_start.ensure(bytes) || q->match_end.ensure(bytes) || q->match_off.ensure(bytes) ||
+        q->gather.ensure((size_t)total))
+        return -1;
+    HIP_TRY(hipMemcpy(q->match_start.p, st.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(q->match_end.p, en.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(q->match_off.p, off.data(), bytes, hipMemcpyHostToDevice));
+    agh_launch_gather_records(q->staging.p, (const uint64_t *)q->match_start.p,
+                              (const uint64_t *)q->match_end.p, (const uint64_t *)q->match_off.p,
+                              (uint32_t)n_matches, q->gather.p, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, q->gather.p, (size_t)total, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -62,3 +62,7 @@ void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_
                        uint32_t n_variants, uint32_t plant_period, uint32_t upper_permille,
                        unsigned long long *planted_dev, hipStream_t st);
 void agh_launch_exp(int exp, const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
+void agh_launch_match_bounds(const void *text, uint64_t n, uint32_t delim, const uint64_t *pos,
+                             uint32_t cnt, uint64_t *start, uint64_t *end, hipStream_t st);
+void agh_launch_gather_records(const void *text, const uint64_t *start, const uint64_t *end,
+                               const uint64_t *off, uint32_t cnt, void *out, hipStream_t st);

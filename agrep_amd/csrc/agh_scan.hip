@@ -160,6 +160,57 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
 }
 
 // ---------------------------------------------------------------------------------------
+// record output: bounds of matched records and their bytes, straight from the staged text
+// (what output()/s_output() derive on the CPU: agrep.c:3805-3956, sgrep.c:1274-1333)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_match_bounds(const uint8_t *__restrict__ text,
+                                                      uint64_t n, uint32_t delim,
+                                                      const uint64_t *__restrict__ pos,
+                                                      uint32_t cnt, uint64_t *__restrict__ start,
+                                                      uint64_t *__restrict__ end)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    uint64_t e = pos[i];
+    if (e > n) e = n;
+    uint64_t s = e;                             // 1 + last delimiter in front of e
+    while (s > 0 && text[s - 1] != delim) --s;
+    uint64_t en = e;                            // first delimiter at or after e
+    while (en < n && text[en] != delim) ++en;
+    start[i] = s;
+    end[i] = en;
+}
+
+// One wave per record: out[off[i] .. off[i] + len) = text[start[i] .. end[i]).
+__global__ __launch_bounds__(256) void k_gather_records(const uint8_t *__restrict__ text,
+                                                        const uint64_t *__restrict__ start,
+                                                        const uint64_t *__restrict__ end,
+                                                        const uint64_t *__restrict__ off,
+                                                        uint32_t cnt, uint8_t *__restrict__ out)
+{
+    const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    if (r >= cnt) return;
+    const uint64_t s = start[r], len = end[r] - s, o = off[r];
+    for (uint64_t b = (uint64_t)lane_id(); b < len; b += WAVE) out[o + b] = text[s + b];
+}
+
+void agh_launch_match_bounds(const void *text, uint64_t n, uint32_t delim, const uint64_t *pos,
+                             uint32_t cnt, uint64_t *start, uint64_t *end, hipStream_t st)
+{
+    if (!cnt) return;
+    hipLaunchKernelGGL(k_match_bounds, dim3((cnt + 255u) / 256u), dim3(256), 0, st,
+                       (const uint8_t *)text, n, delim, pos, cnt, start, end);
+}
+
+void agh_launch_gather_records(const void *text, const uint64_t *start, const uint64_t *end,
+                               const uint64_t *off, uint32_t cnt, void *out, hipStream_t st)
+{
+    if (!cnt) return;
+    hipLaunchKernelGGL(k_gather_records, dim3((cnt + 3u) / 4u), dim3(256), 0, st,
+                       (const uint8_t *)text, start, end, off, cnt, (uint8_t *)out);
+}
+
+// ---------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------
 template <typename WT, int K, int NCH, bool LEAN>

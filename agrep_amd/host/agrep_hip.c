@@ -162,8 +162,7 @@ static int parse_options(int argc, char **argv, char **files)
 struct filehit {
     agh_result res;
     agh_match *matches;
-    unsigned char *text;   /* only kept when records must be printed */
-    size_t len;
+    unsigned char *bytes;  /* matched records back to back (agh_fetch_records) */
 };
 
 static unsigned char *slurp(int fd, size_t *len)
@@ -192,40 +191,48 @@ static unsigned char *slurp(int fd, size_t *len)
     return buf;
 }
 
-/* One file through the device engines; count-only unless records have to be printed. */
+/* One file through the device engines; count-only unless records have to be printed.  The
+ * file is streamed to HBM by the library (pinned double buffering); only the matched
+ * records come back. */
 static int scan_one(agh_query *q, int fd, int want_records, struct filehit *out)
 {
+    size_t cap = 65536, total = 0;
     memset(out, 0, sizeof(*out));
     if (!want_records) {
         unsigned flags = opt.FILENAMEONLY ? AGH_FILENAMEONLY : AGH_COUNT;
         return agh_scan_fd(q, fd, flags, &out->res, NULL, 0);
     }
-    out->text = slurp(fd, &out->len);
-    if (!out->text) return -1;
-    {
-        size_t cap = 1024;
-        for (;;) {
-            out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
-            if (!out->matches) return -1;
-            if (agh_scan_buffer(q, out->text, out->len, 0, &out->res, out->matches, cap)) return -1;
-            if (!out->res.truncated) break;
-            free(out->matches);
-            cap = (size_t)out->res.n_matched + 16;
-        }
+    out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
+    if (!out->matches) return -1;
+    if (agh_scan_fd(q, fd, 0, &out->res, out->matches, cap)) return -1;
+    if (out->res.truncated) {                   /* more matches than guessed: scan the staged text again */
+        free(out->matches);
+        cap = (size_t)out->res.n_matched + 16;
+        out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
+        if (!out->matches) return -1;
+        if (agh_rescan_staged(q, 0, &out->res, out->matches, cap)) return -1;
     }
-    return 0;
+    if (agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, NULL, 0, &total) == 0 &&
+        total == 0)
+        return 0;                               /* nothing to print */
+    out->bytes = (unsigned char *)malloc(total ? total : 1);
+    if (!out->bytes) return -1;
+    return agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, out->bytes, total, &total);
 }
 
 /* agrep.c:3805-3956 output(): [file: ][N: ]record\n */
 static void print_records(const struct filehit *h, const char *name, int with_name)
 {
     uint64_t i;
+    size_t o = 0;
     for (i = 0; i < h->res.n_stored; i++) {
         const agh_match *m = &h->matches[i];
+        const size_t len = (size_t)(m->end - m->start);
         if (with_name) printf("%s: ", name);
         if (opt.LINENUM) printf("%llu: ", (unsigned long long)(m->index + 1));
-        fwrite(h->text + m->start, 1, (size_t)(m->end - m->start), stdout);
+        fwrite(h->bytes + o, 1, len, stdout);
         fputc('\n', stdout);
+        o += len;
     }
 }
 
@@ -264,7 +271,7 @@ static long run_pass(agh_query *q, char **files, int nfiles, int print, int coun
         /* -l counts files, everything else counts records (sgrep.c:1188, Appendix A) */
         total += opt.FILENAMEONLY ? (h.res.n_matched ? 1 : 0) : (long)h.res.n_matched;
         free(h.matches);
-        free(h.text);
+        free(h.bytes);
     }
     return total;
 }

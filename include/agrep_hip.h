@@ -113,9 +113,22 @@ int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q, int *filte
 int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t len, unsigned flags,
                     agh_result *res, agh_match *matches, size_t cap);
 
-/* File mode (fd >= 0, asearch.c:66-324 / sgrep.c:334-547): reads fd to EOF. */
+/* File mode (fd >= 0, asearch.c:66-324 / sgrep.c:334-547): reads fd to EOF through two pinned
+ * buffers (read() of chunk i+1 overlaps the H2D copy of chunk i); works for pipes too. */
 int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res, agh_match *matches,
                 size_t cap);
+
+/* Scan again the text the last agh_scan_fd / agh_scan_buffer staged in HBM (a pipe cannot be
+ * read twice): used after `truncated` with a larger match array. */
+int agh_rescan_staged(agh_query *q, unsigned flags, agh_result *res, agh_match *matches,
+                      size_t cap);
+
+/* Bytes of matched records of the most recent agh_scan_fd / agh_scan_buffer on this query,
+ * concatenated in the order of m[] (no delimiters in between) -- what output() prints
+ * (agrep.c:3930-3945) -- gathered on the device and copied back in one piece.  out_len
+ * receives the number of bytes (also when out_cap is too small, which fails). */
+int agh_fetch_records(agh_query *q, const agh_match *m, size_t n_matches, unsigned char *out,
+                      size_t out_cap, size_t *out_len);
 
 /* Text already resident in HBM (the measured configuration): dev_text is a device pointer,
  * 16-byte aligned, readable up to the next multiple of 16 bytes after len.  stream is a

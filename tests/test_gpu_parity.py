@@ -297,3 +297,43 @@ def test_segmented_scan_cuts_at_record_boundaries(agh, monkeypatch):
     assert parts.n_matched == whole.n_matched == whole_lean.n_matched == parts_lean.n_matched
     assert parts_full.n_matched == whole.n_matched
     assert parts.n_records == whole.n_records == parts_full.n_records
+
+
+def test_scan_fd_streams_files_and_pipes(agh, tmp_path):
+    """agh_scan_fd: pinned double-buffered staging (several 32 MiB chunks), regular file and
+    pipe; matched records come back through the device-side gather (agh_fetch_records)."""
+    import threading
+    text, _ = O.corpus((80 << 20) // 4096, seed=31, variants=O.VARIANTS_C2, plant_period=3000)
+    tb = text.tobytes()
+    want_n, want_recs = O.asearch(O.PATTERN_C2, 2, tb, cap=100000)
+    p = tmp_path / "big.txt"
+    p.write_bytes(tb)
+    with agh.Query(O.PATTERN_C2, 2) as q:
+        fd = os.open(str(p), os.O_RDONLY)
+        try:
+            res, ms = q.scan_fd(fd, cap=100000)
+        finally:
+            os.close(fd)
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == (want_n, want_recs)
+        recs = q.fetch_records(ms)
+        assert recs == [tb[s:e] for s, e in want_recs]
+        # too small a match array: truncated, then the staged text is scanned again
+        res_t, ms_t = q.scan_fd(os.open(str(p), os.O_RDONLY), cap=5)
+        assert res_t.truncated and res_t.n_matched == want_n and len(ms_t) == 5
+        # a pipe: length unknown in advance, the device buffer grows
+        r, w = os.pipe()
+
+        def feed():
+            with os.fdopen(w, "wb") as f:
+                for i in range(0, len(tb), 1 << 20):
+                    f.write(tb[i:i + (1 << 20)])
+        th = threading.Thread(target=feed)
+        th.start()
+        try:
+            res_p, ms_p = q.scan_fd(r, cap=100000)
+        finally:
+            th.join()
+            os.close(r)
+        assert (res_p.n_matched, [(s, e) for s, e, _ in ms_p]) == (want_n, want_recs)
+        res_c, _ = q.scan_fd(os.open(str(p), os.O_RDONLY), flags=agh.COUNT)
+        assert res_c.n_matched == want_n
