@@ -91,7 +91,7 @@ struct agh_query {
     void *d_mask = nullptr;             // 256 x uint32_t or uint64_t
     uint8_t *d_ftab = nullptr;          // AGH_FT_SIZE bytes
     // per-query workspace (grown lazily, reused across scans)
-    dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, hashset, staging, match_pos,
+    dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, hashset, dbm, staging, match_pos,
         match_rec, match_start, match_end, match_off, gather;
     uint64_t staged_len = 0;            // bytes of the text currently held in `staging`
     hipStream_t stage_stream = nullptr; // H2D copies of agh_scan_fd
@@ -216,10 +216,6 @@ extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, 
         fail("delimiter length %d outside 1..%d", dlen, AGH_MAX_DELIM);
         return nullptr;
     }
-    if (dlen != 1) {
-        fail("multi-byte delimiters are not implemented on the device path yet");
-        return nullptr;
-    }
     agh_query *q = new agh_query();
     q->m = m;
     q->k = D;
@@ -272,10 +268,6 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
             return nullptr;
         }
     }
-    if (D_length != 1) {
-        fail("multi-byte delimiters are not implemented on the device path yet");
-        return nullptr;
-    }
     agh_query *q = new agh_query();
     q->m = m;
     q->k = D;
@@ -311,6 +303,7 @@ extern "C" void agh_query_free(agh_query *q)
     q->wave_cand.release();
     q->bitmap.release();
     q->hashset.release();
+    q->dbm.release();
     q->staging.release();
     q->match_pos.release();
     q->match_rec.release();
@@ -383,13 +376,31 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     agh_dev_query dq;
     dq.m = q->m;
     dq.k = q->k;
-    dq.delim = q->delim[0];
+    dq.delim = q->delim[q->dlen - 1];           // the byte that completes a delimiter
+    dq.dlen = (uint32_t)q->dlen;
+    memset(dq.dbytes, 0, sizeof(dq.dbytes));
+    memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
     dq.fq = q->fq;
     dq.fh = q->fh;
     dq.qmask = q->qmask;
     dq.fold = q->fold;
     dq.head_byte = head_byte;
     dq.tail_virtual = tail_virtual;
+
+    // ---- multi-byte delimiter: mark where (selected) delimiter occurrences end --------------
+    const uint64_t *d_dbm = nullptr;
+    if (q->dlen > 1) {
+        const uint64_t n_words = (n + 63) / 64 + 4;     // readers may touch a few words past n
+        if (q->dbm.ensure(n_words * sizeof(uint64_t))) return -1;
+        HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+        agh_launch_delim_bitmap(d_text, n, dq, (uint64_t *)q->dbm.p, n_words, q->d_counters, st);
+        HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (q->h_counters[AGH_C_DELIM_CHAIN])
+            return fail("a run of overlapping delimiter occurrences exceeds 4 KiB (unsupported)");
+        d_dbm = (const uint64_t *)q->dbm.p;
+    }
 
     // ---- lean pipeline: count-only scans (-c, -l) of a filterable query -------------------
     // No delimiter census, no record numbers: the verifier identifies a matched record by the
@@ -422,6 +433,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         sa.wave_cand = (uint32_t *)q->wave_cand.p;
         sa.counters = q->d_counters;
         sa.chunk_totals = q->d_chunk_totals;
+        sa.dbm = d_dbm;
         sa.lean = 1;
         sa.ev_begin = q->ev2;
         sa.ev_end = q->ev3;
@@ -440,6 +452,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.wave_cand = (const uint32_t *)q->wave_cand.p;
         va.nw = (uint32_t)nw;
         va.wave_prefix = (const uint32_t *)q->wave_totals.p;
+        va.dbm = d_dbm;
         agh_launch_verify_lean(va, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)q->wave_cand.p, (uint32_t)nw, q->d_counters, st);
@@ -508,6 +521,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.wave_cand = (uint32_t *)q->wave_cand.p;
             sa.counters = q->d_counters;
             sa.chunk_totals = q->d_chunk_totals;
+            sa.dbm = d_dbm;
             sa.lean = 0;
             sa.ev_begin = q->ev2;
             sa.ev_end = q->ev3;
@@ -526,6 +540,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.strip_prefix = (const uint32_t *)q->strip_prefix.p;
         va.wave_prefix = (const uint32_t *)q->wave_totals.p;
         va.n_strips = (uint32_t)n_strips;
+        va.dbm = d_dbm;
         va.mk.bitmap = (uint32_t *)q->bitmap.p;
         va.mk.bitmap_bits = (uint32_t)std::min<uint64_t>(bm_words * 32, 0xffffffffu);
         va.mk.counters = q->d_counters;
@@ -564,7 +579,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             bits_hint = (uint64_t)n_delims + 1024;
             continue;
         }
-        out->records = (uint64_t)n_delims + (q->h_counters[AGH_C_LASTBYTE] != q->delim[0] ? 1u : 0u);
+        out->records = (uint64_t)n_delims +
+                       (q->h_counters[AGH_C_LASTBYTE] != q->delim[q->dlen - 1] ? 1u : 0u);
         out->candidates = use_filter ? q->h_counters[AGH_C_CAND] : 0;
         out->engine = use_filter ? AGH_ENGINE_FILTER : AGH_ENGINE_FULLSCAN;
         out->matched = q->h_counters[AGH_C_MATCHED];
@@ -606,6 +622,9 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
     bool first = true;
     while (off < len) {
         uint64_t end = len;
+        if (end - off > AGH_SEG_MAX && q->dlen > 1)
+            return fail("multi-byte delimiters: inputs above the %llu-byte segment limit are not "
+                        "supported yet", (unsigned long long)AGH_SEG_MAX);
         if (end - off > AGH_SEG_MAX) {
             uint64_t want = (off + AGH_SEG_MAX) & ~(uint64_t)15;
             if (find_cut(q, base, off, want, st, &end)) return -1;
@@ -656,9 +675,14 @@ static int collect_matches(agh_query *q, uint64_t len, const agh_result *res, ag
     if (!ns) return 0;
     if (q->match_start.ensure(ns * sizeof(uint64_t))) return -1;
     if (q->match_end.ensure(ns * sizeof(uint64_t))) return -1;
-    agh_launch_match_bounds(q->staging.p, len, q->delim[0], (const uint64_t *)q->match_pos.p,
-                            (uint32_t)ns, (uint64_t *)q->match_start.p,
-                            (uint64_t *)q->match_end.p, nullptr);
+    agh_dev_query dq;
+    memset(&dq, 0, sizeof(dq));
+    dq.delim = q->delim[q->dlen - 1];
+    dq.dlen = (uint32_t)q->dlen;
+    memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
+    agh_launch_match_bounds(q->staging.p, len, dq, (const uint64_t *)q->dbm.p,
+                            (const uint64_t *)q->match_pos.p, (uint32_t)ns,
+                            (uint64_t *)q->match_start.p, (uint64_t *)q->match_end.p, nullptr);
     HIP_TRY(hipGetLastError());
     std::vector<uint64_t> st(ns), en(ns);
     std::vector<uint32_t> rec(ns);

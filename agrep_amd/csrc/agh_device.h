@@ -33,14 +33,17 @@ enum agh_counter {
     AGH_C_LASTBYTE = 5,  // text[n-1]
     AGH_C_CHECK = 6,     // read-probe checksum sink
     AGH_C_BM_OVERFLOW = 7, // a record number did not fit the record bitmap
-    AGH_C_LEAN_FALLBACK = 8, // lean scan gave up (record start too far back / hash set full)
+    AGH_C_LEAN_FALLBACK = 8,
+    AGH_C_DELIM_CHAIN = 9, // multi-byte delimiter: overlapping occurrences chain > 4 KiB (unsupported) // lean scan gave up (record start too far back / hash set full)
     AGH_C_COUNT = 12
 };
 
 struct agh_dev_query {
     int32_t m;          // pattern positions
     int32_t k;          // errors
-    uint32_t delim;     // single-byte delimiter
+    uint32_t delim;     // the delimiter byte (last byte of a multi-byte delimiter)
+    uint32_t dlen;      // delimiter length in bytes; > 1: delimiter ends come from the bitmap
+    uint8_t dbytes[8];  // the delimiter
     int32_t fq;         // filter: sample length in bytes (1..4), 0 = no filter
     int32_t fh;         // filter: sample stride in bytes (4, 8 or 16)
     uint32_t qmask;     // low fq bytes

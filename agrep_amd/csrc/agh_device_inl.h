@@ -55,3 +55,64 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
     return v;
 }
 
+
+// ---- multi-byte delimiters: bit i of the delimiter bitmap <=> a (selected, i.e. leftmost
+// non-overlapping: asearch.c:54-57 D_Mask) delimiter occurrence ENDS at text byte i ----------
+__device__ __forceinline__ uint32_t dbm_bit(const uint64_t *__restrict__ dbm, uint64_t pos)
+{
+    return (uint32_t)(dbm[pos >> 6] >> (pos & 63)) & 1u;
+}
+
+// 64 bitmap bits starting at bit position pos (any alignment)
+__device__ __forceinline__ uint64_t dbm_bits64(const uint64_t *__restrict__ dbm, uint64_t pos)
+{
+    const uint64_t w = pos >> 6;
+    const uint32_t sh = (uint32_t)(pos & 63);
+    const uint64_t lo = dbm[w];
+    if (sh == 0) return lo;
+    return (lo >> sh) | (dbm[w + 1] << (64 - sh));
+}
+
+// positions j of the delimiter whose byte equals c (bit j)
+__device__ __forceinline__ uint32_t delim_class(const agh_dev_query &q, uint32_t c)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j)
+        if (j < q.dlen && q.dbytes[j] == c) m |= 1u << j;
+    return m;
+}
+
+// number of set bitmap bits at positions [a, b)
+__device__ __forceinline__ uint32_t dbm_count(const uint64_t *__restrict__ dbm, uint64_t a,
+                                              uint64_t b)
+{
+    uint32_t c = 0;
+    while (a < b) {
+        const uint64_t w = dbm[a >> 6] >> (a & 63);
+        const uint64_t take = 64 - (a & 63) < b - a ? 64 - (a & 63) : b - a;
+        c += (uint32_t)__popcll(take == 64 ? w : (w & ((1ull << take) - 1ull)));
+        a += take;
+    }
+    return c;
+}
+
+// position of the last set bit below pos, looking back at most cap bits; -1: none down to
+// bit 0; -2: none within cap
+__device__ __forceinline__ int64_t dbm_prev(const uint64_t *__restrict__ dbm, uint64_t pos,
+                                            uint64_t cap)
+{
+    const uint64_t stop = pos > cap ? pos - cap : 0;
+    while (pos > stop) {
+        const uint64_t wi = (pos - 1) >> 6;
+        uint64_t w = dbm[wi];
+        const uint32_t top = (uint32_t)((pos - 1) & 63);        // highest bit still in range
+        if (top < 63) w &= (1ull << (top + 1)) - 1ull;
+        if (w) {
+            const uint64_t at = (wi << 6) + 63 - (uint64_t)__clzll((long long)w);
+            return at >= stop ? (int64_t)at : (stop ? -2 : -1);
+        }
+        pos = wi << 6;
+    }
+    return stop ? -2 : -1;
+}

@@ -27,6 +27,7 @@ struct agh_sweep_args {
     uint64_t *cand;          // nw slices of AGH_SLICE_CAP entries: (record count << 32) | dword
     uint32_t *wave_cand;     // nw candidate counts
     uint32_t *chunk_totals;  // 2 * 64 scratch words of the prefix scan
+    const uint64_t *dbm;     // multi-byte delimiters: delimiter-end bitmap (else NULL)
     uint32_t *counters;
     int lean;                // 1: no delimiter census (count-only scans)
     hipEvent_t ev_begin;     // optional: recorded right before / after the k_sweep launch
@@ -44,6 +45,7 @@ struct agh_scan_args {
     uint32_t nw;
     const uint32_t *strip_prefix;
     const uint32_t *wave_prefix;
+    const uint64_t *dbm;     // multi-byte delimiters: delimiter-end bitmap (else NULL)
     uint32_t n_strips;
     agh_marks mk;
 };
@@ -62,7 +64,10 @@ void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_
                        uint32_t n_variants, uint32_t plant_period, uint32_t upper_permille,
                        unsigned long long *planted_dev, hipStream_t st);
 void agh_launch_exp(int exp, const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
-void agh_launch_match_bounds(const void *text, uint64_t n, uint32_t delim, const uint64_t *pos,
-                             uint32_t cnt, uint64_t *start, uint64_t *end, hipStream_t st);
+void agh_launch_match_bounds(const void *text, uint64_t n, const agh_dev_query &q,
+                             const uint64_t *dbm, const uint64_t *pos, uint32_t cnt,
+                             uint64_t *start, uint64_t *end, hipStream_t st);
 void agh_launch_gather_records(const void *text, const uint64_t *start, const uint64_t *end,
                                const uint64_t *off, uint32_t cnt, void *out, hipStream_t st);
+void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &q, uint64_t *dbm,
+                             uint64_t n_words, uint32_t *counters, hipStream_t st);

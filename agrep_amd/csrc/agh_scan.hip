@@ -7,14 +7,15 @@
 // ---------------------------------------------------------------------------------------
 // verify: one workgroup per AGH_VGROUP sweep-wave slices, one lane per candidate sample
 // ---------------------------------------------------------------------------------------
-template <typename WT, int K, int NCH, bool LEAN>
+template <typename WT, int K, int NCH, bool LEAN, bool MB>
 __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text, uint64_t n,
                                                 agh_dev_query q,
                                                 const WT *__restrict__ mask_g,
                                                 const uint64_t *__restrict__ cand,
                                                 const uint32_t *__restrict__ wave_cand,
                                                 const uint32_t *__restrict__ wave_prefix,
-                                                uint32_t nw, agh_marks mk)
+                                                uint32_t nw, agh_marks mk,
+                                                const uint64_t *__restrict__ dbm)
 {
     __shared__ WT lmask[256];
     __shared__ uint32_t pre[AGH_VGROUP + 1];
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
     const uint32_t total = pre[AGH_VGROUP];
     if (total == 0) return;
     VerifyCtx<WT, K> c;
-    verify_ctx_init<WT, K>(c, text, n, q, lmask, mk);
+    verify_ctx_init<WT, K>(c, text, n, q, lmask, mk, dbm);
 
     for (uint32_t ci = threadIdx.x; ci < total; ci += 256) {
         uint32_t sl = 0;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
         for (uint32_t i = 1; i < AGH_VGROUP; ++i) sl += (pre[i] <= ci) ? 1u : 0u;
         const uint32_t w = g0 + sl;
         const uint64_t ent = cand[(uint64_t)w * AGH_SLICE_CAP + (ci - pre[sl])];
-        verify_candidate<WT, K, NCH, LEAN>(c, ent, LEAN ? 0u : wave_prefix[w]);
+        verify_candidate<WT, K, NCH, LEAN, MB>(c, ent, LEAN ? 0u : wave_prefix[w]);
     }
 }
 
@@ -54,8 +55,10 @@ template <typename WT, int K>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q,
     const WT *__restrict__ mask_g, const uint32_t *__restrict__ strip_prefix,
-    const uint32_t *__restrict__ wave_prefix, uint32_t n_strips, agh_marks mk)
+    const uint32_t *__restrict__ wave_prefix, uint32_t n_strips, agh_marks mk,
+    const uint64_t *__restrict__ dbm)
 {
+    const bool mb = q.dlen > 1;                 // delimiter ends come from the bitmap
     // slot 0 = the 256 bytes in front of the tile (warm-up halo), slots 1..256 = lane chunks
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     WT *lmask = reinterpret_cast<WT *>(lds);
@@ -90,7 +93,9 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
         uint32_t my_delims = 0;
         uint64_t ce = cs + AGH_FS_CHUNK;
         if (ce > n) ce = n;
-        if (cs < n) {
+        if (cs < n && mb) {
+            my_delims = dbm_count(dbm, cs, ce);
+        } else if (cs < n) {
             const uint32_t len = (uint32_t)(ce - cs);
             for (uint32_t i = 0; i < (len >> 4); ++i)
                 my_delims += delims_in(*reinterpret_cast<const uint4 *>(mine + i * 16), dd);
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
             for (uint32_t i = 0; i < warm; ++i) {
                 const uint32_t c = halo[i];
                 A.step(lmask[c], finalbit);
-                if (c == q.delim) {
+                if (mb ? dbm_bit(dbm, cs - warm + i) != 0 : c == q.delim) {
                     A.reset();
                     A.step(lmask[c], finalbit);
                 }
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
                 seen = true;
                 mark_record(mk, rec, cs + i);
             }
-            if (c == q.delim) {
+            if (mb ? dbm_bit(dbm, cs + i) != 0 : c == q.delim) {
                 A.reset();
                 ++rec;
                 seen = false;
@@ -151,11 +156,8 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
                 }
             }
         }
-        if (ce == n && q.tail_virtual) {        // asearch.c:87-91
-            if (A.step(lmask[q.delim], finalbit) && !seen) mark_record(mk, rec, n);
-            A.reset();
-            if (A.step(lmask[q.delim], finalbit)) mark_record(mk, rec + 1u, n);
-        }
+        if (ce == n && q.tail_virtual)          // asearch.c:87-91
+            feed_virtual_tail<WT, K, false>(text, n, q, lmask, dbm, A, seen, rec, 0, mk);
     }
 }
 
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
 // (what output()/s_output() derive on the CPU: agrep.c:3805-3956, sgrep.c:1274-1333)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_match_bounds(const uint8_t *__restrict__ text,
-                                                      uint64_t n, uint32_t delim,
+                                                      uint64_t n, agh_dev_query q,
+                                                      const uint64_t *__restrict__ dbm,
                                                       const uint64_t *__restrict__ pos,
                                                       uint32_t cnt, uint64_t *__restrict__ start,
                                                       uint64_t *__restrict__ end)
@@ -173,10 +176,19 @@ __global__ __launch_bounds__(256) void k_match_bounds(const uint8_t *__restrict_
     if (i >= cnt) return;
     uint64_t e = pos[i];
     if (e > n) e = n;
-    uint64_t s = e;                             // 1 + last delimiter in front of e
-    while (s > 0 && text[s - 1] != delim) --s;
-    uint64_t en = e;                            // first delimiter at or after e
-    while (en < n && text[en] != delim) ++en;
+    uint64_t s = e, en = e;
+    if (q.dlen > 1) {
+        // record = (end of the last delimiter in front of e, start of the next delimiter]
+        const int64_t d = dbm_prev(dbm, e, ~0ull);
+        s = d >= 0 ? (uint64_t)d + 1 : 0;
+        while (en < n && !dbm_bit(dbm, en)) ++en;      // en = end byte of the next delimiter
+        if (en < n) en = en + 1 >= q.dlen ? en + 1 - q.dlen : 0;
+        else en = virtual_close_start(text, n, q, dbm);   // closed by the appended delimiter
+        if (en < s) en = s;
+    } else {
+        while (s > 0 && text[s - 1] != q.delim) --s;   // 1 + last delimiter in front of e
+        while (en < n && text[en] != q.delim) ++en;    // first delimiter at or after e
+    }
     start[i] = s;
     end[i] = en;
 }
@@ -194,12 +206,13 @@ __global__ __launch_bounds__(256) void k_gather_records(const uint8_t *__restric
     for (uint64_t b = (uint64_t)lane_id(); b < len; b += WAVE) out[o + b] = text[s + b];
 }
 
-void agh_launch_match_bounds(const void *text, uint64_t n, uint32_t delim, const uint64_t *pos,
-                             uint32_t cnt, uint64_t *start, uint64_t *end, hipStream_t st)
+void agh_launch_match_bounds(const void *text, uint64_t n, const agh_dev_query &q,
+                             const uint64_t *dbm, const uint64_t *pos, uint32_t cnt,
+                             uint64_t *start, uint64_t *end, hipStream_t st)
 {
     if (!cnt) return;
     hipLaunchKernelGGL(k_match_bounds, dim3((cnt + 255u) / 256u), dim3(256), 0, st,
-                       (const uint8_t *)text, n, delim, pos, cnt, start, end);
+                       (const uint8_t *)text, n, q, dbm, pos, cnt, start, end);
 }
 
 void agh_launch_gather_records(const void *text, const uint64_t *start, const uint64_t *end,
@@ -218,9 +231,14 @@ static void launch_verify_n(const agh_scan_args &a, hipStream_t st)
 {
     uint32_t blocks = (a.nw + AGH_VGROUP - 1u) / AGH_VGROUP;
     if (!blocks) return;
-    hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN>), dim3(blocks), dim3(256), 0, st,
-                       (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
-                       a.wave_cand, a.wave_prefix, a.nw, a.mk);
+    if (a.q.dlen > 1)
+        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, true>), dim3(blocks), dim3(256), 0, st,
+                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
+                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm);
+    else
+        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false>), dim3(blocks), dim3(256), 0, st,
+                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
+                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm);
 }
 
 template <typename WT, int K, bool LEAN>
@@ -248,7 +266,7 @@ static void launch_fullscan_t(const agh_scan_args &a, hipStream_t st)
     const size_t lds = 256 * sizeof(WT) + (size_t)(AGH_FS_THREADS + 1) * AGH_FS_SLOT;
     hipLaunchKernelGGL((k_fullscan<WT, K>), dim3(blocks), dim3(AGH_FS_THREADS), lds, st,
                        (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.strip_prefix,
-                       a.wave_prefix, a.n_strips, a.mk);
+                       a.wave_prefix, a.n_strips, a.mk, a.dbm);
 }
 
 template <typename WT>

@@ -34,7 +34,8 @@
 // MODE bit 0: the query folds ASCII case (OR 0x20 into every sampled byte);
 // MODE bit 1: 4-byte samples (no mask needed, 32-bit hash) instead of <= 3-byte samples;
 // MODE bit 2: lean sweep -- no delimiter census (count-only scans identify a record by the
-//             offset of its first byte, found by the verifier, instead of by its number).
+//             offset of its first byte, found by the verifier, instead of by its number);
+// MODE bit 3: multi-byte delimiter -- the census reads the delimiter-end bitmap.
 template <int MODE>
 __device__ __forceinline__ uint32_t probe(uint32_t w, const agh_dev_query &q,
                                           const uint8_t *ftab)
@@ -52,9 +53,15 @@ __device__ __forceinline__ uint32_t probe(uint32_t w, const agh_dev_query &q,
 template <int H, int MODE>
 __device__ __forceinline__ void sweep_chunk(uint4 v, uint32_t dd, const agh_dev_query &q,
                                             const uint8_t *ftab, uint32_t &acc,
-                                            uint32_t &hits, int bitbase)
+                                            uint32_t &hits, int bitbase, uint32_t dbits16 = 0)
 {
-    if (!(MODE & 4)) acc += nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
+    if (MODE & 8) {
+        // multi-byte delimiter: the chunk's 16 delimiter-end bits come from the bitmap; keep
+        // the "128 minus delimiters" convention of the SWAR census
+        if (!(MODE & 4)) acc += 128u - (uint32_t)__popc(dbits16 & 0xffffu);
+    } else if (!(MODE & 4)) {
+        acc += nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
+    }
     if (H > 0) {
         hits |= probe<MODE>(v.x, q, ftab) << bitbase;
         if (H <= 8) hits |= probe<MODE>(v.z, q, ftab) << (bitbase + 2);
@@ -139,7 +146,7 @@ __device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, const
 // One supertile = 4 consecutive strips (4 KiB) of one wave: census, probes, prefix, emit.
 template <int H, int MODE>
 __device__ __forceinline__ void sweep_supertile(uint4 v0, uint4 v1, uint4 v2, uint4 v3,
-                                                uint64_t s, int lane, uint32_t dd,
+                                                uint2 db, uint64_t s, int lane, uint32_t dd,
                                                 const agh_dev_query &q, const uint8_t *ftab,
                                                 uint32_t *__restrict__ strip_prefix,
                                                 uint64_t *cq, uint32_t &qn,
@@ -147,10 +154,10 @@ __device__ __forceinline__ void sweep_supertile(uint4 v0, uint4 v1, uint4 v2, ui
                                                 uint32_t &ncand, uint32_t *counters)
 {
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, hits = 0;
-    sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0);
-    sweep_chunk<H, MODE>(v1, dd, q, ftab, a1, hits, 4);
-    sweep_chunk<H, MODE>(v2, dd, q, ftab, a2, hits, 8);
-    sweep_chunk<H, MODE>(v3, dd, q, ftab, a3, hits, 12);
+    sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0, db.x);
+    sweep_chunk<H, MODE>(v1, dd, q, ftab, a1, hits, 4, db.x >> 16);
+    sweep_chunk<H, MODE>(v2, dd, q, ftab, a2, hits, 8, db.y);
+    sweep_chunk<H, MODE>(v3, dd, q, ftab, a3, hits, 12, db.y >> 16);
     if (MODE & 4) {
         if (__ballot(hits != 0)) {
             const uint32_t rc[4] = {0u, 0u, 0u, 0u};
@@ -197,7 +204,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
                                                  uint32_t *__restrict__ wave_totals,
                                                  uint64_t *__restrict__ cand,
                                                  uint32_t *__restrict__ wave_cand,
-                                                 uint32_t *__restrict__ counters)
+                                                 uint32_t *__restrict__ counters,
+                                                 const uint16_t *__restrict__ dbm16)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ftab[H > 0 ? AGH_FT_SIZE : 16];
     __shared__ uint64_t cq_all[H > 0 ? (BLOCK / WAVE) * AGH_CQ_LEN : 1];
@@ -227,33 +235,44 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
     uint64_t *slice = cand + w * AGH_SLICE_CAP;
     uint64_t s = s0;
 
+    // delimiter-end bits of the lane's four chunks (multi-byte delimiters + census only)
+    auto dbits = [&](uint64_t st) -> uint2 {
+        if (!(MODE & 8) || (MODE & 4)) return make_uint2(0u, 0u);
+        const uint16_t *d = dbm16 + st * 64 + lane;
+        return make_uint2((uint32_t)d[0] | ((uint32_t)d[64] << 16),
+                          (uint32_t)d[128] | ((uint32_t)d[192] << 16));
+    };
     if (PREFETCH) {
         if (s + 4 <= s1) {
             const uint4 *p = text + s * 64 + lane;
             uint4 c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192];
+            uint2 cd = dbits(s);
             for (; s + 8 <= s1; s += 4) {
                 const uint4 *pn = text + (s + 4) * 64 + lane;
                 uint4 n0 = pn[0], n1 = pn[64], n2 = pn[128], n3 = pn[192];
-                sweep_supertile<H, MODE>(c0, c1, c2, c3, s, lane, dd, q, ftab, strip_prefix, cq, qn,
-                                   slice, run, ncand, counters);
+                uint2 nd = dbits(s + 4);
+                sweep_supertile<H, MODE>(c0, c1, c2, c3, cd, s, lane, dd, q, ftab, strip_prefix,
+                                         cq, qn, slice, run, ncand, counters);
                 c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+                cd = nd;
             }
-            sweep_supertile<H, MODE>(c0, c1, c2, c3, s, lane, dd, q, ftab, strip_prefix, cq, qn, slice,
-                               run, ncand, counters);
+            sweep_supertile<H, MODE>(c0, c1, c2, c3, cd, s, lane, dd, q, ftab, strip_prefix, cq,
+                                     qn, slice, run, ncand, counters);
             s += 4;
         }
     } else {
         for (; s + 4 <= s1; s += 4) {
             const uint4 *p = text + s * 64 + lane;
             uint4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];   // 4 x 1 KiB in flight
-            sweep_supertile<H, MODE>(v0, v1, v2, v3, s, lane, dd, q, ftab, strip_prefix, cq, qn, slice,
-                               run, ncand, counters);
+            sweep_supertile<H, MODE>(v0, v1, v2, v3, dbits(s), s, lane, dd, q, ftab,
+                                     strip_prefix, cq, qn, slice, run, ncand, counters);
         }
     }
     for (; s < s1; ++s) {                       // < 4 strips left in the range
         uint4 v0 = text[s * 64 + lane];
         uint32_t a0 = 0, hits = 0;
-        sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0);
+        sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0,
+                             ((MODE & 8) && !(MODE & 4)) ? (uint32_t)dbm16[s * 64 + lane] : 0u);
         if (MODE & 4) {
             if (__ballot(hits != 0)) {
                 const uint32_t rc[4] = {0u, 0u, 0u, 0u};
@@ -289,7 +308,8 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
                                                    uint32_t *__restrict__ wave_totals,
                                                    uint64_t *__restrict__ cand,
                                                    uint32_t *__restrict__ wave_cand,
-                                                   uint32_t *__restrict__ counters)
+                                                   uint32_t *__restrict__ counters,
+                                                   const uint16_t *__restrict__ dbm16)
 {
     __shared__ uint64_t cq[AGH_CQ_LEN];
     uint32_t qn = 0;
@@ -304,7 +324,8 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
         if (off + 16 > n) v = mask_tail(v, (int)(n - off), fill4);
     }
     uint32_t a0 = 0, hits = 0;
-    sweep_chunk<H, MODE>(v, dd, q, ftab_g, a0, hits, 0);      // table straight from global/L2
+    sweep_chunk<H, MODE>(v, dd, q, ftab_g, a0, hits, 0,       // table straight from global/L2
+                         ((MODE & 8) && !(MODE & 4) && off < n) ? (uint32_t)dbm16[off >> 4] : 0u);
     const uint32_t sc0 = (MODE & 4) ? 0u : wave_sum_to_lane63(a0);
     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)sc0, 63);
     const uint32_t z = (MODE & 4) ? 0u : 8192u - p0;
@@ -328,6 +349,70 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
         if (H == 0) strip_prefix[s] = before;
         wave_totals[w] = before + z;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Multi-byte delimiters (-d 'From ', -d '$$'): one pass marks where delimiter occurrences end,
+// leftmost and non-overlapping exactly as the in-word delimiter automaton of the reference
+// selects them (asearch.c:54-57, 175-186: after a detection the delimiter positions are
+// cleared, so an occurrence overlapping a selected one is skipped).  One lane per 64 text
+// bytes; a lane restarts the little shift-AND automaton at a point no occurrence straddles
+// (for delimiters without a border that is simply dlen-1 bytes in front of its bytes).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool delim_occurs_at(const uint8_t *__restrict__ text, uint64_t n,
+                                                uint64_t s, const agh_dev_query &q)
+{
+    if (s + q.dlen > n) return false;
+    for (uint32_t j = 0; j < q.dlen; ++j)
+        if (text[s + j] != q.dbytes[j]) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_delim_bitmap(const uint8_t *__restrict__ text,
+                                                      uint64_t n, agh_dev_query q,
+                                                      uint64_t *__restrict__ dbm,
+                                                      uint64_t n_words,
+                                                      uint32_t *__restrict__ counters)
+{
+    const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    const uint64_t b = wi * 64;
+    if (b >= n) { dbm[wi] = 0; return; }
+    // restart point: no occurrence may start before r and end at or after r
+    uint64_t r = b >= q.dlen - 1 ? b - (q.dlen - 1) : 0;
+    uint32_t steps = 0;
+    for (;;) {
+        bool covered = false;
+        if (r > 0) {
+            const uint64_t lo = r >= q.dlen - 1 ? r - (q.dlen - 1) : 0;
+            for (uint64_t st = lo; st < r && !covered; ++st)
+                covered = delim_occurs_at(text, n, st, q) && st + q.dlen > r;
+        }
+        if (!covered) break;
+        --r;
+        if (++steps > 4096u) { counters[AGH_C_DELIM_CHAIN] = 1u; break; }
+    }
+    // the virtual byte in front of the text (asearch.c:69-78) takes part in delimiter matching
+    uint32_t ds = r == 0 ? (delim_class(q, q.head_byte) & 1u) : 0u;
+    uint64_t out = 0;
+    const uint32_t endbit = 1u << (q.dlen - 1);
+    const uint64_t hi = b + 64 < n ? b + 64 : n;
+    for (uint64_t i = r; i < hi; ++i) {
+        ds = ((ds << 1) | 1u) & delim_class(q, text[i]);
+        if (ds & endbit) {
+            if (i >= b) out |= 1ull << (i - b);
+            ds = 0;
+        }
+    }
+    dbm[wi] = out;
+}
+
+void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &q, uint64_t *dbm,
+                             uint64_t n_words, uint32_t *counters, hipStream_t st)
+{
+    if (!n_words) return;
+    hipLaunchKernelGGL(k_delim_bitmap, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, st,
+                       (const uint8_t *)text, n, q, dbm, n_words, counters);
 }
 
 // Exclusive scan of the per-wave delimiter totals, two small multi-block kernels:
@@ -375,7 +460,8 @@ __global__ __launch_bounds__(256) void k_scan_fixup(uint32_t *__restrict__ wave_
                                                     uint32_t nw,
                                                     const uint32_t *__restrict__ chunk_totals,
                                                     uint32_t n_chunks, const uint8_t *text,
-                                                    uint64_t n, uint32_t *__restrict__ counters)
+                                                    uint64_t n, uint32_t *__restrict__ counters,
+                                                    const uint64_t *__restrict__ dbm)
 {
     __shared__ uint32_t sh_before;
     if (threadIdx.x < WAVE) {
@@ -390,7 +476,10 @@ __global__ __launch_bounds__(256) void k_scan_fixup(uint32_t *__restrict__ wave_
             if (blockIdx.x == 0) {
                 counters[AGH_C_NDELIM] = dall;
                 counters[AGH_C_CAND] = call;
-                counters[AGH_C_LASTBYTE] = n ? (uint32_t)text[n - 1] : 0xffffffffu;
+                // does the text end with a delimiter?  (multi-byte: a selected occurrence)
+                if (!n) counters[AGH_C_LASTBYTE] = 0xffffffffu;
+                else if (dbm) counters[AGH_C_LASTBYTE] = dbm_bit(dbm, n - 1) ? (uint32_t)text[n - 1] : 0xffffffffu;
+                else counters[AGH_C_LASTBYTE] = (uint32_t)text[n - 1];
             }
         }
     }
@@ -588,13 +677,14 @@ static void launch_sweep_hm(const agh_sweep_args &a, hipStream_t st)
         hipLaunchKernelGGL((k_sweep<H, MODE, AGH_SWEEP_BLOCK, true>), dim3(blocks),
                            dim3(AGH_SWEEP_BLOCK), 0, st, (const uint4 *)a.text, n_full, a.q,
                            a.ftab, a.strip_prefix, a.wave_totals, a.cand, a.wave_cand,
-                           a.counters);
+                           a.counters, (const uint16_t *)a.dbm);
     }
     if (a.ev_end) (void)hipEventRecord(a.ev_end, st);
     if (a.n & (AGH_STRIP - 1))
         hipLaunchKernelGGL((k_sweep_tail<H, MODE>), dim3(1), dim3(64), 0, st,
                            (const uint4 *)a.text, a.n, a.q, a.ftab, a.strip_prefix,
-                           a.wave_totals, a.cand, a.wave_cand, a.counters);
+                           a.wave_totals, a.cand, a.wave_cand, a.counters,
+                           (const uint16_t *)a.dbm);
     if (MODE & 4) return;                       // lean: no record numbering, nothing to scan
     const uint64_t n_strips = (a.n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint32_t nw = (uint32_t)((n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS);
@@ -604,13 +694,15 @@ static void launch_sweep_hm(const agh_sweep_args &a, hipStream_t st)
                        a.chunk_totals);
     hipLaunchKernelGGL(k_scan_fixup, dim3(n_chunks), dim3(256), 0, st, a.wave_totals, nw,
                        (const uint32_t *)a.chunk_totals, n_chunks, (const uint8_t *)a.text, a.n,
-                       a.counters);
+                       a.counters, (const uint64_t *)a.dbm);
 }
 
 template <int H>
 static void launch_sweep_t(const agh_sweep_args &a, hipStream_t st)
 {
-    const int mode = (a.q.fold ? 1 : 0) | (a.q.fq == 4 ? 2 : 0) | (a.lean ? 4 : 0);
+    // lean sweeps never look at delimiters, so bit 3 only matters for census sweeps
+    const int mode = (a.q.fold ? 1 : 0) | (a.q.fq == 4 ? 2 : 0) | (a.lean ? 4 : 0) |
+                     ((a.q.dlen > 1 && !a.lean) ? 8 : 0);
     switch (mode) {
     case 0: launch_sweep_hm<H, 0>(a, st); break;
     case 1: launch_sweep_hm<H, 1>(a, st); break;
@@ -619,14 +711,21 @@ static void launch_sweep_t(const agh_sweep_args &a, hipStream_t st)
     case 4: launch_sweep_hm<H, 4>(a, st); break;
     case 5: launch_sweep_hm<H, 5>(a, st); break;
     case 6: launch_sweep_hm<H, 6>(a, st); break;
-    default: launch_sweep_hm<H, 7>(a, st); break;
+    case 7: launch_sweep_hm<H, 7>(a, st); break;
+    case 8: launch_sweep_hm<H, 8>(a, st); break;
+    case 9: launch_sweep_hm<H, 9>(a, st); break;
+    case 10: launch_sweep_hm<H, 10>(a, st); break;
+    default: launch_sweep_hm<H, 11>(a, st); break;
     }
 }
 
 void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st)
 {
     switch (H) {
-    case 0: launch_sweep_hm<0, 0>(a, st); break;
+    case 0:
+        if (a.q.dlen > 1) launch_sweep_hm<0, 8>(a, st);
+        else launch_sweep_hm<0, 0>(a, st);
+        break;
     case 4: launch_sweep_t<4>(a, st); break;
     case 8: launch_sweep_t<8>(a, st); break;
     default: launch_sweep_t<16>(a, st); break;

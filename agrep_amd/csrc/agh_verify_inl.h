@@ -69,24 +69,15 @@ __device__ uint64_t lean_record_start(const uint8_t *__restrict__ text, uint64_t
     return ~0ull;
 }
 
-// Number of delimiters at byte positions < e (= 0-based record number of position e).
-__device__ uint32_t record_of(const uint8_t *__restrict__ text, uint64_t n, uint64_t e,
-                              const uint32_t *__restrict__ strip_prefix,
-                              const uint32_t *__restrict__ wave_prefix, uint32_t n_strips,
-                              uint32_t total_delims, uint32_t delim)
+// Multi-byte delimiters: the same through the delimiter-end bitmap.
+__device__ __forceinline__ uint64_t lean_record_start_mb(const uint64_t *__restrict__ dbm,
+                                                         uint64_t pos, const agh_marks &mk)
 {
-    const uint64_t strip = e >> AGH_STRIP_SHIFT;
-    if (strip >= n_strips) return total_delims;
-    uint32_t r = wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip];
-    const uint32_t dd = delim * 0x01010101u;
-    const uint32_t fill4 = (~delim & 0xffu) * 0x01010101u;
-    const uint64_t p = strip << AGH_STRIP_SHIFT;
-    const uint4 *t4 = reinterpret_cast<const uint4 *>(text + p);
-    const uint32_t span = (uint32_t)(e - p);
-    const uint32_t full = span >> 4;
-    for (uint32_t i = 0; i < full; ++i) r += delims_in(t4[i], dd);
-    if (span & 15u) r += delims_in(mask_tail(t4[full], (int)(span & 15u), fill4), dd);
-    return r;
+    const int64_t d = dbm_prev(dbm, pos, AGH_LEAN_BACK_CAP);
+    if (d >= 0) return (uint64_t)d + 1;
+    if (d == -1) return 0;
+    mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
+    return ~0ull;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -127,22 +118,93 @@ struct Automaton {
 // ---------------------------------------------------------------------------------------
 // Byte-wise reference walk of one window: used for windows at the head / tail of the text
 // (virtual head byte, appended delimiter) where the register fast path does not apply.
+// Where the last, unterminated record ends once the delimiter is appended at EOF: the appended
+// bytes may complete a partial delimiter the real text ended with (text "...x\n" with
+// delimiter "\n\n": the record ends in front of that "\n").  Equals n for 1-byte delimiters.
+__device__ __forceinline__ uint64_t virtual_close_start(const uint8_t *__restrict__ text,
+                                                        uint64_t n, const agh_dev_query &q,
+                                                        const uint64_t *__restrict__ dbm)
+{
+    if (q.dlen <= 1) return n;
+    uint32_t ds = 0;
+    uint64_t from = n >= q.dlen - 1 ? n - (q.dlen - 1) : 0;
+    const int64_t last = dbm_prev(dbm, n, q.dlen);
+    if (last >= 0 && (uint64_t)last + 1 > from) from = (uint64_t)last + 1;
+    if (from == 0) ds = delim_class(q, q.head_byte) & 1u;   // the virtual byte in front
+    for (uint64_t i = from; i < n; ++i) ds = ((ds << 1) | 1u) & delim_class(q, text[i]);
+    const uint32_t endbit = 1u << (q.dlen - 1);
+    for (uint32_t j = 0; j < q.dlen; ++j) {
+        ds = ((ds << 1) | 1u) & delim_class(q, q.dbytes[j]);
+        if (ds & endbit) {
+            const uint64_t endpos = n + j + 1;              // one past the completing byte
+            return endpos >= q.dlen ? endpos - q.dlen : 0;
+        }
+    }
+    return n;
+}
+
+// The delimiter appended at EOF (asearch.c:87-91), byte by byte, for any delimiter length: the
+// automaton sees the bytes as text, the little delimiter automaton `ds` completes whatever
+// partial delimiter the real text ended with.  A / seen / rec / rstart continue from the walk.
+template <typename WT, int K, bool LEAN>
+__device__ __forceinline__ void feed_virtual_tail(const uint8_t *__restrict__ text, uint64_t n,
+                                                  const agh_dev_query &q, const WT *lmask,
+                                                  const uint64_t *__restrict__ dbm,
+                                                  Automaton<WT, K> &A, bool seen, uint32_t rec,
+                                                  uint64_t rstart, const agh_marks &mk)
+{
+    const WT finalbit = (WT)1 << (q.m - 1);
+    uint32_t ds = 0;
+    if (q.dlen > 1) {
+        // progress of a partial delimiter at the end of the real text: only the last dlen-1
+        // bytes after the last selected delimiter end matter
+        uint64_t from = n >= q.dlen - 1 ? n - (q.dlen - 1) : 0;
+        const int64_t last = dbm_prev(dbm, n, q.dlen);
+        if (last >= 0 && (uint64_t)last + 1 > from) from = (uint64_t)last + 1;
+        if (from == 0) ds = delim_class(q, q.head_byte) & 1u;   // the virtual byte in front
+        for (uint64_t i = from; i < n; ++i) ds = ((ds << 1) | 1u) & delim_class(q, text[i]);
+    }
+    const uint32_t endbit = 1u << (q.dlen - 1);
+    for (uint32_t j = 0; j < q.dlen; ++j) {
+        const uint32_t c = q.dbytes[j];
+        if (A.step(lmask[c], finalbit) && !seen) {
+            seen = true;
+            if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
+        }
+        ds = ((ds << 1) | 1u) & delim_class(q, c);
+        if (ds & endbit) {
+            ds = 0;
+            A.reset();
+            ++rec;
+            rstart = n + j + 1;
+            seen = false;
+            if (A.step(lmask[c], finalbit)) {
+                seen = true;
+                if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
+            }
+        }
+    }
+}
+
 template <typename WT, int K, bool LEAN>
 __device__ __noinline__ void verify_window_slow(const uint8_t *__restrict__ text, uint64_t n,
                                                 const agh_dev_query &q, const WT *lmask,
+                                                const uint64_t *__restrict__ dbm,
                                                 uint64_t ws, uint64_t we, uint64_t anchor,
                                                 uint32_t rc_anchor, const agh_marks &mk)
 {
     const WT finalbit = (WT)1 << (q.m - 1);
+    const bool mb = q.dlen > 1;
     uint32_t rec = 0;
     uint64_t rstart = 0;                        // LEAN: first byte of the current record
     if (LEAN) {
-        rstart = lean_record_start(text, ws, q.delim, mk);
+        rstart = mb ? lean_record_start_mb(dbm, ws, mk) : lean_record_start(text, ws, q.delim, mk);
         if (rstart == ~0ull) return;
     } else {
         // delimiters in [ws, anchor): the anchor's record number is known, ws's is derived
         uint32_t back = 0;
-        for (uint64_t i = ws; i < anchor; ++i) back += (text[i] == q.delim);
+        if (mb) back = dbm_count(dbm, ws, anchor);
+        else for (uint64_t i = ws; i < anchor; ++i) back += (text[i] == q.delim);
         rec = rc_anchor - back;
     }
     Automaton<WT, K> A;
@@ -155,7 +217,7 @@ __device__ __noinline__ void verify_window_slow(const uint8_t *__restrict__ text
             seen = true;
             if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, i);
         }
-        if (c == q.delim) {
+        if (mb ? dbm_bit(dbm, i) != 0 : c == q.delim) {
             A.reset();
             ++rec;
             rstart = i + 1;
@@ -166,15 +228,8 @@ __device__ __noinline__ void verify_window_slow(const uint8_t *__restrict__ text
             }
         }
     }
-    if (we == n && q.tail_virtual) {
-        if (A.step(lmask[q.delim], finalbit) && !seen) {
-            if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
-        }
-        A.reset();
-        if (A.step(lmask[q.delim], finalbit)) {
-            if (LEAN) lean_insert(mk, n + 1); else mark_record(mk, rec + 1u, n);
-        }
-    }
+    if (we == n && q.tail_virtual)
+        feed_virtual_tail<WT, K, LEAN>(text, n, q, lmask, dbm, A, seen, rec, rstart, mk);
 }
 
 // Unaligned 16-byte view of the text (gfx9+ global loads accept any byte address).
@@ -188,6 +243,7 @@ struct VerifyCtx {
     uint64_t n, n16;
     const agh_dev_query *q;  // points at the kernel argument (kept out of scratch)
     const WT *lmask;         // LDS copy of the 256 position masks
+    const uint64_t *dbm;     // multi-byte delimiters: delimiter-end bitmap
     WT finalbit;
     uint32_t Lw, tailw, span;
     Automaton<WT, K> RF;     // state right after a record boundary (reset + re-fed delimiter)
@@ -198,9 +254,11 @@ struct VerifyCtx {
 template <typename WT, int K>
 __device__ __forceinline__ void verify_ctx_init(VerifyCtx<WT, K> &c, const uint8_t *text,
                                                 uint64_t n, const agh_dev_query &q,
-                                                const WT *lmask, const agh_marks &mk)
+                                                const WT *lmask, const agh_marks &mk,
+                                                const uint64_t *dbm)
 {
     c.text = text;
+    c.dbm = dbm;
     c.n = n;
     c.n16 = (n + 15) & ~(uint64_t)15;
     c.q = &q;
@@ -219,7 +277,7 @@ __device__ __forceinline__ void verify_ctx_init(VerifyCtx<WT, K> &c, const uint8
 // loads issued together and walked branch-free out of registers.  Match positions and
 // delimiter positions are collected as bit masks; record numbers are derived from them after
 // the walk.  Windows that touch the head or the tail of the text take the byte-wise path.
-template <typename WT, int K, int NCH, bool LEAN>
+template <typename WT, int K, int NCH, bool LEAN, bool MB>
 __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint64_t ent,
                                                  uint32_t wave_base)
 {
@@ -234,7 +292,8 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
         const uint64_t ws = j > c.Lw ? j - c.Lw : 0;
         uint64_t we = j + c.tailw;
         if (we > c.n) we = c.n;
-        verify_window_slow<WT, K, LEAN>(c.text, c.n, *c.q, c.lmask, ws, we, anchor, rc_anchor, *c.mk);
+        verify_window_slow<WT, K, LEAN>(c.text, c.n, *c.q, c.lmask, c.dbm, ws, we, anchor, rc_anchor,
+                                        *c.mk);
         return;
     }
     const uint64_t ws = j - c.Lw;
@@ -249,15 +308,27 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
     uint64_t hitm[NMW], hit2m[NMW], dm[NMW];
 #pragma unroll
     for (int i = 0; i < NMW; ++i) hitm[i] = hit2m[i] = dm[i] = 0;
+    if (MB) {
+        // delimiter ends inside the window, straight from the bitmap (bits >= span cleared)
+#pragma unroll
+        for (int i = 0; i < NMW; ++i) {
+            uint64_t w = dbm_bits64(c.dbm, ws + 64u * (uint32_t)i);
+            const int lo = i * 64;
+            if ((int)c.span <= lo) w = 0;
+            else if ((int)c.span < lo + 64) w &= (1ull << (c.span - lo)) - 1ull;
+            dm[i] = w;
+        }
+    }
 #pragma unroll
     for (int p = 0; p < NCH * 16; ++p) {
         if ((uint32_t)p >= c.span) break;             // wave-uniform
         const uint32_t dwv = ch[p >> 4][(p >> 2) & 3];
         const uint32_t byte = (dwv >> (8 * (p & 3))) & 0xffu;
         const uint32_t hit = A.step(c.lmask[byte], c.finalbit) ? 1u : 0u;
-        const uint32_t isd = (byte == c.q->delim) ? 1u : 0u;
+        const uint32_t isd = MB ? (uint32_t)(dm[p >> 6] >> (p & 63)) & 1u
+                                : ((byte == c.q->delim) ? 1u : 0u);
         hitm[p >> 6] |= (uint64_t)(hit & ~seen) << (p & 63);
-        dm[p >> 6] |= (uint64_t)isd << (p & 63);
+        if (!MB) dm[p >> 6] |= (uint64_t)isd << (p & 63);
         seen |= hit;
         if (isd) {                                  // select, no branch: see RF above
 #pragma unroll
@@ -290,7 +361,9 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
         auto start_of = [&](uint32_t x) -> uint64_t {
             const int d = last_delim_below(x);
             if (d >= 0) return ws + (uint64_t)d + 1;
-            if (before_ws == ~1ull) before_ws = lean_record_start(c.text, ws, c.q->delim, *c.mk);
+            if (before_ws == ~1ull)
+                before_ws = MB ? lean_record_start_mb(c.dbm, ws, *c.mk)
+                               : lean_record_start(c.text, ws, c.q->delim, *c.mk);
             return before_ws;
         };
 #pragma unroll

@@ -94,6 +94,23 @@ def test_cli_single_byte_delimiter_counts(tmp_path):
         assert (rc_g, out_g) == (rc_r, out_r), (k, out_g, out_r)
 
 
+@needs_ref
+def test_cli_multi_byte_delimiter_counts(tmp_path):
+    """-d 'From ' (mbox) and -d '$$' (paragraphs): counts equal the reference's asearch path."""
+    mbox = (b"From alice\nsubject: approximate matching\nbody\n"
+            b"From bob\nnothing here\n\nFrom carol\napproximatematch is here\n"
+            b"From dave\naproximatemach twice removed\n")
+    para = b"para one\nline\n\npara two approximatematch\n\n\npara three aproximatematc\nx\n\n"
+    for text, dl in ((mbox, "From "), (para, "$$")):
+        p = tmp_path / "d.txt"
+        p.write_bytes(text)
+        for k in (0, 1, 2):
+            a = ["-V0", "-i"] + (["-%d" % k] if k else []) + ["-c", "-d", dl, "approximatematch", str(p)]
+            rc_r, out_r, _ = _run(REF, a)
+            rc_g, out_g, _ = _run(CLI, a)
+            assert (rc_g, out_g) == (rc_r, out_r), (dl, k, out_g, out_r)
+
+
 def test_cli_rejects_what_is_outside_the_hot_path(files):
     for a in (["-2", "a|b", files[0]], ["-2", "[ab]cdefgh", files[0]], ["-v", "x", files[0]],
               ["-9", "approximatematch", files[0]], ["-2", "ab", files[0]]):

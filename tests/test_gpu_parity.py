@@ -22,8 +22,8 @@ def agh():
     return agrep_amd
 
 
-def _gpu(agh, pat, k, text, nocase=False, flags=0, cap=200000):
-    with agh.Query(pat, k, nocase=nocase) as q:
+def _gpu(agh, pat, k, text, nocase=False, flags=0, cap=200000, delim=b"\n"):
+    with agh.Query(pat, k, nocase=nocase, delim=delim) as q:
         res, ms = q.scan_buffer(text, flags=flags, cap=cap)
     assert not res.truncated
     return res, [(s, e) for s, e, _ in ms], [i for _, _, i in ms]
@@ -337,3 +337,35 @@ def test_scan_fd_streams_files_and_pipes(agh, tmp_path):
         assert (res_p.n_matched, [(s, e) for s, e, _ in ms_p]) == (want_n, want_recs)
         res_c, _ = q.scan_fd(os.open(str(p), os.O_RDONLY), flags=agh.COUNT)
         assert res_c.n_matched == want_n
+
+
+@pytest.mark.parametrize("delim", [b"FROM ", b"\n\n", b"#%", b"@@@", b"ab", b"aa", b"\n.\n"])
+def test_multi_byte_delimiters(agh, delim):
+    """-d with 2..8 byte delimiters (-d 'From ', -d '$$'): leftmost non-overlapping delimiter
+    occurrences, reset after the delimiter's last byte -- bit-exact with asearch.c, including
+    delimiters that overlap themselves ("\\n\\n", "aa") or share letters with the pattern."""
+    rng = random.Random(len(delim) * 131 + delim[0])
+    for it in range(30):
+        pat, k, text = _rand_case(rng, 6, max_m=20)
+        text = text.replace(b"\n", delim if rng.random() < 0.7 else b"\n")
+        if it % 5 == 0:
+            text = text + delim * rng.randint(1, 4)            # runs of delimiters at the end
+        if it % 7 == 0:
+            text = delim * rng.randint(1, 5) + text
+        want = O.asearch(pat, k, text, delim=delim, cap=100000)
+        for flags in (0, agh.FORCE_FULLSCAN):
+            res, recs, _ = _gpu(agh, pat, k, text, flags=flags, delim=delim)
+            assert (res.n_matched, recs) == want, (delim, pat, k, flags, text)
+        with agh.Query(pat, k, delim=delim) as q:
+            rc, _ = q.scan_buffer(text, flags=agh.COUNT)
+        assert rc.n_matched == want[0], ("lean", delim, pat, k, text)
+    # a planted corpus with paragraph / mbox style delimiters, all engines
+    base, _ = O.corpus(64, seed=5, variants=O.VARIANTS_C2, plant_period=6)
+    text = base.tobytes().replace(b"\n", delim)
+    for k in (0, 2, 3):
+        want = O.asearch(O.PATTERN_C2, k, text, delim=delim, cap=100000)
+        for flags in (0, agh.FORCE_FULLSCAN):
+            res, recs, _ = _gpu(agh, O.PATTERN_C2, k, text, flags=flags, delim=delim)
+            assert (res.n_matched, recs) == want, (delim, k, flags)
+        with agh.Query(O.PATTERN_C2, k, delim=delim) as q:
+            assert q.scan_buffer(text, flags=agh.COUNT)[0].n_matched == want[0]
