@@ -51,19 +51,48 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
 // ---------------------------------------------------------------------------------------
 // fullscan: the automaton over every byte
 // ---------------------------------------------------------------------------------------
-template <typename WT, int K>
+// 16 consecutive text bytes (one LDS b128 read) through the automaton, branch-free: returns
+// the 16-bit masks of new-match positions (h16) and delimiter-end positions (d16; an input in
+// MB mode, where delimiter ends come from the bitmap).
+template <typename WT, int K, bool MB>
+__device__ __forceinline__ void fullscan_piece(uint4 v, const WT *lmask, WT finalbit,
+                                               uint32_t delim, const Automaton<WT, K> &RF,
+                                               uint32_t rf_hit, Automaton<WT, K> &A,
+                                               uint32_t &seen, uint32_t &h16, uint32_t &d16)
+{
+    const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+    uint32_t h = 0, d = MB ? d16 : 0u;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const uint32_t byte = (dws[b >> 2] >> (8 * (b & 3))) & 0xffu;
+        const uint32_t hit = A.step(lmask[byte], finalbit) ? 1u : 0u;
+        const uint32_t isd = MB ? (d >> b) & 1u : ((byte == delim) ? 1u : 0u);
+        h |= (hit & ~seen) << b;
+        if (!MB) d |= isd << b;
+        seen |= hit;
+        if (isd) {
+#pragma unroll
+            for (int e = 0; e <= K; ++e) A.R[e] = RF.R[e];
+            seen = rf_hit;
+        }
+    }
+    h16 = h;
+    d16 = d;
+}
+
+template <typename WT, int K, bool MB>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q,
     const WT *__restrict__ mask_g, const uint32_t *__restrict__ strip_prefix,
     const uint32_t *__restrict__ wave_prefix, uint32_t n_strips, agh_marks mk,
     const uint64_t *__restrict__ dbm)
 {
-    const bool mb = q.dlen > 1;                 // delimiter ends come from the bitmap
     // slot 0 = the 256 bytes in front of the tile (warm-up halo), slots 1..256 = lane chunks
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     WT *lmask = reinterpret_cast<WT *>(lds);
     uint8_t *tile = lds + 256 * sizeof(WT);
     lmask[threadIdx.x] = mask_g[threadIdx.x];
+    __syncthreads();
 
     const uint64_t tile_bytes = (uint64_t)AGH_FS_THREADS * AGH_FS_CHUNK;
     const uint64_t n_tiles = (n + tile_bytes - 1) / tile_bytes;
@@ -73,6 +102,11 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
     const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
     const uint64_t n16 = (n + 15) & ~(uint64_t)15;
     const uint32_t warm = ((uint32_t)(q.m + q.k + 1) + 15u) & ~15u;   // <= 80 bytes
+
+    // state right after a record boundary: reset + re-fed delimiter byte (asearch.c:175-186)
+    Automaton<WT, K> RF;
+    RF.reset();
+    const uint32_t rf_hit = RF.step(lmask[q.delim], finalbit) ? 1u : 0u;
 
     for (uint64_t tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
         const uint64_t t0 = tix * tile_bytes;
@@ -93,7 +127,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
         uint32_t my_delims = 0;
         uint64_t ce = cs + AGH_FS_CHUNK;
         if (ce > n) ce = n;
-        if (cs < n && mb) {
+        if (cs < n && MB) {
             my_delims = dbm_count(dbm, cs, ce);
         } else if (cs < n) {
             const uint32_t len = (uint32_t)(ce - cs);
@@ -124,40 +158,57 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
 
         Automaton<WT, K> A;
         A.reset();
+        uint32_t seen = 0;
         if (cs == 0) {
             A.step(lmask[q.head_byte], finalbit); // asearch.c:69-78
         } else {
+            // rebuild the state from the m+k+1 (rounded to 16) bytes in front of the chunk
             const uint8_t *halo = tile + threadIdx.x * AGH_FS_SLOT + (AGH_FS_CHUNK - warm);
-            for (uint32_t i = 0; i < warm; ++i) {
-                const uint32_t c = halo[i];
-                A.step(lmask[c], finalbit);
-                if (mb ? dbm_bit(dbm, cs - warm + i) != 0 : c == q.delim) {
-                    A.reset();
-                    A.step(lmask[c], finalbit);
-                }
+            for (uint32_t t = 0; t < warm / 16; ++t) {
+                uint32_t h16 = 0, d16 = 0;
+                if (MB) d16 = (uint32_t)dbm_bits64(dbm, cs - warm + 16u * t) & 0xffffu;
+                fullscan_piece<WT, K, MB>(*reinterpret_cast<const uint4 *>(halo + 16 * t), lmask,
+                                          finalbit, q.delim, RF, rf_hit, A, seen, h16, d16);
             }
+            seen = 0;                           // matches before cs belong to the previous lane
         }
-        bool seen = false;
         const uint32_t len = (uint32_t)(ce - cs);
-        for (uint32_t i = 0; i < len; ++i) {
+        const uint32_t full = len >> 4;
+        for (uint32_t t = 0; t < full; ++t) {
+            uint32_t h16 = 0, d16 = 0;
+            if (MB) d16 = (uint32_t)dbm_bits64(dbm, cs + 16u * t) & 0xffffu;
+            fullscan_piece<WT, K, MB>(*reinterpret_cast<const uint4 *>(mine + 16 * t), lmask,
+                                      finalbit, q.delim, RF, rf_hit, A, seen, h16, d16);
+            uint32_t ev = h16 | (rf_hit ? d16 : 0u);
+            while (ev) {                        // rare: a record matched in this piece
+                const uint32_t b = (uint32_t)__ffs((int)ev) - 1u;
+                ev &= ev - 1u;
+                const uint32_t below = (uint32_t)__popc(d16 & ((1u << b) - 1u));
+                if ((h16 >> b) & 1u) mark_record(mk, rec + below, cs + 16u * t + b);
+                if (rf_hit && ((d16 >> b) & 1u)) mark_record(mk, rec + below + 1u, cs + 16u * t + b + 1u);
+            }
+            rec += (uint32_t)__popc(d16);
+        }
+        bool seenb = seen != 0;
+        for (uint32_t i = full * 16; i < len; ++i) {     // the last, partial piece of the text
             const uint32_t c = mine[i];
             bool hit = A.step(lmask[c], finalbit);
-            if (hit && !seen) {
-                seen = true;
+            if (hit && !seenb) {
+                seenb = true;
                 mark_record(mk, rec, cs + i);
             }
-            if (mb ? dbm_bit(dbm, cs + i) != 0 : c == q.delim) {
+            if (MB ? dbm_bit(dbm, cs + i) != 0 : c == q.delim) {
                 A.reset();
                 ++rec;
-                seen = false;
+                seenb = false;
                 if (A.step(lmask[c], finalbit)) {
-                    seen = true;
+                    seenb = true;
                     mark_record(mk, rec, cs + i + 1);
                 }
             }
         }
         if (ce == n && q.tail_virtual)          // asearch.c:87-91
-            feed_virtual_tail<WT, K, false>(text, n, q, lmask, dbm, A, seen, rec, 0, mk);
+            feed_virtual_tail<WT, K, false>(text, n, q, lmask, dbm, A, seenb, rec, 0, mk);
     }
 }
 
@@ -264,9 +315,14 @@ static void launch_fullscan_t(const agh_scan_args &a, hipStream_t st)
     if (!n_tiles) return;
     uint32_t blocks = n_tiles > 65536 ? 65536u : (uint32_t)n_tiles;
     const size_t lds = 256 * sizeof(WT) + (size_t)(AGH_FS_THREADS + 1) * AGH_FS_SLOT;
-    hipLaunchKernelGGL((k_fullscan<WT, K>), dim3(blocks), dim3(AGH_FS_THREADS), lds, st,
-                       (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.strip_prefix,
-                       a.wave_prefix, a.n_strips, a.mk, a.dbm);
+    if (a.q.dlen > 1)
+        hipLaunchKernelGGL((k_fullscan<WT, K, true>), dim3(blocks), dim3(AGH_FS_THREADS), lds, st,
+                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask,
+                           a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm);
+    else
+        hipLaunchKernelGGL((k_fullscan<WT, K, false>), dim3(blocks), dim3(AGH_FS_THREADS), lds,
+                           st, (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask,
+                           a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm);
 }
 
 template <typename WT>
