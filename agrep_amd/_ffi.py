@@ -57,6 +57,9 @@ def lib():
                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u8p,
                                          C.c_int, C.c_int, C.c_int]
     L.agh_query_from_maskgen.restype = vp
+    L.agh_query_multi.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, u8p,
+                                  C.c_int]
+    L.agh_query_multi.restype = vp
     L.agh_query_free.argtypes = [vp]
     L.agh_query_free.restype = None
     L.agh_query_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
@@ -127,6 +130,17 @@ class Query:
         old_D_pat = bytes(old_D_pat)
         h = lib().agh_query_from_maskgen(arr, Init0, Init1, NO_ERR_MASK, endposition, D_endpos,
                                          M, old_D_pat, len(old_D_pat), D, AND)
+        if not h:
+            raise AghError(lib().agh_last_error().decode("latin1"))
+        return cls(None, _handle=h)
+
+    @classmethod
+    def multi(cls, patterns, nocase=False, delim=b"\n"):
+        """-f: exact multi-pattern query (agh_query_multi)."""
+        pats = [bytes(p) for p in patterns]
+        arr = (C.c_char_p * len(pats))(*pats)
+        lens = (C.c_int * len(pats))(*[len(p) for p in pats])
+        h = lib().agh_query_multi(arr, lens, len(pats), int(nocase), bytes(delim), len(delim))
         if not h:
             raise AghError(lib().agh_last_error().decode("latin1"))
         return cls(None, _handle=h)

@@ -105,6 +105,12 @@ struct agh_query {
     uint64_t hashset_slots_hint = 0;    // lean scans: slots wanted by the previous scan
     bool hashset_dirty = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    // multi-pattern (-f) queries
+    bool multi = false;
+    bool multi_dense = false;           // hits are too dense for the candidate slices
+    int npat = 0;
+    void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_off = nullptr,
+         *d_mp_pool = nullptr;
 };
 
 static bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
@@ -144,6 +150,18 @@ static void choose_filter(agh_query *q)
     q->fold = any_pair ? (0x20202020u & q->qmask) : 0u;
 }
 
+static int upload_common(agh_query *q)
+{
+    HIP_TRY(hipMalloc((void **)&q->d_counters, AGH_C_COUNT * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&q->d_chunk_totals, 128 * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&q->h_counters, AGH_C_COUNT * sizeof(uint32_t)));
+    HIP_TRY(hipEventCreate(&q->ev0));
+    HIP_TRY(hipEventCreate(&q->ev1));
+    HIP_TRY(hipEventCreate(&q->ev2));
+    HIP_TRY(hipEventCreate(&q->ev3));
+    return 0;
+}
+
 static int upload_tables(agh_query *q)
 {
     if (q->wide) {
@@ -174,14 +192,7 @@ static int upload_tables(agh_query *q)
         HIP_TRY(hipMalloc((void **)&q->d_ftab, AGH_FT_SIZE));
         HIP_TRY(hipMemcpy(q->d_ftab, tab.data(), AGH_FT_SIZE, hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc((void **)&q->d_counters, AGH_C_COUNT * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&q->d_chunk_totals, 128 * sizeof(uint32_t)));
-    HIP_TRY(hipHostMalloc((void **)&q->h_counters, AGH_C_COUNT * sizeof(uint32_t)));
-    HIP_TRY(hipEventCreate(&q->ev0));
-    HIP_TRY(hipEventCreate(&q->ev1));
-    HIP_TRY(hipEventCreate(&q->ev2));
-    HIP_TRY(hipEventCreate(&q->ev3));
-    return 0;
+    return upload_common(q);
 }
 
 static agh_query *finish_query(agh_query *q)
@@ -285,11 +296,90 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
     return finish_query(q);
 }
 
+// -f patternfile: the role of prepf() (newmgrep.c:192-375).  Exact matching only, like the
+// reference (compat.c:34-37: "approximate matching is not supported with -f").
+extern "C" agh_query *agh_query_multi(const unsigned char *const *pats, const int *lens, int npat,
+                                      int nocase, const unsigned char *delim, int dlen)
+{
+    if (!pats || !lens || npat < 1) { fail("no patterns"); return nullptr; }
+    if (!delim || dlen != 1) {
+        fail("multi-pattern scans support single-byte delimiters only");
+        return nullptr;
+    }
+    int minlen = 1 << 30;
+    for (int p = 0; p < npat; ++p) {
+        if (lens[p] < 1 || lens[p] > 255) { fail("pattern %d: length %d outside 1..255", p, lens[p]); return nullptr; }
+        if (lens[p] < minlen) minlen = lens[p];
+    }
+    if (agh_device_count() <= 0) { fail("no usable HIP device: libagrep_hip has no CPU path"); return nullptr; }
+    agh_query *q = new agh_query();
+    q->multi = true;
+    q->npat = npat;
+    q->m = minlen;
+    q->k = 0;
+    q->dlen = 1;
+    q->delim[0] = delim[0];
+    q->fq = minlen < 4 ? minlen : 4;            // prefix length probed at every text position
+    q->fh = 1;
+    q->qmask = q->fq == 4 ? 0xffffffffu : ((1u << (8 * q->fq)) - 1u);
+    q->fold = nocase ? (0x20202020u & q->qmask) : 0u;
+    memset(q->mask, 0, sizeof(q->mask));
+
+    std::vector<uint32_t> bits((1u << AGH_MP_BITS) / 32, 0), off(npat + 1, 0);
+    std::vector<uint8_t> pool;
+    std::vector<uint32_t> bucket_of(npat);
+    const uint32_t NB = 1u << AGH_MP_BUCKET_BITS;
+    std::vector<uint32_t> bstart(NB + 1, 0), items(npat);
+    std::vector<char> usable(npat, 1);
+    for (int p = 0; p < npat; ++p) {
+        off[p] = (uint32_t)pool.size();
+        uint32_t g = 0;
+        for (int t = 0; t < lens[p]; ++t) {
+            unsigned char c = pats[p][t];
+            if (c == delim[0]) usable[p] = 0;   // can never lie inside one record
+            if (nocase && is_upper(c)) c += 32;
+            pool.push_back(c);
+            if (t < q->fq) g |= (uint32_t)pats[p][t] << (8 * t);
+        }
+        g = (g & q->qmask) | q->fold;
+        bucket_of[p] = agh_mp_bucket(g);
+        if (usable[p]) {
+            const uint32_t h = q->fq == 4 ? agh_sample_hash18_q4(g) : agh_sample_hash18_q3(g);
+            bits[h >> 5] |= 1u << (h & 31u);
+            bstart[bucket_of[p] + 1]++;
+        }
+    }
+    off[npat] = (uint32_t)pool.size();
+    for (uint32_t b = 0; b < NB; ++b) bstart[b + 1] += bstart[b];
+    {
+        std::vector<uint32_t> fill(bstart.begin(), bstart.end() - 1);
+        for (int p = 0; p < npat; ++p)
+            if (usable[p]) items[fill[bucket_of[p]]++] = (uint32_t)p;
+    }
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(dst, bytes ? bytes : 4));
+        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (up(&q->d_mp_bits, bits.data(), bits.size() * 4) || up(&q->d_mp_bstart, bstart.data(), bstart.size() * 4) ||
+        up(&q->d_mp_items, items.data(), items.size() * 4) || up(&q->d_mp_off, off.data(), off.size() * 4) ||
+        up(&q->d_mp_pool, pool.data(), pool.size()) || upload_common(q)) {
+        agh_query_free(q);
+        return nullptr;
+    }
+    return q;
+}
+
 extern "C" void agh_query_free(agh_query *q)
 {
     if (!q) return;
     if (q->d_mask) (void)hipFree(q->d_mask);
     if (q->d_ftab) (void)hipFree(q->d_ftab);
+    if (q->d_mp_bits) (void)hipFree(q->d_mp_bits);
+    if (q->d_mp_bstart) (void)hipFree(q->d_mp_bstart);
+    if (q->d_mp_items) (void)hipFree(q->d_mp_items);
+    if (q->d_mp_off) (void)hipFree(q->d_mp_off);
+    if (q->d_mp_pool) (void)hipFree(q->d_mp_pool);
     if (q->d_counters) (void)hipFree(q->d_counters);
     if (q->d_chunk_totals) (void)hipFree(q->d_chunk_totals);
     if (q->h_counters) (void)hipHostFree(q->h_counters);
@@ -329,6 +419,17 @@ extern "C" int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q,
     return 0;
 }
 
+static agh_multi_dev multi_dev(const agh_query *q)
+{
+    agh_multi_dev m;
+    m.bits = (const uint32_t *)q->d_mp_bits;
+    m.bucket_start = (const uint32_t *)q->d_mp_bstart;
+    m.bucket_items = (const uint32_t *)q->d_mp_items;
+    m.pat_off = (const uint32_t *)q->d_mp_off;
+    m.pool = (const uint8_t *)q->d_mp_pool;
+    return m;
+}
+
 // ---------------------------------------------------------------------------------------
 // one segment (<= AGH_SEG_MAX bytes) resident in HBM
 // ---------------------------------------------------------------------------------------
@@ -363,6 +464,9 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     if (((uintptr_t)d_text & 15u) != 0) return fail("device text must be 16-byte aligned");
     const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint64_t nw = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+    if (q->multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
+    if (q->multi && (flags & AGH_FORCE_FULLSCAN))
+        return fail("multi-pattern queries have no full-scan engine");
     const bool want_filter = q->fq > 0 && !(flags & AGH_FORCE_FULLSCAN);
     if (!want_filter && (flags & AGH_FORCE_FILTER))
         return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
@@ -426,7 +530,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         sa.text = d_text;
         sa.n = n;
         sa.q = dq;
-        sa.ftab = q->d_ftab;
+        sa.ftab = q->multi ? (const uint8_t *)q->d_mp_bits : q->d_ftab;
         sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
         sa.wave_totals = (uint32_t *)q->wave_totals.p;
         sa.cand = (uint64_t *)q->cand.p;
@@ -442,7 +546,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.counters = q->d_counters;
         va.mk.hashset = (uint64_t *)q->hashset.p;
         va.mk.hashset_mask = (uint32_t)(slots - 1);
-        agh_launch_sweep(sa, q->fh, st);
+        if (q->multi) agh_launch_sweep_multi(sa, multi_dev(q), va.mk, q->multi_dense, st);
+        else agh_launch_sweep(sa, q->fh, st);
         va.text = d_text;
         va.n = n;
         va.q = dq;
@@ -453,7 +558,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.nw = (uint32_t)nw;
         va.wave_prefix = (const uint32_t *)q->wave_totals.p;
         va.dbm = d_dbm;
-        agh_launch_verify_lean(va, st);
+        if (q->multi) agh_launch_verify_multi(va, multi_dev(q), true, st);
+        else agh_launch_verify_lean(va, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)q->wave_cand.p, (uint32_t)nw, q->d_counters, st);
         HIP_TRY(hipGetLastError());
@@ -462,6 +568,12 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         q->hashset_dirty = false;
+        if (q->multi && q->h_counters[AGH_C_OVERFLOW] && !q->multi_dense) {
+            // dense hit set (many very short patterns): check hits inline from now on
+            q->multi_dense = true;
+            return scan_segment(q, d_text, n, st, flags, head_byte, tail_virtual, d_match_pos,
+                                d_match_rec, match_cap, out);
+        }
         const bool gave_up = q->h_counters[AGH_C_LEAN_FALLBACK] || q->h_counters[AGH_C_OVERFLOW];
         if (!gave_up) {
             HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
@@ -514,7 +626,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.text = d_text;
             sa.n = n;
             sa.q = dq;
-            sa.ftab = q->d_ftab;
+            sa.ftab = q->multi ? (const uint8_t *)q->d_mp_bits : q->d_ftab;
             sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
             sa.wave_totals = (uint32_t *)q->wave_totals.p;
             sa.cand = (uint64_t *)q->cand.p;
@@ -525,7 +637,28 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.lean = 0;
             sa.ev_begin = q->ev2;
             sa.ev_end = q->ev3;
-            agh_launch_sweep(sa, use_filter ? q->fh : 0, st);
+            if (q->multi && q->multi_dense) {
+                // census first (plain H=0 sweep + prefix scan), then the inline multi sweep
+                // numbers records from that prefix and marks them directly
+                agh_launch_sweep(sa, 0, st);
+                agh_marks mk0;
+                memset(&mk0, 0, sizeof(mk0));
+                mk0.bitmap = (uint32_t *)q->bitmap.p;
+                mk0.bitmap_bits = (uint32_t)std::min<uint64_t>(bm_words * 32, 0xffffffffu);
+                mk0.counters = q->d_counters;
+                mk0.match_pos = d_match_pos;
+                mk0.match_rec = d_match_rec;
+                mk0.match_cap = match_cap;
+                sa.ev_begin = sa.ev_end = nullptr;
+                agh_launch_sweep_multi(sa, multi_dev(q), mk0, true, st);
+            } else if (q->multi) {
+                agh_marks none;
+                memset(&none, 0, sizeof(none));
+                agh_launch_sweep_multi(sa, multi_dev(q), none, false, st);
+                agh_launch_census_scan(sa, true, st);
+            } else {
+                agh_launch_sweep(sa, use_filter ? q->fh : 0, st);
+            }
             HIP_TRY(hipGetLastError());
         }
         agh_scan_args va;
@@ -549,7 +682,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.match_cap = match_cap;
         va.mk.hashset = nullptr;
         va.mk.hashset_mask = 0;
-        if (use_filter) agh_launch_verify(va, st);
+        if (q->multi) agh_launch_verify_multi(va, multi_dev(q), false, st);
+        else if (use_filter) agh_launch_verify(va, st);
         else agh_launch_fullscan(va, st);
         agh_launch_bitmap_count((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), q->d_counters, st);
         HIP_TRY(hipGetLastError());
@@ -570,7 +704,13 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         const bool bm_overflow = q->h_counters[AGH_C_BM_OVERFLOW] != 0 ||
                                  (uint64_t)n_delims + 2 > (uint64_t)bm_words * 32;
         if (slice_overflow) {
-            if (flags & AGH_FORCE_FILTER)
+            if (q->multi && !q->multi_dense) {
+                q->multi_dense = true;          // dense hit set: check hits inline from now on
+                swept = false;
+                bits_hint = (uint64_t)n_delims + 1024;
+                continue;
+            }
+            if ((flags & AGH_FORCE_FILTER) || q->multi)
                 return fail("candidate slices overflowed (%u candidates)", q->h_counters[AGH_C_CAND]);
             use_filter = false;                 // not selective on this text: automaton everywhere
             swept = false;                      // the full scan needs the H=0 sweep's strip prefix

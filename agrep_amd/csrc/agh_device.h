@@ -53,6 +53,11 @@ struct agh_dev_query {
     int32_t tail_virtual; // 1: the delimiter is appended at the segment end (asearch.c:87-91)
 };
 
+// Multi-pattern (-f) scans: 2^18-bit table of pattern-prefix q-grams (32 KiB, LDS) and the
+// bucket directory the verifier walks.
+#define AGH_MP_BITS 18
+#define AGH_MP_BUCKET_BITS 14
+
 // Hash of one text/pattern sample (already masked and folded) into the filter table.
 // Identical on host (table construction) and device (probe).  v_mul_u32_u24 is full rate.
 #if defined(__HIPCC__)
@@ -66,6 +71,24 @@ AGH_HD uint32_t agh_sample_hash_q4(uint32_t s)
     uint32_t t = (s ^ (s >> 11)) & 0xffffffu;
     uint32_t p = t * 0x9E3779u;              // 24 x 24 -> low 32 bits (v_mul_u32_u24)
     return (p >> 14) & (AGH_FT_SIZE - 1u);
+}
+// 18-bit variants for the multi-pattern bit table (same multipliers, more result bits).
+AGH_HD uint32_t agh_sample_hash18_q4(uint32_t s)
+{
+    uint32_t t = (s ^ (s >> 11)) & 0xffffffu;
+    uint32_t p = t * 0x9E3779u;
+    return (p >> 14) & ((1u << AGH_MP_BITS) - 1u);
+}
+AGH_HD uint32_t agh_sample_hash18_q3(uint32_t s)
+{
+    uint32_t p = (s & 0xffffffu) * 0x85EBCAu;
+    return (p >> 13) & ((1u << AGH_MP_BITS) - 1u);
+}
+// bucket of a pattern prefix in the verifier's directory
+AGH_HD uint32_t agh_mp_bucket(uint32_t s)
+{
+    uint32_t x = s * 0x9E3779B1u;
+    return (x ^ (x >> 15)) >> (32 - AGH_MP_BUCKET_BITS);
 }
 // q <= 3: the sample already fits 24 bits.
 AGH_HD uint32_t agh_sample_hash_q3(uint32_t s)

@@ -71,3 +71,17 @@ void agh_launch_gather_records(const void *text, const uint64_t *start, const ui
                                const uint64_t *off, uint32_t cnt, void *out, hipStream_t st);
 void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &q, uint64_t *dbm,
                              uint64_t n_words, uint32_t *counters, hipStream_t st);
+
+// multi-pattern (-f) device tables
+struct agh_multi_dev {
+    const uint32_t *bits;          // 2^18-bit prefix table
+    const uint32_t *bucket_start;
+    const uint32_t *bucket_items;
+    const uint32_t *pat_off;
+    const uint8_t *pool;
+};
+void agh_launch_sweep_multi(const agh_sweep_args &a, const agh_multi_dev &m, const agh_marks &mk,
+                            bool inl, hipStream_t st);
+void agh_launch_verify_multi(const agh_scan_args &a, const agh_multi_dev &m, bool lean,
+                             hipStream_t st);
+void agh_launch_census_scan(const agh_sweep_args &a, bool with_cand, hipStream_t st);

@@ -83,26 +83,6 @@ __device__ __forceinline__ void sweep_chunk(uint4 v, uint32_t dd, const agh_dev_
 // rc[u] = delimiters (inside this wave's range) in front of the lane's chunk of strip s+u --
 // stored with the candidate so that the verifier can number records without re-reading text.
 // qn (queued) and cnt (already in the slice) are wave-uniform.
-#define AGH_CQ_LEN 96
-
-__device__ __forceinline__ void flush_candidates(uint64_t *cq, uint32_t &qn, uint32_t take,
-                                                 uint64_t *__restrict__ slice, uint32_t &cnt,
-                                                 uint32_t *counters)
-{
-    const uint32_t lane = (uint32_t)lane_id();
-    if (lane < take) {
-        const uint32_t idx = cnt + lane;
-        if (idx < AGH_SLICE_CAP) slice[idx] = cq[lane];
-        else counters[AGH_C_OVERFLOW] = 1u;
-    }
-    cnt += take;
-    const uint32_t rest = qn - take;            // < 32: move it to the front
-    uint64_t keep = 0;
-    if (lane < rest) keep = cq[take + lane];
-    if (lane < rest) cq[lane] = keep;
-    qn = rest;
-}
-
 template <typename OnFull>
 __device__ __forceinline__ void emit_candidates_to(uint32_t hits, uint64_t s,
                                                    const uint32_t rc[4], uint64_t *cq,
@@ -665,6 +645,20 @@ __global__ __launch_bounds__(64) void k_corpus(uint64_t *__restrict__ out, uint6
 // DESIGN.md): 256-thread workgroups, next supertile prefetched.
 #define AGH_SWEEP_BLOCK 256
 
+// exclusive scan of the per-wave delimiter totals (+ candidate total, last byte)
+void agh_launch_census_scan(const agh_sweep_args &a, bool with_cand, hipStream_t st)
+{
+    const uint64_t n_strips = (a.n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
+    const uint32_t nw = (uint32_t)((n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS);
+    const uint32_t n_chunks = (nw + AGH_SCAN_CHUNK - 1) / AGH_SCAN_CHUNK;
+    hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, st, a.wave_totals,
+                       with_cand ? (const uint32_t *)a.wave_cand : (const uint32_t *)nullptr, nw,
+                       a.chunk_totals);
+    hipLaunchKernelGGL(k_scan_fixup, dim3(n_chunks), dim3(256), 0, st, a.wave_totals, nw,
+                       (const uint32_t *)a.chunk_totals, n_chunks, (const uint8_t *)a.text, a.n,
+                       a.counters, (const uint64_t *)a.dbm);
+}
+
 template <int H, int MODE>
 static void launch_sweep_hm(const agh_sweep_args &a, hipStream_t st)
 {
@@ -686,15 +680,7 @@ static void launch_sweep_hm(const agh_sweep_args &a, hipStream_t st)
                            a.wave_totals, a.cand, a.wave_cand, a.counters,
                            (const uint16_t *)a.dbm);
     if (MODE & 4) return;                       // lean: no record numbering, nothing to scan
-    const uint64_t n_strips = (a.n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
-    const uint32_t nw = (uint32_t)((n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS);
-    const uint32_t n_chunks = (nw + AGH_SCAN_CHUNK - 1) / AGH_SCAN_CHUNK;
-    hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, st, a.wave_totals,
-                       H > 0 ? (const uint32_t *)a.wave_cand : (const uint32_t *)nullptr, nw,
-                       a.chunk_totals);
-    hipLaunchKernelGGL(k_scan_fixup, dim3(n_chunks), dim3(256), 0, st, a.wave_totals, nw,
-                       (const uint32_t *)a.chunk_totals, n_chunks, (const uint8_t *)a.text, a.n,
-                       a.counters, (const uint64_t *)a.dbm);
+    agh_launch_census_scan(a, H > 0, st);
 }
 
 template <int H>

@@ -42,13 +42,14 @@ static struct {
     unsigned char delim[AGH_MAX_DELIM + 1];
     int dlen;
     const char *pattern;
+    const char *pattern_file;  /* -f  PAT_FILE */
 } opt;
 
 static void die_usage(const char *msg)
 {
     fprintf(stderr, "%s: %s\n", Progname, msg);
     fprintf(stderr,
-            "usage: %s [-#cilnhsyB] [-V0] [-d delim] [-e pattern | pattern] [file ...]\n",
+            "usage: %s [-#cilnhsyB] [-V0] [-d delim] [-e pattern | -f patternfile | pattern] [file ...]\n",
             Progname);
     exit(2);
 }
@@ -132,6 +133,13 @@ static int parse_options(int argc, char **argv, char **files)
                     opt.pattern = argv[++i];
                     p = (char *)"";
                     break;
+                case 'f':                       /* agrep.c:2410-2460: patterns, one per line */
+                    if (*p) opt.pattern_file = p;
+                    else if (i + 1 < argc) opt.pattern_file = argv[++i];
+                    else die_usage("the -f option must have a file name argument");
+                    opt.pattern = "";           /* no pattern argument follows */
+                    p = (char *)"";
+                    break;
                 default:
                     fprintf(stderr, "%s: option -%c is outside the GPU hot path of this build\n",
                             Progname, c);
@@ -146,6 +154,15 @@ static int parse_options(int argc, char **argv, char **files)
         }
     }
     if (opt.pattern == NULL) die_usage("no pattern");
+    if (opt.pattern_file) {
+        /* compat.c:26-37: -B is ignored with -f; -# is not supported with -f (warning only) */
+        if (opt.BESTMATCH) opt.BESTMATCH = 0;
+        if (opt.APPROX && opt.D > 0)
+            fprintf(stderr, "%s: approximate matching is not supported with -f option\n", Progname);
+        opt.D = 0;
+        if (opt.COUNT && opt.FILENAMEONLY) opt.FILENAMEONLY = 0;
+        return nfiles;
+    }
     if (!literal_only && !pattern_is_literal(opt.pattern)) {
         fprintf(stderr,
                 "%s: pattern '%s' uses regular-expression / boolean / class syntax, which is "
@@ -284,6 +301,48 @@ int main(int argc, char **argv)
     agh_query *q;
 
     nfiles = parse_options(argc, argv, files);
+    if (opt.pattern_file) {
+        /* prepf() (newmgrep.c:192-375): one literal pattern per line, empty lines skipped */
+        size_t len = 0, i, start = 0, np = 0, cap = 64;
+        int fd = open(opt.pattern_file, O_RDONLY);
+        unsigned char *buf;
+        const unsigned char **pp;
+        int *ll;
+        if (fd < 0) {
+            fprintf(stderr, "%s: can't open pattern file for reading: %s\n", Progname, opt.pattern_file);
+            exit(2);
+        }
+        buf = slurp(fd, &len);
+        close(fd);
+        if (!buf) exit(2);
+        pp = (const unsigned char **)malloc(cap * sizeof(*pp));
+        ll = (int *)malloc(cap * sizeof(*ll));
+        for (i = 0; i <= len; i++)
+            if (i == len || buf[i] == '\n') {
+                if (i > start) {
+                    if (np == cap) {
+                        cap *= 2;
+                        pp = (const unsigned char **)realloc(pp, cap * sizeof(*pp));
+                        ll = (int *)realloc(ll, cap * sizeof(*ll));
+                    }
+                    pp[np] = buf + start;
+                    ll[np] = (int)(i - start);
+                    np++;
+                }
+                start = i + 1;
+            }
+        if (np == 0) die_usage("the pattern file holds no pattern");
+        if (agh_device_count() <= 0) {
+            fprintf(stderr, "%s: no usable HIP device (this build has no CPU scan engine)\n", Progname);
+            exit(2);
+        }
+        q = agh_query_multi(pp, ll, (int)np, opt.NOUPPER, opt.delim, opt.dlen);
+        if (!q) { fprintf(stderr, "%s: %s\n", Progname, agh_last_error()); exit(2); }
+        total = run_pass(q, files, nfiles, 1, 0, &files_matched);
+        agh_query_free(q);
+        if (opt.VERBOSE > 0 && !opt.SILENT) printf("Grand Total: %ld match(es) found.\n", total);
+        return (int)total;
+    }
     m = (int)strlen(opt.pattern);
     if (opt.D >= m) {                           /* checksg.c:34-41 */
         fprintf(stderr, "%s: size of pattern must be greater than number of errors\n", Progname);

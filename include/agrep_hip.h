@@ -99,6 +99,12 @@ agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint
                                   uint32_t D_endpos, int M, const unsigned char *old_D_pat,
                                   int D_length, int D, int AND);
 
+/* Replaces prepf() (newmgrep.c:192-375, called from agrep_init for -f / -m): npat literal
+ * patterns pats[i][0..lens[i]).  A record matches iff it contains any pattern verbatim --
+ * exact matching only, like mgrep() (compat.c:34-37 ignores -# with -f).  nocase = -i. */
+agh_query *agh_query_multi(const unsigned char *const *pats, const int *lens, int npat,
+                           int nocase, const unsigned char *delim, int dlen);
+
 void agh_query_free(agh_query *q);
 
 /* Introspection used by tests/bench: pattern length, errors, filter sample shape

@@ -1,0 +1,126 @@
+"""-f multi-pattern scans (newmgrep.c semantics: a record matches iff it contains any pattern
+verbatim) against the naive oracle, and -- for <= 16 patterns, where the reference is reliable
+ -- against the reference CLI."""
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "agrep_amd", "agrep-hip")
+REF = os.path.join(O.REF_DIR, "agrep")
+
+
+@pytest.fixture(scope="module")
+def agh():
+    import agrep_amd
+    assert agrep_amd.device_count() >= 1
+    return agrep_amd
+
+
+def _rand_patterns(rng, n, lo, hi, alphabet=b"abcdefghijklmnopqrstuvwxyz"):
+    out = set()
+    while len(out) < n:
+        out.add(bytes(rng.choice(alphabet) for _ in range(rng.randint(lo, hi))))
+    return sorted(out)
+
+
+def _plant(text, pats, rng, every):
+    a = bytearray(text)
+    pos = 0
+    while True:
+        nl = a.find(b"\n", pos)
+        if nl < 0:
+            break
+        if rng.random() < 1.0 / every and nl - pos > 40:
+            p = rng.choice(pats)
+            at = rng.randint(pos, nl - len(p))
+            a[at:at + len(p)] = p
+        pos = nl + 1
+    return bytes(a)
+
+
+def _check(agh, pats, text, nocase=False):
+    want = O.multi_exact_count(pats, text, nocase=nocase, cap=200000)
+    with agh.Query.multi(pats, nocase=nocase) as q:
+        res, ms = q.scan_buffer(text, cap=200000)
+        res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+    assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want
+    assert res_c.n_matched == want[0]
+    return res
+
+
+@pytest.mark.parametrize("npat,lo,hi", [(1, 6, 6), (16, 4, 12), (50, 4, 12), (1024, 4, 12), (300, 1, 3),
+                                        (5, 13, 40)])
+def test_multi_pattern_counts_and_records(agh, npat, lo, hi):
+    rng = random.Random(npat * 7 + lo)
+    pats = _rand_patterns(rng, npat, lo, hi)
+    base, _ = O.corpus(96, seed=npat, variants=(), plant_period=0)
+    text = _plant(base.tobytes(), pats, rng, every=9)
+    res = _check(agh, pats, text)
+    assert res.n_matched > 0
+
+
+def test_multi_pattern_nocase_and_edges(agh):
+    rng = random.Random(3)
+    pats = [b"Needle", b"haystack", b"XyZ", b"q"]
+    base, _ = O.corpus(32, seed=1, variants=(), plant_period=0, upper_permille=400)
+    text = _plant(base.tobytes(), [b"nEEdle", b"HAYSTACK", b"xyz"], rng, every=5)
+    _check(agh, pats[:3], text, nocase=True)
+    _check(agh, pats[:3], text, nocase=False)
+    for t in (b"", b"\n", b"needle", b"x needle", b"needle\n" * 3000, b"nee\ndle\n", b"a" * 5000 + b"needle"):
+        _check(agh, [b"needle", b"zzz"], t)
+    # patterns across strip / range boundaries
+    for boundary in (1024, 4096, 262144):
+        t = bytearray(b"z" * (boundary + 2048))
+        for i in range(70, len(t), 91):
+            t[i] = 10
+        for shift in (1, 3, 5, 11):
+            at = boundary - shift
+            t[at:at + 6] = b"needle"
+            for p in range(at - 1, at + 8):
+                if t[p] == 10:
+                    t[p] = ord("z")
+        _check(agh, [b"needle", b"absent"], bytes(t))
+
+
+def test_multi_pattern_resident_scale(agh):
+    """Config-5 shape: 1024 patterns of 4..12 bytes, 1 GiB resident; lean == numbered and a
+    16 MiB slice equals the oracle."""
+    import torch
+    rng = random.Random(1024)
+    pats = _rand_patterns(rng, 1024, 4, 12)
+    pages = (1 << 30) // 4096
+    t = torch.empty(pages * 4096, dtype=torch.uint8, device="cuda")
+    agh.corpus_fill_device(t.data_ptr(), pages, seed=5, variants=tuple(pats[:7]), plant_period=300)
+    with agh.Query.multi(pats) as q:
+        a = q.scan_device(t.data_ptr(), t.numel())
+        b = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+        sl = q.scan_device(t.data_ptr(), 16 << 20, flags=agh.COUNT)
+    assert a.n_matched == b.n_matched > 0
+    assert sl.n_matched == O.multi_exact_count(pats, t[:16 << 20].cpu().numpy())[0]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/agrep not built")
+def test_cli_pattern_file_matches_reference(agh, tmp_path):
+    if not os.path.exists(CLI):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "agrep_amd", "host")])
+    rng = random.Random(16)
+    pats = _rand_patterns(rng, 12, 5, 10)
+    base, _ = O.corpus(40, seed=77, variants=(), plant_period=0)
+    text = _plant(base.tobytes(), pats, rng, every=7)
+    f = tmp_path / "text.txt"
+    f.write_bytes(text)
+    pf = tmp_path / "pats.txt"
+    pf.write_bytes(b"\n".join(pats) + b"\n")
+    for args in (["-V0", "-c"], ["-V0"], ["-V0", "-l"], ["-c"], ["-V0", "-i", "-c"]):
+        a = args + ["-f", str(pf), str(f)]
+        r = subprocess.run([REF] + a, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        g = subprocess.run([CLI] + a, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert g.stdout == r.stdout, (args, g.stdout[:200], r.stdout[:200])
+        assert g.returncode == r.returncode, args
