@@ -60,6 +60,8 @@ def lib():
     L.agh_query_multi.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, u8p,
                                   C.c_int]
     L.agh_query_multi.restype = vp
+    L.agh_query_set_costs.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.agh_query_set_costs.restype = C.c_int
     L.agh_query_free.argtypes = [vp]
     L.agh_query_free.restype = None
     L.agh_query_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
@@ -144,6 +146,10 @@ class Query:
         if not h:
             raise AghError(lib().agh_last_error().decode("latin1"))
         return cls(None, _handle=h)
+
+    def set_costs(self, insertion=1, substitution=1, deletion=1):
+        _check(lib().agh_query_set_costs(self._h, insertion, substitution, deletion))
+        return self
 
     def info(self):
         m, d, fq, fh = C.c_int(), C.c_int(), C.c_int(), C.c_int()

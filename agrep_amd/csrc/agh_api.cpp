@@ -106,6 +106,10 @@ struct agh_query {
     bool hashset_dirty = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     // multi-pattern (-f) queries
+    // general automaton (asearch1.c costs, <exact> segments): full scan only
+    bool general = false;
+    int ci = 1, cs = 1, cd = 1;
+    uint64_t no_err = ~0ull;
     bool multi = false;
     bool multi_dense = false;           // hits are too dense for the candidate slices
     int npat = 0;
@@ -271,14 +275,12 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
         fail("wildcard / sticky positions are outside the supported subset");
         return nullptr;
     }
-    // NO_ERR_MASK must only forbid errors into the delimiter positions (no <exact> parts)
-    {
-        uint32_t pattern_bits = (1u << m) - 1u;
-        if ((NO_ERR_MASK & pattern_bits) != pattern_bits) {
-            fail("<exact> pattern segments are outside the supported subset");
-            return nullptr;
-        }
-    }
+    // NO_ERR_MASK: 0-bits forbid error transitions into a position (<exact> segments,
+    // maskgen.c:80-95, 222-223); pattern position p is reference bit (m - p) -> device bit p-1
+    uint64_t no_err = 0;
+    for (int p = 1; p <= m; ++p)
+        if ((NO_ERR_MASK >> (m - p)) & 1u) no_err |= (uint64_t)1 << (p - 1);
+    const bool exact_parts = no_err != (m == 64 ? ~0ull : (((uint64_t)1 << m) - 1));
     agh_query *q = new agh_query();
     q->m = m;
     q->k = D;
@@ -292,6 +294,10 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
         for (int p = 1; p <= m; ++p)
             if ((Mask[c] >> (m - p)) & 1u) v |= (uint64_t)1 << (p - 1);
         q->mask[c] = v;
+    }
+    if (exact_parts) {
+        q->general = true;
+        q->no_err = no_err;
     }
     return finish_query(q);
 }
@@ -368,6 +374,21 @@ extern "C" agh_query *agh_query_multi(const unsigned char *const *pats, const in
         return nullptr;
     }
     return q;
+}
+
+// asearch1.c:42-44 / agrep.c:2680-2696 (-I# -S# -D#): non-unit edit costs.  Such queries run
+// on the general automaton (full scan).
+extern "C" int agh_query_set_costs(agh_query *q, int I, int S, int DD)
+{
+    if (!q) return fail("null query");
+    if (q->multi) return fail("multi-pattern queries are exact");
+    if (I < 1 || S < 1 || DD < 1)
+        return fail("costs must be >= 1 (cost 0 turns every position into a self loop, asearch1.c:41)");
+    q->ci = I;
+    q->cs = S;
+    q->cd = DD;
+    if (I != 1 || S != 1 || DD != 1) q->general = true;
+    return 0;
 }
 
 extern "C" void agh_query_free(agh_query *q)
@@ -467,7 +488,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     if (q->multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
     if (q->multi && (flags & AGH_FORCE_FULLSCAN))
         return fail("multi-pattern queries have no full-scan engine");
-    const bool want_filter = q->fq > 0 && !(flags & AGH_FORCE_FULLSCAN);
+    const bool want_filter = q->fq > 0 && !(flags & AGH_FORCE_FULLSCAN) && !q->general;
     if (!want_filter && (flags & AGH_FORCE_FILTER))
         return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
     if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
@@ -488,6 +509,10 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     dq.fh = q->fh;
     dq.qmask = q->qmask;
     dq.fold = q->fold;
+    dq.ci = (uint32_t)std::min(q->ci, q->k + 1);       // asearch1.c:42-44
+    dq.cs = (uint32_t)std::min(q->cs, q->k + 1);
+    dq.cd = (uint32_t)std::min(q->cd, q->k + 1);
+    dq.no_err = q->no_err;
     dq.head_byte = head_byte;
     dq.tail_virtual = tail_virtual;
 
@@ -667,6 +692,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.q = dq;
         va.mask = q->d_mask;
         va.wide = q->wide;
+        va.general = q->general;
         va.cand = (const uint64_t *)q->cand.p;
         va.wave_cand = (const uint32_t *)q->wave_cand.p;
         va.nw = (uint32_t)nw;

@@ -51,6 +51,9 @@ struct agh_dev_query {
     uint32_t head_byte; // byte fed in front of the segment: '\n' for the first segment of a
                         // file (asearch.c:69-78), the delimiter for later segments
     int32_t tail_virtual; // 1: the delimiter is appended at the segment end (asearch.c:87-91)
+    // general automaton (asearch1.c costs, <exact> segments): used by the full-scan kernel only
+    uint32_t ci, cs, cd;  // cost of insertion / substitution / deletion (1..k+1)
+    uint64_t no_err;      // bit p-1 clear: position p may not be entered through an error
 };
 
 // Multi-pattern (-f) scans: 2^18-bit table of pattern-prefix q-grams (32 KiB, LDS) and the

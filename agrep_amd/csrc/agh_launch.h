@@ -40,6 +40,7 @@ struct agh_scan_args {
     agh_dev_query q;
     const void *mask;        // 256 x uint32_t or uint64_t (device)
     int wide;                // 1: 64-bit state words
+    int general;             // 1: general automaton (costs / <exact>), full scan only
     const uint64_t *cand;
     const uint32_t *wave_cand;
     uint32_t nw;

@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
 // 16 consecutive text bytes (one LDS b128 read) through the automaton, branch-free: returns
 // the 16-bit masks of new-match positions (h16) and delimiter-end positions (d16; an input in
 // MB mode, where delimiter ends come from the bitmap).
-template <typename WT, int K, bool MB>
+template <typename WT, int K, bool MB, bool GEN>
 __device__ __forceinline__ void fullscan_piece(uint4 v, const WT *lmask, WT finalbit,
-                                               uint32_t delim, const Automaton<WT, K> &RF,
+                                               const agh_dev_query &q, const Automaton<WT, K> &RF,
                                                uint32_t rf_hit, Automaton<WT, K> &A,
                                                uint32_t &seen, uint32_t &h16, uint32_t &d16)
 {
@@ -65,8 +65,8 @@ __device__ __forceinline__ void fullscan_piece(uint4 v, const WT *lmask, WT fina
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
         const uint32_t byte = (dws[b >> 2] >> (8 * (b & 3))) & 0xffu;
-        const uint32_t hit = A.step(lmask[byte], finalbit) ? 1u : 0u;
-        const uint32_t isd = MB ? (d >> b) & 1u : ((byte == delim) ? 1u : 0u);
+        const uint32_t hit = A.template step_q<GEN>(lmask[byte], finalbit, q) ? 1u : 0u;
+        const uint32_t isd = MB ? (d >> b) & 1u : ((byte == q.delim) ? 1u : 0u);
         h |= (hit & ~seen) << b;
         if (!MB) d |= isd << b;
         seen |= hit;
@@ -80,7 +80,8 @@ __device__ __forceinline__ void fullscan_piece(uint4 v, const WT *lmask, WT fina
     d16 = d;
 }
 
-template <typename WT, int K, bool MB>
+// GEN: the general automaton (non-unit costs / <exact> segments) instead of the unit-cost one.
+template <typename WT, int K, bool MB, bool GEN>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q,
     const WT *__restrict__ mask_g, const uint32_t *__restrict__ strip_prefix,
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
     // state right after a record boundary: reset + re-fed delimiter byte (asearch.c:175-186)
     Automaton<WT, K> RF;
     RF.reset();
-    const uint32_t rf_hit = RF.step(lmask[q.delim], finalbit) ? 1u : 0u;
+    const uint32_t rf_hit = RF.template step_q<GEN>(lmask[q.delim], finalbit, q) ? 1u : 0u;
 
     for (uint64_t tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
         const uint64_t t0 = tix * tile_bytes;
@@ -160,15 +161,15 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
         A.reset();
         uint32_t seen = 0;
         if (cs == 0) {
-            A.step(lmask[q.head_byte], finalbit); // asearch.c:69-78
+            A.template step_q<GEN>(lmask[q.head_byte], finalbit, q); // asearch.c:69-78
         } else {
             // rebuild the state from the m+k+1 (rounded to 16) bytes in front of the chunk
             const uint8_t *halo = tile + threadIdx.x * AGH_FS_SLOT + (AGH_FS_CHUNK - warm);
             for (uint32_t t = 0; t < warm / 16; ++t) {
                 uint32_t h16 = 0, d16 = 0;
                 if (MB) d16 = (uint32_t)dbm_bits64(dbm, cs - warm + 16u * t) & 0xffffu;
-                fullscan_piece<WT, K, MB>(*reinterpret_cast<const uint4 *>(halo + 16 * t), lmask,
-                                          finalbit, q.delim, RF, rf_hit, A, seen, h16, d16);
+                fullscan_piece<WT, K, MB, GEN>(*reinterpret_cast<const uint4 *>(halo + 16 * t),
+                                               lmask, finalbit, q, RF, rf_hit, A, seen, h16, d16);
             }
             seen = 0;                           // matches before cs belong to the previous lane
         }
@@ -177,8 +178,8 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
         for (uint32_t t = 0; t < full; ++t) {
             uint32_t h16 = 0, d16 = 0;
             if (MB) d16 = (uint32_t)dbm_bits64(dbm, cs + 16u * t) & 0xffffu;
-            fullscan_piece<WT, K, MB>(*reinterpret_cast<const uint4 *>(mine + 16 * t), lmask,
-                                      finalbit, q.delim, RF, rf_hit, A, seen, h16, d16);
+            fullscan_piece<WT, K, MB, GEN>(*reinterpret_cast<const uint4 *>(mine + 16 * t), lmask,
+                                           finalbit, q, RF, rf_hit, A, seen, h16, d16);
             uint32_t ev = h16 | (rf_hit ? d16 : 0u);
             while (ev) {                        // rare: a record matched in this piece
                 const uint32_t b = (uint32_t)__ffs((int)ev) - 1u;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
         bool seenb = seen != 0;
         for (uint32_t i = full * 16; i < len; ++i) {     // the last, partial piece of the text
             const uint32_t c = mine[i];
-            bool hit = A.step(lmask[c], finalbit);
+            bool hit = A.template step_q<GEN>(lmask[c], finalbit, q);
             if (hit && !seenb) {
                 seenb = true;
                 mark_record(mk, rec, cs + i);
@@ -201,14 +202,14 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
                 A.reset();
                 ++rec;
                 seenb = false;
-                if (A.step(lmask[c], finalbit)) {
+                if (A.template step_q<GEN>(lmask[c], finalbit, q)) {
                     seenb = true;
                     mark_record(mk, rec, cs + i + 1);
                 }
             }
         }
         if (ce == n && q.tail_virtual)          // asearch.c:87-91
-            feed_virtual_tail<WT, K, false>(text, n, q, lmask, dbm, A, seenb, rec, 0, mk);
+            feed_virtual_tail<WT, K, false, GEN>(text, n, q, lmask, dbm, A, seenb, rec, 0, mk);
     }
 }
 
@@ -315,14 +316,16 @@ static void launch_fullscan_t(const agh_scan_args &a, hipStream_t st)
     if (!n_tiles) return;
     uint32_t blocks = n_tiles > 65536 ? 65536u : (uint32_t)n_tiles;
     const size_t lds = 256 * sizeof(WT) + (size_t)(AGH_FS_THREADS + 1) * AGH_FS_SLOT;
-    if (a.q.dlen > 1)
-        hipLaunchKernelGGL((k_fullscan<WT, K, true>), dim3(blocks), dim3(AGH_FS_THREADS), lds, st,
-                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask,
-                           a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm);
-    else
-        hipLaunchKernelGGL((k_fullscan<WT, K, false>), dim3(blocks), dim3(AGH_FS_THREADS), lds,
-                           st, (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask,
-                           a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm);
+#define AGH_FS_LAUNCH(MBV, GENV)                                                              \
+    hipLaunchKernelGGL((k_fullscan<WT, K, MBV, GENV>), dim3(blocks), dim3(AGH_FS_THREADS), lds,  \
+                       st, (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask,                \
+                       a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm)
+    const bool mbv = a.q.dlen > 1, genv = a.general != 0;
+    if (mbv && genv) AGH_FS_LAUNCH(true, true);
+    else if (mbv) AGH_FS_LAUNCH(true, false);
+    else if (genv) AGH_FS_LAUNCH(false, true);
+    else AGH_FS_LAUNCH(false, false);
+#undef AGH_FS_LAUNCH
 }
 
 template <typename WT>

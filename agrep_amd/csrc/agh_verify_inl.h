@@ -111,6 +111,41 @@ struct Automaton {
         }
         return (R[K] & finalbit) != 0;
     }
+    // asearch1.c:88-97: levels are accumulated cost; insertion comes from level e-ci,
+    // substitution from e-cs, deletion from the NEW level e-cd; positions whose no_err bit is
+    // clear cannot be entered through an error (maskgen.c:80-95 "<...>").  The start state is
+    // shifted in only when a source level exists (the reference's dummy levels are zero words).
+    __device__ __forceinline__ bool step_general(WT cm, WT finalbit, uint32_t ci, uint32_t cs,
+                                                 uint32_t cd, WT no_err)
+    {
+        WT old[K + 1], nw[K + 1];
+#pragma unroll
+        for (int e = 0; e <= K; ++e) old[e] = R[e];
+        nw[0] = ((old[0] << 1) | (WT)1) & cm;
+#pragma unroll
+        for (int e = 1; e <= K; ++e) {
+            WT ins = 0, via = 0;
+            bool have = false;
+#pragma unroll
+            for (int s = 0; s < e; ++s) {
+                const uint32_t d = (uint32_t)(e - s);
+                if (d == ci) ins = old[s];
+                if (d == cs) { via |= old[s]; have = true; }
+                if (d == cd) { via |= nw[s]; have = true; }
+            }
+            const WT err = have ? (((via << 1) | (WT)1) & no_err) : (WT)0;
+            nw[e] = (((old[e] << 1) | (WT)1) & cm) | ins | err;
+        }
+#pragma unroll
+        for (int e = 0; e <= K; ++e) R[e] = nw[e];
+        return (R[K] & finalbit) != 0;
+    }
+    template <bool GEN>
+    __device__ __forceinline__ bool step_q(WT cm, WT finalbit, const agh_dev_query &q)
+    {
+        if (GEN) return step_general(cm, finalbit, q.ci, q.cs, q.cd, (WT)q.no_err);
+        return step(cm, finalbit);
+    }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -146,7 +181,7 @@ __device__ __forceinline__ uint64_t virtual_close_start(const uint8_t *__restric
 // The delimiter appended at EOF (asearch.c:87-91), byte by byte, for any delimiter length: the
 // automaton sees the bytes as text, the little delimiter automaton `ds` completes whatever
 // partial delimiter the real text ended with.  A / seen / rec / rstart continue from the walk.
-template <typename WT, int K, bool LEAN>
+template <typename WT, int K, bool LEAN, bool GEN = false>
 __device__ __forceinline__ void feed_virtual_tail(const uint8_t *__restrict__ text, uint64_t n,
                                                   const agh_dev_query &q, const WT *lmask,
                                                   const uint64_t *__restrict__ dbm,
@@ -167,7 +202,7 @@ __device__ __forceinline__ void feed_virtual_tail(const uint8_t *__restrict__ te
     const uint32_t endbit = 1u << (q.dlen - 1);
     for (uint32_t j = 0; j < q.dlen; ++j) {
         const uint32_t c = q.dbytes[j];
-        if (A.step(lmask[c], finalbit) && !seen) {
+        if (A.template step_q<GEN>(lmask[c], finalbit, q) && !seen) {
             seen = true;
             if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
         }
@@ -178,7 +213,7 @@ __device__ __forceinline__ void feed_virtual_tail(const uint8_t *__restrict__ te
             ++rec;
             rstart = n + j + 1;
             seen = false;
-            if (A.step(lmask[c], finalbit)) {
+            if (A.template step_q<GEN>(lmask[c], finalbit, q)) {
                 seen = true;
                 if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
             }

@@ -1,6 +1,6 @@
 /*
  * agrep_hip.c -- C host side of the MI355X agrep scanner: the command-line surface of the
- * reference for the k-error hot path ( -# -c -l -i -d -B -y -n -h -s -e -k -V0 ), driving the
+ * reference for the k-error hot path ( -# -c -l -i -d -B -y -n -h -s -e -k -f -I -S -D -V0 ), driving the
  * HIP C-ABI of include/agrep_hip.h.  It mirrors, for literal patterns,
  *
  *   option parsing      agrep.c:2121-2739  (grouped flags, a digit run ends its group)
@@ -39,6 +39,7 @@ static struct {
     int NOPROMPT;          /* -y  */
     int VERBOSE;           /* -V# (default 1: print the Grand Total line) */
     int APPROX;            /* a -# was given */
+    int I, S, DD;          /* -I# -S# -D#: edit costs (asearch1.c), 0 = not given */
     unsigned char delim[AGH_MAX_DELIM + 1];
     int dlen;
     const char *pattern;
@@ -122,6 +123,9 @@ static int parse_options(int argc, char **argv, char **files)
                     opt.VERBOSE = (*p >= '0' && *p <= '9') ? atoi(p) : 1;
                     while (*p >= '0' && *p <= '9') p++;
                     break;
+                case 'I': opt.I = atoi(p); p = (char *)""; break;    /* agrep.c:2680-2696 */
+                case 'S': opt.S = atoi(p); p = (char *)""; break;
+                case 'D': opt.DD = atoi(p); p = (char *)""; break;
                 case 'd':
                     if (*p) set_delimiter(p);
                     else if (i + 1 < argc) set_delimiter(argv[++i]);
@@ -357,6 +361,11 @@ int main(int argc, char **argv)
         q = agh_query_literal((const unsigned char *)opt.pattern, m, opt.D, opt.NOUPPER,
                               opt.delim, opt.dlen);
         if (!q) { fprintf(stderr, "%s: %s\n", Progname, agh_last_error()); exit(2); }
+        if ((opt.I || opt.S || opt.DD) &&
+            agh_query_set_costs(q, opt.I ? opt.I : 1, opt.S ? opt.S : 1, opt.DD ? opt.DD : 1)) {
+            fprintf(stderr, "%s: %s\n", Progname, agh_last_error());
+            exit(2);
+        }
         total = run_pass(q, files, nfiles, 1, 0, &files_matched);
         agh_query_free(q);
     } else {

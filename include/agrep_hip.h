@@ -93,7 +93,8 @@ agh_query *agh_query_literal(const unsigned char *pat, int m, int D, int nocase,
  * them (maskgen.c:218-266); M = maskgen's return value; old_D_pat / D_length = raw
  * delimiter (asearch.c:54); D = errors; AND = the AND flag (maskgen.c:150-163).
  * Supported subset: one pattern end bit (endposition == 1), no wildcards (Init1 sticky
- * bits == Init0 | endposition | D_endpos), no <exact> segments; anything else -> NULL. */
+ * bits == Init0 | endposition | D_endpos); <exact> segments (NO_ERR_MASK) are honoured;
+ * anything else -> NULL. */
 agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint32_t Init1,
                                   uint32_t NO_ERR_MASK, uint32_t endposition,
                                   uint32_t D_endpos, int M, const unsigned char *old_D_pat,
@@ -104,6 +105,11 @@ agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint
  * exact matching only, like mgrep() (compat.c:34-37 ignores -# with -f).  nocase = -i. */
 agh_query *agh_query_multi(const unsigned char *const *pats, const int *lens, int npat,
                            int nocase, const unsigned char *delim, int dlen);
+
+/* Replaces the cost globals I, S, DD of asearch1() (asearch1.c:28-44, options -I# -S# -D#,
+ * agrep.c:2680-2696): cost of an insertion / substitution / deletion, each >= 1; a record
+ * matches iff some substring is within total cost D.  Costs above D behave as D + 1. */
+int agh_query_set_costs(agh_query *q, int I, int S, int DD);
 
 void agh_query_free(agh_query *q);
 

@@ -116,6 +116,7 @@ int orc_maskgen_literal(const uint8_t *pat, int m, const uint8_t *delim, int dle
 typedef struct {
     const orc_tables *t;
     int k;
+    int ci, cs, cd;        /* costs of insertion / substitution / deletion (asearch1.c) */
     uint32_t B[ORC_MAXERR + 1];
     uint32_t D_Mask;
     uint64_t rec_start;
@@ -134,11 +135,12 @@ static void as_feed(as_state *st, uint32_t c, int64_t i)
     uint32_t CM = t->Mask[c & 255];
     int e;
 
-    /* asearch.c:94-116 */
+    /* asearch.c:94-116; with costs asearch1.c:88-97 (levels below cost 0 are zero words) */
+#define LV(arr, idx) ((idx) >= 0 ? (arr)[idx] : 0u)
     A[0] = ((st->B[0] >> 1) & CM) | (t->Init1 & st->B[0]);
     for (e = 1; e <= k; e++)
-        A[e] = ((st->B[e] >> 1) & CM) | (t->Init1 & st->B[e]) | st->B[e - 1] |
-               (((A[e - 1] | st->B[e - 1]) >> 1) & t->NO_ERR_MASK);
+        A[e] = ((st->B[e] >> 1) & CM) | (t->Init1 & st->B[e]) | LV(st->B, e - st->ci) |
+               (((LV(A, e - st->cd) | LV(st->B, e - st->cs)) >> 1) & t->NO_ERR_MASK);
 
     if (A[0] & t->D_endpos) {                          /* asearch.c:119 record boundary */
         uint32_t r1 = A[k];
@@ -160,23 +162,35 @@ static void as_feed(as_state *st, uint32_t c, int64_t i)
         for (e = 0; e <= k; e++) st->B[e] = t->Init0;
         A[0] = (((st->B[0] >> 1) & CM) | (st->B[0] & t->Init1)) & st->D_Mask;
         for (e = 1; e <= k; e++)
-            A[e] = ((st->B[e] >> 1) & CM) | (t->Init1 & st->B[e]) | st->B[e - 1] |
-                   (((A[e - 1] | st->B[e - 1]) >> 1) & t->NO_ERR_MASK);
+            A[e] = ((st->B[e] >> 1) & CM) | (t->Init1 & st->B[e]) | LV(st->B, e - st->ci) |
+                   (((LV(A, e - st->cd) | LV(st->B, e - st->cs)) >> 1) & t->NO_ERR_MASK);
     }
+#undef LV
     for (e = 0; e <= k; e++) st->B[e] = A[e];
 }
 
 int64_t orc_asearch(const orc_tables *t, int k, const uint8_t *text, size_t n,
                     const uint8_t *delim, int dlen, orc_record *recs, size_t cap)
 {
+    return orc_asearch_costs(t, k, 1, 1, 1, text, n, delim, dlen, recs, cap);
+}
+
+int64_t orc_asearch_costs(const orc_tables *t, int k, int ci, int cs, int cd,
+                          const uint8_t *text, size_t n, const uint8_t *delim, int dlen,
+                          orc_record *recs, size_t cap)
+{
     as_state st;
     size_t i;
     int e;
 
     if (k < 0 || k > ORC_MAXERR || dlen != t->D_length) return -1;
+    if (ci < 1 || cs < 1 || cd < 1) return -1;
     memset(&st, 0, sizeof(st));
     st.t = t;
     st.k = k;
+    st.ci = ci > k ? k + 1 : ci;                       /* asearch1.c:42-44 */
+    st.cs = cs > k ? k + 1 : cs;
+    st.cd = cd > k ? k + 1 : cd;
     st.recs = recs;
     st.cap = cap;
     st.n = n;

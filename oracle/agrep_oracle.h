@@ -64,6 +64,15 @@ int orc_maskgen_literal(const uint8_t *pat, int m, const uint8_t *delim, int dle
 int64_t orc_asearch(const orc_tables *t, int k, const uint8_t *text, size_t n,
                     const uint8_t *delim, int dlen, orc_record *recs, size_t cap);
 
+/* asearch1.c:28-435: non-unit costs (-I# -S# -D#).  State words are indexed by accumulated
+ * cost 0..D (the reference keeps them at A[D..2D] above D dummy zero words, asearch1.c:55-56);
+ * insertion reads level cost-I, substitution cost-S, deletion the NEW level cost-DD
+ * (asearch1.c:90-97); costs above D are clamped to D+1 (asearch1.c:42-44).  Same text
+ * framing as orc_asearch.  I = S = DD = 1 is orc_asearch. */
+int64_t orc_asearch_costs(const orc_tables *t, int k, int ci, int cs, int cd,
+                          const uint8_t *text, size_t n, const uint8_t *delim, int dlen,
+                          orc_record *recs, size_t cap);
+
 /* sgrep.c:1023-1051 (initmask) + the verify loop sgrep.c:1166-1239 run over the whole text
  * (the BM/hash candidate filter sgrep.c:1130-1154 is lossless, so its windows are replaced
  * by "everything").  Newline is the hard-wired reset character (sgrep.c:1179-1181).

@@ -152,6 +152,46 @@ def gen_scan():
     print("scan.json:", len(cases), "cases")
 
 
+def gen_costs():
+    """-I# -S# -D# (asearch1.c): counts and lines from the reference CLI."""
+    cases = []
+    pat = O.PATTERN_C2.decode()
+    text, _ = O.corpus(24, seed=99, variants=O.VARIANTS_C2, plant_period=3)
+    tb = text.tobytes()
+    extra = (b"approximatematch\naproximatematch\napproxximatematch\napproxXmatematch\n"
+             b"apprximatemtch\napproximatematchh\nappproximatematch\nfoo\n")
+    for body, kind in ((tb, {"kind": "corpus", "pages": 24, "seed": 99, "period": 3}),
+                       (extra, {"kind": "literal", "latin1": extra.decode("latin1")})):
+        for k, costs in ((2, (2, 1, 1)), (2, (1, 2, 1)), (2, (1, 1, 2)), (2, (3, 1, 3)), (1, (1, 2, 1)),
+                         (2, (1, 2, 1)), (3, (2, 2, 1)), (3, (1, 3, 2)), (4, (2, 3, 2)), (2, (1, 1, 1)),
+                         (2, (9, 9, 9))):
+            opts = ["-I%d" % costs[0], "-S%d" % costs[1], "-D%d" % costs[2]]
+            cnt, lines = ref_scan(body, pat, k, opts, "file")
+            cases.append({"text": kind, "pattern": pat, "k": k, "costs": list(costs), "count": cnt,
+                          "n_lines": lines.count("\n"),
+                          "lines_sha256": hashlib.sha256(lines.encode("latin1")).hexdigest()})
+    with open(os.path.join(OUT, "costs.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "cases": cases}, f, indent=0)
+    print("costs.json:", len(cases), "cases", [c["count"] for c in cases])
+
+
+def gen_exact_segments():
+    """<...> exact segments (NO_ERR_MASK, maskgen.c:80-95): tables + counts from the reference."""
+    cases = []
+    text, _ = O.corpus(24, seed=99, variants=O.VARIANTS_C2, plant_period=3)
+    tb = text.tobytes()
+    for pat, k in (("<appro>ximatematch", 2), ("approxi<matematch>", 2), ("ap<proxim>atematch", 1),
+                   ("<approximatematch>", 2)):
+        rc, out, err = run([HARNESS, "tables", "-%d" % k, "-n", pat])
+        t = json.loads(out)
+        cnt, lines = ref_scan(tb, pat, k, ["-n"], "file")
+        cases.append({"pattern": pat, "k": k, "tables": t, "count": cnt,
+                      "text": {"kind": "corpus", "pages": 24, "seed": 99, "period": 3}})
+    with open(os.path.join(OUT, "exact_segments.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "cases": cases}, f, indent=0)
+    print("exact_segments.json:", [(c["pattern"], c["count"], hex(c["tables"]["NO_ERR_MASK"])) for c in cases])
+
+
 def gen_quirks():
     q = []
     pat = "approximatematch"
@@ -184,3 +224,5 @@ if __name__ == "__main__":
     gen_maskgen()
     gen_scan()
     gen_quirks()
+    gen_costs()
+    gen_exact_segments()

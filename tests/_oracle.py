@@ -42,6 +42,10 @@ def lib():
         L.orc_asearch.argtypes = [C.POINTER(OrcTables), C.c_int, C.c_void_p, C.c_size_t, u8p,
                                   C.c_int, C.POINTER(OrcRecord), C.c_size_t]
         L.orc_asearch.restype = C.c_int64
+        L.orc_asearch_costs.argtypes = [C.POINTER(OrcTables), C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_size_t, u8p, C.c_int,
+                                        C.POINTER(OrcRecord), C.c_size_t]
+        L.orc_asearch_costs.restype = C.c_int64
         L.orc_sgrep_verify.argtypes = [u8p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
                                        C.POINTER(OrcRecord), C.c_size_t]
         L.orc_sgrep_verify.restype = C.c_int64
@@ -95,6 +99,36 @@ def asearch(pat, k, text, delim=b"\n", nocase=False, cap=0):
     p, n, keep = _buf(text)
     recs = _recs(cap)
     cnt = lib().orc_asearch(C.byref(t), k, p, n, delim, len(delim), recs, cap)
+    return cnt, _collect(recs, cnt, cap)
+
+
+def tables_from_golden(g, M, dlen=1):
+    """OrcTables from a tests/golden 'tables' object (the reference's own maskgen output)."""
+    t = OrcTables()
+    for i, v in enumerate(g["Mask"]):
+        t.Mask[i] = v
+    t.Init0, t.Init1, t.NO_ERR_MASK = g["Init0"], g["Init1"], g["NO_ERR_MASK"]
+    t.endposition, t.D_endpos, t.wildmask = g["endposition"], g["D_endpos"], g["wildmask"]
+    t.M, t.D_length, t.AND = M, dlen, g["AND"]
+    return t
+
+
+def asearch_tables(t, k, text, delim=b"\n", cap=0):
+    p, n, keep = _buf(text)
+    recs = _recs(cap)
+    cnt = lib().orc_asearch(C.byref(t), k, p, n, delim, len(delim), recs, cap)
+    return cnt, _collect(recs, cnt, cap)
+
+
+def asearch_costs(pat, k, costs, text, delim=b"\n", nocase=False, cap=0):
+    """costs = (I, S, D): insertion, substitution, deletion (asearch1.c)"""
+    M, t = maskgen(pat, delim, nocase)
+    if M < 0:
+        raise ValueError("pattern too long for the reference word")
+    p, n, keep = _buf(text)
+    recs = _recs(cap)
+    cnt = lib().orc_asearch_costs(C.byref(t), k, costs[0], costs[1], costs[2], p, n, delim,
+                                  len(delim), recs, cap)
     return cnt, _collect(recs, cnt, cap)
 
 

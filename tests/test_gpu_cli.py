@@ -42,6 +42,7 @@ needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/agre
     ["-V0", "-2", "-c"], ["-2", "-c"], ["-V0", "-2"], ["-2"], ["-V0", "-i", "-2"],
     ["-V0", "-1", "-l"], ["-2", "-l"], ["-V0", "-2", "-h"], ["-V0", "-i", "-n", "-2"],
     ["-V0", "-c"], ["-V0", "-s", "-2"], ["-V0", "-3", "-ci"], ["-V0", "-ic", "-2"],
+    ["-V0", "-I2", "-c", "-2"], ["-V0", "-D2", "-S2", "-2"], ["-V0", "-I3", "-D3", "-c", "-3"],
 ])
 def test_cli_matches_reference(files, args):
     for fl in (files[:1], files):

@@ -369,3 +369,54 @@ def test_multi_byte_delimiters(agh, delim):
             assert (res.n_matched, recs) == want, (delim, k, flags)
         with agh.Query(O.PATTERN_C2, k, delim=delim) as q:
             assert q.scan_buffer(text, flags=agh.COUNT)[0].n_matched == want[0]
+
+
+def _golden(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)["cases"]
+
+
+def test_weighted_costs(agh):
+    """-I# -S# -D# (asearch1.c) on the general automaton: the reference's own numbers
+    (tests/golden/costs.json) and the cost oracle on fuzzed inputs."""
+    for case in _golden("costs.json"):
+        spec = case["text"]
+        text = spec["latin1"].encode("latin1") if spec["kind"] == "literal" else \
+            O.corpus(spec["pages"], seed=spec["seed"], variants=O.VARIANTS_C2,
+                     plant_period=spec["period"])[0].tobytes()
+        pat = case["pattern"].encode()
+        with agh.Query(pat, case["k"]) as q:
+            q.set_costs(*case["costs"])
+            res, ms = q.scan_buffer(text, cap=100000)
+            res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+        assert res.n_matched == case["count"] == res_c.n_matched, case["costs"]
+        want = O.asearch_costs(pat, case["k"], tuple(case["costs"]), text, cap=100000)
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want
+    rng = random.Random(11)
+    for it in range(40):
+        pat, k, text = _rand_case(rng, 5, max_m=24)
+        if k == 0:
+            continue
+        costs = (rng.randint(1, 3), rng.randint(1, 3), rng.randint(1, 3))
+        want = O.asearch_costs(pat, k, costs, text, cap=100000)
+        with agh.Query(pat, k) as q:
+            q.set_costs(*costs)
+            res, ms = q.scan_buffer(text, cap=100000)
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (pat, k, costs)
+
+
+def test_exact_segments_from_maskgen_tables(agh):
+    """<...> segments arrive through maskgen's NO_ERR_MASK (agh_query_from_maskgen)."""
+    for case in _golden("exact_segments.json"):
+        spec = case["text"]
+        text = O.corpus(spec["pages"], seed=spec["seed"], variants=O.VARIANTS_C2,
+                        plant_period=spec["period"])[0].tobytes()
+        t = case["tables"]
+        m = len(case["pattern"]) - 2
+        q = agh.Query.from_maskgen(t["Mask"], t["Init0"], t["Init1"], t["NO_ERR_MASK"],
+                                   t["endposition"], t["D_endpos"], m + 2, b"\n", case["k"], t["AND"])
+        res, ms = q.scan_buffer(text, cap=100000)
+        q.close()
+        assert res.n_matched == case["count"], case["pattern"]      # the reference's own count
+        want = O.asearch_tables(O.tables_from_golden(t, m + 2), case["k"], text, cap=100000)
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want

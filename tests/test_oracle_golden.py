@@ -143,3 +143,28 @@ def test_quirks_are_reproduced_and_classified():
     assert c["sgrep_count"] == 2
     assert O.dp_count(b"hello", 0, c["text"].encode("latin1"))[0] == 1
     assert O.dp_count(b"hello", 0, c["text"].encode("latin1"), nocase=True)[0] == 2
+
+
+@pytest.mark.parametrize("case", _load("costs.json"),
+                         ids=lambda c: "%s_k%d_I%dS%dD%d" % (c["text"]["kind"][:4], c["k"], *c["costs"]))
+def test_weighted_costs_match_reference(case):
+    """asearch1.c (-I# -S# -D#): counts and printed records of the reference CLI."""
+    text = _case_text(case["text"])
+    pat = case["pattern"].encode("latin1")
+    n, recs = O.asearch_costs(pat, case["k"], tuple(case["costs"]), text, cap=100000)
+    assert n == case["count"]
+    lines = b"".join(text[s:e] + b"\n" for s, e in recs).decode("latin1")
+    assert len(recs) == case["n_lines"]
+    assert hashlib.sha256(lines.encode("latin1")).hexdigest() == case["lines_sha256"]
+    if tuple(case["costs"]) == (1, 1, 1):
+        assert (n, recs) == O.asearch(pat, case["k"], text, cap=100000)
+
+
+@pytest.mark.parametrize("case", _load("exact_segments.json"), ids=lambda c: c["pattern"])
+def test_exact_segments_match_reference(case):
+    """<...> segments: the oracle automaton driven by the reference's own tables reproduces the
+    reference count (NO_ERR_MASK forbids error transitions into those positions)."""
+    text = _case_text(case["text"])
+    m = len(case["pattern"]) - 2                      # '<' and '>' are not positions
+    t = O.tables_from_golden(case["tables"], m + 2)
+    assert O.asearch_tables(t, case["k"], text)[0] == case["count"]
