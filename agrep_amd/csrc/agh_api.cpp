@@ -468,6 +468,8 @@ static uint64_t seg_max()
     return AGH_SEG_MAX_DEFAULT;
 }
 #define AGH_SEG_MAX (seg_max())
+// multi-pattern candidates carry 32-bit byte offsets
+#define AGH_SEG_MAX_Q(q) ((q)->multi ? std::min<uint64_t>(seg_max(), (uint64_t)4 << 30) : seg_max())
 
 struct seg_result {
     uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
@@ -788,11 +790,11 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
     bool first = true;
     while (off < len) {
         uint64_t end = len;
-        if (end - off > AGH_SEG_MAX && q->dlen > 1)
+        if (end - off > AGH_SEG_MAX_Q(q) && q->dlen > 1)
             return fail("multi-byte delimiters: inputs above the %llu-byte segment limit are not "
                         "supported yet", (unsigned long long)AGH_SEG_MAX);
-        if (end - off > AGH_SEG_MAX) {
-            uint64_t want = (off + AGH_SEG_MAX) & ~(uint64_t)15;
+        if (end - off > AGH_SEG_MAX_Q(q)) {
+            uint64_t want = (off + AGH_SEG_MAX_Q(q)) & ~(uint64_t)15;
             if (find_cut(q, base, off, want, st, &end)) return -1;
             // keep the next segment 16-byte aligned: back off to an aligned delimiter-free cut
             // is not possible in general, so require alignment of the cut instead

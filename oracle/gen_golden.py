@@ -192,6 +192,30 @@ def gen_exact_segments():
     print("exact_segments.json:", [(c["pattern"], c["count"], hex(c["tables"]["NO_ERR_MASK"])) for c in cases])
 
 
+def gen_pattern_language():
+    """Non-literal patterns whose whole meaning is in maskgen's tables: character classes,
+    -w word guards, -x whole-line guards.  Tables + counts from the reference."""
+    cases = []
+    text, _ = O.corpus(24, seed=99, variants=O.VARIANTS_C2, plant_period=3)
+    words = (b"the car is red\ncars are fast\na scar\ncar\ncharacter\nmy car.\ncat\n"
+             b"approximatematch\nxapproximatematch\napproximatematch x\n")
+    tb = text.tobytes() + words
+    for pat, k, opts in (("appr[ox]ximatematch", 2, []), ("approx[a-m]matematch", 1, []),
+                         ("[^b-z]pproximatematch", 2, []), ("car", 1, ["-w"]), ("car", 0, ["-w"]),
+                         ("approximatematch", 2, ["-w"]), ("approximatematch", 1, ["-x"]),
+                         ("car", 0, ["-x"])):
+        kopt = ["-%d" % k] if k else []
+        rc, out, err = run([HARNESS, "tables"] + kopt + ["-n"] + opts + [pat])
+        t = json.loads(out)
+        cnt, lines = ref_scan(tb, pat, k, ["-n"] + opts, "file")
+        cases.append({"pattern": pat, "k": k, "opts": opts, "tables": t, "count": cnt,
+                      "extra_latin1": words.decode("latin1"),
+                      "text": {"kind": "corpus", "pages": 24, "seed": 99, "period": 3}})
+    with open(os.path.join(OUT, "pattern_language.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "cases": cases}, f, indent=0)
+    print("pattern_language.json:", [(c["pattern"], c["opts"], c["count"], c["tables"]["ret"]) for c in cases])
+
+
 def gen_quirks():
     q = []
     pat = "approximatematch"
@@ -226,3 +250,4 @@ if __name__ == "__main__":
     gen_quirks()
     gen_costs()
     gen_exact_segments()
+    gen_pattern_language()

@@ -420,3 +420,21 @@ def test_exact_segments_from_maskgen_tables(agh):
         assert res.n_matched == case["count"], case["pattern"]      # the reference's own count
         want = O.asearch_tables(O.tables_from_golden(t, m + 2), case["k"], text, cap=100000)
         assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want
+
+
+def test_pattern_language_from_maskgen_tables(agh):
+    """[classes], -w and -x handed over as the reference's own maskgen tables."""
+    for case in _golden("pattern_language.json"):
+        spec = case["text"]
+        text = O.corpus(spec["pages"], seed=spec["seed"], variants=O.VARIANTS_C2,
+                        plant_period=spec["period"])[0].tobytes() + case["extra_latin1"].encode("latin1")
+        t = case["tables"]
+        M = t["D_endpos"].bit_length()
+        q = agh.Query.from_maskgen(t["Mask"], t["Init0"], t["Init1"], t["NO_ERR_MASK"],
+                                   t["endposition"], t["D_endpos"], M, b"\n", case["k"], t["AND"])
+        for flags in (0, agh.FORCE_FULLSCAN):
+            res, ms = q.scan_buffer(text, cap=100000, flags=flags)
+            assert res.n_matched == case["count"], (case["pattern"], case["opts"], flags)
+            want = O.asearch_tables(O.tables_from_golden(t, M), case["k"], text, cap=100000)
+            assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (case["pattern"], case["opts"])
+        q.close()

@@ -168,3 +168,20 @@ def test_exact_segments_match_reference(case):
     m = len(case["pattern"]) - 2                      # '<' and '>' are not positions
     t = O.tables_from_golden(case["tables"], m + 2)
     assert O.asearch_tables(t, case["k"], text)[0] == case["count"]
+
+
+def _lang_M(t):
+    return t["D_endpos"].bit_length()           # D_endpos = 1 << (M - 1) for a one-byte delimiter
+
+
+def _lang_text(case):
+    return _case_text(case["text"]) + case["extra_latin1"].encode("latin1")
+
+
+@pytest.mark.parametrize("case", _load("pattern_language.json"),
+                         ids=lambda c: "%s_k%d_%s" % (c["pattern"], c["k"], "".join(c["opts"]) or "plain"))
+def test_pattern_language_tables_match_reference(case):
+    """Character classes, -w and -x live entirely in maskgen's tables (preproce.c:148-175,
+    maskgen.c:86-170): the oracle automaton driven by those tables gives the reference count."""
+    t = O.tables_from_golden(case["tables"], _lang_M(case["tables"]))
+    assert O.asearch_tables(t, case["k"], _lang_text(case))[0] == case["count"]
