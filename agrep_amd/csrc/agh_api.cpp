@@ -108,6 +108,8 @@ struct agh_query {
     // multi-pattern (-f) queries
     // general automaton (asearch1.c costs, <exact> segments): full scan only
     bool general = false;
+    bool table = false;                 // table engine: mask[] holds the reference's Mask[]
+    agh_dev_tables tab;
     int ci = 1, cs = 1, cd = 1;
     uint64_t no_err = ~0ull;
     bool multi = false;
@@ -246,6 +248,88 @@ extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, 
     return finish_query(q);
 }
 
+// One byte through asearch.c's recurrence on reference-layout tables (host copy of what
+// agh_table.hip runs; used only to reject degenerate queries when the query is built).
+static uint32_t table_feed(const agh_dev_tables &T, const uint32_t *Mask, int k, uint32_t *B,
+                           unsigned c)
+{
+    uint32_t A[AGH_MAX_ERRORS + 1], CM = Mask[c & 255u], ret = 0;
+    A[0] = ((B[0] >> 1) & CM) | (T.Init1 & B[0]);
+    for (int e = 1; e <= k; ++e)
+        A[e] = ((B[e] >> 1) & CM) | (T.Init1 & B[e]) | B[e - 1] |
+               (((A[e - 1] | B[e - 1]) >> 1) & T.NO_ERR);
+    if (A[0] & T.D_endpos) {
+        const uint32_t r1 = A[k] & T.endposition;
+        ret = 1u | ((T.AND ? r1 == T.endposition : r1 != 0u) ? 2u : 0u);
+        A[0] = (((T.Init0 >> 1) & CM) | (T.Init0 & T.Init1)) & T.D_Mask;
+        for (int e = 1; e <= k; ++e)
+            A[e] = ((T.Init0 >> 1) & CM) | (T.Init1 & T.Init0) | T.Init0 |
+                   (((A[e - 1] | T.Init0) >> 1) & T.NO_ERR);
+    }
+    for (int e = 0; e <= k; ++e) B[e] = A[e];
+    return ret;
+}
+
+// Queries whose state is not bounded by the last m+k+1 bytes ('#' wildcards, -p) or whose
+// verdict needs several end bits (';' AND, ',' OR): the reference tables are kept as they are
+// and run by the table engine (agh_table.hip).
+static agh_query *table_query(const uint32_t Mask[256], uint32_t Init0, uint32_t Init1,
+                              uint32_t NO_ERR_MASK, uint32_t endposition, uint32_t D_endpos,
+                              int M, const unsigned char *old_D_pat, int D_length, int D, int AND)
+{
+    if (D_length != 1) {
+        fail("wildcard / AND / OR patterns support single-byte delimiters only");
+        return nullptr;
+    }
+    unsigned char dc = old_D_pat[0];
+    if (dc == '^' || dc == '$') dc = '\n';                          // bitap.c:92-94
+    int members = 0;
+    for (int c = 0; c < 256; ++c) members += (Mask[c] & D_endpos) ? 1 : 0;
+    if (members != 1 || !(Mask[dc] & D_endpos)) {
+        fail("the delimiter position of the tables is not the single byte 0x%02x", dc);
+        return nullptr;
+    }
+    agh_query *q = new agh_query();
+    q->table = true;
+    q->tab.Init0 = Init0;
+    q->tab.Init1 = Init1;
+    q->tab.NO_ERR = NO_ERR_MASK;
+    q->tab.endposition = endposition;
+    q->tab.D_endpos = D_endpos;
+    q->tab.D_Mask = ~D_endpos;                                      // asearch.c:54-57, D_length 1
+    q->tab.AND = AND ? 1u : 0u;
+    q->m = M - D_length - 1;
+    q->k = D;
+    q->dlen = 1;
+    q->delim[0] = dc;
+    memset(q->mask, 0, sizeof(q->mask));
+    for (int c = 0; c < 256; ++c) q->mask[c] = Mask[c];             // uploaded unchanged
+    // An empty record must not match (the virtual '\n' in front of the text and the delimiter
+    // appended at EOF would otherwise produce records that do not exist, asearch.c:69-91).
+    {
+        uint32_t B[AGH_MAX_ERRORS + 1];
+        for (int e = 0; e <= D; ++e) B[e] = Init0;
+        uint32_t r0 = table_feed(q->tab, Mask, D, B, '\n');
+        uint32_t r1 = table_feed(q->tab, Mask, D, B, dc);
+        uint32_t r2 = table_feed(q->tab, Mask, D, B, dc);
+        if ((r0 & 2u) || (r1 & 2u) || (r2 & 2u)) {
+            delete q;
+            fail("the pattern matches the empty record with %d errors", D);
+            return nullptr;
+        }
+    }
+    if (agh_device_count() <= 0) {
+        fail("no usable HIP device: libagrep_hip has no CPU path");
+        delete q;
+        return nullptr;
+    }
+    if (upload_tables(q) != 0) {
+        agh_query_free(q);
+        return nullptr;
+    }
+    return q;
+}
+
 extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0,
                                              uint32_t Init1, uint32_t NO_ERR_MASK,
                                              uint32_t endposition, uint32_t D_endpos, int M,
@@ -266,15 +350,10 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
     }
     const uint32_t sep = 1u << (M - D_length - 1);
     const uint32_t pad = M == 32 ? 0u : ~((1u << M) - 1u);
-    if (AND || endposition != 1u) {
-        fail("AND/OR patterns (endposition=0x%x) are outside the supported subset", endposition);
-        return nullptr;
-    }
-    if (Init0 != (pad | sep) || Init1 != (Init0 | 1u | D_endpos) ||
-        D_endpos != (1u << (M - D_length))) {
-        fail("wildcard / sticky positions are outside the supported subset");
-        return nullptr;
-    }
+    if (AND || endposition != 1u || Init0 != (pad | sep) || Init1 != (Init0 | 1u | D_endpos) ||
+        D_endpos != (1u << (M - D_length)))
+        return table_query(Mask, Init0, Init1, NO_ERR_MASK, endposition, D_endpos, M, old_D_pat,
+                           D_length, D, AND);
     // NO_ERR_MASK: 0-bits forbid error transitions into a position (<exact> segments,
     // maskgen.c:80-95, 222-223); pattern position p is reference bit (m - p) -> device bit p-1
     uint64_t no_err = 0;
@@ -382,6 +461,8 @@ extern "C" int agh_query_set_costs(agh_query *q, int I, int S, int DD)
 {
     if (!q) return fail("null query");
     if (q->multi) return fail("multi-pattern queries are exact");
+    if (q->table && (I != 1 || S != 1 || DD != 1))
+        return fail("edit costs are not supported together with wildcards / AND / OR");
     if (I < 1 || S < 1 || DD < 1)
         return fail("costs must be >= 1 (cost 0 turns every position into a self loop, asearch1.c:41)");
     q->ci = I;
@@ -490,7 +571,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     if (q->multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
     if (q->multi && (flags & AGH_FORCE_FULLSCAN))
         return fail("multi-pattern queries have no full-scan engine");
-    const bool want_filter = q->fq > 0 && !(flags & AGH_FORCE_FULLSCAN) && !q->general;
+    const bool want_filter = q->fq > 0 && !(flags & AGH_FORCE_FULLSCAN) && !q->general && !q->table;
     if (!want_filter && (flags & AGH_FORCE_FILTER))
         return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
     if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
@@ -544,9 +625,9 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         uint64_t slots = 1u << 20;
         while (slots < q->hashset_slots_hint) slots <<= 1;
         {
-            const void *before = q->hashset.p;
+            const size_t cap_before = q->hashset.cap;   // (a new block may reuse the old address)
             if (q->hashset.ensure(slots * sizeof(uint64_t))) return -1;
-            if (q->hashset.p != before || q->hashset_dirty)
+            if (q->hashset.cap != cap_before || q->hashset_dirty)
                 HIP_TRY(hipMemsetAsync(q->hashset.p, 0, q->hashset.cap, st));
             q->hashset_dirty = true;
         }
@@ -629,9 +710,9 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     for (int attempt = 0; attempt < 4; ++attempt) {
         const size_t bm_words = (size_t)(((bits_hint + 64 + 127) / 128) * 4);   // 16-byte units
         {
-            const void *before = q->bitmap.p;
+            const size_t cap_before = q->bitmap.cap;    // (a new block may reuse the old address)
             if (q->bitmap.ensure(bm_words * sizeof(uint32_t))) return -1;
-            if (q->bitmap.p != before || q->bitmap_dirty) {
+            if (q->bitmap.cap != cap_before || q->bitmap_dirty) {
                 // fresh allocation (or an aborted scan): zero everything once; afterwards
                 // k_bitmap_count leaves the bitmap clean
                 HIP_TRY(hipMemsetAsync(q->bitmap.p, 0, q->bitmap.cap, st));
@@ -695,6 +776,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mask = q->d_mask;
         va.wide = q->wide;
         va.general = q->general;
+        va.table = q->table;
+        va.tab = q->tab;
         va.cand = (const uint64_t *)q->cand.p;
         va.wave_cand = (const uint32_t *)q->wave_cand.p;
         va.nw = (uint32_t)nw;
@@ -712,6 +795,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.hashset_mask = 0;
         if (q->multi) agh_launch_verify_multi(va, multi_dev(q), false, st);
         else if (use_filter) agh_launch_verify(va, st);
+        else if (q->table) agh_launch_tablescan(va, st);
         else agh_launch_fullscan(va, st);
         agh_launch_bitmap_count((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), q->d_counters, st);
         HIP_TRY(hipGetLastError());

@@ -38,6 +38,11 @@ enum agh_counter {
     AGH_C_COUNT = 12
 };
 
+// The reference's own query tables for the table engine (agh_table.hip), maskgen.c layout.
+struct agh_dev_tables {
+    uint32_t Init0, Init1, NO_ERR, endposition, D_endpos, D_Mask, AND;
+};
+
 struct agh_dev_query {
     int32_t m;          // pattern positions
     int32_t k;          // errors

@@ -41,6 +41,8 @@ struct agh_scan_args {
     const void *mask;        // 256 x uint32_t or uint64_t (device)
     int wide;                // 1: 64-bit state words
     int general;             // 1: general automaton (costs / <exact>), full scan only
+    int table;               // 1: table engine (mask = the reference's Mask[], tab = its scalars)
+    agh_dev_tables tab;
     const uint64_t *cand;
     const uint32_t *wave_cand;
     uint32_t nw;
@@ -54,6 +56,7 @@ struct agh_scan_args {
 void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st);
 void agh_launch_verify(const agh_scan_args &a, hipStream_t st);
 void agh_launch_fullscan(const agh_scan_args &a, hipStream_t st);
+void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st);
 void agh_launch_bitmap_count(uint32_t *bitmap, uint32_t n_words, uint32_t *counters,
                              hipStream_t st);
 void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *wave_cand,

@@ -1,0 +1,154 @@
+// agh_table.hip -- the table engine: asearch.c's recurrence run literally on the reference's own
+// maskgen tables (Mask[], Init[0], Init1, NO_ERR_MASK, endposition, D_endpos; right-shifting
+// words, position 1 at the MSB side, agrep.c:281-282), for the part of the pattern language
+// whose state is not a function of the last m+k+1 bytes: '#' wildcards and -p (sticky positions
+// through Init1, maskgen.c:231-232), ';' AND / ',' OR (several end bits, verdict taken when the
+// record closes, asearch.c:119-128).
+//
+// Parallel over records instead of over bytes: a lane owns the records whose first byte lies
+// in its 256-byte chunk and runs each of them from its start (reset + re-fed delimiter,
+// asearch.c:175-186) to the delimiter that closes it, wherever that is.  Record numbers come
+// from the same delimiter census the full scan uses.
+#include "agh_verify_inl.h"
+
+#define AGH_TS_CHUNK 256u
+
+template <int K>
+struct TableAutomaton {
+    uint32_t B[K + 1];
+
+    __device__ __forceinline__ void reset(const agh_dev_tables &T)
+    {
+#pragma unroll
+        for (int e = 0; e <= K; ++e) B[e] = T.Init0;           // asearch.c:63-64
+    }
+    // One text byte.  Returns bit 0 = the byte closed a record, bit 1 = that record matched.
+    __device__ __forceinline__ uint32_t feed(uint32_t CM, const agh_dev_tables &T)
+    {
+        uint32_t A[K + 1];
+        A[0] = ((B[0] >> 1) & CM) | (T.Init1 & B[0]);          // asearch.c:94-116
+#pragma unroll
+        for (int e = 1; e <= K; ++e)
+            A[e] = ((B[e] >> 1) & CM) | (T.Init1 & B[e]) | B[e - 1] |
+                   (((A[e - 1] | B[e - 1]) >> 1) & T.NO_ERR);
+        uint32_t ret = 0;
+        if (A[0] & T.D_endpos) {                               // asearch.c:119
+            const uint32_t r1 = A[K] & T.endposition;
+            const bool hit = T.AND ? (r1 == T.endposition) : (r1 != 0u);   // asearch.c:128
+            ret = 1u | (hit ? 2u : 0u);
+            // asearch.c:175-186: every level back to Init[0], the same byte consumed again,
+            // level 0 masked so that the delimiter is not detected twice
+            A[0] = (((T.Init0 >> 1) & CM) | (T.Init0 & T.Init1)) & T.D_Mask;
+#pragma unroll
+            for (int e = 1; e <= K; ++e)
+                A[e] = ((T.Init0 >> 1) & CM) | (T.Init1 & T.Init0) | T.Init0 |
+                       (((A[e - 1] | T.Init0) >> 1) & T.NO_ERR);
+        }
+#pragma unroll
+        for (int e = 0; e <= K; ++e) B[e] = A[e];
+        return ret;
+    }
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void k_tablescan(const uint8_t *__restrict__ text, uint64_t n,
+                                                   agh_dev_query q, agh_dev_tables T,
+                                                   const uint32_t *__restrict__ mask_g,
+                                                   const uint32_t *__restrict__ strip_prefix,
+                                                   const uint32_t *__restrict__ wave_prefix,
+                                                   uint32_t n_strips, agh_marks mk)
+{
+    __shared__ uint32_t lmask[256];
+    lmask[threadIdx.x] = mask_g[threadIdx.x];
+    __syncthreads();
+    const uint64_t n_chunks = (n + AGH_TS_CHUNK - 1) / AGH_TS_CHUNK;
+    const uint32_t dd = q.delim * 0x01010101u;
+    const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
+
+    for (uint64_t base = (uint64_t)blockIdx.x * 256u; base < n_chunks;
+         base += (uint64_t)gridDim.x * 256u) {
+        const uint64_t cs = (base + threadIdx.x) * AGH_TS_CHUNK;
+        uint64_t ce = cs + AGH_TS_CHUNK;
+        if (ce > n) ce = n;
+        // delimiters of my chunk, and of the chunks of my 1 KiB strip in front of it
+        uint32_t my_delims = 0;
+        if (cs < n) {
+            const uint32_t len = (uint32_t)(ce - cs);
+            for (uint32_t i = 0; i < (len >> 4); ++i)
+                my_delims += delims_in(*reinterpret_cast<const uint4 *>(text + cs + i * 16), dd);
+            if (len & 15u)
+                my_delims += delims_in(
+                    mask_tail(*reinterpret_cast<const uint4 *>(text + cs + (len & ~15u)),
+                              (int)(len & 15u), fill4), dd);
+        }
+        uint32_t before = 0;
+        {
+            const int l4 = (int)(threadIdx.x & 3u);
+            uint32_t v1 = (uint32_t)__shfl_up((int)my_delims, 1, 4);
+            uint32_t v2 = (uint32_t)__shfl_up((int)my_delims, 2, 4);
+            uint32_t v3 = (uint32_t)__shfl_up((int)my_delims, 3, 4);
+            if (l4 >= 1) before += v1;
+            if (l4 >= 2) before += v2;
+            if (l4 >= 3) before += v3;
+        }
+        if (cs >= n) continue;
+        if (cs != 0 && my_delims == 0) continue;            // no record starts in my chunk
+
+        const uint64_t strip = cs >> AGH_STRIP_SHIFT;
+        // number of the record that contains byte cs
+        uint32_t rec = (strip < n_strips)
+                           ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] + before
+                           : 0u;
+        TableAutomaton<K> A;
+        A.reset(T);
+        bool active = false;
+        if (cs == 0) {
+            (void)A.feed(lmask[q.head_byte], T);            // asearch.c:69-78 (never a hit: host check)
+            active = true;
+        }
+        bool done = false;
+        for (uint64_t p0 = cs; !done; p0 += 16) {
+            if (p0 >= n) break;
+            const uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
+            const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const uint64_t pos = p0 + (uint32_t)b;
+                if (!done && pos < n) {
+                    const uint32_t c = (dws[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                    const uint32_t r = A.feed(lmask[c], T);
+                    if (r & 1u) {
+                        if (active && (r & 2u)) mark_record(mk, rec, pos);
+                        if (pos >= ce) done = true;        // that closed my last record
+                        active = true;
+                        ++rec;
+                    }
+                }
+            }
+        }
+        if (!done && active && q.tail_virtual) {            // asearch.c:87-91
+            const uint32_t r = A.feed(lmask[q.delim], T);
+            if ((r & 3u) == 3u) mark_record(mk, rec, n);
+        }
+    }
+}
+
+void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
+{
+    const uint64_t n_chunks = (a.n + AGH_TS_CHUNK - 1) / AGH_TS_CHUNK;
+    if (!n_chunks) return;
+    uint64_t want = (n_chunks + 255) / 256;
+    const uint32_t blocks = want > 65536 ? 65536u : (uint32_t)want;
+#define AGH_CASE(KK)                                                                          \
+    case KK:                                                                                  \
+        hipLaunchKernelGGL((k_tablescan<KK>), dim3(blocks), dim3(256), 0, st,                 \
+                           (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                           a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);                  \
+        break;
+    switch (a.q.k) {
+        AGH_CASE(0) AGH_CASE(1) AGH_CASE(2) AGH_CASE(3) AGH_CASE(4)
+        AGH_CASE(5) AGH_CASE(6) AGH_CASE(7) AGH_CASE(8)
+    default: break;
+    }
+#undef AGH_CASE
+}

@@ -92,9 +92,11 @@ agh_query *agh_query_literal(const unsigned char *pat, int m, int D, int nocase,
  * Mask[256], Init0 = Init[0], Init1, NO_ERR_MASK, endposition, D_endpos as maskgen() left
  * them (maskgen.c:218-266); M = maskgen's return value; old_D_pat / D_length = raw
  * delimiter (asearch.c:54); D = errors; AND = the AND flag (maskgen.c:150-163).
- * Supported subset: one pattern end bit (endposition == 1), no wildcards (Init1 sticky
- * bits == Init0 | endposition | D_endpos); <exact> segments (NO_ERR_MASK) are honoured;
- * anything else -> NULL. */
+ * Literals, [classes], -w / -x guards and <exact> segments (NO_ERR_MASK) run on the byte-
+ * parallel engines; tables with '#' wildcards (sticky Init1 bits, maskgen.c:231-232) or
+ * ';' AND / ',' OR (several endposition bits, maskgen.c:136-163) are kept unchanged and run
+ * record-parallel by the table engine (single-byte delimiter, unit costs).  NULL for a
+ * pattern that matches the empty record and for malformed tables. */
 agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint32_t Init1,
                                   uint32_t NO_ERR_MASK, uint32_t endposition,
                                   uint32_t D_endpos, int M, const unsigned char *old_D_pat,

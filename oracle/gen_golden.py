@@ -203,7 +203,12 @@ def gen_pattern_language():
     for pat, k, opts in (("appr[ox]ximatematch", 2, []), ("approx[a-m]matematch", 1, []),
                          ("[^b-z]pproximatematch", 2, []), ("car", 1, ["-w"]), ("car", 0, ["-w"]),
                          ("approximatematch", 2, ["-w"]), ("approximatematch", 1, ["-x"]),
-                         ("car", 0, ["-x"])):
+                         ("car", 0, ["-x"]),
+                         ("approx#match", 0, []), ("approx#match", 1, []), ("appr#mate#ch", 2, []),
+                         ("approxi;matematch", 0, []), ("approxi;matematch", 1, []),
+                         ("matematch;approx", 2, []), ("cars;fast", 0, []),
+                         ("approxi,xyzzyq", 0, []), ("aproxi,matemmat", 1, []), ("scar,cat", 0, []),
+                         ("a#h", 0, ["-w"]), ("car;red", 1, [])):
         kopt = ["-%d" % k] if k else []
         rc, out, err = run([HARNESS, "tables"] + kopt + ["-n"] + opts + [pat])
         t = json.loads(out)

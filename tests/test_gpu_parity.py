@@ -438,3 +438,31 @@ def test_pattern_language_from_maskgen_tables(agh):
             want = O.asearch_tables(O.tables_from_golden(t, M), case["k"], text, cap=100000)
             assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (case["pattern"], case["opts"])
         q.close()
+
+
+def test_table_engine_adversarial_texts(agh):
+    """'#' wildcards, ';' AND and ',' OR run by the table engine (agh_table.hip): records from
+    empty to 300 KiB, chunk-straddling records, no trailing delimiter -- always the oracle's
+    answer on the reference's own tables (which reproduced the reference counts on CPU)."""
+    rng = np.random.default_rng(7)
+    alpha = np.frombuffer(b"acrest\n", dtype=np.uint8)
+    texts = [b"", b"car", b"\n", b"\n\n\n", b"cars are fast", b"red car\n\ncar red\nfast cars"]
+    t = alpha[rng.integers(0, len(alpha), 200000)].tobytes()
+    texts += [t, t.rstrip(b"\n") + b"s"]
+    long_rec = alpha[rng.integers(0, len(alpha) - 1, 300 * 1024)].tobytes()      # no newline
+    texts.append(b"red\n" + long_rec + b"car\n" + long_rec[:5000] + b"\nfast cars\n")
+    words = [b"car", b"cars", b"red", b"fast", b"scar", b"cat", b"a", b"h", b"ah", b"arch", b" ", b"\n", b"\n"]
+    texts.append(b"".join(words[i] for i in rng.integers(0, len(words), 60000)))
+    for case in _golden("pattern_language.json"):
+        tb = case["tables"]
+        M = tb["D_endpos"].bit_length()
+        q = agh.Query.from_maskgen(tb["Mask"], tb["Init0"], tb["Init1"], tb["NO_ERR_MASK"],
+                                   tb["endposition"], tb["D_endpos"], M, b"\n", case["k"], tb["AND"])
+        ot = O.tables_from_golden(tb, M)
+        for i, text in enumerate(texts):
+            res, ms = q.scan_buffer(text, cap=200000)
+            want = O.asearch_tables(ot, case["k"], text, cap=200000)
+            assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (case["pattern"], case["opts"], i)
+            res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+            assert res_c.n_matched == want[0]
+        q.close()
