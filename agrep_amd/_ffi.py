@@ -60,6 +60,9 @@ def lib():
     L.agh_query_multi.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, u8p,
                                   C.c_int]
     L.agh_query_multi.restype = vp
+    L.agh_query_multi_approx.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                         C.c_int, u8p, C.c_int]
+    L.agh_query_multi_approx.restype = vp
     L.agh_query_set_costs.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.agh_query_set_costs.restype = C.c_int
     L.agh_query_free.argtypes = [vp]
@@ -137,12 +140,17 @@ class Query:
         return cls(None, _handle=h)
 
     @classmethod
-    def multi(cls, patterns, nocase=False, delim=b"\n"):
-        """-f: exact multi-pattern query (agh_query_multi)."""
+    def multi(cls, patterns, nocase=False, delim=b"\n", k=0):
+        """-f: multi-pattern query; exact (agh_query_multi) or with k errors
+        (agh_query_multi_approx)."""
         pats = [bytes(p) for p in patterns]
         arr = (C.c_char_p * len(pats))(*pats)
         lens = (C.c_int * len(pats))(*[len(p) for p in pats])
-        h = lib().agh_query_multi(arr, lens, len(pats), int(nocase), bytes(delim), len(delim))
+        if k:
+            h = lib().agh_query_multi_approx(arr, lens, len(pats), int(k), int(nocase), bytes(delim),
+                                             len(delim))
+        else:
+            h = lib().agh_query_multi(arr, lens, len(pats), int(nocase), bytes(delim), len(delim))
         if not h:
             raise AghError(lib().agh_last_error().decode("latin1"))
         return cls(None, _handle=h)

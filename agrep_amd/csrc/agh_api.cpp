@@ -116,7 +116,8 @@ struct agh_query {
     bool multi_dense = false;           // hits are too dense for the candidate slices
     int npat = 0;
     void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_off = nullptr,
-         *d_mp_pool = nullptr;
+         *d_mp_pool = nullptr, *d_mp_owner = nullptr, *d_mp_po = nullptr, *d_mp_olen = nullptr,
+         *d_mp_omask = nullptr;
 };
 
 static bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
@@ -381,27 +382,51 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
     return finish_query(q);
 }
 
-// -f patternfile: the role of prepf() (newmgrep.c:192-375).  Exact matching only, like the
-// reference (compat.c:34-37: "approximate matching is not supported with -f").
-extern "C" agh_query *agh_query_multi(const unsigned char *const *pats, const int *lens, int npat,
-                                      int nocase, const unsigned char *delim, int dlen)
+// -f patternfile: the role of prepf() (newmgrep.c:192-375).  D = 0 is the reference's behaviour
+// (compat.c:34-37: "approximate matching is not supported with -f"); D > 0 is the union of the
+// single-pattern k-error predicate over all patterns (BASELINE config 5), filtered through
+// D+1 verbatim pieces per pattern (agh_multi.hip).
+static agh_query *build_multi(const unsigned char *const *pats, const int *lens, int npat, int D,
+                              int nocase, const unsigned char *delim, int dlen)
 {
     if (!pats || !lens || npat < 1) { fail("no patterns"); return nullptr; }
     if (!delim || dlen != 1) {
         fail("multi-pattern scans support single-byte delimiters only");
         return nullptr;
     }
-    int minlen = 1 << 30;
+    if (D < 0 || D > AGH_MAX_ERRORS) { fail("number of errors %d outside 0..%d", D, AGH_MAX_ERRORS); return nullptr; }
     for (int p = 0; p < npat; ++p) {
         if (lens[p] < 1 || lens[p] > 255) { fail("pattern %d: length %d outside 1..255", p, lens[p]); return nullptr; }
-        if (lens[p] < minlen) minlen = lens[p];
+        if (D > 0 && (lens[p] > 32 || lens[p] <= D)) {
+            fail("pattern %d: with %d errors the length %d must be in %d..32", p, D, lens[p], D + 1);
+            return nullptr;
+        }
+        if (D > 0)
+            for (int t = 0; t < lens[p]; ++t)
+                if (pats[p][t] == delim[0] || pats[p][t] == '\n') {
+                    fail("pattern %d holds a delimiter byte (not supported with errors)", p);
+                    return nullptr;
+                }
     }
     if (agh_device_count() <= 0) { fail("no usable HIP device: libagrep_hip has no CPU path"); return nullptr; }
+
+    // table entries: whole patterns (D = 0) or D+1 disjoint pieces of every pattern
+    struct piece { int owner, po, len; };
+    std::vector<piece> pcs;
+    int minlen = 1 << 30;
+    for (int p = 0; p < npat; ++p)
+        for (int i = 0; i <= D; ++i) {
+            const int a = (int)((long)i * lens[p] / (D + 1)), b = (int)((long)(i + 1) * lens[p] / (D + 1));
+            pcs.push_back({p, a, b - a});
+            if (b - a < minlen) minlen = b - a;
+        }
+    const int npc = (int)pcs.size();
+
     agh_query *q = new agh_query();
     q->multi = true;
     q->npat = npat;
     q->m = minlen;
-    q->k = 0;
+    q->k = D;
     q->dlen = 1;
     q->delim[0] = delim[0];
     q->fq = minlen < 4 ? minlen : 4;            // prefix length probed at every text position
@@ -410,36 +435,55 @@ extern "C" agh_query *agh_query_multi(const unsigned char *const *pats, const in
     q->fold = nocase ? (0x20202020u & q->qmask) : 0u;
     memset(q->mask, 0, sizeof(q->mask));
 
-    std::vector<uint32_t> bits((1u << AGH_MP_BITS) / 32, 0), off(npat + 1, 0);
+    std::vector<uint32_t> bits((1u << AGH_MP_BITS) / 32, 0), off(npc + 1, 0);
     std::vector<uint8_t> pool;
-    std::vector<uint32_t> bucket_of(npat);
+    std::vector<uint32_t> bucket_of(npc);
     const uint32_t NB = 1u << AGH_MP_BUCKET_BITS;
-    std::vector<uint32_t> bstart(NB + 1, 0), items(npat);
-    std::vector<char> usable(npat, 1);
-    for (int p = 0; p < npat; ++p) {
-        off[p] = (uint32_t)pool.size();
+    std::vector<uint32_t> bstart(NB + 1, 0), items(npc);
+    std::vector<char> usable(npc, 1);
+    std::vector<uint32_t> piece_owner(npc);
+    std::vector<uint8_t> piece_po(npc), owner_len(npat);
+    for (int i = 0; i < npc; ++i) {
+        const unsigned char *src = pats[pcs[i].owner] + pcs[i].po;
+        off[i] = (uint32_t)pool.size();
+        piece_owner[i] = (uint32_t)pcs[i].owner;
+        piece_po[i] = (uint8_t)pcs[i].po;
         uint32_t g = 0;
-        for (int t = 0; t < lens[p]; ++t) {
-            unsigned char c = pats[p][t];
-            if (c == delim[0]) usable[p] = 0;   // can never lie inside one record
+        for (int t = 0; t < pcs[i].len; ++t) {
+            unsigned char c = src[t];
+            if (c == delim[0]) usable[i] = 0;   // can never lie inside one record
             if (nocase && is_upper(c)) c += 32;
             pool.push_back(c);
-            if (t < q->fq) g |= (uint32_t)pats[p][t] << (8 * t);
+            if (t < q->fq) g |= (uint32_t)src[t] << (8 * t);
         }
         g = (g & q->qmask) | q->fold;
-        bucket_of[p] = agh_mp_bucket(g);
-        if (usable[p]) {
+        bucket_of[i] = agh_mp_bucket(g);
+        if (usable[i]) {
             const uint32_t h = q->fq == 4 ? agh_sample_hash18_q4(g) : agh_sample_hash18_q3(g);
             bits[h >> 5] |= 1u << (h & 31u);
-            bstart[bucket_of[p] + 1]++;
+            bstart[bucket_of[i] + 1]++;
         }
     }
-    off[npat] = (uint32_t)pool.size();
+    off[npc] = (uint32_t)pool.size();
     for (uint32_t b = 0; b < NB; ++b) bstart[b + 1] += bstart[b];
     {
         std::vector<uint32_t> fill(bstart.begin(), bstart.end() - 1);
-        for (int p = 0; p < npat; ++p)
-            if (usable[p]) items[fill[bucket_of[p]]++] = (uint32_t)p;
+        for (int i = 0; i < npc; ++i)
+            if (usable[i]) items[fill[bucket_of[i]]++] = (uint32_t)i;
+    }
+    // per-pattern position masks for the verifying automaton (as agh_query_literal builds them)
+    std::vector<uint32_t> omask;
+    if (D > 0) {
+        omask.assign((size_t)npat * 256, 0u);
+        for (int p = 0; p < npat; ++p) {
+            owner_len[p] = (uint8_t)lens[p];
+            for (int t = 0; t < lens[p]; ++t) {
+                int c = pats[p][t];
+                if (nocase && is_upper(c)) c += 32;
+                omask[(size_t)p * 256 + c] |= 1u << t;
+                if (nocase && is_lower(c)) omask[(size_t)p * 256 + c - 32] |= 1u << t;
+            }
+        }
     }
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
         HIP_TRY(hipMalloc(dst, bytes ? bytes : 4));
@@ -448,11 +492,28 @@ extern "C" agh_query *agh_query_multi(const unsigned char *const *pats, const in
     };
     if (up(&q->d_mp_bits, bits.data(), bits.size() * 4) || up(&q->d_mp_bstart, bstart.data(), bstart.size() * 4) ||
         up(&q->d_mp_items, items.data(), items.size() * 4) || up(&q->d_mp_off, off.data(), off.size() * 4) ||
-        up(&q->d_mp_pool, pool.data(), pool.size()) || upload_common(q)) {
+        up(&q->d_mp_pool, pool.data(), pool.size()) ||
+        up(&q->d_mp_owner, piece_owner.data(), piece_owner.size() * 4) ||
+        up(&q->d_mp_po, piece_po.data(), piece_po.size()) ||
+        up(&q->d_mp_olen, owner_len.data(), owner_len.size()) ||
+        up(&q->d_mp_omask, omask.data(), omask.size() * 4) || upload_common(q)) {
         agh_query_free(q);
         return nullptr;
     }
     return q;
+}
+
+extern "C" agh_query *agh_query_multi(const unsigned char *const *pats, const int *lens, int npat,
+                                      int nocase, const unsigned char *delim, int dlen)
+{
+    return build_multi(pats, lens, npat, 0, nocase, delim, dlen);
+}
+
+extern "C" agh_query *agh_query_multi_approx(const unsigned char *const *pats, const int *lens,
+                                             int npat, int D, int nocase,
+                                             const unsigned char *delim, int dlen)
+{
+    return build_multi(pats, lens, npat, D, nocase, delim, dlen);
 }
 
 // asearch1.c:42-44 / agrep.c:2680-2696 (-I# -S# -D#): non-unit edit costs.  Such queries run
@@ -460,7 +521,7 @@ extern "C" agh_query *agh_query_multi(const unsigned char *const *pats, const in
 extern "C" int agh_query_set_costs(agh_query *q, int I, int S, int DD)
 {
     if (!q) return fail("null query");
-    if (q->multi) return fail("multi-pattern queries are exact");
+    if (q->multi) return fail("multi-pattern queries use unit costs");
     if (q->table && (I != 1 || S != 1 || DD != 1))
         return fail("edit costs are not supported together with wildcards / AND / OR");
     if (I < 1 || S < 1 || DD < 1)
@@ -482,6 +543,10 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_mp_items) (void)hipFree(q->d_mp_items);
     if (q->d_mp_off) (void)hipFree(q->d_mp_off);
     if (q->d_mp_pool) (void)hipFree(q->d_mp_pool);
+    if (q->d_mp_owner) (void)hipFree(q->d_mp_owner);
+    if (q->d_mp_po) (void)hipFree(q->d_mp_po);
+    if (q->d_mp_olen) (void)hipFree(q->d_mp_olen);
+    if (q->d_mp_omask) (void)hipFree(q->d_mp_omask);
     if (q->d_counters) (void)hipFree(q->d_counters);
     if (q->d_chunk_totals) (void)hipFree(q->d_chunk_totals);
     if (q->h_counters) (void)hipHostFree(q->h_counters);
@@ -529,6 +594,10 @@ static agh_multi_dev multi_dev(const agh_query *q)
     m.bucket_items = (const uint32_t *)q->d_mp_items;
     m.pat_off = (const uint32_t *)q->d_mp_off;
     m.pool = (const uint8_t *)q->d_mp_pool;
+    m.piece_owner = (const uint32_t *)q->d_mp_owner;
+    m.piece_po = (const uint8_t *)q->d_mp_po;
+    m.owner_len = (const uint8_t *)q->d_mp_olen;
+    m.owner_mask = (const uint32_t *)q->d_mp_omask;
     return m;
 }
 
@@ -577,7 +646,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
     if (q->wave_totals.ensure((nw + 8) * sizeof(uint32_t))) return -1;
     if (want_filter) {
-        if (q->cand.ensure(nw * AGH_SLICE_CAP * sizeof(uint64_t))) return -1;
+        if (q->cand.ensure(nw * (q->multi ? AGH_MP_SLICE_CAP : AGH_SLICE_CAP) * sizeof(uint64_t))) return -1;
         if (q->wave_cand.ensure((nw + 8) * sizeof(uint32_t))) return -1;
     }
 

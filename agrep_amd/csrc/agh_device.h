@@ -13,6 +13,8 @@
 // Candidate slots owned by one sweep wave (one per 64 text bytes; more means the filter is
 // not selective on this text and the scan falls back to the full automaton).
 #define AGH_SLICE_CAP (AGH_WAVE_STRIPS * 16u)
+// multi-pattern scans probe every byte position: room for one hit per 16 bytes
+#define AGH_MP_SLICE_CAP (AGH_WAVE_STRIPS * 64u)
 // Lean scans: how far back the verifier looks for the start of a matched record before the
 // scan falls back to the numbered (census) mode.
 #define AGH_LEAN_BACK_CAP (64u * 1024u)
@@ -39,6 +41,8 @@ enum agh_counter {
 };
 
 // The reference's own query tables for the table engine (agh_table.hip), maskgen.c layout.
+#define AGH_MAX_ERRORS_DEV 8   // = AGH_MAX_ERRORS of the C-ABI (agrep.h:44 MaxError)
+
 struct agh_dev_tables {
     uint32_t Init0, Init1, NO_ERR, endposition, D_endpos, D_Mask, AND;
 };

@@ -120,6 +120,7 @@ __device__ __forceinline__ int64_t dbm_prev(const uint64_t *__restrict__ dbm, ui
 // ---- per-wave LDS candidate queue, flushed 64 entries at a time with one coalesced store ---
 #define AGH_CQ_LEN 96
 
+template <uint32_t CAP = AGH_SLICE_CAP>
 __device__ __forceinline__ void flush_candidates(uint64_t *cq, uint32_t &qn, uint32_t take,
                                                  uint64_t *__restrict__ slice, uint32_t &cnt,
                                                  uint32_t *counters)
@@ -127,7 +128,7 @@ __device__ __forceinline__ void flush_candidates(uint64_t *cq, uint32_t &qn, uin
     const uint32_t lane = (uint32_t)lane_id();
     if (lane < take) {
         const uint32_t idx = cnt + lane;
-        if (idx < AGH_SLICE_CAP) slice[idx] = cq[lane];
+        if (idx < CAP) slice[idx] = cq[lane];
         else counters[AGH_C_OVERFLOW] = 1u;
     }
     cnt += take;

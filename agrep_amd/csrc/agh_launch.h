@@ -83,6 +83,10 @@ struct agh_multi_dev {
     const uint32_t *bucket_items;
     const uint32_t *pat_off;
     const uint8_t *pool;
+    const uint32_t *piece_owner;   // k-error queries: see agh_multi.hip
+    const uint8_t *piece_po;
+    const uint8_t *owner_len;
+    const uint32_t *owner_mask;
 };
 void agh_launch_sweep_multi(const agh_sweep_args &a, const agh_multi_dev &m, const agh_marks &mk,
                             bool inl, hipStream_t st);

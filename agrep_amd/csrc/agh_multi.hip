@@ -16,6 +16,11 @@ struct agh_multi_tables {
     const uint32_t *bucket_items;  // pattern numbers grouped by prefix bucket
     const uint32_t *pat_off;       // npat + 1 offsets into pool
     const uint8_t *pool;           // pattern bytes (lower-cased when the query folds case)
+    // k-error queries (agh_query_multi_approx): the table entries are PIECES of patterns
+    const uint32_t *piece_owner;   // pattern number a piece was cut from
+    const uint8_t *piece_po;       // its offset inside that pattern
+    const uint8_t *owner_len;      // pattern lengths (<= 32)
+    const uint32_t *owner_mask;    // [pattern][256] position masks (bit p-1 = position p)
 };
 
 #define AGH_MP_WORDS ((1u << AGH_MP_BITS) / 32u)
@@ -97,6 +102,120 @@ __device__ __forceinline__ bool multi_match_at(const uint8_t *__restrict__ text,
     return false;
 }
 
+// ---- -f with errors ---------------------------------------------------------------------
+// A record matches iff it holds a substring within edit distance k of ANY pattern (union of the
+// single-pattern predicate; the reference itself ignores -# together with -f, compat.c:34-37).
+// Partition filter: an occurrence with <= k errors contains at least one of k+1 disjoint pieces
+// of its pattern verbatim.  The pieces are the entries of the exact multi-pattern tables; a
+// verbatim piece at text position j sends the k-error automaton of its pattern over the bytes
+// the occurrence can cover: [j - po - k, j + (m - po) + k).
+struct AutomatonRT {                    // k is a run-time value here (one kernel for every k)
+    uint32_t R[AGH_MAX_ERRORS_DEV + 1];
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int e = 0; e <= AGH_MAX_ERRORS_DEV; ++e) R[e] = 0;
+    }
+    __device__ __forceinline__ bool step(uint32_t cm, uint32_t finalbit, int k)
+    {
+        uint32_t po = R[0];
+        uint32_t pn = ((po << 1) | 1u) & cm;
+        R[0] = pn;
+        uint32_t top = pn;
+#pragma unroll
+        for (int e = 1; e <= AGH_MAX_ERRORS_DEV; ++e) {
+            if (e <= k) {
+                const uint32_t cur = R[e];
+                const uint32_t ne = (((cur << 1) | 1u) & cm) | po | (((po | pn) << 1) | 1u);
+                po = cur;
+                pn = ne;
+                R[e] = ne;
+                top = ne;
+            }
+        }
+        return (top & finalbit) != 0;
+    }
+};
+
+// The automaton of one pattern over [ws, we); same record bookkeeping as verify_window_slow.
+template <bool LEAN>
+__device__ __noinline__ void approx_window(const uint8_t *__restrict__ text, uint64_t n,
+                                           const agh_dev_query &q,
+                                           const uint32_t *__restrict__ pmask, uint32_t m,
+                                           uint64_t ws, uint64_t we, uint64_t anchor,
+                                           uint32_t rc_anchor, const agh_marks &mk)
+{
+    const uint32_t finalbit = 1u << (m - 1);
+    const int k = (int)q.k;
+    uint32_t rec = 0;
+    uint64_t rstart = 0;
+    if (LEAN) {
+        rstart = lean_record_start(text, ws, q.delim, mk);
+        if (rstart == ~0ull) return;
+    } else {
+        uint32_t back = 0;                      // delimiters in [ws, anchor)
+        for (uint64_t i = ws; i < anchor; ++i) back += (text[i] == q.delim);
+        rec = rc_anchor - back;
+    }
+    AutomatonRT A;
+    A.reset();
+    bool seen = false;
+    if (ws == 0) A.step(pmask[q.head_byte], finalbit, k);
+    for (uint64_t i = ws; i < we; ++i) {
+        const uint32_t c = text[i];
+        if (A.step(pmask[c], finalbit, k) && !seen) {
+            seen = true;
+            if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, i);
+        }
+        if (c == q.delim) {
+            A.reset();
+            ++rec;
+            rstart = i + 1;
+            seen = false;
+            A.step(pmask[c], finalbit, k);      // patterns never hold the delimiter byte
+        }
+    }
+    if (we == n && q.tail_virtual) {            // asearch.c:87-91
+        if (A.step(pmask[q.delim], finalbit, k) && !seen) {
+            if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
+        }
+    }
+}
+
+// Every piece that occurs verbatim at text position j gets its pattern verified.
+template <bool LEAN>
+__device__ __noinline__ void multi_approx_at(const uint8_t *__restrict__ text, uint64_t n,
+                                             const agh_dev_query &q, const agh_multi_tables &mt,
+                                             uint64_t j, uint32_t rc_chunk, const agh_marks &mk)
+{
+    const uint32_t fold = q.fold ? 0x20u : 0u;
+    uint32_t g = 0;
+    for (uint32_t t = 0; t < (uint32_t)q.fq && j + t < n; ++t) g |= (uint32_t)text[j + t] << (8 * t);
+    g = (g & q.qmask) | q.fold;
+    const uint32_t b = agh_mp_bucket(g);
+    for (uint32_t it = mt.bucket_start[b]; it < mt.bucket_start[b + 1]; ++it) {
+        const uint32_t pc = mt.bucket_items[it];
+        const uint32_t o = mt.pat_off[pc], len = mt.pat_off[pc + 1] - o;
+        if (j + len > n) continue;
+        uint32_t t = 0;
+        for (; t < len; ++t) {
+            uint32_t c = text[j + t];
+            if (fold && c >= 'A' && c <= 'Z') c += 32u;
+            if (c != mt.pool[o + t]) break;
+        }
+        if (t != len) continue;
+        const uint32_t owner = mt.piece_owner[pc], po = mt.piece_po[pc], m = mt.owner_len[owner];
+        const uint64_t anchor = j & ~(uint64_t)15;          // rc_chunk = delimiters in front of it
+        const uint64_t back = (uint64_t)po + q.k;
+        uint64_t ws = j > back ? j - back : 0;
+        if (ws > anchor) ws = anchor;
+        uint64_t we = j + (m - po) + q.k;
+        if (we > n) we = n;
+        approx_window<LEAN>(text, n, q, mt.owner_mask + (size_t)owner * 256u, m, ws, we, anchor,
+                            rc_chunk, mk);
+    }
+}
+
 // A verified occurrence at j: count its record once.
 template <bool LEAN>
 __device__ __forceinline__ void multi_mark(const uint8_t *__restrict__ text, const agh_dev_query &q,
@@ -153,8 +272,8 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
     const uint64_t n_dw = ((n + 15) & ~(uint64_t)15) / 4;      // readable dwords
     uint32_t run = (INLINE && !(MODE & 4)) ? wave_totals[w] : 0u, ncand = 0, qn = 0;
     uint64_t *cq = cq_all + wib * (AGH_CQ_LEN + 16);
-    uint64_t *slice = cand + w * AGH_SLICE_CAP;
-    auto flush64 = [&]() { flush_candidates(cq, qn, 64u, slice, ncand, counters); };
+    uint64_t *slice = cand + w * AGH_MP_SLICE_CAP;
+    auto flush64 = [&]() { flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, 64u, slice, ncand, counters); };
     // the dword right behind chunk (strip st, this lane)
     auto next_dw = [&](uint64_t st) -> uint32_t {
         const uint64_t i = (st * 64 + (uint64_t)lane) * 4 + 4;
@@ -176,7 +295,10 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
             while (h) {
                 const uint32_t b = (uint32_t)__ffs((int)h) - 1u;
                 h &= h - 1u;
-                if (multi_match_at(reinterpret_cast<const uint8_t *>(text), n, q, mt, base + b))
+                if (q.k)
+                    multi_approx_at<(MODE & 4) != 0>(reinterpret_cast<const uint8_t *>(text), n, q,
+                                                     mt, base + b, rc, mk);
+                else if (multi_match_at(reinterpret_cast<const uint8_t *>(text), n, q, mt, base + b))
                     multi_mark<(MODE & 4) != 0>(reinterpret_cast<const uint8_t *>(text), q, mk,
                                                 base + b, rc);
             }
@@ -204,10 +326,10 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
         s += 4;
     }
     for (; s < s1; ++s) strip_work(text[s * 64 + lane], next_dw(s), s);
-    if (!INLINE && qn) flush_candidates(cq, qn, qn, slice, ncand, counters);
+    if (!INLINE && qn) flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, qn, slice, ncand, counters);
     if (lane == 0 && !INLINE) {
         wave_totals[w] = run;
-        wave_cand[w] = ncand < AGH_SLICE_CAP ? ncand : AGH_SLICE_CAP;
+        wave_cand[w] = ncand < AGH_MP_SLICE_CAP ? ncand : AGH_MP_SLICE_CAP;
     }
     if (lane == 0 && INLINE) wave_cand[w] = 0u;
 }
@@ -259,15 +381,15 @@ __global__ __launch_bounds__(64) void k_sweep_multi_tail(const uint4 *__restrict
     uint32_t ncand = fresh ? 0u : wave_cand[w];
     ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);
     uint32_t qn = 0;
-    uint64_t *slice = cand + w * AGH_SLICE_CAP;
+    uint64_t *slice = cand + w * AGH_MP_SLICE_CAP;
     if (__ballot(hits != 0)) {
         const uint32_t rc = (MODE & 4) ? 0u : before + 128u * (uint32_t)lane - (sc - acc);
         emit_positions(hits, s, rc, cq, qn,
-                       [&]() { flush_candidates(cq, qn, 64u, slice, ncand, counters); });
-        if (qn) flush_candidates(cq, qn, qn, slice, ncand, counters);
+                       [&]() { flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, 64u, slice, ncand, counters); });
+        if (qn) flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, qn, slice, ncand, counters);
     }
     if (lane == 0) {
-        wave_cand[w] = ncand < AGH_SLICE_CAP ? ncand : AGH_SLICE_CAP;
+        wave_cand[w] = ncand < AGH_MP_SLICE_CAP ? ncand : AGH_MP_SLICE_CAP;
         if (!strip_prefix) wave_totals[w] = before + z;
     }
 }
@@ -285,13 +407,14 @@ __global__ __launch_bounds__(256) void k_verify_multi(const uint8_t *__restrict_
     const uint32_t w = blockIdx.x * 4 + threadIdx.x / WAVE;
     if (w >= nw) return;
     const uint32_t cnt = wave_cand[w];
-    const uint64_t *slice = cand + (uint64_t)w * AGH_SLICE_CAP;
+    const uint64_t *slice = cand + (uint64_t)w * AGH_MP_SLICE_CAP;
     const uint32_t wp = LEAN ? 0u : wave_prefix[w];
     for (uint32_t ci = (uint32_t)lane_id(); ci < cnt; ci += WAVE) {
         const uint64_t ent = slice[ci];
         const uint64_t j = ent & 0xffffffffull;
         if (j >= n) continue;
-        if (multi_match_at(text, n, q, mt, j)) multi_mark<LEAN>(text, q, mk, j, wp + (uint32_t)(ent >> 32));
+        if (q.k) multi_approx_at<LEAN>(text, n, q, mt, j, wp + (uint32_t)(ent >> 32), mk);
+        else if (multi_match_at(text, n, q, mt, j)) multi_mark<LEAN>(text, q, mk, j, wp + (uint32_t)(ent >> 32));
     }
 }
 
@@ -311,6 +434,10 @@ static void launch_sweep_multi_m(const agh_sweep_args &a, const agh_multi_dev &m
     mt.bucket_items = m.bucket_items;
     mt.pat_off = m.pat_off;
     mt.pool = m.pool;
+    mt.piece_owner = m.piece_owner;
+    mt.piece_po = m.piece_po;
+    mt.owner_len = m.owner_len;
+    mt.owner_mask = m.owner_mask;
     if (n_waves && inl)
         hipLaunchKernelGGL((k_sweep_multi<MODE, true>), dim3((uint32_t)((n_waves + 3) / 4)),
                            dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,
@@ -358,6 +485,10 @@ void agh_launch_verify_multi(const agh_scan_args &a, const agh_multi_dev &m, boo
     mt.bucket_items = m.bucket_items;
     mt.pat_off = m.pat_off;
     mt.pool = m.pool;
+    mt.piece_owner = m.piece_owner;
+    mt.piece_po = m.piece_po;
+    mt.owner_len = m.owner_len;
+    mt.owner_mask = m.owner_mask;
     const uint32_t blocks = (a.nw + 3u) / 4u;
     if (!blocks) return;
     if (lean)

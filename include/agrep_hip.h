@@ -108,6 +108,13 @@ agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint
 agh_query *agh_query_multi(const unsigned char *const *pats, const int *lens, int npat,
                            int nocase, const unsigned char *delim, int dlen);
 
+/* -f with errors (BASELINE config 5; beyond the reference, which ignores -# together with -f,
+ * compat.c:34-37): a record matches iff it holds a substring within edit distance D of ANY
+ * pattern -- the union over the patterns of agh_query_literal(pat, D)'s predicate.  Pattern
+ * lengths D+1..32, no delimiter / newline bytes inside patterns; D = 0 is agh_query_multi. */
+agh_query *agh_query_multi_approx(const unsigned char *const *pats, const int *lens, int npat,
+                                  int D, int nocase, const unsigned char *delim, int dlen);
+
 /* Replaces the cost globals I, S, DD of asearch1() (asearch1.c:28-44, options -I# -S# -D#,
  * agrep.c:2680-2696): cost of an insertion / substitution / deletion, each >= 1; a record
  * matches iff some substring is within total cost D.  Costs above D behave as D + 1. */

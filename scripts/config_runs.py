@@ -53,3 +53,24 @@ if "c5" in which:
         t0 = time.perf_counter(); r = q.scan_device(t.data_ptr(), n, flags=A.FILENAMEONLY); xs.append(time.perf_counter() - t0)
     w = sorted(xs)[1]
     print("c5 1024 patterns exact 8 GiB -l wall %.3f ms  %.0f GB/s  matched records %d cand %d" % (w * 1e3, n / 1e9 / w, r.n_matched, r.n_candidates))
+    q.close()
+if "c5k" in which:
+    # -f with k = 1 (the config as BASELINE words it).  Patterns of 4..5 bytes with one error
+    # match almost every record; 8..12-byte patterns are the selective case.
+    rng = random.Random(1024)
+    for lo, hi, mib in ((8, 12, 1024), (4, 12, 256)):
+        pats = set()
+        while len(pats) < 1024:
+            pats.add(bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(lo, hi))))
+        pats = sorted(pats)
+        n = mib << 20
+        t = torch.empty(n, dtype=torch.uint8, device='cuda')
+        A.corpus_fill_device(t.data_ptr(), n // 4096, seed=5, variants=tuple(pats[:7]), plant_period=500)
+        q = A.Query.multi(pats, k=1)
+        xs = []
+        for i in range(3):
+            t0 = time.perf_counter(); r = q.scan_device(t.data_ptr(), n, flags=A.FILENAMEONLY); xs.append(time.perf_counter() - t0)
+        w = sorted(xs)[1]
+        print("c5k 1024 patterns len %d..%d k=1 %d MiB wall %.3f ms  %.1f GB/s  matched records %d cand %d"
+              % (lo, hi, mib, w * 1e3, n / 1e9 / w, r.n_matched, r.n_candidates))
+        q.close(); del t

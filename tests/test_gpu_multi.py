@@ -124,3 +124,72 @@ def test_cli_pattern_file_matches_reference(agh, tmp_path):
         g = subprocess.run([CLI] + a, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert g.stdout == r.stdout, (args, g.stdout[:200], r.stdout[:200])
         assert g.returncode == r.returncode, args
+
+
+# ---- -f with errors (agh_query_multi_approx): union of the single-pattern k-error predicate ----
+def _mutate(p, k, rng, alphabet=b"abcdefghijklmnopqrstuvwxyz"):
+    a = bytearray(p)
+    for _ in range(k):
+        op = rng.randint(0, 2)
+        at = rng.randint(0, max(0, len(a) - 1))
+        if op == 0 and len(a) > 1:
+            del a[at]
+        elif op == 1:
+            a.insert(at, rng.choice(alphabet))
+        else:
+            a[at] = rng.choice(alphabet)
+    return bytes(a)
+
+
+def _approx_want(pats, k, text, nocase=False):
+    recs = set()
+    for p in pats:
+        recs.update(O.asearch(p, k, text, nocase=nocase, cap=400000)[1])
+    return sorted(recs)
+
+
+def _check_approx(agh, pats, k, text, nocase=False):
+    want = _approx_want(pats, k, text, nocase)
+    with agh.Query.multi(pats, nocase=nocase, k=k) as q:
+        res, ms = q.scan_buffer(text, cap=400000)
+        res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+        res_n, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
+    assert [(s, e) for s, e, _ in ms] == want
+    assert res.n_matched == res_c.n_matched == res_n.n_matched == len(want)
+    return res
+
+
+@pytest.mark.parametrize("npat,lo,hi,k", [(1, 8, 8, 1), (16, 6, 12, 1), (64, 8, 12, 2), (200, 4, 12, 1),
+                                          (12, 10, 12, 3), (40, 2, 3, 1)])
+def test_multi_pattern_with_errors(agh, npat, lo, hi, k):
+    rng = random.Random(npat * 11 + k)
+    pats = _rand_patterns(rng, npat, lo, hi)
+    base, _ = O.corpus(48, seed=npat + k, variants=(), plant_period=0)
+    planted = [_mutate(rng.choice(pats), rng.randint(0, k + 1), rng) for _ in range(64)]
+    text = _plant(base.tobytes(), planted, rng, every=6)
+    res = _check_approx(agh, pats, k, text)
+    assert res.n_matched > 0
+
+
+def test_multi_pattern_with_errors_edges(agh):
+    rng = random.Random(5)
+    pats = [b"needle", b"haystack", b"Thread"]
+    for t in (b"", b"\n", b"nedle", b"x neeedle", b"needl", b"eedle\nhaystac\n\nthreat\n", b"need\nle\n",
+              b"a" * 5000 + b"hay5tack", b"needl\n" * 3000):
+        _check_approx(agh, pats, 1, t)
+        _check_approx(agh, pats, 2, t, nocase=True)
+    for boundary in (1024, 4096, 262144):           # occurrences across strip / range boundaries
+        t = bytearray(b"z" * (boundary + 2048))
+        for i in range(70, len(t), 91):
+            t[i] = 10
+        for shift in (1, 3, 5, 11):
+            at = boundary - shift
+            t[at:at + 5] = b"nedle"
+            for p in range(at - 2, at + 8):
+                if t[p] == 10:
+                    t[p] = ord("z")
+        _check_approx(agh, [b"needle", b"absent"], 1, bytes(t))
+    with pytest.raises(agh.AghError):
+        agh.Query.multi([b"ab", b"needle"], k=2)        # length must exceed k
+    with pytest.raises(agh.AghError):
+        agh.Query.multi([b"nee\ndle"], k=1)
