@@ -90,6 +90,8 @@ struct agh_query {
     // device-resident tables
     void *d_mask = nullptr;             // 256 x uint32_t or uint64_t
     uint8_t *d_ftab = nullptr;          // AGH_FT_SIZE bytes
+    uint64_t *d_gtab = nullptr;         // AGH_FT_SIZE x (gram, first/last offset): tight verify windows
+    uint32_t gram_spread = 0;           // max (last - first offset) over the grams in d_gtab
     // per-query workspace (grown lazily, reused across scans)
     dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, hashset, dbm, staging, match_pos,
         match_rec, match_start, match_end, match_off, gather;
@@ -198,6 +200,36 @@ static int upload_tables(agh_query *q)
         }
         HIP_TRY(hipMalloc((void **)&q->d_ftab, AGH_FT_SIZE));
         HIP_TRY(hipMemcpy(q->d_ftab, tab.data(), AGH_FT_SIZE, hipMemcpyHostToDevice));
+        // Per hash slot: which gram sits there and where in the pattern it occurs -- the lean
+        // verifier drops hash false positives before running the automaton and, knowing the
+        // gram's offset o, walks [j-o-k, j-o+m+k) instead of the offset-blind window.
+        //   bits 0..31 gram, 32..39 first offset, 40..47 last offset, bit 63: ambiguous
+        //   (two different grams share the slot, or offsets too far apart) -> full window
+        std::vector<uint64_t> gt(AGH_FT_SIZE, AGH_GT_AMBIGUOUS);
+        std::vector<char> used(AGH_FT_SIZE, 0);
+        for (int i = 0; i + q->fq <= q->m; ++i) {
+            uint32_t s = 0;
+            for (int t = 0; t < q->fq; ++t) s |= (uint32_t)rep[i + t] << (8 * t);
+            s = (s & q->qmask) | q->fold;
+            const uint32_t h = q->fq == 4 ? agh_sample_hash_q4(s) : agh_sample_hash_q3(s);
+            if (!used[h]) {
+                used[h] = 1;
+                gt[h] = (uint64_t)s | ((uint64_t)i << 32) | ((uint64_t)i << 40);
+            } else if (!(gt[h] & AGH_GT_AMBIGUOUS) && (uint32_t)gt[h] == s) {
+                gt[h] = (gt[h] & ~((uint64_t)0xff << 40)) | ((uint64_t)i << 40);   // last offset
+            } else {
+                gt[h] = AGH_GT_AMBIGUOUS;
+            }
+        }
+        q->gram_spread = 0;
+        for (uint32_t h = 0; h < AGH_FT_SIZE; ++h) {
+            if (!used[h] || (gt[h] & AGH_GT_AMBIGUOUS)) continue;
+            const uint32_t sp = (uint32_t)((gt[h] >> 40) & 0xff) - (uint32_t)((gt[h] >> 32) & 0xff);
+            if (sp > 8) gt[h] = AGH_GT_AMBIGUOUS;
+            else if (sp > q->gram_spread) q->gram_spread = sp;
+        }
+        HIP_TRY(hipMalloc((void **)&q->d_gtab, AGH_FT_SIZE * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(q->d_gtab, gt.data(), AGH_FT_SIZE * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
     return upload_common(q);
 }
@@ -538,6 +570,7 @@ extern "C" void agh_query_free(agh_query *q)
     if (!q) return;
     if (q->d_mask) (void)hipFree(q->d_mask);
     if (q->d_ftab) (void)hipFree(q->d_ftab);
+    if (q->d_gtab) (void)hipFree(q->d_gtab);
     if (q->d_mp_bits) (void)hipFree(q->d_mp_bits);
     if (q->d_mp_bstart) (void)hipFree(q->d_mp_bstart);
     if (q->d_mp_items) (void)hipFree(q->d_mp_items);
@@ -584,6 +617,13 @@ extern "C" int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q,
     if (filter_q) *filter_q = q->fq;
     if (filter_h) *filter_h = q->fh;
     return 0;
+}
+
+// AGH_TIGHT_VERIFY=0: offset-blind verify windows, no false-positive rejection (A/B runs).
+static bool tight_verify_enabled()
+{
+    const char *e = getenv("AGH_TIGHT_VERIFY");
+    return !(e && e[0] == '0');
 }
 
 static agh_multi_dev multi_dev(const agh_query *q)
@@ -735,6 +775,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.nw = (uint32_t)nw;
         va.wave_prefix = (const uint32_t *)q->wave_totals.p;
         va.dbm = d_dbm;
+        va.gtab = tight_verify_enabled() ? q->d_gtab : nullptr;
+        va.gram_spread = q->gram_spread;
         if (q->multi) agh_launch_verify_multi(va, multi_dev(q), true, st);
         else agh_launch_verify_lean(va, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
@@ -839,6 +881,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             HIP_TRY(hipGetLastError());
         }
         agh_scan_args va;
+        memset(&va, 0, sizeof(va));
         va.text = d_text;
         va.n = n;
         va.q = dq;

@@ -41,6 +41,7 @@ enum agh_counter {
 };
 
 // The reference's own query tables for the table engine (agh_table.hip), maskgen.c layout.
+#define AGH_GT_AMBIGUOUS ((uint64_t)1 << 63)   // gram table entry: no offset information
 #define AGH_MAX_ERRORS_DEV 8   // = AGH_MAX_ERRORS of the C-ABI (agrep.h:44 MaxError)
 
 struct agh_dev_tables {

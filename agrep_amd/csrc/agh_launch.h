@@ -50,6 +50,8 @@ struct agh_scan_args {
     const uint32_t *wave_prefix;
     const uint64_t *dbm;     // multi-byte delimiters: delimiter-end bitmap (else NULL)
     uint32_t n_strips;
+    const uint64_t *gtab;    // lean verify: gram table (gram, first/last pattern offset) or NULL
+    uint32_t gram_spread;
     agh_marks mk;
 };
 

@@ -15,7 +15,9 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
                                                 const uint32_t *__restrict__ wave_cand,
                                                 const uint32_t *__restrict__ wave_prefix,
                                                 uint32_t nw, agh_marks mk,
-                                                const uint64_t *__restrict__ dbm)
+                                                const uint64_t *__restrict__ dbm,
+                                                const uint64_t *__restrict__ gtab,
+                                                uint32_t tspan)
 {
     __shared__ WT lmask[256];
     __shared__ uint32_t pre[AGH_VGROUP + 1];
@@ -37,6 +39,10 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
     if (total == 0) return;
     VerifyCtx<WT, K> c;
     verify_ctx_init<WT, K>(c, text, n, q, lmask, mk, dbm);
+    if (LEAN) {
+        c.gtab = gtab;
+        c.tspan = tspan;
+    }
 
     for (uint32_t ci = threadIdx.x; ci < total; ci += 256) {
         uint32_t sl = 0;
@@ -279,18 +285,19 @@ void agh_launch_gather_records(const void *text, const uint64_t *start, const ui
 // host-callable launchers
 // ---------------------------------------------------------------------------------------
 template <typename WT, int K, int NCH, bool LEAN>
-static void launch_verify_n(const agh_scan_args &a, hipStream_t st)
+static void launch_verify_n(const agh_scan_args &a, const uint64_t *gtab, uint32_t tspan,
+                            hipStream_t st)
 {
     uint32_t blocks = (a.nw + AGH_VGROUP - 1u) / AGH_VGROUP;
     if (!blocks) return;
     if (a.q.dlen > 1)
         hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, true>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
-                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm);
+                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm, gtab, tspan);
     else
         hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
-                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm);
+                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm, gtab, tspan);
 }
 
 template <typename WT, int K, bool LEAN>
@@ -299,12 +306,29 @@ static void launch_verify_t(const agh_scan_args &a, hipStream_t st)
     // window span = max(m+k+1, 16) + q + m + k bytes, fetched as ceil(span/16) pieces
     const int lw = a.q.m + a.q.k + 1 > 16 ? a.q.m + a.q.k + 1 : 16;
     const int nch = (lw + a.q.fq + a.q.m + a.q.k + 15) / 16;
+    if constexpr (LEAN) {
+        if (a.gtab) {
+            // gram offsets known: one warm-up byte + (m + 2k + spread) bytes per candidate
+            const uint32_t tspan = (uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread;
+            const int tn = (int)((tspan + 15u) / 16u);
+            if (sizeof(WT) == 4) {
+                if (tn <= 2) launch_verify_n<WT, K, 2, true>(a, a.gtab, tspan, st);
+                else if (tn <= 3) launch_verify_n<WT, K, 3, true>(a, a.gtab, tspan, st);
+                else launch_verify_n<WT, K, 6, true>(a, a.gtab, tspan, st);
+            } else {
+                if (tn <= 4) launch_verify_n<WT, K, 4, true>(a, a.gtab, tspan, st);
+                else if (tn <= 7) launch_verify_n<WT, K, 7, true>(a, a.gtab, tspan, st);
+                else launch_verify_n<WT, K, 10, true>(a, a.gtab, tspan, st);
+            }
+            return;
+        }
+    }
     if (sizeof(WT) == 4) {                  // m <= 32: span <= 85
-        if (nch <= 3) launch_verify_n<WT, K, 3, LEAN>(a, st);
-        else launch_verify_n<WT, K, 6, LEAN>(a, st);
+        if (nch <= 3) launch_verify_n<WT, K, 3, LEAN>(a, nullptr, 0u, st);
+        else launch_verify_n<WT, K, 6, LEAN>(a, nullptr, 0u, st);
     } else {                                // m <= 64: span <= 149
-        if (nch <= 7) launch_verify_n<WT, K, 7, LEAN>(a, st);
-        else launch_verify_n<WT, K, 10, LEAN>(a, st);
+        if (nch <= 7) launch_verify_n<WT, K, 7, LEAN>(a, nullptr, 0u, st);
+        else launch_verify_n<WT, K, 10, LEAN>(a, nullptr, 0u, st);
     }
 }
 

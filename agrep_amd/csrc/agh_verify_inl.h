@@ -281,6 +281,8 @@ struct VerifyCtx {
     const uint64_t *dbm;     // multi-byte delimiters: delimiter-end bitmap
     WT finalbit;
     uint32_t Lw, tailw, span;
+    const uint64_t *gtab;    // lean scans: per hash slot (gram, first/last offset) or NULL
+    uint32_t tspan;          // window length when the gram's offset is known: m + 2k + spread
     Automaton<WT, K> RF;     // state right after a record boundary (reset + re-fed delimiter)
     bool rf_hit;
     const agh_marks *mk;     // likewise
@@ -303,6 +305,8 @@ __device__ __forceinline__ void verify_ctx_init(VerifyCtx<WT, K> &c, const uint8
     c.Lw = (uint32_t)(q.m + q.k + 1) > 16u ? (uint32_t)(q.m + q.k + 1) : 16u;
     c.tailw = (uint32_t)(q.fq + q.m + q.k);
     c.span = c.Lw + c.tailw;                    // <= 16 * NCH by construction
+    c.gtab = nullptr;
+    c.tspan = 0;
     c.RF.reset();
     c.rf_hit = c.RF.step(lmask[q.delim], c.finalbit);   // asearch.c:175-186
 }
@@ -322,7 +326,27 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
     const uint32_t rc_anchor = LEAN ? 0u : wave_base + (uint32_t)(ent >> 32);  // record no. at anchor
     const uint64_t anchor = j & ~(uint64_t)15;                           // sample's chunk start
 
-    const bool fast = j >= c.Lw && j + c.tailw < c.n && (j - c.Lw) + 16u * NCH <= c.n16;
+    // Lean scans with a gram table: the sample's q-gram says where in the pattern it sits.
+    // A gram that is not the pattern's (hash false positive) is dropped here; otherwise an
+    // occurrence containing it starts in [j-o-k, j-o+k] and ends before j-o+m+k, so a fresh
+    // automaton over [j - o_last - k - 1, j - o_first + m + k) finds it -- about half the bytes
+    // of the offset-blind window.  (The extra leading byte gives level e its e leading
+    // deletions, exactly as the re-fed delimiter does at a record start.)
+    uint32_t lw = c.Lw, span = c.span;
+    bool fast = true;
+    if (LEAN && c.gtab) {
+        const uint32_t dw = *reinterpret_cast<const uint32_t *>(c.text + j);   // j is 4-aligned
+        const uint32_t g = (dw & c.q->qmask) | c.q->fold;
+        const uint64_t e = c.gtab[c.q->fq == 4 ? agh_sample_hash_q4(g) : agh_sample_hash_q3(g)];
+        if (e & AGH_GT_AMBIGUOUS) {
+            fast = false;                       // full window, byte-wise
+        } else {
+            if ((uint32_t)e != g) return;
+            lw = (uint32_t)((e >> 40) & 0xffu) + (uint32_t)c.q->k + 1u;   // + one warm-up byte
+            span = c.tspan;
+        }
+    }
+    fast = fast && j >= lw && (j - lw) + span < c.n && (j - lw) + 16u * NCH <= c.n16;
     if (!fast) {
         const uint64_t ws = j > c.Lw ? j - c.Lw : 0;
         uint64_t we = j + c.tailw;
@@ -331,7 +355,7 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
                                         *c.mk);
         return;
     }
-    const uint64_t ws = j - c.Lw;
+    const uint64_t ws = j - lw;
     u32x4_u ch[NCH];
 #pragma unroll
     for (int ic = 0; ic < NCH; ++ic)
@@ -349,14 +373,14 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
         for (int i = 0; i < NMW; ++i) {
             uint64_t w = dbm_bits64(c.dbm, ws + 64u * (uint32_t)i);
             const int lo = i * 64;
-            if ((int)c.span <= lo) w = 0;
-            else if ((int)c.span < lo + 64) w &= (1ull << (c.span - lo)) - 1ull;
+            if ((int)span <= lo) w = 0;
+            else if ((int)span < lo + 64) w &= (1ull << (span - lo)) - 1ull;
             dm[i] = w;
         }
     }
 #pragma unroll
     for (int p = 0; p < NCH * 16; ++p) {
-        if ((uint32_t)p >= c.span) break;             // wave-uniform
+        if ((uint32_t)p >= span) break;               // uniform but for dropped lanes
         const uint32_t dwv = ch[p >> 4][(p >> 2) & 3];
         const uint32_t byte = (dwv >> (8 * (p & 3))) & 0xffu;
         const uint32_t hit = A.step(c.lmask[byte], c.finalbit) ? 1u : 0u;
