@@ -115,6 +115,11 @@ struct agh_query {
     int ci = 1, cs = 1, cd = 1;
     uint64_t no_err = ~0ull;
     bool multi = false;
+    // piece engine for a single literal pattern the sample filter cannot take (short pattern /
+    // many errors): the multi-pattern tables hold its k+1 pieces (or the pattern itself, k = 0)
+    bool piece_single = false;
+    int pe_fq = 0, pe_minlen = 0;
+    uint32_t pe_qmask = 0, pe_fold = 0;
     bool multi_dense = false;           // hits are too dense for the candidate slices
     int npat = 0;
     void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_off = nullptr,
@@ -234,6 +239,44 @@ static int upload_tables(agh_query *q)
     return upload_common(q);
 }
 
+static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, const int *lens,
+                             int npat, int D, int nocase, unsigned char delim0, int *fq_out,
+                             uint32_t *qmask_out, uint32_t *fold_out, int *minlen_out);
+
+// A literal pattern without a usable sample filter (m < 5k+6: short words, many errors) would
+// read every byte through the automaton (~1 TB/s).  The partition lemma still applies: give
+// it the multi-pattern engine with its k+1 pieces as entries (agh_multi.hip).
+static int attach_piece_engine(agh_query *q)
+{
+    if (q->fq || q->general || q->table || q->dlen != 1 || q->m > 32 || q->m <= q->k) return 0;
+    if (q->m / (q->k + 1) < 2) return 0;            // 1-byte pieces select nothing
+    unsigned char pat[32];
+    bool any_pair = false, any_single_letter = false;
+    for (int p = 0; p < q->m; ++p) {
+        int members = 0, lo = -1;
+        for (int c = 0; c < 256; ++c)
+            if ((q->mask[c] >> p) & 1) { ++members; if (lo < 0) lo = c; }
+        if (members == 2 && is_upper(lo) && ((q->mask[lo + 32] >> p) & 1)) {
+            any_pair = true;
+            pat[p] = (unsigned char)(lo + 32);
+        } else if (members == 1) {
+            if (is_upper(lo) || is_lower(lo)) any_single_letter = true;
+            pat[p] = (unsigned char)lo;
+        } else {
+            return 0;                               // a class: not a literal
+        }
+        if (pat[p] == q->delim[0] || pat[p] == '\n') return 0;
+    }
+    if (any_pair && any_single_letter) return 0;    // neither plain nor -i
+    const unsigned char *pp = pat;
+    const int len = q->m;
+    if (fill_multi_tables(q, &pp, &len, 1, q->k, any_pair ? 1 : 0, q->delim[0], &q->pe_fq,
+                          &q->pe_qmask, &q->pe_fold, &q->pe_minlen))
+        return -1;
+    q->piece_single = true;
+    return 0;
+}
+
 static agh_query *finish_query(agh_query *q)
 {
     q->wide = q->m > 32;
@@ -243,7 +286,7 @@ static agh_query *finish_query(agh_query *q)
         delete q;
         return nullptr;
     }
-    if (upload_tables(q) != 0) {
+    if (upload_tables(q) != 0 || attach_piece_engine(q) != 0) {
         agh_query_free(q);
         return nullptr;
     }
@@ -414,34 +457,12 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
     return finish_query(q);
 }
 
-// -f patternfile: the role of prepf() (newmgrep.c:192-375).  D = 0 is the reference's behaviour
-// (compat.c:34-37: "approximate matching is not supported with -f"); D > 0 is the union of the
-// single-pattern k-error predicate over all patterns (BASELINE config 5), filtered through
-// D+1 verbatim pieces per pattern (agh_multi.hip).
-static agh_query *build_multi(const unsigned char *const *pats, const int *lens, int npat, int D,
-                              int nocase, const unsigned char *delim, int dlen)
+// Device tables of the multi-pattern engine for `q` (prefix bit table, buckets, piece pool,
+// per-pattern masks).  Entries: whole patterns (D = 0) or D+1 disjoint pieces of every pattern.
+static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, const int *lens,
+                             int npat, int D, int nocase, unsigned char delim0, int *fq_out,
+                             uint32_t *qmask_out, uint32_t *fold_out, int *minlen_out)
 {
-    if (!pats || !lens || npat < 1) { fail("no patterns"); return nullptr; }
-    if (!delim || dlen != 1) {
-        fail("multi-pattern scans support single-byte delimiters only");
-        return nullptr;
-    }
-    if (D < 0 || D > AGH_MAX_ERRORS) { fail("number of errors %d outside 0..%d", D, AGH_MAX_ERRORS); return nullptr; }
-    for (int p = 0; p < npat; ++p) {
-        if (lens[p] < 1 || lens[p] > 255) { fail("pattern %d: length %d outside 1..255", p, lens[p]); return nullptr; }
-        if (D > 0 && (lens[p] > 32 || lens[p] <= D)) {
-            fail("pattern %d: with %d errors the length %d must be in %d..32", p, D, lens[p], D + 1);
-            return nullptr;
-        }
-        if (D > 0)
-            for (int t = 0; t < lens[p]; ++t)
-                if (pats[p][t] == delim[0] || pats[p][t] == '\n') {
-                    fail("pattern %d holds a delimiter byte (not supported with errors)", p);
-                    return nullptr;
-                }
-    }
-    if (agh_device_count() <= 0) { fail("no usable HIP device: libagrep_hip has no CPU path"); return nullptr; }
-
     // table entries: whole patterns (D = 0) or D+1 disjoint pieces of every pattern
     struct piece { int owner, po, len; };
     std::vector<piece> pcs;
@@ -454,18 +475,13 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
         }
     const int npc = (int)pcs.size();
 
-    agh_query *q = new agh_query();
-    q->multi = true;
-    q->npat = npat;
-    q->m = minlen;
-    q->k = D;
-    q->dlen = 1;
-    q->delim[0] = delim[0];
-    q->fq = minlen < 4 ? minlen : 4;            // prefix length probed at every text position
-    q->fh = 1;
-    q->qmask = q->fq == 4 ? 0xffffffffu : ((1u << (8 * q->fq)) - 1u);
-    q->fold = nocase ? (0x20202020u & q->qmask) : 0u;
-    memset(q->mask, 0, sizeof(q->mask));
+    const int fq = minlen < 4 ? minlen : 4;     // prefix length probed at every text position
+    const uint32_t qmask = fq == 4 ? 0xffffffffu : ((1u << (8 * fq)) - 1u);
+    const uint32_t fold = nocase ? (0x20202020u & qmask) : 0u;
+    *fq_out = fq;
+    *qmask_out = qmask;
+    *fold_out = fold;
+    *minlen_out = minlen;
 
     std::vector<uint32_t> bits((1u << AGH_MP_BITS) / 32, 0), off(npc + 1, 0);
     std::vector<uint8_t> pool;
@@ -483,15 +499,15 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
         uint32_t g = 0;
         for (int t = 0; t < pcs[i].len; ++t) {
             unsigned char c = src[t];
-            if (c == delim[0]) usable[i] = 0;   // can never lie inside one record
+            if (c == delim0) usable[i] = 0;   // can never lie inside one record
             if (nocase && is_upper(c)) c += 32;
             pool.push_back(c);
-            if (t < q->fq) g |= (uint32_t)src[t] << (8 * t);
+            if (t < fq) g |= (uint32_t)src[t] << (8 * t);
         }
-        g = (g & q->qmask) | q->fold;
+        g = (g & qmask) | fold;
         bucket_of[i] = agh_mp_bucket(g);
         if (usable[i]) {
-            const uint32_t h = q->fq == 4 ? agh_sample_hash18_q4(g) : agh_sample_hash18_q3(g);
+            const uint32_t h = fq == 4 ? agh_sample_hash18_q4(g) : agh_sample_hash18_q3(g);
             bits[h >> 5] |= 1u << (h & 31u);
             bstart[bucket_of[i] + 1]++;
         }
@@ -528,7 +544,51 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
         up(&q->d_mp_owner, piece_owner.data(), piece_owner.size() * 4) ||
         up(&q->d_mp_po, piece_po.data(), piece_po.size()) ||
         up(&q->d_mp_olen, owner_len.data(), owner_len.size()) ||
-        up(&q->d_mp_omask, omask.data(), omask.size() * 4) || upload_common(q)) {
+        up(&q->d_mp_omask, omask.data(), omask.size() * 4))
+        return -1;
+    return 0;
+}
+
+
+// -f patternfile: the role of prepf() (newmgrep.c:192-375).  D = 0 is the reference's behaviour
+// (compat.c:34-37: "approximate matching is not supported with -f"); D > 0 is the union of the
+// single-pattern k-error predicate over all patterns (BASELINE config 5), filtered through
+// D+1 verbatim pieces per pattern (agh_multi.hip).
+static agh_query *build_multi(const unsigned char *const *pats, const int *lens, int npat, int D,
+                              int nocase, const unsigned char *delim, int dlen)
+{
+    if (!pats || !lens || npat < 1) { fail("no patterns"); return nullptr; }
+    if (!delim || dlen != 1) {
+        fail("multi-pattern scans support single-byte delimiters only");
+        return nullptr;
+    }
+    if (D < 0 || D > AGH_MAX_ERRORS) { fail("number of errors %d outside 0..%d", D, AGH_MAX_ERRORS); return nullptr; }
+    for (int p = 0; p < npat; ++p) {
+        if (lens[p] < 1 || lens[p] > 255) { fail("pattern %d: length %d outside 1..255", p, lens[p]); return nullptr; }
+        if (D > 0 && (lens[p] > 32 || lens[p] <= D)) {
+            fail("pattern %d: with %d errors the length %d must be in %d..32", p, D, lens[p], D + 1);
+            return nullptr;
+        }
+        if (D > 0)
+            for (int t = 0; t < lens[p]; ++t)
+                if (pats[p][t] == delim[0] || pats[p][t] == '\n') {
+                    fail("pattern %d holds a delimiter byte (not supported with errors)", p);
+                    return nullptr;
+                }
+    }
+    if (agh_device_count() <= 0) { fail("no usable HIP device: libagrep_hip has no CPU path"); return nullptr; }
+
+    agh_query *q = new agh_query();
+    q->multi = true;
+    q->npat = npat;
+    q->k = D;
+    q->dlen = 1;
+    q->delim[0] = delim[0];
+    q->fh = 1;
+    memset(q->mask, 0, sizeof(q->mask));
+    if (fill_multi_tables(q, pats, lens, npat, D, nocase, delim[0], &q->fq, &q->qmask, &q->fold,
+                          &q->m) ||
+        upload_common(q)) {
         agh_query_free(q);
         return nullptr;
     }
@@ -659,7 +719,7 @@ static uint64_t seg_max()
 }
 #define AGH_SEG_MAX (seg_max())
 // multi-pattern candidates carry 32-bit byte offsets
-#define AGH_SEG_MAX_Q(q) ((q)->multi ? std::min<uint64_t>(seg_max(), (uint64_t)4 << 30) : seg_max())
+#define AGH_SEG_MAX_Q(q) (((q)->multi || (q)->piece_single) ? std::min<uint64_t>(seg_max(), (uint64_t)4 << 30) : seg_max())
 
 struct seg_result {
     uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
@@ -675,18 +735,21 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     *out = seg_result();
     if (n == 0) return 0;
     if (((uintptr_t)d_text & 15u) != 0) return fail("device text must be 16-byte aligned");
+    // piece engine of a single literal pattern (see attach_piece_engine)
+    const bool pe = q->piece_single && !q->general && !(flags & AGH_FORCE_FULLSCAN);
+    const bool multi = q->multi || pe;
     const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint64_t nw = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
-    if (q->multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
-    if (q->multi && (flags & AGH_FORCE_FULLSCAN))
+    if (multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
+    if (multi && (flags & AGH_FORCE_FULLSCAN))
         return fail("multi-pattern queries have no full-scan engine");
-    const bool want_filter = q->fq > 0 && !(flags & AGH_FORCE_FULLSCAN) && !q->general && !q->table;
+    const bool want_filter = (q->fq > 0 || pe) && !(flags & AGH_FORCE_FULLSCAN) && !q->general && !q->table;
     if (!want_filter && (flags & AGH_FORCE_FILTER))
         return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
     if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
     if (q->wave_totals.ensure((nw + 8) * sizeof(uint32_t))) return -1;
     if (want_filter) {
-        if (q->cand.ensure(nw * (q->multi ? AGH_MP_SLICE_CAP : AGH_SLICE_CAP) * sizeof(uint64_t))) return -1;
+        if (q->cand.ensure(nw * (multi ? AGH_MP_SLICE_CAP : AGH_SLICE_CAP) * sizeof(uint64_t))) return -1;
         if (q->wave_cand.ensure((nw + 8) * sizeof(uint32_t))) return -1;
     }
 
@@ -697,10 +760,10 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     dq.dlen = (uint32_t)q->dlen;
     memset(dq.dbytes, 0, sizeof(dq.dbytes));
     memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
-    dq.fq = q->fq;
-    dq.fh = q->fh;
-    dq.qmask = q->qmask;
-    dq.fold = q->fold;
+    dq.fq = pe ? q->pe_fq : q->fq;
+    dq.fh = pe ? 1 : q->fh;
+    dq.qmask = pe ? q->pe_qmask : q->qmask;
+    dq.fold = pe ? q->pe_fold : q->fold;
     dq.ci = (uint32_t)std::min(q->ci, q->k + 1);       // asearch1.c:42-44
     dq.cs = (uint32_t)std::min(q->cs, q->k + 1);
     dq.cd = (uint32_t)std::min(q->cd, q->k + 1);
@@ -747,7 +810,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         sa.text = d_text;
         sa.n = n;
         sa.q = dq;
-        sa.ftab = q->multi ? (const uint8_t *)q->d_mp_bits : q->d_ftab;
+        sa.ftab = multi ? (const uint8_t *)q->d_mp_bits : q->d_ftab;
         sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
         sa.wave_totals = (uint32_t *)q->wave_totals.p;
         sa.cand = (uint64_t *)q->cand.p;
@@ -763,7 +826,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.counters = q->d_counters;
         va.mk.hashset = (uint64_t *)q->hashset.p;
         va.mk.hashset_mask = (uint32_t)(slots - 1);
-        if (q->multi) agh_launch_sweep_multi(sa, multi_dev(q), va.mk, q->multi_dense, st);
+        if (multi) agh_launch_sweep_multi(sa, multi_dev(q), va.mk, q->multi_dense, st);
         else agh_launch_sweep(sa, q->fh, st);
         va.text = d_text;
         va.n = n;
@@ -777,7 +840,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.dbm = d_dbm;
         va.gtab = tight_verify_enabled() ? q->d_gtab : nullptr;
         va.gram_spread = q->gram_spread;
-        if (q->multi) agh_launch_verify_multi(va, multi_dev(q), true, st);
+        if (multi) agh_launch_verify_multi(va, multi_dev(q), true, st);
         else agh_launch_verify_lean(va, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)q->wave_cand.p, (uint32_t)nw, q->d_counters, st);
@@ -787,7 +850,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         q->hashset_dirty = false;
-        if (q->multi && q->h_counters[AGH_C_OVERFLOW] && !q->multi_dense) {
+        if (multi && q->h_counters[AGH_C_OVERFLOW] && !q->multi_dense) {
             // dense hit set (many very short patterns): check hits inline from now on
             q->multi_dense = true;
             return scan_segment(q, d_text, n, st, flags, head_byte, tail_virtual, d_match_pos,
@@ -845,7 +908,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.text = d_text;
             sa.n = n;
             sa.q = dq;
-            sa.ftab = q->multi ? (const uint8_t *)q->d_mp_bits : q->d_ftab;
+            sa.ftab = multi ? (const uint8_t *)q->d_mp_bits : q->d_ftab;
             sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
             sa.wave_totals = (uint32_t *)q->wave_totals.p;
             sa.cand = (uint64_t *)q->cand.p;
@@ -856,7 +919,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.lean = 0;
             sa.ev_begin = q->ev2;
             sa.ev_end = q->ev3;
-            if (q->multi && q->multi_dense) {
+            if (multi && q->multi_dense) {
                 // census first (plain H=0 sweep + prefix scan), then the inline multi sweep
                 // numbers records from that prefix and marks them directly
                 agh_launch_sweep(sa, 0, st);
@@ -870,7 +933,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                 mk0.match_cap = match_cap;
                 sa.ev_begin = sa.ev_end = nullptr;
                 agh_launch_sweep_multi(sa, multi_dev(q), mk0, true, st);
-            } else if (q->multi) {
+            } else if (multi) {
                 agh_marks none;
                 memset(&none, 0, sizeof(none));
                 agh_launch_sweep_multi(sa, multi_dev(q), none, false, st);
@@ -905,7 +968,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.match_cap = match_cap;
         va.mk.hashset = nullptr;
         va.mk.hashset_mask = 0;
-        if (q->multi) agh_launch_verify_multi(va, multi_dev(q), false, st);
+        if (multi) agh_launch_verify_multi(va, multi_dev(q), false, st);
         else if (use_filter) agh_launch_verify(va, st);
         else if (q->table) agh_launch_tablescan(va, st);
         else agh_launch_fullscan(va, st);
@@ -928,13 +991,13 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         const bool bm_overflow = q->h_counters[AGH_C_BM_OVERFLOW] != 0 ||
                                  (uint64_t)n_delims + 2 > (uint64_t)bm_words * 32;
         if (slice_overflow) {
-            if (q->multi && !q->multi_dense) {
+            if (multi && !q->multi_dense) {
                 q->multi_dense = true;          // dense hit set: check hits inline from now on
                 swept = false;
                 bits_hint = (uint64_t)n_delims + 1024;
                 continue;
             }
-            if ((flags & AGH_FORCE_FILTER) || q->multi)
+            if ((flags & AGH_FORCE_FILTER) || multi)
                 return fail("candidate slices overflowed (%u candidates)", q->h_counters[AGH_C_CAND]);
             use_filter = false;                 // not selective on this text: automaton everywhere
             swept = false;                      // the full scan needs the H=0 sweep's strip prefix

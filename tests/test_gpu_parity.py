@@ -77,8 +77,9 @@ def test_headline_pattern_on_generated_corpus(agh, k, nocase):
     text, planted = O.corpus(512, seed=12345, variants=O.VARIANTS_C2, plant_period=40,
                              upper_permille=500 if nocase else 0)
     res = _check(agh, O.PATTERN_C2, k, text, nocase)
-    # m=16: the sample lemma admits a filter up to k=2 (test_filter_shape_selection)
-    assert res.engine == (agh.ENGINE_FILTER if k <= 2 else agh.ENGINE_FULLSCAN)
+    # m=16: the sample lemma admits a filter up to k=2 (test_filter_shape_selection); k=3 goes
+    # through the piece engine (4 pieces of 4 bytes), which is a filter as well
+    assert res.engine == agh.ENGINE_FILTER
     if k >= 2 and not nocase:
         assert res.n_matched >= sum(planted)
 
@@ -227,7 +228,7 @@ def test_resident_corpus_properties_at_scale(agh):
             r2 = q.scan_device(t.data_ptr(), t.numel(), flags=agh.FORCE_FULLSCAN)
             r3 = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
         assert r3.n_matched == r1.n_matched
-        assert r1.engine == (agh.ENGINE_FILTER if k <= 2 else agh.ENGINE_FULLSCAN)
+        assert r1.engine == agh.ENGINE_FILTER       # k = 3: the piece engine
         assert r2.engine == agh.ENGINE_FULLSCAN
         assert r1.n_matched == r2.n_matched and r1.n_records == r2.n_records
         assert r1.n_matched >= prev
@@ -466,3 +467,35 @@ def test_table_engine_adversarial_texts(agh):
             res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
             assert res_c.n_matched == want[0]
         q.close()
+
+
+def test_piece_engine_for_short_patterns(agh):
+    """Patterns the sample lemma cannot filter (m < 5k+6) run through the piece engine: k+1
+    verbatim pieces found by the multi-pattern sweep, the pattern's automaton on the window.
+    Every engine (pieces, full scan, lean, numbered) equals the oracle."""
+    rng = random.Random(11)
+    text, _ = O.corpus(256, seed=3, variants=O.VARIANTS_C2, plant_period=25, upper_permille=300)
+    tb = bytearray(text.tobytes())
+    words = [b"match", b"mat ch", b"aproxim", b"approxim", b"Approxim", b"appr", b"apr", b"mtch", b"matc",
+             b"xmatch", b"approximate", b"aproximte"]
+    pos = 0
+    while True:                                         # sprinkle near-misses of the short words
+        nl = tb.find(b"\n", pos)
+        if nl < 0:
+            break
+        if rng.random() < 0.2 and nl - pos > 30:
+            w = rng.choice(words)
+            at = rng.randint(pos, nl - len(w))
+            tb[at:at + len(w)] = w
+        pos = nl + 1
+    tb = bytes(tb)
+    for pat, k, nocase in ((b"match", 1, False), (b"approxim", 1, False), (b"approxim", 2, True),
+                           (b"appr", 0, False), (b"appr", 1, True), (b"approximate", 3, False),
+                           (b"ab", 0, False), (b"abc", 1, False), (b"approximatematch", 4, True),
+                           (b"approximatematch", 7, False)):
+        with agh.Query(pat, k, nocase=nocase) as q:
+            assert q.info()["filter_q"] == 0            # not sample-filterable
+        res = _check(agh, pat, k, tb, nocase)
+        assert res.engine in (agh.ENGINE_FILTER, agh.ENGINE_FULLSCAN)
+    for t in (b"", b"match", b"mtch\n", b"x\nmatc", b"m\natch\n"):   # tiny texts, virtual head / tail
+        _check(agh, b"match", 1, t)
