@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "../../include/agrep_hip.h"
@@ -1171,11 +1172,21 @@ extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res
     }
     struct stat sb;
     size_t want = AGH_STAGE_CHUNK * 2;
+    uint64_t file_left = 0;                     // > 0: seekable regular file, bytes still to read
+    off_t file_pos = 0;
     if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
         off_t cur = lseek(fd, 0, SEEK_CUR);
+        if (cur >= 0 && cur < sb.st_size) {
+            file_pos = cur;
+            file_left = (uint64_t)(sb.st_size - cur);
+        }
         if (cur < 0) cur = 0;
         want = (size_t)(sb.st_size - cur) + 64;
     }
+    unsigned n_readers = std::thread::hardware_concurrency();
+    if (n_readers > 16) n_readers = 16;
+    if (const char *e = getenv("AGH_READERS")) n_readers = (unsigned)atoi(e);
+    if (n_readers < 1) n_readers = 1;
     if (q->staging.ensure(want + 32)) return -1;
     size_t used = 0;
     int b = 0;
@@ -1184,14 +1195,50 @@ extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res
         if (busy[b]) HIP_TRY(hipEventSynchronize(q->pinned_ev[b]));   // its H2D copy finished
         busy[b] = false;
         size_t got = 0;
-        while (got < AGH_STAGE_CHUNK) {
-            ssize_t r = read(fd, q->pinned[b] + got, AGH_STAGE_CHUNK - got);
-            if (r < 0) {
-                if (errno == EINTR) continue;
-                return fail("read failed: %s", strerror(errno));
+        if (file_left >= AGH_STAGE_CHUNK / 2 && n_readers > 1) {
+            // regular file: the chunk is cut into n_readers pieces read concurrently (one
+            // read(2) stream copies ~10 GB/s out of the page cache, PCIe takes five times that)
+            const size_t take = std::min<uint64_t>(AGH_STAGE_CHUNK, file_left);
+            const size_t piece = ((take + n_readers - 1) / n_readers + 4095) & ~(size_t)4095;
+            std::vector<std::thread> th;
+            std::vector<ssize_t> done(n_readers, 0);
+            for (unsigned t = 0; t < n_readers; ++t) {
+                const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
+                if (lo >= hi) break;
+                th.emplace_back([&, t, lo, hi]() {
+                    size_t at = lo;
+                    while (at < hi) {
+                        ssize_t r = pread(fd, q->pinned[b] + at, hi - at, file_pos + (off_t)at);
+                        if (r < 0 && errno == EINTR) continue;
+                        if (r <= 0) break;
+                        at += (size_t)r;
+                    }
+                    done[t] = (ssize_t)(at - lo);
+                });
             }
-            if (r == 0) break;
-            got += (size_t)r;
+            for (auto &x : th) x.join();
+            // contiguous prefix that really arrived (a file truncated meanwhile ends the scan)
+            for (unsigned t = 0; t < th.size(); ++t) {
+                const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
+                got += (size_t)done[t];
+                if ((size_t)done[t] < hi - lo) break;
+            }
+            file_pos += (off_t)got;
+            file_left -= std::min<uint64_t>(file_left, got);
+            if (got < take) file_left = 0;
+            (void)lseek(fd, file_pos, SEEK_SET);
+        } else {
+            while (got < AGH_STAGE_CHUNK) {
+                ssize_t r = read(fd, q->pinned[b] + got, AGH_STAGE_CHUNK - got);
+                if (r < 0) {
+                    if (errno == EINTR) continue;
+                    return fail("read failed: %s", strerror(errno));
+                }
+                if (r == 0) break;
+                got += (size_t)r;
+            }
+            file_left -= std::min<uint64_t>(file_left, got);
+            file_pos += (off_t)got;
         }
         if (got == 0) break;
         if (used + got + 32 > q->staging.cap) {     // unknown length (pipe): grow, keep contents

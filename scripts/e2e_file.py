@@ -17,6 +17,23 @@ torch.cuda.empty_cache()
 cli = os.path.join(ROOT, "agrep_amd", "agrep-hip")
 ref = os.path.join(ROOT, "oracle", "_ref", "agrep")
 try:
+    import ctypes
+    for readers in (1, 8, 16):
+        os.environ["AGH_READERS"] = str(readers)
+        q = A.Query(b"approximatematch", 2)
+        fd = os.open(path, os.O_RDONLY)
+        best = None
+        for rep in range(3):
+            os.lseek(fd, 0, os.SEEK_SET)
+            t0 = time.time()
+            r, _ = q.scan_fd(fd, flags=A.COUNT)
+            dt = time.time() - t0
+            best = dt if best is None else min(best, dt)
+        os.close(fd)
+        q.close()
+        print("agh_scan_fd in-process, %d reader thread(s): %.3f s  %.2f GB/s -> %d" % (readers, best, n / 1e9 / best, r.n_matched))
+    del os.environ["AGH_READERS"]
+    print("host cores:", os.cpu_count())
     for name, exe in (("agrep-hip", cli), ("reference", ref)):
         if not os.path.exists(exe):
             continue
