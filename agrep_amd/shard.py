@@ -46,7 +46,8 @@ def reduce_counts(n_matched, n_records=0, device=None, group=None):
     t = torch.tensor([int(n_matched), int(n_records)], dtype=torch.int64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return int(t[0].item()), int(t[1].item())
+    m, r = t.tolist()                           # one device-to-host round trip
+    return int(m), int(r)
 
 
 def reduce_file_hits(hits, device=None, group=None):
