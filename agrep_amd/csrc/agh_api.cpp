@@ -987,6 +987,12 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         swept = true;
 
         const uint32_t n_delims = q->h_counters[AGH_C_NDELIM];
+        if (getenv("AGH_DEBUG"))
+            fprintf(stderr, "[agh] attempt %d multi %d dense %d filter %d: ndelim %u cand %u overflow %u "
+                            "bm_overflow %u matched %u bm_bits %llu\n", attempt, (int)multi,
+                    (int)q->multi_dense, (int)use_filter, n_delims, q->h_counters[AGH_C_CAND],
+                    q->h_counters[AGH_C_OVERFLOW], q->h_counters[AGH_C_BM_OVERFLOW],
+                    q->h_counters[AGH_C_MATCHED], (unsigned long long)bm_words * 32);
         q->bitmap_bits_hint = (uint64_t)n_delims + n_delims / 4 + 1024;
         const bool slice_overflow = use_filter && q->h_counters[AGH_C_OVERFLOW];
         const bool bm_overflow = q->h_counters[AGH_C_BM_OVERFLOW] != 0 ||
@@ -1005,6 +1011,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         }
         if (slice_overflow || bm_overflow) {
             bits_hint = (uint64_t)n_delims + 1024;
+            if (multi && q->multi_dense) swept = false;     // the inline sweep does the marking
             continue;
         }
         out->records = (uint64_t)n_delims +

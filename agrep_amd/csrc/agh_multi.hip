@@ -376,7 +376,9 @@ __global__ __launch_bounds__(64) void k_sweep_multi_tail(const uint4 *__restrict
     const uint32_t z = (MODE & 4) ? 0u : 8192u - (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
     const uint64_t w = s / AGH_WAVE_STRIPS;
     const bool fresh = (s % AGH_WAVE_STRIPS) == 0;
-    uint32_t before = strip_prefix ? wave_totals[w] + strip_prefix[s] : (fresh ? 0u : wave_totals[w]);
+    // delimiters of this wave's range in front of the strip (the verifier adds the prefix of
+    // the ranges before it)
+    uint32_t before = strip_prefix ? strip_prefix[s] : (fresh ? 0u : wave_totals[w]);
     before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
     uint32_t ncand = fresh ? 0u : wave_cand[w];
     ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);

@@ -499,3 +499,16 @@ def test_piece_engine_for_short_patterns(agh):
         assert res.engine in (agh.ENGINE_FILTER, agh.ENGINE_FULLSCAN)
     for t in (b"", b"match", b"mtch\n", b"x\nmatc", b"m\natch\n"):   # tiny texts, virtual head / tail
         _check(agh, b"match", 1, t)
+
+
+def test_dense_hits_with_partial_last_strip(agh):
+    """Two-letter alphabet: every position is a candidate, the piece engine checks hits inline
+    (dense mode); the text length is not a multiple of 1 KiB, so the last strip takes the
+    slice path with record numbers relative to its range (regression: they were absolute)."""
+    rng = np.random.default_rng(5)
+    for n in (600000, 262144 + 77, 1500):
+        a = rng.integers(0, 2, n).astype(np.uint8) + ord("a")
+        a[rng.integers(0, n, n // 80)] = 10
+        text = a.tobytes()
+        for pat, k in ((b"aab", 0), (b"bbabba", 1), (b"bbabbabbababaa", 2)):
+            _check(agh, pat, k, text)
