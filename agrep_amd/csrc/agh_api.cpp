@@ -310,6 +310,15 @@ extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, 
         fail("delimiter length %d outside 1..%d", dlen, AGH_MAX_DELIM);
         return nullptr;
     }
+    if (nocase)
+        for (int i = 0; i < dlen; ++i)
+            if (is_upper(delim[i]) || is_lower(delim[i])) {
+                // maskgen.c:259-266 aliases the upper-case rows of Mask[] for the delimiter
+                // positions too: under -i "X" would end a record of -d x.  The device kernels
+                // compare delimiter bytes verbatim.
+                fail("-i together with letters in the delimiter is not supported");
+                return nullptr;
+            }
     agh_query *q = new agh_query();
     q->m = m;
     q->k = D;
@@ -424,6 +433,15 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
     if (D < 0 || D > AGH_MAX_ERRORS || D >= m) {
         fail("number of errors %d must be smaller than the pattern length %d", D, m);
         return nullptr;
+    }
+    for (int p = 1; p <= D_length; ++p) {           // delimiter position p lives at bit M - p
+        int members = 0;
+        for (int c = 0; c < 256; ++c) members += (Mask[c] >> (M - p)) & 1u;
+        if (members != 1) {
+            fail("delimiter position %d matches %d different bytes (-i with letters in the "
+                 "delimiter is not supported)", p, members);
+            return nullptr;
+        }
     }
     const uint32_t sep = 1u << (M - D_length - 1);
     const uint32_t pad = M == 32 ? 0u : ~((1u << M) - 1u);

@@ -23,8 +23,24 @@ while time.time() < t_end:
     letters = bytes(c for c in alpha if c != 10) or b"a"
     pat = bytes(rng.choice(letters) for _ in range(m))
     nocase = rng.random() < 0.3
+    kind = rng.choice(["single"] * 6 + ["mbdelim", "wide", "multi", "multi"])
     delim = b"\n" if rng.random() < 0.8 else bytes([rng.choice(b";|\t")])
-    if delim[0] in pat:
+    if kind == "mbdelim":
+        delim = rng.choice([b"\n\n", b";;", b"\r\n", b"ab\n", b"$$"])
+        alpha = alpha + delim
+    if kind == "wide":
+        m = rng.choice([30, 33, 40, 48, 64])
+        k = min(k, 4)
+        pat = bytes(rng.choice(letters) for _ in range(m))
+        alpha = b"abcdefgh\n" if len(letters) < 4 else alpha
+        letters = bytes(c for c in alpha if c != 10)
+        pat = bytes(rng.choice(letters) for _ in range(m))
+    if nocase and any(chr(c).isalpha() for c in delim):
+        nocase = False                  # -i with letters in the delimiter: rejected by design
+    if kind == "mbdelim" and len(pat) + len(delim) > 29:
+        pat = pat[:20]
+        k = min(k, len(pat) - 1)
+    if (kind != "mbdelim" and any(c in pat for c in delim)) or 10 in pat:
         continue
     n = rng.choice([0, 1, 5, 100, 1023, 1024, 1025, 4096, 70000, 262144, 262145, 600000])
     arr = np.frombuffer(bytes(rng.choice(alpha) for _ in range(min(n, 4096))), dtype=np.uint8)
@@ -54,7 +70,35 @@ while time.time() < t_end:
     if rng.random() < 0.5 and text and text[-1] != delim[0]:
         text += delim
     text = bytes(text)
-    want = O.asearch(pat, k, text, delim=delim, nocase=nocase, cap=300000)
+    if not text and len(delim) > 1:
+        continue                        # empty text: only the appended delimiter could match (Q11)
+    if kind == "multi":
+        npat = rng.choice([1, 2, 5, 20])
+        pats = sorted({bytes(rng.choice(letters) for _ in range(rng.randint(max(2, k + 1), 10))) for _ in range(npat)})
+        if len(delim) != 1 or any(delim[0] in x for x in pats) or len(text) > 300000:
+            continue
+        recs = set()
+        for x in pats:
+            recs.update(O.asearch(x, k, text, delim=delim, nocase=nocase, cap=300000)[1])
+        want_m = sorted(recs)
+        try:
+            with A.Query.multi(pats, nocase=nocase, delim=delim, k=k) as q:
+                r1, ms = q.scan_buffer(text, cap=300000)
+                r2, _ = q.scan_buffer(text, flags=A.COUNT)
+                r3, _ = q.scan_buffer(text, flags=A.COUNT | A.FORCE_NUMBERED)
+            got_m = [(s_, e_) for s_, e_, _ in ms]
+            if got_m != want_m or not (r1.n_matched == r2.n_matched == r3.n_matched == len(want_m)):
+                fails += 1
+                print("MISMATCH multi", pats, "k", k, nocase, delim, len(text), len(want_m), r1.n_matched, r2.n_matched, r3.n_matched, flush=True)
+        except A.AghError as e:
+            print("ERROR multi", e, pats, k, flush=True)
+            fails += 1
+        n_cases += 1
+        continue
+    if len(pat) + len(delim) <= 30:
+        want = O.asearch(pat, k, text, delim=delim, nocase=nocase, cap=300000)
+    else:
+        want = O.wm_count(pat, k, text, delim=delim, nocase=nocase, word_bits=64, cap=300000)
     try:
         with A.Query(pat, k, nocase=nocase, delim=delim) as q:
             got = {}
