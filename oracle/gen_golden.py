@@ -208,7 +208,9 @@ def gen_pattern_language():
                          ("approxi;matematch", 0, []), ("approxi;matematch", 1, []),
                          ("matematch;approx", 2, []), ("cars;fast", 0, []),
                          ("approxi,xyzzyq", 0, []), ("aproxi,matemmat", 1, []), ("scar,cat", 0, []),
-                         ("a#h", 0, ["-w"]), ("car;red", 1, [])):
+                         ("a#h", 0, ["-w"]), ("car;red", 1, []),
+                         ("^appro", 0, []), ("^aproxi", 1, []), ("tematch$", 1, []), ("^car$", 0, []),
+                         ("^cars", 1, []), ("fast$", 0, [])):
         kopt = ["-%d" % k] if k else []
         rc, out, err = run([HARNESS, "tables"] + kopt + ["-n"] + opts + [pat])
         t = json.loads(out)
