@@ -7,6 +7,7 @@ LIB_PATH = os.path.join(_HERE, "libagrep_hip.so")
 
 COUNT = 0x01
 FILENAMEONLY = 0x02
+INVERT = 0x04
 FORCE_FULLSCAN = 0x10
 FORCE_FILTER = 0x20
 FORCE_NUMBERED = 0x40

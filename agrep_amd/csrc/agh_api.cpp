@@ -84,6 +84,7 @@ struct dev_buf {
 
 struct agh_query {
     int m = 0, k = 0, dlen = 1, wide = 0;
+    bool delim_fold = false;            // -i with letters in a multi-byte delimiter
     unsigned char delim[AGH_MAX_DELIM] = {'\n'};
     uint64_t mask[256];                 // bit (p-1) set iff byte is in the class of position p
     int fq = 0, fh = 0;                 // filter sample shape (0: no filter)
@@ -310,20 +311,25 @@ extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, 
         fail("delimiter length %d outside 1..%d", dlen, AGH_MAX_DELIM);
         return nullptr;
     }
-    if (nocase)
-        for (int i = 0; i < dlen; ++i)
-            if (is_upper(delim[i]) || is_lower(delim[i])) {
-                // maskgen.c:259-266 aliases the upper-case rows of Mask[] for the delimiter
-                // positions too: under -i "X" would end a record of -d x.  The device kernels
-                // compare delimiter bytes verbatim.
-                fail("-i together with letters in the delimiter is not supported");
-                return nullptr;
-            }
+    bool delim_letters = false;
+    for (int i = 0; i < dlen; ++i) delim_letters = delim_letters || is_upper(delim[i]) || is_lower(delim[i]);
+    if (nocase && delim_letters && dlen == 1) {
+        // maskgen.c:259-266 aliases the upper-case rows of Mask[] for the delimiter positions
+        // too: under -i "X" would end a record of -d x.  The kernels compare a single-byte
+        // delimiter verbatim (multi-byte delimiters go through delim_class, which folds).
+        fail("-i together with a letter as the delimiter is not supported");
+        return nullptr;
+    }
     agh_query *q = new agh_query();
     q->m = m;
     q->k = D;
     q->dlen = dlen;
     memcpy(q->delim, delim, (size_t)dlen);
+    if (nocase && delim_letters) {
+        q->delim_fold = true;
+        for (int i = 0; i < dlen; ++i)
+            if (is_upper(q->delim[i])) q->delim[i] = (unsigned char)(q->delim[i] + 32);
+    }
     memset(q->mask, 0, sizeof(q->mask));
     for (int p = 0; p < m; ++p) {
         int c = pat[p];
@@ -434,12 +440,16 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
         fail("number of errors %d must be smaller than the pattern length %d", D, m);
         return nullptr;
     }
+    bool delim_fold = false;
     for (int p = 1; p <= D_length; ++p) {           // delimiter position p lives at bit M - p
-        int members = 0;
-        for (int c = 0; c < 256; ++c) members += (Mask[c] >> (M - p)) & 1u;
+        int members = 0, lo = -1;
+        for (int c = 0; c < 256; ++c)
+            if ((Mask[c] >> (M - p)) & 1u) { ++members; if (lo < 0) lo = c; }
+        const bool pair = members == 2 && is_upper(lo) && ((Mask[lo + 32] >> (M - p)) & 1u);
+        if (pair && D_length > 1) { delim_fold = true; continue; }
         if (members != 1) {
-            fail("delimiter position %d matches %d different bytes (-i with letters in the "
-                 "delimiter is not supported)", p, members);
+            fail("delimiter position %d matches %d different bytes (-i with a letter as a "
+                 "single-byte delimiter is not supported)", p, members);
             return nullptr;
         }
     }
@@ -462,7 +472,9 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
     for (int i = 0; i < D_length; ++i) {
         unsigned char c = old_D_pat[i];
         q->delim[i] = (c == '^' || c == '$') ? '\n' : c;    // bitap.c:92-94
+        if (delim_fold && is_upper(q->delim[i])) q->delim[i] = (unsigned char)(q->delim[i] + 32);
     }
+    q->delim_fold = delim_fold;
     for (int c = 0; c < 256; ++c) {
         uint64_t v = 0;
         for (int p = 1; p <= m; ++p)
@@ -755,14 +767,20 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     if (n == 0) return 0;
     if (((uintptr_t)d_text & 15u) != 0) return fail("device text must be 16-byte aligned");
     // piece engine of a single literal pattern (see attach_piece_engine)
-    const bool pe = q->piece_single && !q->general && !(flags & AGH_FORCE_FULLSCAN);
+    // -v with a record list needs the census arrays of the byte-parallel engines
+    const bool invert = (flags & AGH_INVERT) != 0;
+    const bool invert_list = invert && d_match_pos != nullptr;
+    if (invert_list && q->multi) return fail("-v with record output is not supported for pattern files");
+    if (invert_list && q->dlen > 1) return fail("-v with record output supports single-byte delimiters only");
+    const bool pe = q->piece_single && !q->general && !(flags & AGH_FORCE_FULLSCAN) && !invert_list;
     const bool multi = q->multi || pe;
     const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint64_t nw = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
     if (multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
     if (multi && (flags & AGH_FORCE_FULLSCAN))
         return fail("multi-pattern queries have no full-scan engine");
-    const bool want_filter = (q->fq > 0 || pe) && !(flags & AGH_FORCE_FULLSCAN) && !q->general && !q->table;
+    const bool want_filter = (q->fq > 0 || pe) && !(flags & AGH_FORCE_FULLSCAN) && !q->general && !q->table &&
+                             !invert_list;
     if (!want_filter && (flags & AGH_FORCE_FILTER))
         return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
     if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
@@ -779,6 +797,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     dq.dlen = (uint32_t)q->dlen;
     memset(dq.dbytes, 0, sizeof(dq.dbytes));
     memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
+    dq.dfold = q->delim_fold ? 1u : 0u;
     dq.fq = pe ? q->pe_fq : q->fq;
     dq.fh = pe ? 1 : q->fh;
     dq.qmask = pe ? q->pe_qmask : q->qmask;
@@ -811,7 +830,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     // of occupied slots.  Gives up (-> numbered pipeline below) when a record start lies more
     // than AGH_LEAN_BACK_CAP bytes in front of a match, the set fills up, or slices overflow.
     const bool lean_ok = want_filter && !d_match_pos && (flags & (AGH_COUNT | AGH_FILENAMEONLY)) &&
-                         !(flags & AGH_FORCE_NUMBERED);
+                         !(flags & AGH_FORCE_NUMBERED) && !invert;      // -v needs the record count
     if (lean_ok) {
         uint64_t slots = 1u << 20;
         while (slots < q->hashset_slots_hint) slots <<= 1;
@@ -982,15 +1001,21 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.bitmap = (uint32_t *)q->bitmap.p;
         va.mk.bitmap_bits = (uint32_t)std::min<uint64_t>(bm_words * 32, 0xffffffffu);
         va.mk.counters = q->d_counters;
-        va.mk.match_pos = d_match_pos;
-        va.mk.match_rec = d_match_rec;
-        va.mk.match_cap = match_cap;
+        va.mk.match_pos = invert_list ? nullptr : d_match_pos;     // -v: bits only, list below
+        va.mk.match_rec = invert_list ? nullptr : d_match_rec;
+        va.mk.match_cap = invert_list ? 0u : match_cap;
         va.mk.hashset = nullptr;
         va.mk.hashset_mask = 0;
         if (multi) agh_launch_verify_multi(va, multi_dev(q), false, st);
         else if (use_filter) agh_launch_verify(va, st);
         else if (q->table) agh_launch_tablescan(va, st);
         else agh_launch_fullscan(va, st);
+        if (invert_list) {                      // the records whose bit stayed clear
+            va.mk.match_pos = d_match_pos;
+            va.mk.match_rec = d_match_rec;
+            va.mk.match_cap = match_cap;
+            agh_launch_unmatched(va, st);
+        }
         agh_launch_bitmap_count((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), q->d_counters, st);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(q->ev1, st));
@@ -1037,6 +1062,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         out->candidates = use_filter ? q->h_counters[AGH_C_CAND] : 0;
         out->engine = use_filter ? AGH_ENGINE_FILTER : AGH_ENGINE_FULLSCAN;
         out->matched = q->h_counters[AGH_C_MATCHED];
+        if (invert) out->matched = out->records - out->matched;
         out->stored = std::min<uint64_t>(q->h_counters[AGH_C_STORED], match_cap);
         out->truncated = q->h_counters[AGH_C_STORED] > match_cap;
         out->ms = total_ms;
@@ -1133,6 +1159,7 @@ static int collect_matches(agh_query *q, uint64_t len, const agh_result *res, ag
     dq.delim = q->delim[q->dlen - 1];
     dq.dlen = (uint32_t)q->dlen;
     memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
+    dq.dfold = q->delim_fold ? 1u : 0u;
     agh_launch_match_bounds(q->staging.p, len, dq, (const uint64_t *)q->dbm.p,
                             (const uint64_t *)q->match_pos.p, (uint32_t)ns,
                             (uint64_t *)q->match_start.p, (uint64_t *)q->match_end.p, nullptr);

@@ -54,6 +54,7 @@ struct agh_dev_query {
     uint32_t delim;     // the delimiter byte (last byte of a multi-byte delimiter)
     uint32_t dlen;      // delimiter length in bytes; > 1: delimiter ends come from the bitmap
     uint8_t dbytes[8];  // the delimiter
+    uint32_t dfold;     // 1: delimiter bytes match case-insensitively (multi-byte delimiters, -i)
     int32_t fq;         // filter: sample length in bytes (1..4), 0 = no filter
     int32_t fh;         // filter: sample stride in bytes (4, 8 or 16)
     uint32_t qmask;     // low fq bytes

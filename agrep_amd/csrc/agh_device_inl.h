@@ -77,6 +77,9 @@ __device__ __forceinline__ uint64_t dbm_bits64(const uint64_t *__restrict__ dbm,
 __device__ __forceinline__ uint32_t delim_class(const agh_dev_query &q, uint32_t c)
 {
     uint32_t m = 0;
+    // -i: maskgen.c:259-266 aliases the upper-case rows of Mask[] for the delimiter positions
+    // as well, so "FROM " ends a record of -d 'From ' (dbytes are lower-cased by the host then)
+    if (q.dfold && c >= 'A' && c <= 'Z') c += 32u;
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j)
         if (j < q.dlen && q.dbytes[j] == c) m |= 1u << j;

@@ -59,6 +59,7 @@ void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st);
 void agh_launch_verify(const agh_scan_args &a, hipStream_t st);
 void agh_launch_fullscan(const agh_scan_args &a, hipStream_t st);
 void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st);
+void agh_launch_unmatched(const agh_scan_args &a, hipStream_t st);
 void agh_launch_bitmap_count(uint32_t *bitmap, uint32_t n_words, uint32_t *counters,
                              hipStream_t st);
 void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *wave_cand,

@@ -152,3 +152,102 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
     }
 #undef AGH_CASE
 }
+
+// ---------------------------------------------------------------------------------------
+// -v (INVERSE, asearch.c:128): the records whose bit is NOT set in the record bitmap.  Text-
+// parallel like k_tablescan: a lane looks at the delimiters of its 256-byte chunk; the record
+// a delimiter closes has the number "delimiters in front of it".  Emits (position of the
+// closing delimiter, record number) for k_match_bounds; one atomic per wave.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_unmatched(const uint8_t *__restrict__ text, uint64_t n,
+                                                   agh_dev_query q,
+                                                   const uint32_t *__restrict__ strip_prefix,
+                                                   const uint32_t *__restrict__ wave_prefix,
+                                                   uint32_t n_strips, agh_marks mk)
+{
+    const uint64_t n_chunks = (n + AGH_TS_CHUNK - 1) / AGH_TS_CHUNK;
+    const uint32_t dd = q.delim * 0x01010101u;
+    const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256u; base < n_chunks;
+         base += (uint64_t)gridDim.x * 256u) {
+        const uint64_t cs = (base + threadIdx.x) * AGH_TS_CHUNK;
+        uint64_t ce = cs + AGH_TS_CHUNK;
+        if (ce > n) ce = n;
+        uint32_t my_delims = 0;
+        if (cs < n) {
+            const uint32_t len = (uint32_t)(ce - cs);
+            for (uint32_t i = 0; i < (len >> 4); ++i)
+                my_delims += delims_in(*reinterpret_cast<const uint4 *>(text + cs + i * 16), dd);
+            if (len & 15u)
+                my_delims += delims_in(
+                    mask_tail(*reinterpret_cast<const uint4 *>(text + cs + (len & ~15u)),
+                              (int)(len & 15u), fill4), dd);
+        }
+        uint32_t before = 0;
+        {
+            const int l4 = (int)(threadIdx.x & 3u);
+            uint32_t v1 = (uint32_t)__shfl_up((int)my_delims, 1, 4);
+            uint32_t v2 = (uint32_t)__shfl_up((int)my_delims, 2, 4);
+            uint32_t v3 = (uint32_t)__shfl_up((int)my_delims, 3, 4);
+            if (l4 >= 1) before += v1;
+            if (l4 >= 2) before += v2;
+            if (l4 >= 3) before += v3;
+        }
+        const uint64_t strip = cs >> AGH_STRIP_SHIFT;
+        uint32_t rec = (cs < n && strip < n_strips)
+                           ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] + before
+                           : 0u;
+        // the last, unterminated record is closed by the delimiter appended at EOF
+        const bool open_tail = cs < n && ce == n && q.tail_virtual && text[n - 1] != q.delim;
+        // pass 1: how many of my records are unmatched
+        uint32_t mine = 0;
+        if (cs < n) {
+            uint32_t r = rec;
+            for (uint64_t p = cs; p < ce; ++p)
+                if (text[p] == q.delim) {
+                    if (r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) ++mine;
+                    ++r;
+                }
+            if (open_tail && r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) ++mine;
+        }
+        // one reservation per wave
+        const uint32_t incl = wave_sum_to_lane63(mine);
+        uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t wave_base = 0;
+        if (wave_total) {
+            if (lane_id() == 63) wave_base = atomicAdd(&mk.counters[AGH_C_STORED], wave_total);
+            wave_base = (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 63);
+        }
+        uint32_t at = wave_base + incl - mine;
+        if (mine) {
+            uint32_t r = rec;
+            for (uint64_t p = cs; p < ce; ++p)
+                if (text[p] == q.delim) {
+                    if (r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) {
+                        if (at < mk.match_cap) {
+                            mk.match_pos[at] = p;
+                            if (mk.match_rec) mk.match_rec[at] = r;
+                        }
+                        ++at;
+                    }
+                    ++r;
+                }
+            if (open_tail && r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) {
+                if (at < mk.match_cap) {
+                    mk.match_pos[at] = n;
+                    if (mk.match_rec) mk.match_rec[at] = r;
+                }
+            }
+        }
+    }
+}
+
+void agh_launch_unmatched(const agh_scan_args &a, hipStream_t st)
+{
+    const uint64_t n_chunks = (a.n + AGH_TS_CHUNK - 1) / AGH_TS_CHUNK;
+    if (!n_chunks) return;
+    uint64_t want = (n_chunks + 255) / 256;
+    const uint32_t blocks = want > 65536 ? 65536u : (uint32_t)want;
+    hipLaunchKernelGGL(k_unmatched, dim3(blocks), dim3(256), 0, st, (const uint8_t *)a.text, a.n,
+                       a.q, a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);
+}

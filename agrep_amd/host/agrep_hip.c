@@ -35,6 +35,7 @@ static struct {
     int LINENUM;           /* -n  */
     int NOFILENAME;        /* -h  */
     int SILENT;            /* -s  */
+    int INVERSE;           /* -v  */
     int BESTMATCH;         /* -B  */
     int NOPROMPT;          /* -y  */
     int VERBOSE;           /* -V# (default 1: print the Grand Total line) */
@@ -50,7 +51,7 @@ static void die_usage(const char *msg)
 {
     fprintf(stderr, "%s: %s\n", Progname, msg);
     fprintf(stderr,
-            "usage: %s [-#cilnhsyB] [-V0] [-d delim] [-e pattern | -f patternfile | pattern] [file ...]\n",
+            "usage: %s [-#cilnhsvyB] [-V0] [-d delim] [-e pattern | -f patternfile | pattern] [file ...]\n",
             Progname);
     exit(2);
 }
@@ -116,6 +117,7 @@ static int parse_options(int argc, char **argv, char **files)
                 case 'n': opt.LINENUM = 1; break;
                 case 'h': opt.NOFILENAME = 1; break;
                 case 's': opt.SILENT = 1; break;
+                case 'v': opt.INVERSE = 1; break;
                 case 'y': opt.NOPROMPT = 1; break;
                 case 'B': opt.BESTMATCH = 1; break;
                 case 'k': literal_only = 1; break;
@@ -220,18 +222,18 @@ static int scan_one(agh_query *q, int fd, int want_records, struct filehit *out)
     size_t cap = 65536, total = 0;
     memset(out, 0, sizeof(*out));
     if (!want_records) {
-        unsigned flags = opt.FILENAMEONLY ? AGH_FILENAMEONLY : AGH_COUNT;
+        unsigned flags = (opt.FILENAMEONLY ? AGH_FILENAMEONLY : AGH_COUNT) | (opt.INVERSE ? AGH_INVERT : 0u);
         return agh_scan_fd(q, fd, flags, &out->res, NULL, 0);
     }
     out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
     if (!out->matches) return -1;
-    if (agh_scan_fd(q, fd, 0, &out->res, out->matches, cap)) return -1;
+    if (agh_scan_fd(q, fd, opt.INVERSE ? AGH_INVERT : 0u, &out->res, out->matches, cap)) return -1;
     if (out->res.truncated) {                   /* more matches than guessed: scan the staged text again */
         free(out->matches);
         cap = (size_t)out->res.n_matched + 16;
         out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
         if (!out->matches) return -1;
-        if (agh_rescan_staged(q, 0, &out->res, out->matches, cap)) return -1;
+        if (agh_rescan_staged(q, opt.INVERSE ? AGH_INVERT : 0u, &out->res, out->matches, cap)) return -1;
     }
     if (agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, NULL, 0, &total) == 0 &&
         total == 0)

@@ -44,6 +44,7 @@ extern "C" {
 /* scan flags (the reference passes these through globals, asearch.c:4-24) */
 #define AGH_COUNT          0x01u  /* -c  COUNT: only count matched records */
 #define AGH_FILENAMEONLY   0x02u  /* -l  FILENAMEONLY: caller only needs n_matched > 0 */
+#define AGH_INVERT         0x04u  /* -v  INVERSE (asearch.c:128): the records that do NOT match */
 #define AGH_FORCE_FULLSCAN 0x10u  /* diagnostics: skip the q-gram filter, run the automaton
                                      over every byte (the asearch.c shape) */
 #define AGH_FORCE_FILTER   0x20u  /* diagnostics: fail instead of falling back to full scan */

@@ -35,8 +35,8 @@ while time.time() < t_end:
         alpha = b"abcdefgh\n" if len(letters) < 4 else alpha
         letters = bytes(c for c in alpha if c != 10)
         pat = bytes(rng.choice(letters) for _ in range(m))
-    if nocase and any(chr(c).isalpha() for c in delim):
-        nocase = False                  # -i with letters in the delimiter: rejected by design
+    if nocase and len(delim) == 1 and chr(delim[0]).isalpha():
+        nocase = False                  # -i with a letter as single-byte delimiter: rejected by design
     if kind == "mbdelim" and len(pat) + len(delim) > 29:
         pat = pat[:20]
         k = min(k, len(pat) - 1)

@@ -55,6 +55,21 @@ def test_cli_matches_reference(files, args):
 
 
 @needs_ref
+@pytest.mark.parametrize("args", [["-V0", "-i", "-v", "-2", "-c"], ["-V0", "-i", "-v", "-2"],
+                                  ["-V0", "-i", "-v", "-n", "-1"], ["-V0", "-i", "-v", "-l", "-2"],
+                                  ["-V0", "-i", "-vc", "-1"]])
+def test_cli_inverse_matches_reference(files, args):
+    """-v on the asearch.c path (-i with errors keeps the reference off sgrep.c, whose engines
+    ignore -v: `agrep -v -c pat` == `agrep -c pat` there)."""
+    for fl in (files[1:2], files):
+        a = args + ["approximatematch"] + fl
+        rc_r, out_r, err_r = _run(REF, a)
+        rc_g, out_g, err_g = _run(CLI, a)
+        assert out_g == out_r, (a, out_g[:300], out_r[:300])
+        assert rc_g == rc_r, a
+
+
+@needs_ref
 def test_cli_stdin_and_missing_file(files):
     data = open(files[1], "rb").read()
     rc_r, out_r, _ = _run(REF, ["-V0", "-2", "-c", "approximatematch", "/dev/stdin"], stdin=data)
@@ -113,7 +128,7 @@ def test_cli_multi_byte_delimiter_counts(tmp_path):
 
 
 def test_cli_rejects_what_is_outside_the_hot_path(files):
-    for a in (["-2", "a|b", files[0]], ["-2", "[ab]cdefgh", files[0]], ["-v", "x", files[0]],
+    for a in (["-2", "a|b", files[0]], ["-2", "[ab]cdefgh", files[0]], ["-w", "x", files[0]],
               ["-9", "approximatematch", files[0]], ["-2", "ab", files[0]]):
         rc, out, err = _run(CLI, a)
         assert rc == 2 and err

@@ -512,3 +512,28 @@ def test_dense_hits_with_partial_last_strip(agh):
         text = a.tobytes()
         for pat, k in ((b"aab", 0), (b"bbabba", 1), (b"bbabbabbababaa", 2)):
             _check(agh, pat, k, text)
+
+
+def test_inverse_is_the_complement_of_the_record_set(agh):
+    """AGH_INVERT (-v, asearch.c:128): count = records - matched, list = the other records,
+    for the filter, piece, full-scan and table engines, with and without a trailing newline."""
+    text, _ = O.corpus(96, seed=21, variants=O.VARIANTS_C2, plant_period=7)
+    base = text.tobytes()
+    for tb in (base, base[:-1], b"", b"\n", b"\n\nabc\n\napproximatematch\n\n", b"approximatematch"):
+        nl = [i for i, c in enumerate(tb) if c == 10]
+        starts = [0] + [i + 1 for i in nl]
+        ends = nl + [len(tb)]
+        recs_all = [(s, e) for s, e in zip(starts, ends) if s < len(tb) or (s == len(tb) and False)]
+        if tb.endswith(b"\n") or not tb:
+            recs_all = list(zip(starts[:-1], ends[:-1]))
+        for pat, k in ((O.PATTERN_C2, 2), (b"approxim", 1), (O.PATTERN_C2, 0)):
+            hit = set(O.asearch(pat, k, tb, cap=200000)[1])
+            want = [r for r in recs_all if r not in hit]
+            with agh.Query(pat, k) as q:
+                for extra in (0, agh.FORCE_FULLSCAN):
+                    res, ms = q.scan_buffer(tb, flags=agh.INVERT | extra, cap=200000)
+                    assert res.n_matched == len(want), (pat, k, len(tb), extra)
+                    assert [(s, e) for s, e, _ in ms] == want
+                    assert [i for _, _, i in ms] == [recs_all.index(r) for r in want[:50]] + [i for _, _, i in ms][50:]
+                rc, _ = q.scan_buffer(tb, flags=agh.INVERT | agh.COUNT)
+                assert rc.n_matched == len(want)
