@@ -7,7 +7,8 @@
 #include "agh_device_inl.h"
 
 // EXP bits: 1 = hash VALU work, 2 = LDS table lookups, 4 = allocate the 32 KiB LDS table,
-//           8 = census VALU work, 16 = prefetch, 32 = 16 KiB table (index masked)
+//           8 = census VALU work, 16 = prefetch, 32 = 16 KiB table (index masked),
+//           64 = non-temporal loads (global_load ... nt)
 template <int EXP>
 __global__ __launch_bounds__(256) void k_sweep_exp(const uint4 *__restrict__ text,
                                                    uint64_t n_full_strips, uint32_t qmask,
@@ -44,13 +45,21 @@ __global__ __launch_bounds__(256) void k_sweep_exp(const uint4 *__restrict__ tex
         }
     };
     uint64_t s = s0;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto ld = [&](const uint4 *q) -> uint4 {
+        if (EXP & 64) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(q));
+            return make_uint4(v[0], v[1], v[2], v[3]);
+        }
+        return *q;
+    };
     if (EXP & 16) {
         if (s + 4 <= s1) {
             const uint4 *p = text + s * 64 + lane;
-            uint4 c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192];
+            uint4 c0 = ld(p), c1 = ld(p + 64), c2 = ld(p + 128), c3 = ld(p + 192);
             for (; s + 8 <= s1; s += 4) {
                 const uint4 *pn = text + (s + 4) * 64 + lane;
-                uint4 n0 = pn[0], n1 = pn[64], n2 = pn[128], n3 = pn[192];
+                uint4 n0 = ld(pn), n1 = ld(pn + 64), n2 = ld(pn + 128), n3 = ld(pn + 192);
                 chunk(c0); chunk(c1); chunk(c2); chunk(c3);
                 c0 = n0; c1 = n1; c2 = n2; c3 = n3;
             }
@@ -59,7 +68,7 @@ __global__ __launch_bounds__(256) void k_sweep_exp(const uint4 *__restrict__ tex
     } else {
         for (; s + 4 <= s1; s += 4) {
             const uint4 *p = text + s * 64 + lane;
-            uint4 c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192];
+            uint4 c0 = ld(p), c1 = ld(p + 64), c2 = ld(p + 128), c3 = ld(p + 192);
             chunk(c0); chunk(c1); chunk(c2); chunk(c3);
         }
     }
@@ -88,6 +97,9 @@ void agh_launch_exp(int exp, const void *text, uint64_t n, uint32_t *counters, h
     case 1 + 2 + 4: launch_exp<1 + 2 + 4>(text, n, counters, st); break;
     case 8 + 16: launch_exp<8 + 16>(text, n, counters, st); break;
     case 1 + 2 + 4 + 8 + 16: launch_exp<1 + 2 + 4 + 8 + 16>(text, n, counters, st); break;
+    case 64: launch_exp<64>(text, n, counters, st); break;
+    case 64 + 16: launch_exp<64 + 16>(text, n, counters, st); break;
+    case 64 + 1 + 2 + 4 + 16: launch_exp<64 + 1 + 2 + 4 + 16>(text, n, counters, st); break;
     default: break;
     }
 }

@@ -310,11 +310,11 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
     uint64_t s = s0;
     if (s + 4 <= s1) {
         const uint4 *p = text + s * 64 + lane;
-        uint4 c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192];
+        uint4 c0 = ld_stream(p), c1 = ld_stream(p + 64), c2 = ld_stream(p + 128), c3 = ld_stream(p + 192);
         uint32_t x0 = next_dw(s), x1 = next_dw(s + 1), x2 = next_dw(s + 2), x3 = next_dw(s + 3);
         for (; s + 8 <= s1; s += 4) {
             const uint4 *pn = text + (s + 4) * 64 + lane;
-            uint4 n0 = pn[0], n1 = pn[64], n2 = pn[128], n3 = pn[192];
+            uint4 n0 = ld_stream(pn), n1 = ld_stream(pn + 64), n2 = ld_stream(pn + 128), n3 = ld_stream(pn + 192);
             uint32_t y0 = next_dw(s + 4), y1 = next_dw(s + 5), y2 = next_dw(s + 6), y3 = next_dw(s + 7);
             strip_work(c0, x0, s); strip_work(c1, x1, s + 1);
             strip_work(c2, x2, s + 2); strip_work(c3, x3, s + 3);

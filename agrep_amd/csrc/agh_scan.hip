@@ -124,7 +124,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
             const uint32_t slot = pc / (AGH_FS_CHUNK / 16), sub = pc % (AGH_FS_CHUNK / 16);
             const int64_t g = (int64_t)t0 - (int64_t)AGH_FS_CHUNK + (int64_t)pc * 16;
             uint4 v = make_uint4(fill4, fill4, fill4, fill4);
-            if (g >= 0 && (uint64_t)g < n16) v = *reinterpret_cast<const uint4 *>(text + g);
+            if (g >= 0 && (uint64_t)g < n16) v = ld_stream(reinterpret_cast<const uint4 *>(text + g));
             *reinterpret_cast<uint4 *>(tile + slot * AGH_FS_SLOT + sub * 16) = v;
         }
         __syncthreads();

@@ -225,11 +225,11 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
     if (PREFETCH) {
         if (s + 4 <= s1) {
             const uint4 *p = text + s * 64 + lane;
-            uint4 c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192];
+            uint4 c0 = ld_stream(p), c1 = ld_stream(p + 64), c2 = ld_stream(p + 128), c3 = ld_stream(p + 192);
             uint2 cd = dbits(s);
             for (; s + 8 <= s1; s += 4) {
                 const uint4 *pn = text + (s + 4) * 64 + lane;
-                uint4 n0 = pn[0], n1 = pn[64], n2 = pn[128], n3 = pn[192];
+                uint4 n0 = ld_stream(pn), n1 = ld_stream(pn + 64), n2 = ld_stream(pn + 128), n3 = ld_stream(pn + 192);
                 uint2 nd = dbits(s + 4);
                 sweep_supertile<H, MODE>(c0, c1, c2, c3, cd, s, lane, dd, q, ftab, strip_prefix,
                                          cq, qn, slice, run, ncand, counters);
@@ -243,13 +243,13 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
     } else {
         for (; s + 4 <= s1; s += 4) {
             const uint4 *p = text + s * 64 + lane;
-            uint4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];   // 4 x 1 KiB in flight
+            uint4 v0 = ld_stream(p), v1 = ld_stream(p + 64), v2 = ld_stream(p + 128), v3 = ld_stream(p + 192);   // 4 x 1 KiB in flight
             sweep_supertile<H, MODE>(v0, v1, v2, v3, dbits(s), s, lane, dd, q, ftab,
                                      strip_prefix, cq, qn, slice, run, ncand, counters);
         }
     }
     for (; s < s1; ++s) {                       // < 4 strips left in the range
-        uint4 v0 = text[s * 64 + lane];
+        uint4 v0 = ld_stream(text + s * 64 + lane);
         uint32_t a0 = 0, hits = 0;
         sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0,
                              ((MODE & 8) && !(MODE & 4)) ? (uint32_t)dbm16[s * 64 + lane] : 0u);
@@ -565,12 +565,12 @@ __global__ __launch_bounds__(256) void k_read_probe(const uint4 *__restrict__ te
     uint64_t s = s0;
     for (; s + 4 <= s1; s += 4) {
         const uint4 *p = text + s * 64 + lane;
-        uint4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];
+        uint4 v0 = ld_stream(p), v1 = ld_stream(p + 64), v2 = ld_stream(p + 128), v3 = ld_stream(p + 192);
         acc ^= v0.x ^ v0.y ^ v0.z ^ v0.w ^ v1.x ^ v1.y ^ v1.z ^ v1.w;
         acc ^= v2.x ^ v2.y ^ v2.z ^ v2.w ^ v3.x ^ v3.y ^ v3.z ^ v3.w;
     }
     for (; s < s1; ++s) {
-        uint4 v0 = text[s * 64 + lane];
+        uint4 v0 = ld_stream(text + s * 64 + lane);
         acc ^= v0.x ^ v0.y ^ v0.z ^ v0.w;
     }
     if (acc == 0x9e3779b9u) counters[AGH_C_CHECK] = acc;   // keeps the loads alive

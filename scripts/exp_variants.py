@@ -12,7 +12,8 @@ A.corpus_fill_device(t.data_ptr(), n // 4096, seed=12345, variants=O.VARIANTS_C2
 names = {-1: "read probe (8 waves/SIMD, no prefetch)", 0: "bare loop, no prefetch", 16: "bare + prefetch",
          20: "+32K LDS alloc (5 waves/SIMD)", 17: "hash VALU, no LDS", 21: "hash VALU + LDS alloc",
          23: "hash + LDS lookups (32K)", 55: "hash + LDS lookups (16K table)", 7: "hash+lookups, no prefetch",
-         24: "census VALU only", 31: "hash + lookups + census"}
+         24: "census VALU only", 31: "hash + lookups + census",
+         64: "bare loop, nt loads", 80: "bare + prefetch, nt loads", 87: "hash + LDS lookups (32K), nt loads"}
 res = {e: [] for e in names}
 for rnd in range(6):
     for e in names:
