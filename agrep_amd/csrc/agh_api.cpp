@@ -1006,6 +1006,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.match_cap = invert_list ? 0u : match_cap;
         va.mk.hashset = nullptr;
         va.mk.hashset_mask = 0;
+        va.gtab = (tight_verify_enabled() && !multi) ? q->d_gtab : nullptr;
+        va.gram_spread = q->gram_spread;
         if (multi) agh_launch_verify_multi(va, multi_dev(q), false, st);
         else if (use_filter) agh_launch_verify(va, st);
         else if (q->table) agh_launch_tablescan(va, st);

@@ -39,10 +39,8 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
     if (total == 0) return;
     VerifyCtx<WT, K> c;
     verify_ctx_init<WT, K>(c, text, n, q, lmask, mk, dbm);
-    if (LEAN) {
-        c.gtab = gtab;
-        c.tspan = tspan;
-    }
+    c.gtab = gtab;
+    c.tspan = tspan;
 
     for (uint32_t ci = threadIdx.x; ci < total; ci += 256) {
         uint32_t sl = 0;
@@ -306,22 +304,23 @@ static void launch_verify_t(const agh_scan_args &a, hipStream_t st)
     // window span = max(m+k+1, 16) + q + m + k bytes, fetched as ceil(span/16) pieces
     const int lw = a.q.m + a.q.k + 1 > 16 ? a.q.m + a.q.k + 1 : 16;
     const int nch = (lw + a.q.fq + a.q.m + a.q.k + 15) / 16;
-    if constexpr (LEAN) {
-        if (a.gtab) {
-            // gram offsets known: one warm-up byte + (m + 2k + spread) bytes per candidate
-            const uint32_t tspan = (uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread;
-            const int tn = (int)((tspan + 15u) / 16u);
-            if (sizeof(WT) == 4) {
-                if (tn <= 2) launch_verify_n<WT, K, 2, true>(a, a.gtab, tspan, st);
-                else if (tn <= 3) launch_verify_n<WT, K, 3, true>(a, a.gtab, tspan, st);
-                else launch_verify_n<WT, K, 6, true>(a, a.gtab, tspan, st);
-            } else {
-                if (tn <= 4) launch_verify_n<WT, K, 4, true>(a, a.gtab, tspan, st);
-                else if (tn <= 7) launch_verify_n<WT, K, 7, true>(a, a.gtab, tspan, st);
-                else launch_verify_n<WT, K, 10, true>(a, a.gtab, tspan, st);
-            }
-            return;
+    if (a.gtab && (LEAN || (int)(((uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread + 15u + 15u) / 16u) < nch)) {
+        // gram offsets known: one warm-up byte + (m + 2k + spread) bytes per candidate; numbered
+        // scans may start up to 15 bytes earlier (at the sample's 16-byte chunk)
+        const uint32_t tspan = (uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread + (LEAN ? 0u : 15u);
+        const int tn = (int)((tspan + 15u) / 16u);
+        // (numbered scans come here only when the window gets shorter by at least one 16-byte
+        // piece: the table costs two dependent loads per candidate)
+        if (sizeof(WT) == 4) {
+            if (tn <= 2 && LEAN) launch_verify_n<WT, K, LEAN ? 2 : 3, LEAN>(a, a.gtab, tspan, st);
+            else if (tn <= 3) launch_verify_n<WT, K, 3, LEAN>(a, a.gtab, tspan, st);
+            else launch_verify_n<WT, K, 6, LEAN>(a, a.gtab, tspan, st);
+        } else {
+            if (tn <= 4 && LEAN) launch_verify_n<WT, K, LEAN ? 4 : 7, LEAN>(a, a.gtab, tspan, st);
+            else if (tn <= 7) launch_verify_n<WT, K, 7, LEAN>(a, a.gtab, tspan, st);
+            else launch_verify_n<WT, K, 10, LEAN>(a, a.gtab, tspan, st);
         }
+        return;
     }
     if (sizeof(WT) == 4) {                  // m <= 32: span <= 85
         if (nch <= 3) launch_verify_n<WT, K, 3, LEAN>(a, nullptr, 0u, st);

@@ -334,7 +334,7 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
     // deletions, exactly as the re-fed delimiter does at a record start.)
     uint32_t lw = c.Lw, span = c.span;
     bool fast = true;
-    if (LEAN && c.gtab) {
+    if (c.gtab) {
         const uint32_t dw = *reinterpret_cast<const uint32_t *>(c.text + j);   // j is 4-aligned
         const uint32_t g = (dw & c.q->qmask) | c.q->fold;
         const uint64_t e = c.gtab[c.q->fq == 4 ? agh_sample_hash_q4(g) : agh_sample_hash_q3(g)];
@@ -344,6 +344,9 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
             if ((uint32_t)e != g) return;
             lw = (uint32_t)((e >> 40) & 0xffu) + (uint32_t)c.q->k + 1u;   // + one warm-up byte
             span = c.tspan;
+            // numbered scans count delimiters from the window start to the sample's chunk
+            // (anchor): start no later than that; tspan has 15 bytes of slack for it
+            if (!LEAN && lw < (uint32_t)(j - anchor)) lw = (uint32_t)(j - anchor);
         }
     }
     fast = fast && j >= lw && (j - lw) + span < c.n && (j - lw) + 16u * NCH <= c.n16;
