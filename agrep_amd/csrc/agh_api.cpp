@@ -203,8 +203,7 @@ static int upload_tables(agh_query *q)
             uint32_t s = 0;
             for (int t = 0; t < q->fq; ++t) s |= (uint32_t)rep[i + t] << (8 * t);
             s = (s & q->qmask) | q->fold;
-            tab[q->fq == 4 ? agh_sample_hash_q4(s) : agh_sample_hash_q3(s)] |=
-                (uint8_t)(1u << (q->fq == 4 ? agh_sample_plane_q4(s) : agh_sample_plane_q3(s)));
+            tab[q->fq == 4 ? agh_sample_hash_q4(s) : agh_sample_hash_q3(s)] = 1;
         }
         HIP_TRY(hipMalloc((void **)&q->d_ftab, AGH_FT_SIZE));
         HIP_TRY(hipMemcpy(q->d_ftab, tab.data(), AGH_FT_SIZE, hipMemcpyHostToDevice));

@@ -110,14 +110,3 @@ AGH_HD uint32_t agh_sample_hash_q3(uint32_t s)
     uint32_t p = (s & 0xffffffu) * 0x85EBCAu;
     return (p >> 13) & (AGH_FT_SIZE - 1u);
 }
-// The filter table is a byte table (ds_read_u8, no address arithmetic) used as 8 bit planes:
-// the slot comes from the middle bits of the product, the plane from its top 3 bits, so a
-// random sample passes with probability (grams / 2^15) / 8 instead of grams / 2^15.
-AGH_HD uint32_t agh_sample_plane_q3(uint32_t s)
-{
-    return ((s & 0xffffffu) * 0x85EBCAu) >> 29;
-}
-AGH_HD uint32_t agh_sample_plane_q4(uint32_t s)
-{
-    return (((s ^ (s >> 11)) & 0xffffffu) * 0x9E3779u) >> 29;
-}

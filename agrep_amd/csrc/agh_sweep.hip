@@ -42,12 +42,10 @@ __device__ __forceinline__ uint32_t probe(uint32_t w, const agh_dev_query &q,
 {
     if (MODE & 2) {
         const uint32_t s = (MODE & 1) ? (w | q.fold) : w;
-        const uint32_t p = ((s ^ (s >> 11)) & 0xffffffu) * 0x9E3779u;   // = agh_sample_hash_q4 / plane_q4
-        return ((uint32_t)ftab[(p >> 14) & (AGH_FT_SIZE - 1u)] >> (p >> 29)) & 1u;
+        return ftab[agh_sample_hash_q4(s)];
     } else {
         const uint32_t s = (MODE & 1) ? ((w & q.qmask) | q.fold) : (w & q.qmask);
-        const uint32_t p = (s & 0xffffffu) * 0x85EBCAu;                 // = agh_sample_hash_q3 / plane_q3
-        return ((uint32_t)ftab[(p >> 13) & (AGH_FT_SIZE - 1u)] >> (p >> 29)) & 1u;
+        return ftab[agh_sample_hash_q3(s)];
     }
 }
 
