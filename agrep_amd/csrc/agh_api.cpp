@@ -1126,6 +1126,12 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
                          d_match_rec ? d_match_rec + stored : nullptr,
                          d_match_pos ? cap_left : 0, &sr))
             return -1;
+        if (d_match_pos && sr.stored && off > 0) {
+            // the segment's kernels saw positions / record numbers relative to its own start
+            agh_launch_offset_matches(d_match_pos + stored, d_match_rec ? d_match_rec + stored : nullptr,
+                                      (uint32_t)sr.stored, off, (uint32_t)res->n_records, st);
+            HIP_TRY(hipGetLastError());
+        }
         res->n_matched += sr.matched;
         res->n_records += sr.records;
         res->n_candidates += sr.candidates;

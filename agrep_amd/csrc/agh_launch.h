@@ -74,6 +74,8 @@ void agh_launch_exp(int exp, const void *text, uint64_t n, uint32_t *counters, h
 void agh_launch_match_bounds(const void *text, uint64_t n, const agh_dev_query &q,
                              const uint64_t *dbm, const uint64_t *pos, uint32_t cnt,
                              uint64_t *start, uint64_t *end, hipStream_t st);
+void agh_launch_offset_matches(uint64_t *pos, uint32_t *rec, uint32_t cnt, uint64_t pos_off,
+                               uint32_t rec_off, hipStream_t st);
 void agh_launch_gather_records(const void *text, const uint64_t *start, const uint64_t *end,
                                const uint64_t *off, uint32_t cnt, void *out, hipStream_t st);
 void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &q, uint64_t *dbm,

@@ -262,6 +262,25 @@ __global__ __launch_bounds__(256) void k_gather_records(const uint8_t *__restric
     for (uint64_t b = (uint64_t)lane_id(); b < len; b += WAVE) out[o + b] = text[s + b];
 }
 
+// Matches of a later segment: positions and record numbers become absolute.
+__global__ __launch_bounds__(256) void k_offset_matches(uint64_t *__restrict__ pos,
+                                                        uint32_t *__restrict__ rec, uint32_t cnt,
+                                                        uint64_t pos_off, uint32_t rec_off)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    pos[i] += pos_off;
+    if (rec) rec[i] += rec_off;
+}
+
+void agh_launch_offset_matches(uint64_t *pos, uint32_t *rec, uint32_t cnt, uint64_t pos_off,
+                               uint32_t rec_off, hipStream_t st)
+{
+    if (!cnt || (!pos_off && !rec_off)) return;
+    hipLaunchKernelGGL(k_offset_matches, dim3((cnt + 255u) / 256u), dim3(256), 0, st, pos, rec, cnt,
+                       pos_off, rec_off);
+}
+
 void agh_launch_match_bounds(const void *text, uint64_t n, const agh_dev_query &q,
                              const uint64_t *dbm, const uint64_t *pos, uint32_t cnt,
                              uint64_t *start, uint64_t *end, hipStream_t st)

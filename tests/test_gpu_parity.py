@@ -298,6 +298,19 @@ def test_segmented_scan_cuts_at_record_boundaries(agh, monkeypatch):
     assert parts.n_matched == whole.n_matched == whole_lean.n_matched == parts_lean.n_matched
     assert parts_full.n_matched == whole.n_matched
     assert parts.n_records == whole.n_records == parts_full.n_records
+    # record lists of a segmented scan: positions and record numbers are absolute
+    # (regression: they were relative to the segment that found them)
+    tb = t[:48 << 20].cpu().numpy().tobytes()
+    want = O.asearch(O.PATTERN_C2, 2, tb, cap=400000)
+    with agh.Query(O.PATTERN_C2, 2) as q:
+        res, ms = q.scan_buffer(tb, cap=400000)           # 48 MiB in 20 MiB segments
+        inv, ms_inv = q.scan_buffer(tb[:30 << 20], flags=agh.INVERT, cap=600000)
+    assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want
+    nl = np.flatnonzero(np.frombuffer(tb, dtype=np.uint8) == 10)
+    for s, e, i in ms[:20] + ms[-20:]:
+        assert int(np.searchsorted(nl, s)) == i
+    assert inv.n_matched == len(ms_inv) == inv.n_records - sum(1 for s, e, _ in ms if e <= (30 << 20))
+    assert all(a[0] < b[0] and a[2] + 1 <= b[2] for a, b in zip(ms_inv, ms_inv[1:]))
 
 
 def test_scan_fd_streams_files_and_pipes(agh, tmp_path):
