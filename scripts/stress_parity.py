@@ -43,6 +43,11 @@ while time.time() < t_end:
     if (kind != "mbdelim" and any(c in pat for c in delim)) or 10 in pat:
         continue
     n = rng.choice([0, 1, 5, 100, 1023, 1024, 1025, 4096, 70000, 262144, 262145, 600000])
+    if rng.random() < 0.12 and len(delim) == 1:         # several 1 MiB device segments
+        n = rng.choice([2500000, 3 << 20])
+        os.environ["AGH_SEG_MAX_MB"] = "1"
+    else:
+        os.environ.pop("AGH_SEG_MAX_MB", None)
     arr = np.frombuffer(bytes(rng.choice(alpha) for _ in range(min(n, 4096))), dtype=np.uint8)
     if n > 4096:
         arr = np.tile(arr, n // 4096 + 1)[:n].copy()
@@ -105,7 +110,8 @@ while time.time() < t_end:
             for lab, fl, cap in (("default", 0, 300000), ("fullscan", A.FORCE_FULLSCAN, 300000),
                                  ("lean", A.COUNT, 0), ("numbered", A.COUNT | A.FORCE_NUMBERED, 0)):
                 res, ms = q.scan_buffer(text, flags=fl, cap=cap)
-                got[lab] = (res.n_matched, [(s, e) for s, e, _ in ms]) if cap else (res.n_matched, want[1])
+                full_list = cap and want[0] <= cap          # else the device list is a truncated subset
+                got[lab] = (res.n_matched, [(s, e) for s, e, _ in ms]) if full_list else (res.n_matched, want[1])
             for lab, g in got.items():
                 if g != want:
                     fails += 1
