@@ -7,8 +7,8 @@ library is missing or no HIP device is usable, everything here raises.
 """
 from ._ffi import (AghError, Match, Query, Result, corpus_fill_device, device_count, lib,  # noqa: F401
                    probe_read_ms, set_device, ENGINE_FILTER, ENGINE_FULLSCAN, FORCE_FILTER,
-                   FORCE_FULLSCAN, FORCE_NUMBERED, COUNT, FILENAMEONLY, INVERT)
+                   FORCE_FULLSCAN, FORCE_NUMBERED, COUNT, FILENAMEONLY, INVERT, TIME_SWEEP, TIME_SCAN)
 
 __all__ = ["AghError", "Match", "Query", "Result", "corpus_fill_device", "device_count", "lib",
            "probe_read_ms", "set_device", "ENGINE_FILTER", "ENGINE_FULLSCAN", "FORCE_FILTER",
-           "FORCE_FULLSCAN", "FORCE_NUMBERED", "COUNT", "FILENAMEONLY", "INVERT"]
+           "FORCE_FULLSCAN", "FORCE_NUMBERED", "COUNT", "FILENAMEONLY", "INVERT", "TIME_SWEEP", "TIME_SCAN"]

@@ -8,6 +8,8 @@ LIB_PATH = os.path.join(_HERE, "libagrep_hip.so")
 COUNT = 0x01
 FILENAMEONLY = 0x02
 INVERT = 0x04
+TIME_SWEEP = 0x80
+TIME_SCAN = 0x100
 FORCE_FULLSCAN = 0x10
 FORCE_FILTER = 0x20
 FORCE_NUMBERED = 0x40
@@ -203,8 +205,16 @@ class Query:
             o += e - s
         return out
 
-    def scan_device(self, dev_ptr, n, stream=None, flags=0, match_pos_ptr=None, match_cap=0):
-        """dev_ptr: device address (e.g. torch tensor .data_ptr()), n bytes."""
+    def scan_device(self, dev_ptr, n, stream=None, flags=0, match_pos_ptr=None, match_cap=0,
+                    time_sweep=True, time_scan=True):
+        """dev_ptr: device address (e.g. torch tensor .data_ptr()), n bytes.  time_sweep: ask
+        for Result.sweep_ms / device_ms (AGH_TIME_SWEEP, AGH_TIME_SCAN: two HIP events per scan
+        each) -- on by default in
+        this test / measurement binding, off by default in the C-ABI."""
+        if time_sweep:
+            flags |= TIME_SWEEP
+        if time_scan:
+            flags |= TIME_SCAN
         res = Result()
         _check(lib().agh_scan_device(self._h, dev_ptr, n, stream, flags, C.byref(res),
                                      match_pos_ptr, match_cap))

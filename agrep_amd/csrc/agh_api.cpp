@@ -842,7 +842,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             q->hashset_dirty = true;
         }
         dq.tail_virtual = tail_virtual;
-        HIP_TRY(hipEventRecord(q->ev0, st));
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev0, st));
         HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
         agh_sweep_args sa;
         sa.text = d_text;
@@ -859,6 +859,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         sa.lean = 1;
         sa.ev_begin = q->ev2;
         sa.ev_end = q->ev3;
+        if (!(flags & AGH_TIME_SWEEP)) sa.ev_begin = sa.ev_end = nullptr;   // two events cost ~11 us per scan
         agh_scan_args va;
         memset(&va, 0, sizeof(va));
         va.mk.counters = q->d_counters;
@@ -883,7 +884,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)q->wave_cand.p, (uint32_t)nw, q->d_counters, st);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(q->ev1, st));
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev1, st));
         HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -896,8 +897,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         }
         const bool gave_up = q->h_counters[AGH_C_LEAN_FALLBACK] || q->h_counters[AGH_C_OVERFLOW];
         if (!gave_up) {
-            HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
-            HIP_TRY(hipEventElapsedTime(&out->sweep_ms, q->ev2, q->ev3));
+            if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
+            if (sa.ev_begin) HIP_TRY(hipEventElapsedTime(&out->sweep_ms, q->ev2, q->ev3));
             out->matched = q->h_counters[AGH_C_MATCHED];
             out->candidates = q->h_counters[AGH_C_CAND];
             out->records = 0;                   // not computed by a lean scan
@@ -932,7 +933,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             q->bitmap_dirty = true;
         }
 
-        HIP_TRY(hipEventRecord(q->ev0, st));
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev0, st));
         if (!swept) HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
         else {
             // keep the census results (NDELIM, LASTBYTE, CAND), clear the rest
@@ -955,8 +956,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.chunk_totals = q->d_chunk_totals;
             sa.dbm = d_dbm;
             sa.lean = 0;
-            sa.ev_begin = q->ev2;
-            sa.ev_end = q->ev3;
+            sa.ev_begin = (flags & AGH_TIME_SWEEP) ? q->ev2 : nullptr;
+            sa.ev_end = (flags & AGH_TIME_SWEEP) ? q->ev3 : nullptr;
             if (multi && q->multi_dense) {
                 // census first (plain H=0 sweep + prefix scan), then the inline multi sweep
                 // numbers records from that prefix and marks them directly
@@ -1020,15 +1021,15 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         }
         agh_launch_bitmap_count((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), q->d_counters, st);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(q->ev1, st));
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev1, st));
         HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         q->bitmap_dirty = false;
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, q->ev0, q->ev1));
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventElapsedTime(&ms, q->ev0, q->ev1));
         total_ms += ms;
-        if (!swept) HIP_TRY(hipEventElapsedTime(&out->sweep_ms, q->ev2, q->ev3));
+        if (!swept && (flags & AGH_TIME_SWEEP)) HIP_TRY(hipEventElapsedTime(&out->sweep_ms, q->ev2, q->ev3));
         swept = true;
 
         const uint32_t n_delims = q->h_counters[AGH_C_NDELIM];

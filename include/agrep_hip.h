@@ -48,6 +48,10 @@ extern "C" {
 #define AGH_FORCE_FULLSCAN 0x10u  /* diagnostics: skip the q-gram filter, run the automaton
                                      over every byte (the asearch.c shape) */
 #define AGH_FORCE_FILTER   0x20u  /* diagnostics: fail instead of falling back to full scan */
+#define AGH_TIME_SWEEP     0x80u  /* also time the sweep kernel alone (agh_result.sweep_ms) with two extra
+                                     HIP events around it on the scan's stream: ~11 us per scan */
+#define AGH_TIME_SCAN      0x100u /* time the whole kernel sequence of the scan (agh_result.device_ms): two HIP
+                                     events as well */
 #define AGH_FORCE_NUMBERED 0x40u  /* diagnostics: compute record numbers even for -c / -l scans */
 
 /* engine that produced a result */
@@ -73,8 +77,8 @@ typedef struct {
     uint64_t n_stored;      /* matches written to the caller's agh_match array */
     uint32_t engine;        /* AGH_ENGINE_* */
     uint32_t truncated;     /* 1: more matches than the agh_match array could hold */
-    double   device_ms;     /* GPU time of the whole scan (hipEvent), excluding staging */
-    double   sweep_ms;      /* of which: the k_sweep kernel launches (the kernel that reads every
+    double   device_ms;     /* AGH_TIME_SCAN: GPU time of the whole scan (hipEvent), excluding staging; else 0 */
+    double   sweep_ms;      /* AGH_TIME_SWEEP (else 0): of which the k_sweep kernel launches (the kernel that reads every
                                byte), hipEvents recorded right around them on the scan stream */
 } agh_result;
 
