@@ -37,6 +37,48 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 12345
 
 
+def cpu_baseline_extras(ref, host, sample_bytes, k, tmpdir):
+    """the reference is single-threaded, so 'all host cores' = P independent
+    processes on P record-aligned shards started together (aggregate = bytes / max wall time);
+    plus the scalar C restatement (oracle) as a second, quirk-free CPU datapoint."""
+    import _oracle as O
+    out = {}
+    procs = min(os.cpu_count() or 1, 32)
+    pages = sample_bytes // 4096
+    per = (pages + procs - 1) // procs
+    paths = []
+    try:
+        for i in range(procs):
+            lo, hi = i * per * 4096, min(sample_bytes, (i + 1) * per * 4096)
+            if lo >= hi:
+                break
+            pth = os.path.join(tmpdir, "agh_bench_shard_%d_%d.txt" % (os.getpid(), i))
+            host[lo:hi].tofile(pth)                       # pages end with a newline: record aligned
+            paths.append(pth)
+        cmd = [ref, "-V0", "-%d" % k, "-c", PATTERN.decode()]
+        t0 = time.time()
+        ps = [subprocess.Popen(cmd + [pth], stdout=subprocess.PIPE) for pth in paths]
+        outs = [p_.communicate()[0] for p_ in ps]
+        dt = time.time() - t0
+        total = sum(int(o.split()[0]) for o in outs if o.strip())
+        out["all_cores"] = {"value": round(sample_bytes / 1e9 / dt, 3), "unit": "GB/s", "cores": len(paths),
+                            "kind": "reference", "seconds": round(dt, 3), "count": total,
+                            "sample": "the same bytes as %d record-aligned shard files, one agrep process each, "
+                                      "started together" % len(paths)}
+    finally:
+        for pth in paths:
+            if os.path.exists(pth):
+                os.unlink(pth)
+    nb = min(sample_bytes, 256 << 20)
+    t0 = time.time()
+    cnt = O.asearch(PATTERN, k, host[:nb])[0]
+    dt = time.time() - t0
+    out["port"] = {"value": round(nb / 1e9 / dt, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                   "seconds": round(dt, 3), "count": int(cnt),
+                   "sample": "first %.2f GiB, oracle/agrep_oracle.c orc_asearch (scalar restatement of asearch.c)" % (nb / 2**30)}
+    return out
+
+
 def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes):
     """Time the reference CPU agrep (1 core) on the first sample_bytes of the corpus."""
     ref = os.path.join(ROOT, "oracle", "_ref", "agrep")
@@ -56,7 +98,13 @@ def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes):
             if os.path.exists(path):
                 os.unlink(path)
         cnt = int(out.split()[0]) if out.strip() else -1
+        extra = {}
+        try:
+            extra = cpu_baseline_extras(ref, host, sample_bytes, k, d)
+        except Exception as e:                                  # never lose the headline over this
+            extra = {"extras_error": str(e)[:200]}
         return {"value": round(sample_bytes / 1e9 / dt, 4), "unit": "GB/s", "cores": 1,
+                **extra,
                 "kind": "reference",
                 "sample": "first %.2f GiB of the rank-0 shard, `agrep -V0 -%d -c %s` (sgrep.c:agrep() "
                           "path), page cache warm, 1 process" % (sample_bytes / 2**30, k, PATTERN.decode()),
