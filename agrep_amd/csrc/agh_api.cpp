@@ -88,6 +88,7 @@ struct agh_query {
     unsigned char delim[AGH_MAX_DELIM] = {'\n'};
     uint64_t mask[256];                 // bit (p-1) set iff byte is in the class of position p
     int fq = 0, fh = 0;                 // filter sample shape (0: no filter)
+    int run_a = 0, run_len = 0;         // the literal run of positions the samples are taken from
     uint32_t qmask = 0, fold = 0;
     // device-resident tables
     void *d_mask = nullptr;             // 256 x uint32_t or uint64_t
@@ -139,20 +140,43 @@ static void choose_filter(agh_query *q)
 {
     q->fq = q->fh = 0;
     q->qmask = q->fold = 0;
-    // every position must be a single byte or an ASCII case pair
-    bool any_pair = false;
-    for (int p = 0; p < q->m; ++p) {
+    q->run_a = 0;
+    q->run_len = 0;
+    // The samples come from the longest run of positions that are a single byte or an ASCII
+    // case pair.  For a literal pattern that is the whole pattern; for -w / -x / [class]
+    // patterns it is the literal core: an occurrence of the pattern with <= k errors contains
+    // an occurrence of the core with <= k errors, so the lemma applies with the core's length.
+    bool any_pair = false, any_single_letter = false;
+    int best_a = 0, best_len = 0, cur_a = 0, cur_len = 0;
+    for (int p = 0; p <= q->m; ++p) {
+        bool lit = false;
+        if (p < q->m) {
+            int members = 0, lo = -1;
+            for (int c = 0; c < 256; ++c)
+                if ((q->mask[c] >> p) & 1) { ++members; if (lo < 0) lo = c; }
+            if (members == 1) lit = true;
+            else if (members == 2 && is_upper(lo) && ((q->mask[lo + 32] >> p) & 1)) lit = true;
+        }
+        if (lit) {
+            if (!cur_len) cur_a = p;
+            ++cur_len;
+        } else {
+            if (cur_len > best_len) { best_len = cur_len; best_a = cur_a; }
+            cur_len = 0;
+        }
+    }
+    for (int p = best_a; p < best_a + best_len; ++p) {
         int members = 0, lo = -1;
         for (int c = 0; c < 256; ++c)
             if ((q->mask[c] >> p) & 1) { ++members; if (lo < 0) lo = c; }
-        if (members == 1) continue;
-        if (members == 2 && is_upper(lo) && ((q->mask[lo + 32] >> p) & 1)) { any_pair = true; continue; }
-        return;
+        if (members == 2) any_pair = true;
+        else if (is_upper(lo) || is_lower(lo)) any_single_letter = true;
     }
+    (void)any_single_letter;    // folding a single-case letter only widens the candidate set
     static const int hs[3] = {16, 8, 4};
     for (int i = 0; i < 3; ++i) {
         int h = hs[i];
-        int qmax = q->m - q->k + 1 - h * (q->k + 1);
+        int qmax = best_len - q->k + 1 - h * (q->k + 1);
         if (qmax > 4) qmax = 4;
         if (qmax > h) qmax = h;
         if (qmax >= 3) {
@@ -162,6 +186,8 @@ static void choose_filter(agh_query *q)
         }
     }
     if (!q->fq) return;
+    q->run_a = best_a;
+    q->run_len = best_len;
     q->qmask = q->fq == 4 ? 0xffffffffu : ((1u << (8 * q->fq)) - 1u);
     q->fold = any_pair ? (0x20202020u & q->qmask) : 0u;
 }
@@ -199,7 +225,8 @@ static int upload_tables(agh_query *q)
                 if ((q->mask[c] >> p) & 1) { lo = c; break; }
             rep[p] = (unsigned char)lo;
         }
-        for (int i = 0; i + q->fq <= q->m; ++i) {
+        const int run_end = q->run_a + q->run_len;          // grams of the literal run only
+        for (int i = q->run_a; i + q->fq <= run_end; ++i) {
             uint32_t s = 0;
             for (int t = 0; t < q->fq; ++t) s |= (uint32_t)rep[i + t] << (8 * t);
             s = (s & q->qmask) | q->fold;
@@ -214,7 +241,7 @@ static int upload_tables(agh_query *q)
         //   (two different grams share the slot, or offsets too far apart) -> full window
         std::vector<uint64_t> gt(AGH_FT_SIZE, AGH_GT_AMBIGUOUS);
         std::vector<char> used(AGH_FT_SIZE, 0);
-        for (int i = 0; i + q->fq <= q->m; ++i) {
+        for (int i = q->run_a; i + q->fq <= run_end; ++i) {
             uint32_t s = 0;
             for (int t = 0; t < q->fq; ++t) s |= (uint32_t)rep[i + t] << (8 * t);
             s = (s & q->qmask) | q->fold;
@@ -779,8 +806,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     if (multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
     if (multi && (flags & AGH_FORCE_FULLSCAN))
         return fail("multi-pattern queries have no full-scan engine");
-    const bool want_filter = (q->fq > 0 || pe) && !(flags & AGH_FORCE_FULLSCAN) && !q->general && !q->table &&
-                             !invert_list;
+    const bool want_filter = (q->fq > 0 || pe) && !(flags & AGH_FORCE_FULLSCAN) && !q->table && !invert_list &&
+                             !(q->general && (q->dlen > 1 || pe));   // general verify: 1-byte delimiters
     if (!want_filter && (flags & AGH_FORCE_FILTER))
         return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
     if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
@@ -872,6 +899,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.q = dq;
         va.mask = q->d_mask;
         va.wide = q->wide;
+        va.general = q->general;
         va.cand = (const uint64_t *)q->cand.p;
         va.wave_cand = (const uint32_t *)q->wave_cand.p;
         va.nw = (uint32_t)nw;

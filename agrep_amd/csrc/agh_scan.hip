@@ -7,7 +7,8 @@
 // ---------------------------------------------------------------------------------------
 // verify: one workgroup per AGH_VGROUP sweep-wave slices, one lane per candidate sample
 // ---------------------------------------------------------------------------------------
-template <typename WT, int K, int NCH, bool LEAN, bool MB>
+// GEN: the general automaton (edit costs, <exact> segments, -w / -x guards) on the windows.
+template <typename WT, int K, int NCH, bool LEAN, bool MB, bool GEN>
 __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text, uint64_t n,
                                                 agh_dev_query q,
                                                 const WT *__restrict__ mask_g,
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
     const uint32_t total = pre[AGH_VGROUP];
     if (total == 0) return;
     VerifyCtx<WT, K> c;
-    verify_ctx_init<WT, K>(c, text, n, q, lmask, mk, dbm);
+    verify_ctx_init<WT, K, GEN>(c, text, n, q, lmask, mk, dbm);
     c.gtab = gtab;
     c.tspan = tspan;
 
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
         for (uint32_t i = 1; i < AGH_VGROUP; ++i) sl += (pre[i] <= ci) ? 1u : 0u;
         const uint32_t w = g0 + sl;
         const uint64_t ent = cand[(uint64_t)w * AGH_SLICE_CAP + (ci - pre[sl])];
-        verify_candidate<WT, K, NCH, LEAN, MB>(c, ent, LEAN ? 0u : wave_prefix[w]);
+        verify_candidate<WT, K, NCH, LEAN, MB, GEN>(c, ent, LEAN ? 0u : wave_prefix[w]);
     }
 }
 
@@ -307,12 +308,16 @@ static void launch_verify_n(const agh_scan_args &a, const uint64_t *gtab, uint32
 {
     uint32_t blocks = (a.nw + AGH_VGROUP - 1u) / AGH_VGROUP;
     if (!blocks) return;
-    if (a.q.dlen > 1)
-        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, true>), dim3(blocks), dim3(256), 0, st,
+    if (a.general)                          // single-byte delimiters only (the host checks)
+        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, true>), dim3(blocks), dim3(256), 0, st,
+                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
+                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm, gtab, tspan);
+    else if (a.q.dlen > 1)
+        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, true, false>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
                            a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm, gtab, tspan);
     else
-        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false>), dim3(blocks), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, false>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
                            a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm, gtab, tspan);
 }

@@ -221,7 +221,7 @@ __device__ __forceinline__ void feed_virtual_tail(const uint8_t *__restrict__ te
     }
 }
 
-template <typename WT, int K, bool LEAN>
+template <typename WT, int K, bool LEAN, bool GEN = false>
 __device__ __noinline__ void verify_window_slow(const uint8_t *__restrict__ text, uint64_t n,
                                                 const agh_dev_query &q, const WT *lmask,
                                                 const uint64_t *__restrict__ dbm,
@@ -245,10 +245,10 @@ __device__ __noinline__ void verify_window_slow(const uint8_t *__restrict__ text
     Automaton<WT, K> A;
     A.reset();
     bool seen = false;
-    if (ws == 0) A.step(lmask[q.head_byte], finalbit);
+    if (ws == 0) A.template step_q<GEN>(lmask[q.head_byte], finalbit, q);
     for (uint64_t i = ws; i < we; ++i) {
         const uint32_t c = text[i];
-        if (A.step(lmask[c], finalbit) && !seen) {
+        if (A.template step_q<GEN>(lmask[c], finalbit, q) && !seen) {
             seen = true;
             if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, i);
         }
@@ -257,14 +257,14 @@ __device__ __noinline__ void verify_window_slow(const uint8_t *__restrict__ text
             ++rec;
             rstart = i + 1;
             seen = false;
-            if (A.step(lmask[c], finalbit)) {
+            if (A.template step_q<GEN>(lmask[c], finalbit, q)) {
                 seen = true;
                 if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, i + 1);
             }
         }
     }
     if (we == n && q.tail_virtual)
-        feed_virtual_tail<WT, K, LEAN>(text, n, q, lmask, dbm, A, seen, rec, rstart, mk);
+        feed_virtual_tail<WT, K, LEAN, GEN>(text, n, q, lmask, dbm, A, seen, rec, rstart, mk);
 }
 
 // Unaligned 16-byte view of the text (gfx9+ global loads accept any byte address).
@@ -288,7 +288,7 @@ struct VerifyCtx {
     const agh_marks *mk;     // likewise
 };
 
-template <typename WT, int K>
+template <typename WT, int K, bool GEN = false>
 __device__ __forceinline__ void verify_ctx_init(VerifyCtx<WT, K> &c, const uint8_t *text,
                                                 uint64_t n, const agh_dev_query &q,
                                                 const WT *lmask, const agh_marks &mk,
@@ -308,7 +308,7 @@ __device__ __forceinline__ void verify_ctx_init(VerifyCtx<WT, K> &c, const uint8
     c.gtab = nullptr;
     c.tspan = 0;
     c.RF.reset();
-    c.rf_hit = c.RF.step(lmask[q.delim], c.finalbit);   // asearch.c:175-186
+    c.rf_hit = c.RF.template step_q<GEN>(lmask[q.delim], c.finalbit, q);   // asearch.c:175-186
 }
 
 // Fast path geometry, identical for every lane: the window starts Lw = max(m+k+1, 16) bytes in
@@ -316,7 +316,7 @@ __device__ __forceinline__ void verify_ctx_init(VerifyCtx<WT, K> &c, const uint8
 // loads issued together and walked branch-free out of registers.  Match positions and
 // delimiter positions are collected as bit masks; record numbers are derived from them after
 // the walk.  Windows that touch the head or the tail of the text take the byte-wise path.
-template <typename WT, int K, int NCH, bool LEAN, bool MB>
+template <typename WT, int K, int NCH, bool LEAN, bool MB, bool GEN = false>
 __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint64_t ent,
                                                  uint32_t wave_base)
 {
@@ -354,7 +354,7 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
         const uint64_t ws = j > c.Lw ? j - c.Lw : 0;
         uint64_t we = j + c.tailw;
         if (we > c.n) we = c.n;
-        verify_window_slow<WT, K, LEAN>(c.text, c.n, *c.q, c.lmask, c.dbm, ws, we, anchor, rc_anchor,
+        verify_window_slow<WT, K, LEAN, GEN>(c.text, c.n, *c.q, c.lmask, c.dbm, ws, we, anchor, rc_anchor,
                                         *c.mk);
         return;
     }
@@ -386,7 +386,7 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
         if ((uint32_t)p >= span) break;               // uniform but for dropped lanes
         const uint32_t dwv = ch[p >> 4][(p >> 2) & 3];
         const uint32_t byte = (dwv >> (8 * (p & 3))) & 0xffu;
-        const uint32_t hit = A.step(c.lmask[byte], c.finalbit) ? 1u : 0u;
+        const uint32_t hit = A.template step_q<GEN>(c.lmask[byte], c.finalbit, *c.q) ? 1u : 0u;
         const uint32_t isd = MB ? (uint32_t)(dm[p >> 6] >> (p & 63)) & 1u
                                 : ((byte == c.q->delim) ? 1u : 0u);
         hitm[p >> 6] |= (uint64_t)(hit & ~seen) << (p & 63);

@@ -550,3 +550,37 @@ def test_inverse_is_the_complement_of_the_record_set(agh):
                     assert [i for _, _, i in ms] == [recs_all.index(r) for r in want[:50]] + [i for _, _, i in ms][50:]
                 rc, _ = q.scan_buffer(tb, flags=agh.INVERT | agh.COUNT)
                 assert rc.n_matched == len(want)
+
+
+def test_general_queries_take_the_filter_path(agh):
+    """Edit costs, <exact> segments and -w / -x guards keep the q-gram sample filter (samples
+    from the literal core of the pattern) and verify with the general automaton: same records
+    as the full scan and as the cost oracle, engine = filter."""
+    text, _ = O.corpus(512, seed=8, variants=O.VARIANTS_C2, plant_period=9)
+    tb = text.tobytes()
+    for costs, k in (((2, 1, 1), 2), ((1, 2, 1), 2), ((1, 1, 2), 1)):
+        want = O.asearch_costs(O.PATTERN_C2, k, costs, tb, cap=100000)
+        with agh.Query(O.PATTERN_C2, k) as q:
+            q.set_costs(*costs)
+            res, ms = q.scan_buffer(tb, cap=100000)
+            full, ms_f = q.scan_buffer(tb, cap=100000, flags=agh.FORCE_FULLSCAN)
+            lean, _ = q.scan_buffer(tb, flags=agh.COUNT)
+        assert res.engine == agh.ENGINE_FILTER and full.engine == agh.ENGINE_FULLSCAN
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want == (full.n_matched, [(s, e) for s, e, _ in ms_f])
+        assert lean.n_matched == want[0]
+    words = b"approximatematch\nxapproximatematch\napproximatematch x\nan aproximatematch!\n" * 50
+    for case in _golden("pattern_language.json"):
+        if case["pattern"] != "approximatematch":
+            continue
+        t = case["tables"]
+        M = t["D_endpos"].bit_length()
+        q = agh.Query.from_maskgen(t["Mask"], t["Init0"], t["Init1"], t["NO_ERR_MASK"], t["endposition"],
+                                   t["D_endpos"], M, b"\n", case["k"], t["AND"])
+        assert q.info()["filter_q"] >= 3                    # samples from the 16 literal positions
+        for body in (tb + words, words):
+            want = O.asearch_tables(O.tables_from_golden(t, M), case["k"], body, cap=100000)
+            res, ms = q.scan_buffer(body, cap=100000)
+            lean, _ = q.scan_buffer(body, flags=agh.COUNT)
+            assert res.engine == agh.ENGINE_FILTER
+            assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want and lean.n_matched == want[0]
+        q.close()
