@@ -23,7 +23,7 @@ while time.time() < t_end:
     letters = bytes(c for c in alpha if c != 10) or b"a"
     pat = bytes(rng.choice(letters) for _ in range(m))
     nocase = rng.random() < 0.3
-    kind = rng.choice(["single"] * 6 + ["mbdelim", "wide", "multi", "multi"])
+    kind = rng.choice(["single"] * 5 + ["costs", "costs", "mbdelim", "wide", "multi", "multi"])
     delim = b"\n" if rng.random() < 0.8 else bytes([rng.choice(b";|\t")])
     if kind == "mbdelim":
         delim = rng.choice([b"\n\n", b";;", b"\r\n", b"ab\n", b"$$"])
@@ -100,12 +100,18 @@ while time.time() < t_end:
             fails += 1
         n_cases += 1
         continue
-    if len(pat) + len(delim) <= 30:
+    costs = None
+    if kind == "costs" and len(pat) + len(delim) <= 30:
+        costs = (rng.randint(1, 3), rng.randint(1, 3), rng.randint(1, 3))
+        want = O.asearch_costs(pat, k, costs, text, delim=delim, nocase=nocase, cap=300000)
+    elif len(pat) + len(delim) <= 30:
         want = O.asearch(pat, k, text, delim=delim, nocase=nocase, cap=300000)
     else:
         want = O.wm_count(pat, k, text, delim=delim, nocase=nocase, word_bits=64, cap=300000)
     try:
         with A.Query(pat, k, nocase=nocase, delim=delim) as q:
+            if costs:
+                q.set_costs(*costs)
             got = {}
             for lab, fl, cap in (("default", 0, 300000), ("fullscan", A.FORCE_FULLSCAN, 300000),
                                  ("lean", A.COUNT, 0), ("numbered", A.COUNT | A.FORCE_NUMBERED, 0)):
@@ -115,7 +121,7 @@ while time.time() < t_end:
             for lab, g in got.items():
                 if g != want:
                     fails += 1
-                    print("MISMATCH", lab, "pat", pat, "k", k, "nocase", nocase, "delim", delim, "n", len(text),
+                    print("MISMATCH", lab, "costs", costs, "pat", pat, "k", k, "nocase", nocase, "delim", delim, "n", len(text),
                           "want", want[0], "got", g[0], "seed", seed, "case", n_cases, flush=True)
                     if fails <= 3:
                         with open(os.path.join(ROOT, "gpurun_out", "stress_fail_%d_%d.bin" % (seed, n_cases)), "wb") as f:
