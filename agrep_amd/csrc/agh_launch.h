@@ -1,5 +1,5 @@
 // agh_launch.h -- internal C++ interface between the C-ABI layer (agh_api.cpp) and the
-// kernel translation unit (agh_kernels.hip).
+// kernel translation units (agh_sweep / agh_scan / agh_multi / agh_table / agh_exp .hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,25 +1,22 @@
-// agh_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the agrep record scanner.
+// agh_sweep.hip -- the HBM-bound kernels of the agrep record scanner on gfx950 (MI355X / CDNA4):
+// the sweep over every text byte, the prefix scans, the counting kernels, the corpus generator.
 //
-// Data flow of one scan (all buffers in HBM, text read with 16 B/lane coalesced loads):
+// Data flow of one scan (all buffers in HBM; DESIGN.md has the engine table):
 //
-//   k_sweep<H>      streams every text byte once.  Per 1 KiB strip it counts the record
-//                   delimiters (SWAR zero-byte test + v_bcnt) and, when the query admits the
-//                   q-gram sample filter, probes one q-byte sample every H bytes against a
-//                   32 KiB hash table held in LDS; samples that hit are appended to the
-//                   candidate list (wave-aggregated atomics).  HBM-bound: this is the
-//                   kernel the roofline is quoted on.
-//   k_scan_local /  exclusive scan of the per-wave delimiter totals (two tiny multi-block
-//   k_scan_fixup    kernels).
-//   k_verify<W,K>   one lane per candidate: the Wu-Manber k-error shift-AND automaton
-//                   (asearch.c:94-116 restated with left shifts, delimiter out of band) over
-//                   the <= 2(m+k)+q bytes around the sample; every match is turned into a
-//                   record number and marked in a one-bit-per-record bitmap, so a record is
-//                   counted once however many windows or occurrences hit it.
-//   k_fullscan<W,K> the same automaton over every byte (the asearch.c shape), for queries the
-//                   filter cannot serve.  Text is staged through LDS so that each lane walks
-//                   a contiguous 256 B chunk while global loads stay coalesced; a lane starts
-//                   m+k+1 bytes early to rebuild the automaton state (bounded memory,
-//                   SURVEY.md B.5).
+//   k_sweep<H>      streams every text byte once (non-temporal 16 B/lane coalesced loads).  Per
+//                   1 KiB strip it counts the record delimiters (SWAR zero-byte test + v_bcnt;
+//                   skipped by lean = count-only scans) and probes one q-byte sample every H
+//                   bytes against a 32 KiB byte table in LDS; samples that hit go through a
+//                   per-wave LDS queue into the wave's private slice of the candidate buffer
+//                   (no atomics).  This is the kernel the roofline is quoted on.
+//   k_scan_local /  exclusive scan of the per-wave delimiter totals (numbered scans).
+//   k_scan_fixup
+//   k_verify        (agh_scan.hip) one lane per candidate: the k-error automaton over the window
+//                   around the sample; matched records go into a one-bit-per-record bitmap
+//                   (numbered) or a hash set of record starts (lean).
+//   k_bitmap_count / k_hashset_count   count and clear those.
+//   k_fullscan, k_tablescan, k_sweep_multi   the other engines (agh_scan.hip, agh_table.hip,
+//                   agh_multi.hip).
 //
 // No MFMA anywhere: the work is byte/bitwise integer and the bound is HBM read bandwidth.
 #include <stdlib.h>
