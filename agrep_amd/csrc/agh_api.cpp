@@ -859,7 +859,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const bool lean_ok = want_filter && !d_match_pos && (flags & (AGH_COUNT | AGH_FILENAMEONLY)) &&
                          !(flags & AGH_FORCE_NUMBERED) && !invert;      // -v needs the record count
     if (lean_ok) {
-        uint64_t slots = 1u << 20;
+        uint64_t slots = 1u << 17;               // grows with the hint of the previous scan (4 x matched)
         while (slots < q->hashset_slots_hint) slots <<= 1;
         {
             const size_t cap_before = q->hashset.cap;   // (a new block may reuse the old address)
