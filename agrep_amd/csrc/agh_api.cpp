@@ -859,7 +859,11 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const bool lean_ok = want_filter && !d_match_pos && (flags & (AGH_COUNT | AGH_FILENAMEONLY)) &&
                          !(flags & AGH_FORCE_NUMBERED) && !invert;      // -v needs the record count
     if (lean_ok) {
-        uint64_t slots = 1u << 17;               // grows with the hint of the previous scan (4 x matched)
+        // 2^17 slots at least; without a hint from a previous scan (4 x matched) one slot per
+        // 8 KiB of text, i.e. room for a match every 32 KiB at 25 % load -- denser texts fall
+        // back to the numbered pipeline once and come back with a hint
+        uint64_t slots = 1u << 17;
+        if (!q->hashset_slots_hint) while (slots < (n >> 13) && slots < (1u << 26)) slots <<= 1;
         while (slots < q->hashset_slots_hint) slots <<= 1;
         {
             const size_t cap_before = q->hashset.cap;   // (a new block may reuse the old address)
