@@ -140,11 +140,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
+    # Test hooks (1-GPU boxes): AGH_BENCH_BACKEND=gloo + AGH_BENCH_ONE_GPU=1 run all ranks on
+    # GPU 0 with the count reduction on CPU tensors -- exercises the multi-rank control flow.
+    backend = os.environ.get("AGH_BENCH_BACKEND", "nccl")
+    if os.environ.get("AGH_BENCH_ONE_GPU") == "1":
+        local_rank = 0
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     A.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n_pages = int(args.gib * (1 << 30)) // 4096
     n = n_pages * 4096
@@ -162,7 +171,7 @@ def main():
         # AGH_TIME_SWEEP: HIP events around k_sweep on the scan's stream, in every timed step
         res = q.scan_device(text.data_ptr(), n, flags=A.COUNT | A.TIME_SWEEP, time_scan=False)
         if world > 1:                                        # RCCL: the -c aggregate
-            agg[0], agg[1] = shard.reduce_counts(res.n_matched, res.n_records, device="cuda")
+            agg[0], agg[1] = shard.reduce_counts(res.n_matched, res.n_records, device=red_dev)
         return res
 
     def fence():
@@ -182,7 +191,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         matched_all = int(agg[0])

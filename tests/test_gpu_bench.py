@@ -1,0 +1,51 @@
+"""bench.py contract: one JSON line with the required fields, and the multi-rank control flow
+(barriers, count reduction, MAX of the elapsed times) with two ranks sharing the one GPU of
+the test box (gloo for the 16-byte count reduction; the real run uses nccl = RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _last_json(out):
+    for line in reversed(out.decode().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError(out[-2000:])
+
+
+def test_bench_single_and_two_ranks():
+    env = dict(os.environ)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gib", "0.5", "--steps", "3",
+                          "--warmup", "1", "--cpu-sample-gib", "0.125"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = _last_json(one.stdout)
+    for k in REQUIRED:
+        assert k in a, k
+    assert a["n_gpus"] == 1 and a["scaling"] == "weak" and a["dtype"] == "u8" and a["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(a["roofline"])
+    assert a["roofline"]["bound"] == "hbm" and 0 < a["roofline"]["frac"] < 1
+    cb = a["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] in ("reference", "port")
+    if cb["kind"] == "reference":
+        assert cb["count_equals_gpu"] is True
+
+    env.update(AGH_BENCH_BACKEND="gloo", AGH_BENCH_ONE_GPU="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--gib", "0.25", "--steps", "3", "--warmup", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-2000:]
+    b = _last_json(two.stdout)
+    assert b["n_gpus"] == 2 and b["cpu_baseline"] is None
+    # two shards of 0.25 GiB are the same bytes as the one 0.5 GiB corpus
+    assert b["matched_records"] == a["matched_records"]
+    assert b["config"]["bytes_per_gpu"] * 2 == a["config"]["bytes_per_gpu"]
