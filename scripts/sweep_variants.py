@@ -1,4 +1,7 @@
-"""A/B the k_sweep launch variants (AGH_SWEEP_VARIANT) in one process, interleaved rounds."""
+"""A/B the k_sweep launch variants (AGH_SWEEP_VARIANT) in one process, interleaved rounds.
+The env hook is not in the library by default: it is a ten-line dispatch over
+k_sweep<H, MODE, BLOCK, PREFETCH> in launch_sweep_hm (agh_sweep.hip) that was added for the
+tuning rounds recorded in DESIGN.md (d) and removed again."""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
