@@ -567,6 +567,10 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
         if (usable[i]) {
             const uint32_t h = fq == 4 ? agh_sample_hash18_q4(g) : agh_sample_hash18_q3(g);
             bits[h >> 5] |= 1u << (h & 31u);
+            if (fq == 4) {                      // second Bloom probe (agh_multi.hip probe_chunk)
+                const uint32_t h2 = agh_sample_hash18b_q4(g);
+                bits[h2 >> 5] |= 1u << (h2 & 31u);
+            }
             bstart[bucket_of[i] + 1]++;
         }
     }

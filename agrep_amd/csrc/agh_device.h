@@ -93,6 +93,13 @@ AGH_HD uint32_t agh_sample_hash18_q4(uint32_t s)
     uint32_t p = t * 0x9E3779u;
     return (p >> 14) & ((1u << AGH_MP_BITS) - 1u);
 }
+// second, independent 18-bit hash of a 4-byte prefix: the multi-pattern bit table is a Bloom
+// filter with two probes when q == 4 (the second probe runs only on first-level hits)
+AGH_HD uint32_t agh_sample_hash18b_q4(uint32_t s)
+{
+    uint32_t p = s * 0x85EBCA6Bu;
+    return ((p ^ (p >> 15)) >> 3) & ((1u << AGH_MP_BITS) - 1u);
+}
 AGH_HD uint32_t agh_sample_hash18_q3(uint32_t s)
 {
     uint32_t p = (s & 0xffffffu) * 0x85EBCAu;
