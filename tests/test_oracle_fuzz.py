@@ -83,3 +83,23 @@ def test_asearch_path_of_live_reference_equals_dp(sigma):
         finally:
             os.unlink(tf.name)
         assert int(out.split()[0]) == O.dp_count(pat, k, text, nocase=True)[0], (pat, k, text)
+
+
+def test_multi_pattern_with_errors_ground_truth_is_the_dp_union():
+    """What the GPU tests of agh_query_multi_approx compare against (the union over the patterns
+    of the single-pattern automaton) equals the definition: a record matches iff some substring
+    is within edit distance k of some pattern (Sellers DP), on newline-delimited text."""
+    rng = random.Random(2024)
+    for it in range(40):
+        sigma = rng.choice(["ab", "abcd", "abcdefghijklmnop"])
+        k = rng.randint(0, 2)
+        pats = sorted({"".join(rng.choice(sigma) for _ in range(rng.randint(k + 1, 9))).encode()
+                       for _ in range(rng.randint(1, 6))})
+        text = "".join(rng.choice(sigma + "\n") for _ in range(rng.randint(0, 3000))).encode()
+        a, d = set(), set()
+        for p in pats:
+            a.update(O.asearch(p, k, text, cap=10000)[1])
+            d.update(O.dp_count(p, k, text, cap=10000)[1])
+        assert a == d, (pats, k, text[:200])
+        if k == 0:
+            assert sorted(a) == O.multi_exact_count(pats, text, cap=10000)[1]
