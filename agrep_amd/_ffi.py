@@ -28,7 +28,9 @@ class Match(C.Structure):
 class Result(C.Structure):
     _fields_ = [("n_matched", C.c_uint64), ("n_records", C.c_uint64), ("n_bytes", C.c_uint64),
                 ("n_candidates", C.c_uint64), ("n_stored", C.c_uint64), ("engine", C.c_uint32),
-                ("truncated", C.c_uint32), ("device_ms", C.c_double), ("sweep_ms", C.c_double)]
+                ("truncated", C.c_uint32), ("device_ms", C.c_double), ("sweep_ms", C.c_double),
+                ("sweep_launches", C.c_uint32), ("lean_reruns", C.c_uint32),
+                ("n_segments", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _LIB = None
@@ -97,6 +99,25 @@ def lib():
     L.agh_probe_read_ms.restype = C.c_int
     L.agh_probe_variant_ms.argtypes = [vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_double)]
     L.agh_probe_variant_ms.restype = C.c_int
+    L.agh_scan_fd_range.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint, C.POINTER(Result),
+                                    C.POINTER(Match), C.c_size_t]
+    L.agh_scan_fd_range.restype = C.c_int
+    L.agh_shard_cuts_fd.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    L.agh_shard_cuts_fd.restype = C.c_int
+    L.agh_comm_unique_id.argtypes = [C.c_char_p]
+    L.agh_comm_unique_id.restype = C.c_int
+    L.agh_comm_init_rank.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.agh_comm_init_rank.restype = vp
+    L.agh_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    L.agh_comm_init_all.restype = C.c_int
+    L.agh_comm_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 3
+    L.agh_comm_info.restype = C.c_int
+    L.agh_comm_free.argtypes = [vp]
+    L.agh_comm_free.restype = None
+    L.agh_reduce_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.agh_reduce_counts.restype = C.c_int
+    L.agh_reduce_file_hits.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.agh_reduce_file_hits.restype = C.c_int
     L.agh_last_error.restype = C.c_char_p
     L.agh_version.restype = C.c_char_p
     _LIB = L
@@ -189,6 +210,14 @@ class Query:
         _check(lib().agh_scan_fd(self._h, fd, flags, C.byref(res), ms if cap else None, cap))
         return res, [(ms[i].start, ms[i].end, ms[i].index) for i in range(int(res.n_stored))]
 
+    def scan_fd_range(self, fd, begin, end, flags=0, cap=0):
+        """One rank's shard of a seekable file: bytes [begin, end)."""
+        res = Result()
+        ms = (Match * max(cap, 1))()
+        _check(lib().agh_scan_fd_range(self._h, fd, begin, end, flags, C.byref(res),
+                                       ms if cap else None, cap))
+        return res, [(ms[i].start, ms[i].end, ms[i].index) for i in range(int(res.n_stored))]
+
     def fetch_records(self, matches):
         """matches: [(start, end, index)] from the last scan_fd / scan_buffer -> list of bytes"""
         n = len(matches)
@@ -236,6 +265,43 @@ class Query:
 
     def __exit__(self, *a):
         self.close()
+
+
+def shard_cuts_fd(fd, nranks, delim=b"\n"):
+    """Record-aligned shard boundaries of a file (agh_shard_cuts_fd; host-only code)."""
+    cuts = (C.c_uint64 * (nranks + 1))()
+    _check(lib().agh_shard_cuts_fd(fd, bytes(delim), len(delim), nranks, cuts))
+    return list(cuts)
+
+
+class Comm:
+    """RCCL communicator of the C-ABI (one process per GPU): agh_comm_init_rank."""
+
+    def __init__(self, unique_id, nranks, rank):
+        self._h = lib().agh_comm_init_rank(bytes(unique_id), nranks, rank)
+        if not self._h:
+            raise AghError(lib().agh_last_error().decode("latin1"))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().agh_comm_unique_id(buf))
+        return buf.raw
+
+    def reduce_counts(self, n_matched, n_records=0):
+        v = (C.c_uint64 * 2)(int(n_matched), int(n_records))
+        _check(lib().agh_reduce_counts(self._h, v))
+        return int(v[0]), int(v[1])
+
+    def reduce_file_hits(self, hits):
+        buf = C.create_string_buffer(bytes(1 if h else 0 for h in hits), len(hits))
+        _check(lib().agh_reduce_file_hits(self._h, buf, len(hits)))
+        return [b != 0 for b in buf.raw[:len(hits)]]
+
+    def close(self):
+        if self._h:
+            lib().agh_comm_free(self._h)
+            self._h = None
 
 
 def corpus_fill_device(dev_ptr, n_pages, first_page=0, seed=12345, variants=(), plant_period=500,

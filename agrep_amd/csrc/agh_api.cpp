@@ -42,6 +42,10 @@ static int fail(const char *fmt, ...)
     } while (0)
 
 extern "C" const char *agh_last_error(void) { return g_err; }
+extern "C" void agh_set_error(const char *msg)      // agh_comm.cpp reports through the same text
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+}
 extern "C" const char *agh_version(void) { return "agrep-hip 0.1 (gfx950)"; }
 
 extern "C" int agh_device_count(void)
@@ -82,6 +86,9 @@ struct dev_buf {
     }
 };
 
+#define AGH_LEAN_SLOTS 2      // segments of the lean pipeline in flight (sweep i+1 | verify i)
+#define AGH_MAX_SEGS 256      // segments of one scan (8 GiB each: 2 TiB)
+
 struct agh_query {
     int m = 0, k = 0, dlen = 1, wide = 0;
     bool delim_fold = false;            // -i with letters in a multi-byte delimiter
@@ -102,9 +109,15 @@ struct agh_query {
     hipStream_t stage_stream = nullptr; // H2D copies of agh_scan_fd
     unsigned char *pinned[2] = {nullptr, nullptr};
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
-    uint32_t *d_counters = nullptr;
+    uint32_t *d_counters = nullptr;     // AGH_LEAN_SLOTS + 1 counter blocks (block 0: everything but the pipeline)
     uint32_t *d_chunk_totals = nullptr; // scratch of the prefix scan
-    uint32_t *h_counters = nullptr;     // pinned
+    uint32_t *h_counters = nullptr;     // pinned: block 0 + one block per pipelined segment
+    // lean pipeline (lean_run): a second stream for the verifier, a second set of candidate
+    // buffers, dependency / timing events, the device scratch of the segment cutter
+    hipStream_t aux_stream = nullptr;
+    dev_buf cand_b, wave_cand_b, cuts;
+    std::vector<hipEvent_t> dep_events, time_events;
+    uint64_t *h_cuts = nullptr;         // pinned: bounds, lower limits, cuts
     uint64_t bitmap_bits_hint = 0;      // records seen by the previous scan (+25 %)
     bool bitmap_dirty = false;          // a scan was queued but its count-and-clear did not finish
     uint64_t hashset_slots_hint = 0;    // lean scans: slots wanted by the previous scan
@@ -194,9 +207,10 @@ static void choose_filter(agh_query *q)
 
 static int upload_common(agh_query *q)
 {
-    HIP_TRY(hipMalloc((void **)&q->d_counters, AGH_C_COUNT * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&q->d_counters, (AGH_LEAN_SLOTS + 1) * AGH_C_COUNT * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&q->d_chunk_totals, 128 * sizeof(uint32_t)));
-    HIP_TRY(hipHostMalloc((void **)&q->h_counters, AGH_C_COUNT * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&q->h_counters, (AGH_MAX_SEGS + 1) * AGH_C_COUNT * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&q->h_cuts, 3 * AGH_MAX_SEGS * sizeof(uint64_t)));
     HIP_TRY(hipEventCreate(&q->ev0));
     HIP_TRY(hipEventCreate(&q->ev1));
     HIP_TRY(hipEventCreate(&q->ev2));
@@ -705,6 +719,13 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_counters) (void)hipFree(q->d_counters);
     if (q->d_chunk_totals) (void)hipFree(q->d_chunk_totals);
     if (q->h_counters) (void)hipHostFree(q->h_counters);
+    if (q->h_cuts) (void)hipHostFree(q->h_cuts);
+    for (hipEvent_t e : q->dep_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : q->time_events) (void)hipEventDestroy(e);
+    if (q->aux_stream) (void)hipStreamDestroy(q->aux_stream);
+    q->cand_b.release();
+    q->wave_cand_b.release();
+    q->cuts.release();
     if (q->ev0) (void)hipEventDestroy(q->ev0);
     if (q->ev1) (void)hipEventDestroy(q->ev1);
     if (q->ev2) (void)hipEventDestroy(q->ev2);
@@ -766,26 +787,15 @@ static agh_multi_dev multi_dev(const agh_query *q)
 // ---------------------------------------------------------------------------------------
 // one segment (<= AGH_SEG_MAX bytes) resident in HBM
 // ---------------------------------------------------------------------------------------
-static const uint64_t AGH_SEG_MAX_DEFAULT = (uint64_t)8 << 30;
-
-// Largest piece scanned by one kernel sequence (dword indices are 32-bit).  AGH_SEG_MAX_MB
-// lowers it (tests exercise the record-aligned cutting with small inputs).
-static uint64_t seg_max()
-{
-    const char *e = getenv("AGH_SEG_MAX_MB");
-    if (e && *e) {
-        uint64_t mb = strtoull(e, nullptr, 10);
-        if (mb >= 1 && mb <= 8192) return mb << 20;
-    }
-    return AGH_SEG_MAX_DEFAULT;
-}
-#define AGH_SEG_MAX (seg_max())
-// multi-pattern candidates carry 32-bit byte offsets
-#define AGH_SEG_MAX_Q(q) (((q)->multi || (q)->piece_single) ? std::min<uint64_t>(seg_max(), (uint64_t)4 << 30) : seg_max())
+static const uint64_t AGH_SEG_MAX_DEFAULT = (uint64_t)8 << 30;   // nominal segment (plan_segments)
+// lean pipeline defaults (lean_run): part size in MiB (0: one launch per segment) and whether the
+// verifier runs on a second stream; AGH_PART_MB / AGH_OVERLAP override (A/B runs)
+#define AGH_PART_MB_DEFAULT 0
+#define AGH_OVERLAP_DEFAULT 0
 
 struct seg_result {
     uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
-    uint32_t engine = 0, truncated = 0;
+    uint32_t engine = 0, truncated = 0, lean_rerun = 0;
     float ms = 0.f, sweep_ms = 0.f;
 };
 
@@ -796,6 +806,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
 {
     *out = seg_result();
     if (n == 0) return 0;
+    uint32_t lean_rerun = 0;
     if (((uintptr_t)d_text & 15u) != 0) return fail("device text must be 16-byte aligned");
     // piece engine of a single literal pattern (see attach_piece_engine)
     // -v with a record list needs the census arrays of the byte-parallel engines
@@ -808,6 +819,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint64_t nw = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
     if (multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
+    if (n > ((uint64_t)16 << 30) - 4096) return fail("segments are limited to 16 GiB");
     if (multi && (flags & AGH_FORCE_FULLSCAN))
         return fail("multi-pattern queries have no full-scan engine");
     const bool want_filter = (q->fq > 0 || pe) && !(flags & AGH_FORCE_FULLSCAN) && !q->table && !invert_list &&
@@ -943,6 +955,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             return 0;
         }
         q->hashset_slots_hint = 8ull * (q->h_counters[AGH_C_MATCHED] + 1024);
+        lean_rerun = 1;
         // fall through: the numbered pipeline is exact for every input
     }
 
@@ -1105,61 +1118,335 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         out->stored = std::min<uint64_t>(q->h_counters[AGH_C_STORED], match_cap);
         out->truncated = q->h_counters[AGH_C_STORED] > match_cap;
         out->ms = total_ms;
+        out->lean_rerun = lean_rerun;
         return 0;
     }
     return fail("internal error: scan did not converge");
 }
 
-// Largest cut <= want such that text[cut-1] is a delimiter (so segments hold whole records).
-static int find_cut(const agh_query *q, const unsigned char *d_text, uint64_t lo, uint64_t want,
-                    hipStream_t st, uint64_t *cut)
+// ---------------------------------------------------------------------------------------
+// segments: inputs above the per-launch limit are cut where a record ends at a 16-byte aligned
+// offset.  All cuts of a scan are found by one small kernel (k_find_cuts) and read back with one
+// host sync.  Nominal boundaries sit `nominal` bytes apart; a cut lies in (previous boundary,
+// boundary], so a segment is never longer than 2 x nominal (single patterns: 8 GiB nominal under
+// the 16 GiB reach of the 32-bit dword index; -f / piece engine: 2 GiB under 32-bit byte offsets).
+// ---------------------------------------------------------------------------------------
+static uint64_t seg_nominal(const agh_query *q)
 {
-    std::vector<unsigned char> buf(1 << 20);
-    uint64_t hi = want;
-    while (hi > lo) {
-        uint64_t b = hi - lo > buf.size() ? hi - buf.size() : lo;
-        HIP_TRY(hipMemcpyAsync(buf.data(), d_text + b, hi - b, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (uint64_t i = hi; i > b; --i)
-            if (buf[i - 1 - b] == q->delim[0]) { *cut = i; return 0; }
-        hi = b;
+    const char *e = getenv("AGH_SEG_MAX_MB");           // tests: tiny segments
+    if (e && *e) {
+        uint64_t mb = strtoull(e, nullptr, 10);
+        if (mb >= 1 && mb <= 8192) return mb << 20;
     }
-    return fail("a single record exceeds the %llu-byte segment limit",
-                (unsigned long long)AGH_SEG_MAX);
+    return (q->multi || q->piece_single) ? ((uint64_t)2 << 30) : AGH_SEG_MAX_DEFAULT;
+}
+
+static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, hipStream_t st,
+                         std::vector<uint64_t> *cuts)
+{
+    cuts->clear();
+    cuts->push_back(0);
+    const uint64_t nominal = seg_nominal(q);
+    if (len > nominal) {
+        if (q->dlen > 1)
+            return fail("multi-byte delimiters: inputs above the %llu-byte segment limit are not "
+                        "supported yet", (unsigned long long)nominal);
+        const uint64_t nb = (len - 1) / nominal;        // boundaries strictly inside the text
+        if (nb + 1 > AGH_MAX_SEGS) return fail("input too large: more than %d segments", AGH_MAX_SEGS);
+        if (q->cuts.ensure(3 * AGH_MAX_SEGS * sizeof(uint64_t))) return -1;
+        uint64_t *h_bound = q->h_cuts, *h_lo = q->h_cuts + AGH_MAX_SEGS, *h_cut = q->h_cuts + 2 * AGH_MAX_SEGS;
+        for (uint64_t i = 0; i < nb; ++i) {
+            h_bound[i] = (i + 1) * nominal;             // multiples of 16: nominal is a MiB count
+            h_lo[i] = i * nominal;
+        }
+        uint64_t *d = (uint64_t *)q->cuts.p;
+        HIP_TRY(hipMemcpyAsync(d, h_bound, nb * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d + AGH_MAX_SEGS, h_lo, nb * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        agh_launch_find_cuts(base, d, d + AGH_MAX_SEGS, (uint32_t)nb, q->delim[0], d + 2 * AGH_MAX_SEGS, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_cut, d + 2 * AGH_MAX_SEGS, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < nb; ++i) {
+            if (!h_cut[i])
+                return fail("no record ends at a 16-byte aligned offset between byte %llu and %llu "
+                            "(needed to cut an input above the %llu-byte segment limit)",
+                            (unsigned long long)h_lo[i], (unsigned long long)h_bound[i],
+                            (unsigned long long)nominal);
+            cuts->push_back(h_cut[i]);
+        }
+    }
+    cuts->push_back(len);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// lean pipeline over all segments of a count-only scan (-c, -l) of a single-pattern query with
+// a sample filter and a one-byte delimiter -- the headline path.
+//   * every segment is swept in PARTS (wave ranges of the same text, no record alignment
+//     needed: candidates carry text offsets and the verifier reads the whole segment);
+//   * AGH_OVERLAP: the verifier of part p runs on a second stream while part p+1 is swept
+//     (candidate buffers and counter blocks alternate between two sets);
+//   * nothing is read back until every segment is queued: one host sync per scan.  A segment
+//     whose lean scan gave up (record start > 64 KiB back, hash set full, slice overflow) is
+//     run again on the numbered pipeline afterwards; agh_result.lean_reruns counts those;
+//   * AGH_FILENAMEONLY (-l, asearch.c:130-161 returns at the first match): parts grow from
+//     64 MiB, the host looks at the hit flag after each and stops at the first part with a hit.
+// ---------------------------------------------------------------------------------------
+static uint64_t env_mb(const char *name, uint64_t dflt_mb)
+{
+    const char *e = getenv(name);
+    if (e && *e) return strtoull(e, nullptr, 10);
+    return dflt_mb;
+}
+
+static bool lean_pipeline_ok(const agh_query *q, unsigned flags, bool want_list)
+{
+    const bool invert = (flags & AGH_INVERT) != 0;
+    return q->fq > 0 && !q->multi && !q->table && q->dlen == 1 && !want_list && !invert &&
+           (flags & (AGH_COUNT | AGH_FILENAMEONLY)) &&
+           !(flags & (AGH_FORCE_FULLSCAN | AGH_FORCE_NUMBERED)) && !q->general;
+}
+
+static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_t st,
+                        unsigned flags, uint32_t head_byte, int tail_virtual,
+                        uint64_t *d_match_pos, uint32_t *d_match_rec, uint32_t match_cap,
+                        seg_result *out);
+
+static int get_events(std::vector<hipEvent_t> &pool, size_t want, unsigned evflags)
+{
+    while (pool.size() < want) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, evflags));
+        pool.push_back(e);
+    }
+    return 0;
+}
+
+static int lean_run(agh_query *q, const unsigned char *base, const std::vector<uint64_t> &cuts,
+                    hipStream_t st, unsigned flags, agh_result *res, bool is_first, bool is_last)
+{
+    const int nseg = (int)cuts.size() - 1;
+    const bool early = (flags & AGH_FILENAMEONLY) != 0;
+    const bool timing = (flags & AGH_TIME_SWEEP) != 0;
+    // part size: a multiple of 8 wave ranges (2 MiB) so verify workgroups never straddle parts
+    const uint64_t part_unit = (uint64_t)AGH_WAVE_STRIPS * AGH_STRIP * 8u;
+    uint64_t part_bytes = env_mb("AGH_PART_MB", AGH_PART_MB_DEFAULT) << 20;
+    part_bytes = part_bytes / part_unit * part_unit;
+    uint64_t max_n = 0;
+    for (int i = 0; i < nseg; ++i) max_n = std::max(max_n, cuts[i + 1] - cuts[i]);
+    const bool overlap = env_mb("AGH_OVERLAP", AGH_OVERLAP_DEFAULT) != 0 && !early &&
+                         (nseg > 1 || (part_bytes && part_bytes < max_n));
+    const uint64_t max_strips = (max_n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
+    const uint64_t max_nw = (max_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+
+    // buffers for the largest segment, before anything is queued (a hipMalloc / hipFree in the
+    // middle would serialise the streams)
+    dev_buf *cand[2] = {&q->cand, overlap && nseg > 1 ? &q->cand_b : &q->cand};
+    dev_buf *wcand[2] = {&q->wave_cand, overlap && nseg > 1 ? &q->wave_cand_b : &q->wave_cand};
+    for (int b = 0; b < 2; ++b) {
+        if (cand[b]->ensure(max_nw * AGH_SLICE_CAP * sizeof(uint64_t))) return -1;
+        if (wcand[b]->ensure((max_nw + 8) * sizeof(uint32_t))) return -1;
+    }
+    if (q->strip_prefix.ensure(64)) return -1;          // (unused by lean sweeps, never NULL)
+    if (q->wave_totals.ensure((max_nw + 8) * sizeof(uint32_t))) return -1;
+    uint64_t slots = 1u << 17;
+    if (!q->hashset_slots_hint) while (slots < (max_n >> 13) && slots < (1u << 26)) slots <<= 1;
+    while (slots < q->hashset_slots_hint) slots <<= 1;
+    {
+        const size_t cap_before = q->hashset.cap;
+        if (q->hashset.ensure(slots * sizeof(uint64_t))) return -1;
+        if (q->hashset.cap != cap_before || q->hashset_dirty)
+            HIP_TRY(hipMemsetAsync(q->hashset.p, 0, q->hashset.cap, st));
+        q->hashset_dirty = true;
+    }
+    hipStream_t aux = st;
+    if (overlap) {
+        if (!q->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&q->aux_stream, hipStreamNonBlocking));
+        aux = q->aux_stream;
+    }
+    size_t n_dep = 0, n_time = 0;
+    if (overlap && get_events(q->dep_events, 4, hipEventDisableTiming)) return -1;
+
+    agh_dev_query dq;
+    dq.m = q->m;
+    dq.k = q->k;
+    dq.delim = q->delim[0];
+    dq.dlen = 1;
+    memset(dq.dbytes, 0, sizeof(dq.dbytes));
+    dq.dbytes[0] = q->delim[0];
+    dq.dfold = 0;
+    dq.fq = q->fq;
+    dq.fh = q->fh;
+    dq.qmask = q->qmask;
+    dq.fold = q->fold;
+    dq.ci = dq.cs = dq.cd = 1;
+    dq.no_err = q->no_err;
+
+    struct seg_job { int first_time_ev, n_parts; bool done_early; };
+    std::vector<seg_job> jobs((size_t)nseg);
+    bool stop = false;
+    uint64_t scanned = 0;
+    int queued = 0;
+    for (int i = 0; i < nseg && !stop; ++i, ++queued) {
+        const unsigned char *text = base + cuts[i];
+        const uint64_t n = cuts[i + 1] - cuts[i];
+        const int slot = overlap ? (i & 1) : 0;
+        uint32_t *d_cnt = q->d_counters + (size_t)(1 + slot) * AGH_C_COUNT;
+        uint32_t *h_cnt = q->h_counters + (size_t)(1 + i) * AGH_C_COUNT;
+        jobs[i].first_time_ev = (int)n_time;
+        jobs[i].n_parts = 0;
+        jobs[i].done_early = false;
+        dq.head_byte = (i == 0 && is_first) ? '\n' : q->delim[0];
+        dq.tail_virtual = (i == nseg - 1 && is_last) ? 1 : 0;
+        const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
+        const uint32_t nw = (uint32_t)((n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS);
+        // the sweep of segment i reuses the buffers of segment i-2: its verifier must be done
+        if (overlap && i >= 2) HIP_TRY(hipStreamWaitEvent(st, q->dep_events[2 + slot], 0));
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+
+        agh_sweep_args sa;
+        sa.text = text;
+        sa.n = n;
+        sa.q = dq;
+        sa.ftab = q->d_ftab;
+        sa.strip_prefix = (uint32_t *)q->strip_prefix.p;
+        sa.wave_totals = (uint32_t *)q->wave_totals.p;
+        sa.cand = (uint64_t *)cand[slot]->p;
+        sa.wave_cand = (uint32_t *)wcand[slot]->p;
+        sa.counters = d_cnt;
+        sa.chunk_totals = q->d_chunk_totals;
+        sa.dbm = nullptr;
+        sa.lean = 1;
+        agh_scan_args va;
+        memset(&va, 0, sizeof(va));
+        va.mk.counters = d_cnt;
+        va.mk.hashset = (uint64_t *)q->hashset.p;
+        va.mk.hashset_mask = (uint32_t)(slots - 1);
+        va.text = text;
+        va.n = n;
+        va.q = dq;
+        va.mask = q->d_mask;
+        va.wide = q->wide;
+        va.general = 0;
+        va.cand = (const uint64_t *)cand[slot]->p;
+        va.wave_cand = (const uint32_t *)wcand[slot]->p;
+        va.nw = nw;
+        va.wave_prefix = (const uint32_t *)q->wave_totals.p;
+        va.gtab = tight_verify_enabled() ? q->d_gtab : nullptr;
+        va.gram_spread = q->gram_spread;
+
+        uint64_t pb = early ? ((uint64_t)64 << 20) : part_bytes;
+        for (uint64_t off = 0; off < n;) {
+            const uint64_t part_end = (pb && off + pb < n) ? off + pb : n;
+            const bool last = part_end == n;
+            sa.w_begin = va.w_begin = (uint32_t)(off / ((uint64_t)AGH_WAVE_STRIPS * AGH_STRIP));
+            sa.w_end = va.w_end = last ? 0u : (uint32_t)(part_end / ((uint64_t)AGH_WAVE_STRIPS * AGH_STRIP));
+            sa.ev_begin = sa.ev_end = nullptr;
+            if (timing) {
+                if (get_events(q->time_events, n_time + 2, hipEventDefault)) return -1;
+                sa.ev_begin = q->time_events[n_time];
+                sa.ev_end = q->time_events[n_time + 1];
+                n_time += 2;
+            }
+            agh_launch_sweep(sa, q->fh, st);
+            ++jobs[i].n_parts;
+            if (overlap) {                      // the verifier waits for this part's candidates
+                hipEvent_t e = q->dep_events[n_dep & 1];
+                ++n_dep;
+                HIP_TRY(hipEventRecord(e, st));
+                HIP_TRY(hipStreamWaitEvent(aux, e, 0));
+            }
+            agh_launch_verify_lean(va, aux);
+            HIP_TRY(hipGetLastError());
+            off = part_end;
+            if (early) {
+                HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, AGH_C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (h_cnt[AGH_C_ANYHIT] || h_cnt[AGH_C_LEAN_FALLBACK] || h_cnt[AGH_C_OVERFLOW]) {
+                    stop = true;
+                    jobs[i].done_early = !last;
+                    scanned += off;
+                    break;
+                }
+                if (pb < ((uint64_t)4 << 30)) pb <<= 1;
+            }
+        }
+        if (!stop) scanned += n;
+        agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
+                                 (const uint32_t *)wcand[slot]->p, nw, d_cnt, aux);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, AGH_C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, aux));
+        if (overlap) HIP_TRY(hipEventRecord(q->dep_events[2 + slot], aux));
+    }
+    if (overlap) {                              // later work on the caller's stream comes after the verifier
+        const int last_slot = (queued - 1) & 1;
+        HIP_TRY(hipStreamWaitEvent(st, q->dep_events[2 + last_slot], 0));
+        if (queued >= 2) HIP_TRY(hipStreamWaitEvent(st, q->dep_events[2 + (last_slot ^ 1)], 0));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (overlap) HIP_TRY(hipStreamSynchronize(aux));
+    q->hashset_dirty = false;
+
+    res->n_bytes = scanned;
+    res->engine = AGH_ENGINE_FILTER;
+    uint64_t max_matched = 0;
+    for (int i = 0; i < queued; ++i) {
+        const uint32_t *h = q->h_counters + (size_t)(1 + i) * AGH_C_COUNT;
+        const bool gave_up = h[AGH_C_LEAN_FALLBACK] || h[AGH_C_OVERFLOW];
+        if (timing)
+            for (int p = 0; p < jobs[i].n_parts; ++p) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, q->time_events[jobs[i].first_time_ev + 2 * p],
+                                            q->time_events[jobs[i].first_time_ev + 2 * p + 1]));
+                res->sweep_ms += ms;
+                res->sweep_launches += 1;
+            }
+        if (!gave_up) {
+            res->n_matched += h[AGH_C_MATCHED];
+            res->n_candidates += h[AGH_C_CAND];
+            max_matched = std::max<uint64_t>(max_matched, h[AGH_C_MATCHED]);
+            continue;
+        }
+        // exact for every input: the numbered pipeline on the whole segment
+        max_matched = std::max<uint64_t>(max_matched, 2ull * (h[AGH_C_MATCHED] + 1024));
+        seg_result sr;
+        if (scan_segment(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED,
+                         (i == 0 && is_first) ? '\n' : q->delim[0], i == nseg - 1 && is_last, nullptr,
+                         nullptr, 0, &sr))
+            return -1;
+        if (jobs[i].done_early) res->n_bytes = cuts[i + 1];    // the rerun read the whole segment
+        res->n_matched += sr.matched;
+        res->n_candidates += sr.candidates;
+        res->lean_reruns += 1;
+    }
+    res->n_segments = (uint32_t)queued;
+    q->hashset_slots_hint = 4ull * max_matched;
+    return 0;
 }
 
 static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
                             unsigned flags, agh_result *res, uint64_t *d_match_pos,
-                            uint32_t *d_match_rec, size_t match_cap)
+                            uint32_t *d_match_rec, size_t match_cap, bool is_first = true,
+                            bool is_last = true)
 {
     if (!q || !res) return fail("null argument");
     memset(res, 0, sizeof(*res));
     res->n_bytes = len;
+    if (!len) return 0;
+    if (((uintptr_t)dev_text & 15u) != 0) return fail("device text must be 16-byte aligned");
     const unsigned char *base = (const unsigned char *)dev_text;
-    uint64_t off = 0;
-    bool first = true;
-    while (off < len) {
-        uint64_t end = len;
-        if (end - off > AGH_SEG_MAX_Q(q) && q->dlen > 1)
-            return fail("multi-byte delimiters: inputs above the %llu-byte segment limit are not "
-                        "supported yet", (unsigned long long)AGH_SEG_MAX);
-        if (end - off > AGH_SEG_MAX_Q(q)) {
-            uint64_t want = (off + AGH_SEG_MAX_Q(q)) & ~(uint64_t)15;
-            if (find_cut(q, base, off, want, st, &end)) return -1;
-            // keep the next segment 16-byte aligned: back off to an aligned delimiter-free cut
-            // is not possible in general, so require alignment of the cut instead
-            while (end > off && (end & 15u)) {
-                uint64_t c2;
-                if (find_cut(q, base, off, end - 1, st, &c2)) return -1;
-                end = c2;
-            }
-            if (end <= off) return fail("no 16-byte aligned record boundary inside a segment");
-        }
+    std::vector<uint64_t> cuts;
+    if (plan_segments(q, base, len, st, &cuts)) return -1;
+    if (lean_pipeline_ok(q, flags, d_match_pos != nullptr))
+        return lean_run(q, base, cuts, st, flags, res, is_first, is_last);
+    for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+        const uint64_t off = cuts[i], end = cuts[i + 1];
         seg_result sr;
         uint64_t stored = res->n_stored;
         uint32_t cap_left = (uint32_t)std::min<uint64_t>(match_cap - stored, 0xffffffffu);
-        if (scan_segment(q, base + off, end - off, st, flags, first ? '\n' : q->delim[0],
-                         end == len, d_match_pos ? d_match_pos + stored : nullptr,
+        if (scan_segment(q, base + off, end - off, st, flags,
+                         (i == 0 && is_first) ? '\n' : q->delim[0], end == len && is_last,
+                         d_match_pos ? d_match_pos + stored : nullptr,
                          d_match_rec ? d_match_rec + stored : nullptr,
                          d_match_pos ? cap_left : 0, &sr))
             return -1;
@@ -1176,11 +1463,18 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
         res->truncated |= sr.truncated;
         res->device_ms += sr.ms;
         res->sweep_ms += sr.sweep_ms;
+        if (sr.sweep_ms > 0.f) res->sweep_launches += 1;
+        res->lean_reruns += sr.lean_rerun;
         res->engine = sr.engine;
-        off = end;
-        first = false;
+        res->n_segments += 1;
     }
     return 0;
+}
+
+static int scan_device_range(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
+                             unsigned flags, agh_result *res, bool is_first, bool is_last)
+{
+    return scan_device_impl(q, dev_text, len, st, flags, res, nullptr, nullptr, 0, is_first, is_last);
 }
 
 extern "C" int agh_scan_device(agh_query *q, const void *dev_text, size_t len, void *stream,
@@ -1255,35 +1549,218 @@ extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t l
 // (bitap.c:450-477), without an intermediate pageable copy.
 static const size_t AGH_STAGE_CHUNK = (size_t)32 << 20;
 
-extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res,
-                           agh_match *matches, size_t cap)
+// Sequential reader of an fd (or of the byte range [pos, pos + left) of a regular file): a
+// regular file is read by up to 16 pread threads per chunk (one read(2) stream copies ~10 GB/s
+// out of the page cache, PCIe takes five times that), a pipe by read(2).
+struct fd_reader {
+    int fd = -1;
+    bool regular = false;
+    off_t pos = 0;                  // regular files: next byte to read
+    uint64_t left = 0;              // regular files: bytes still to read
+    bool ranged = false;            // an explicit range: never read past it
+    unsigned n_readers = 1;
+
+    int open_fd(int fd_, bool with_range, uint64_t begin, uint64_t end)
+    {
+        fd = fd_;
+        ranged = with_range;
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+            off_t cur = with_range ? (off_t)begin : lseek(fd, 0, SEEK_CUR);
+            if (cur < 0) cur = 0;
+            uint64_t stop = with_range ? std::min<uint64_t>(end, (uint64_t)sb.st_size) : (uint64_t)sb.st_size;
+            regular = true;
+            pos = cur;
+            left = (uint64_t)cur < stop ? stop - (uint64_t)cur : 0;
+        } else if (with_range) {
+            return fail("a byte range needs a seekable regular file");
+        }
+        n_readers = std::thread::hardware_concurrency();
+        if (n_readers > 16) n_readers = 16;
+        if (const char *e = getenv("AGH_READERS")) n_readers = (unsigned)atoi(e);
+        if (n_readers < 1) n_readers = 1;
+        return 0;
+    }
+    uint64_t size_hint() const { return regular ? left : 0; }
+
+    // up to `want` bytes into dst; 0 = end of input; -1 = error (message set)
+    ssize_t fill(unsigned char *dst, size_t want)
+    {
+        size_t got = 0;
+        if (regular && left >= want / 2 && n_readers > 1) {
+            const size_t take = (size_t)std::min<uint64_t>(want, left);
+            const size_t piece = ((take + n_readers - 1) / n_readers + 4095) & ~(size_t)4095;
+            std::vector<std::thread> th;
+            std::vector<ssize_t> done(n_readers, 0);
+            std::vector<int> rd_errno(n_readers, 0);
+            for (unsigned t = 0; t < n_readers; ++t) {
+                const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
+                if (lo >= hi) break;
+                th.emplace_back([&, t, lo, hi]() {
+                    size_t at = lo;
+                    while (at < hi) {
+                        ssize_t r = pread(fd, dst + at, hi - at, pos + (off_t)at);
+                        if (r < 0 && errno == EINTR) continue;
+                        if (r < 0) { rd_errno[t] = errno; break; }   // EIO, ESTALE ...: not a truncation
+                        if (r == 0) break;                           // the file got shorter meanwhile
+                        at += (size_t)r;
+                    }
+                    done[t] = (ssize_t)(at - lo);
+                });
+            }
+            for (auto &x : th) x.join();
+            for (unsigned t = 0; t < th.size(); ++t)
+                if (rd_errno[t]) return fail("read failed: %s", strerror(rd_errno[t]));
+            // contiguous prefix that really arrived (a file truncated meanwhile ends the scan)
+            for (unsigned t = 0; t < th.size(); ++t) {
+                const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
+                got += (size_t)done[t];
+                if ((size_t)done[t] < hi - lo) break;
+            }
+            pos += (off_t)got;
+            left -= std::min<uint64_t>(left, got);
+            if (got < take) left = 0;
+            if (!ranged) (void)lseek(fd, pos, SEEK_SET);
+            return (ssize_t)got;
+        }
+        if (regular) want = (size_t)std::min<uint64_t>(want, left);
+        while (got < want) {
+            ssize_t r = regular ? pread(fd, dst + got, want - got, pos + (off_t)got)
+                                : read(fd, dst + got, want - got);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                return fail("read failed: %s", strerror(errno));
+            }
+            if (r == 0) break;
+            got += (size_t)r;
+        }
+        if (regular) {
+            pos += (off_t)got;
+            left -= std::min<uint64_t>(left, got);
+            if (!ranged) (void)lseek(fd, pos, SEEK_SET);
+        }
+        return (ssize_t)got;
+    }
+};
+
+static int ensure_stage_resources(agh_query *q)
+{
+    if (q->stage_stream) return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipHostMalloc((void **)&q->pinned[b], AGH_STAGE_CHUNK));
+        HIP_TRY(hipEventCreateWithFlags(&q->pinned_ev[b], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+static int scan_device_range(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
+                             unsigned flags, agh_result *res, bool is_first, bool is_last);
+
+// Count-only scans (-c, -l) of a stream: the input passes through ONE device segment
+// (AGH_STREAM_SEG_MB, default 1 GiB) that is scanned whenever it is full, cut after the last
+// delimiter that has arrived; the unfinished record is carried to the front of the next
+// segment -- fill_buf's residue carry (bitap.c:450-477, sgrep.c:465-471) at HBM scale.  HBM use
+// is bounded whatever the input size, a pipe never needs a second copy, and -l stops READING at
+// the first segment with a match (asearch.c:130-161: print the name, return).  The scan of a
+// segment (~0.2 ms per GiB) is not overlapped with the staging (~20 ms per GiB over PCIe).
+static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *res)
+{
+    memset(res, 0, sizeof(*res));
+    const uint64_t seg_cap = std::max<uint64_t>(env_mb("AGH_STREAM_SEG_MB", 1024), 1) << 20;
+    const bool early = (flags & AGH_FILENAMEONLY) != 0;
+    // -l: small first segments so that a hit near the top of a file is reported after ~64 MiB
+    uint64_t target = early ? std::min<uint64_t>(seg_cap, (uint64_t)64 << 20) : seg_cap;
+    const uint64_t hint = rd.size_hint();
+    if (q->staging.ensure(std::min<uint64_t>(seg_cap, hint ? hint : seg_cap) + 2 * AGH_STAGE_CHUNK + 64))
+        return -1;
+    q->staged_len = 0;                          // what stays in HBM is not the whole input
+    uint64_t used = 0;                          // bytes of the current segment staged so far
+    bool first = true, eof = false;
+    int b = 0;
+    bool busy[2] = {false, false};
+    const unsigned char dl = q->delim[0];
+    while (!eof) {
+        if (busy[b]) HIP_TRY(hipEventSynchronize(q->pinned_ev[b]));
+        busy[b] = false;
+        const ssize_t got = rd.fill(q->pinned[b], AGH_STAGE_CHUNK);
+        if (got < 0) return -1;
+        if (got == 0) eof = true;
+        if (got > 0) {
+            if (used + (uint64_t)got + 64 > q->staging.cap) {   // a record longer than the segment: grow
+                dev_buf bigger;
+                if (bigger.ensure((used + (uint64_t)got) * 2 + 64)) return -1;
+                HIP_TRY(hipStreamSynchronize(q->stage_stream));
+                if (used) HIP_TRY(hipMemcpy(bigger.p, q->staging.p, used, hipMemcpyDeviceToDevice));
+                q->staging.release();
+                q->staging = bigger;
+            }
+            HIP_TRY(hipMemcpyAsync((unsigned char *)q->staging.p + used, q->pinned[b], (size_t)got,
+                                   hipMemcpyHostToDevice, q->stage_stream));
+            HIP_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
+            busy[b] = true;
+            used += (uint64_t)got;
+            if ((size_t)got < AGH_STAGE_CHUNK && !rd.regular) { /* short read of a pipe: keep going */ }
+        }
+        if (!eof && used < target) { b ^= 1; continue; }
+        // cut after the last delimiter of the chunk that has just arrived
+        uint64_t cut = used;
+        const unsigned char *tail_src = nullptr;
+        uint64_t tail_len = 0;
+        if (!eof) {
+            const unsigned char *hit = (const unsigned char *)memrchr(q->pinned[b], dl, (size_t)got);
+            if (!hit) { b ^= 1; continue; }     // no record ends here yet: the segment grows
+            const uint64_t idx = (uint64_t)(hit - q->pinned[b]) + 1;
+            cut = used - (uint64_t)got + idx;
+            tail_src = q->pinned[b] + idx;
+            tail_len = (uint64_t)got - idx;
+        }
+        HIP_TRY(hipStreamSynchronize(q->stage_stream));
+        if (cut) {
+            agh_result r;
+            if (scan_device_range(q, q->staging.p, cut, nullptr, flags, &r, first, eof)) return -1;
+            res->n_matched += r.n_matched;
+            res->n_records += r.n_records;
+            res->n_candidates += r.n_candidates;
+            res->n_bytes += r.n_bytes;
+            res->device_ms += r.device_ms;
+            res->sweep_ms += r.sweep_ms;
+            res->sweep_launches += r.sweep_launches;
+            res->lean_reruns += r.lean_reruns;
+            res->n_segments += r.n_segments;
+            res->engine = r.engine;
+            first = false;
+            if (early && res->n_matched) return 0;      // -l: the rest of the input is never read
+        }
+        if (tail_len)                            // the unfinished record opens the next segment
+            HIP_TRY(hipMemcpyAsync(q->staging.p, tail_src, (size_t)tail_len, hipMemcpyHostToDevice,
+                                   q->stage_stream));
+        if (tail_len) {
+            HIP_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
+            busy[b] = true;
+        }
+        used = tail_len;
+        if (early && target < seg_cap) target = std::min<uint64_t>(seg_cap, target * 2);
+        b ^= 1;
+    }
+    return 0;
+}
+
+static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, uint64_t end,
+                        unsigned flags, agh_result *res, agh_match *matches, size_t cap)
 {
     if (!q || !res) return fail("null argument");
     if (fd < 0) return fail("agh_scan_fd needs fd >= 0 (memory mode is agh_scan_buffer)");
-    if (!q->stage_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking));
-        for (int b = 0; b < 2; ++b) {
-            HIP_TRY(hipHostMalloc((void **)&q->pinned[b], AGH_STAGE_CHUNK));
-            HIP_TRY(hipEventCreateWithFlags(&q->pinned_ev[b], hipEventDisableTiming));
-        }
-    }
-    struct stat sb;
-    size_t want = AGH_STAGE_CHUNK * 2;
-    uint64_t file_left = 0;                     // > 0: seekable regular file, bytes still to read
-    off_t file_pos = 0;
-    if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
-        off_t cur = lseek(fd, 0, SEEK_CUR);
-        if (cur >= 0 && cur < sb.st_size) {
-            file_pos = cur;
-            file_left = (uint64_t)(sb.st_size - cur);
-        }
-        if (cur < 0) cur = 0;
-        want = (size_t)(sb.st_size - cur) + 64;
-    }
-    unsigned n_readers = std::thread::hardware_concurrency();
-    if (n_readers > 16) n_readers = 16;
-    if (const char *e = getenv("AGH_READERS")) n_readers = (unsigned)atoi(e);
-    if (n_readers < 1) n_readers = 1;
+    if (with_range && end < begin) return fail("empty byte range");
+    if (ensure_stage_resources(q)) return -1;
+    fd_reader rd;
+    if (rd.open_fd(fd, with_range, begin, end)) return -1;
+    const bool count_only = (flags & (AGH_COUNT | AGH_FILENAMEONLY)) && !(matches && cap);
+    if (count_only && q->dlen == 1 && env_mb("AGH_STREAM", 1) != 0)
+        return stream_scan(q, rd, flags, res);
+
+    // records wanted: the whole input is staged, then scanned (agh_fetch_records gathers from it)
+    size_t want = rd.regular ? (size_t)rd.left + 64 : AGH_STAGE_CHUNK * 2;
     if (q->staging.ensure(want + 32)) return -1;
     size_t used = 0;
     int b = 0;
@@ -1291,52 +1768,9 @@ extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res
     for (;;) {
         if (busy[b]) HIP_TRY(hipEventSynchronize(q->pinned_ev[b]));   // its H2D copy finished
         busy[b] = false;
-        size_t got = 0;
-        if (file_left >= AGH_STAGE_CHUNK / 2 && n_readers > 1) {
-            // regular file: the chunk is cut into n_readers pieces read concurrently (one
-            // read(2) stream copies ~10 GB/s out of the page cache, PCIe takes five times that)
-            const size_t take = std::min<uint64_t>(AGH_STAGE_CHUNK, file_left);
-            const size_t piece = ((take + n_readers - 1) / n_readers + 4095) & ~(size_t)4095;
-            std::vector<std::thread> th;
-            std::vector<ssize_t> done(n_readers, 0);
-            for (unsigned t = 0; t < n_readers; ++t) {
-                const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
-                if (lo >= hi) break;
-                th.emplace_back([&, t, lo, hi]() {
-                    size_t at = lo;
-                    while (at < hi) {
-                        ssize_t r = pread(fd, q->pinned[b] + at, hi - at, file_pos + (off_t)at);
-                        if (r < 0 && errno == EINTR) continue;
-                        if (r <= 0) break;
-                        at += (size_t)r;
-                    }
-                    done[t] = (ssize_t)(at - lo);
-                });
-            }
-            for (auto &x : th) x.join();
-            // contiguous prefix that really arrived (a file truncated meanwhile ends the scan)
-            for (unsigned t = 0; t < th.size(); ++t) {
-                const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
-                got += (size_t)done[t];
-                if ((size_t)done[t] < hi - lo) break;
-            }
-            file_pos += (off_t)got;
-            file_left -= std::min<uint64_t>(file_left, got);
-            if (got < take) file_left = 0;
-            (void)lseek(fd, file_pos, SEEK_SET);
-        } else {
-            while (got < AGH_STAGE_CHUNK) {
-                ssize_t r = read(fd, q->pinned[b] + got, AGH_STAGE_CHUNK - got);
-                if (r < 0) {
-                    if (errno == EINTR) continue;
-                    return fail("read failed: %s", strerror(errno));
-                }
-                if (r == 0) break;
-                got += (size_t)r;
-            }
-            file_left -= std::min<uint64_t>(file_left, got);
-            file_pos += (off_t)got;
-        }
+        const ssize_t r = rd.fill(q->pinned[b], AGH_STAGE_CHUNK);
+        if (r < 0) return -1;
+        const size_t got = (size_t)r;
         if (got == 0) break;
         if (used + got + 32 > q->staging.cap) {     // unknown length (pipe): grow, keep contents
             dev_buf bigger;
@@ -1352,10 +1786,58 @@ extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res
         busy[b] = true;
         used += got;
         b ^= 1;
-        if (got < AGH_STAGE_CHUNK) break;            // EOF inside this chunk
     }
     HIP_TRY(hipStreamSynchronize(q->stage_stream));
     return scan_staged(q, used, flags, res, matches, cap);
+}
+
+extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res,
+                           agh_match *matches, size_t cap)
+{
+    return scan_fd_impl(q, fd, false, 0, 0, flags, res, matches, cap);
+}
+
+extern "C" int agh_scan_fd_range(agh_query *q, int fd, uint64_t begin, uint64_t end,
+                                 unsigned flags, agh_result *res, agh_match *matches, size_t cap)
+{
+    return scan_fd_impl(q, fd, true, begin, end, flags, res, matches, cap);
+}
+
+// cut a file into nranks record-aligned shards (a record belongs to the shard that
+// holds its first byte).  Inner cut r = the nominal offset size * r / nranks if a record starts
+// there, else just after the next delimiter -- the rule of agrep_amd/shard.py:record_cuts.
+// Host-only code (pread); single-byte delimiters.
+extern "C" int agh_shard_cuts_fd(int fd, const unsigned char *delim, int dlen, int nranks,
+                                 uint64_t *cuts)
+{
+    if (fd < 0 || !delim || nranks < 1 || !cuts) return fail("agh_shard_cuts_fd: bad arguments");
+    if (dlen != 1) return fail("sharding a file supports single-byte delimiters only");
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return fail("sharding needs a seekable regular file");
+    const uint64_t size = (uint64_t)sb.st_size;
+    cuts[0] = 0;
+    std::vector<unsigned char> buf(1 << 16);
+    for (int r = 1; r < nranks; ++r) {
+        // size * r / nranks without overflow
+        uint64_t nominal = size / (uint64_t)nranks * (uint64_t)r + size % (uint64_t)nranks * (uint64_t)r / (uint64_t)nranks;
+        if (nominal < cuts[r - 1]) nominal = cuts[r - 1];
+        if (nominal >= size) { cuts[r] = size; continue; }
+        uint64_t cut = size;
+        // one byte in front of the nominal offset decides whether a record starts right there
+        for (uint64_t off = nominal ? nominal - 1 : 0; off < size && cut == size;) {
+            ssize_t got = pread(fd, buf.data(), buf.size(), (off_t)off);
+            if (got < 0 && errno == EINTR) continue;
+            if (got < 0) return fail("read failed: %s", strerror(errno));
+            if (got == 0) break;
+            if (nominal == 0) { cut = 0; break; }
+            const unsigned char *hit = (const unsigned char *)memchr(buf.data(), delim[0], (size_t)got);
+            if (hit) cut = off + (uint64_t)(hit - buf.data()) + 1;   // (the byte at nominal-1 gives cut == nominal)
+            off += (uint64_t)got;
+        }
+        cuts[r] = cut;
+    }
+    cuts[nranks] = size;
+    return 0;
 }
 
 // Scan again what the last agh_scan_fd / agh_scan_buffer staged (e.g. with a larger match

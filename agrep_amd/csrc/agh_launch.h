@@ -32,6 +32,10 @@ struct agh_sweep_args {
     int lean;                // 1: no delimiter census (count-only scans)
     hipEvent_t ev_begin;     // optional: recorded right before / after the k_sweep launch
     hipEvent_t ev_end;
+    // part of the text swept by this launch: wave ranges [w_begin, w_end) (a wave range is
+    // AGH_WAVE_STRIPS KiB); w_end == 0: the whole text.  Lean sweeps only: parts let the
+    // verifier of one part run while the next part is swept, and let -l stop early.
+    uint32_t w_begin = 0, w_end = 0;
 };
 
 struct agh_scan_args {
@@ -53,6 +57,7 @@ struct agh_scan_args {
     const uint64_t *gtab;    // lean verify: gram table (gram, first/last pattern offset) or NULL
     uint32_t gram_spread;
     agh_marks mk;
+    uint32_t w_begin, w_end; // lean verify: slices [w_begin, w_end) only (w_end == 0: all nw)
 };
 
 void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st);
@@ -65,6 +70,8 @@ void agh_launch_bitmap_count(uint32_t *bitmap, uint32_t n_words, uint32_t *count
 void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *wave_cand,
                               uint32_t nw, uint32_t *counters, hipStream_t st);
 void agh_launch_verify_lean(const agh_scan_args &a, hipStream_t st);
+void agh_launch_find_cuts(const void *text, const uint64_t *bound, const uint64_t *lo,
+                          uint32_t n_bounds, uint32_t delim, uint64_t *cut, hipStream_t st);
 void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
 void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_t seed,
                        const unsigned char *variants, const uint32_t *vlen,

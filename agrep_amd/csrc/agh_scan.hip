@@ -18,12 +18,12 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
                                                 uint32_t nw, agh_marks mk,
                                                 const uint64_t *__restrict__ dbm,
                                                 const uint64_t *__restrict__ gtab,
-                                                uint32_t tspan)
+                                                uint32_t tspan, uint32_t g_base)
 {
     __shared__ WT lmask[256];
     __shared__ uint32_t pre[AGH_VGROUP + 1];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
-    const uint32_t g0 = blockIdx.x * AGH_VGROUP;        // first slice of this workgroup
+    const uint32_t g0 = g_base + blockIdx.x * AGH_VGROUP;   // first slice of this workgroup
     if (threadIdx.x < AGH_VGROUP)               // the 8 counts arrive in one round trip
         pre[threadIdx.x + 1] = (g0 + threadIdx.x < nw) ? wave_cand[g0 + threadIdx.x] : 0u;
     __syncthreads();
@@ -306,20 +306,23 @@ template <typename WT, int K, int NCH, bool LEAN>
 static void launch_verify_n(const agh_scan_args &a, const uint64_t *gtab, uint32_t tspan,
                             hipStream_t st)
 {
-    uint32_t blocks = (a.nw + AGH_VGROUP - 1u) / AGH_VGROUP;
-    if (!blocks) return;
+    // slices [w_begin, w_end) of a lean part (w_begin is a multiple of AGH_VGROUP), else all
+    const uint32_t w_hi = (a.w_end && a.w_end < a.nw) ? a.w_end : a.nw;
+    const uint32_t g_base = a.w_begin;
+    if (w_hi <= g_base) return;
+    uint32_t blocks = (w_hi - g_base + AGH_VGROUP - 1u) / AGH_VGROUP;
     if (a.general)                          // single-byte delimiters only (the host checks)
         hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, true>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
-                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm, gtab, tspan);
+                           a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
     else if (a.q.dlen > 1)
         hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, true, false>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
-                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm, gtab, tspan);
+                           a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
     else
         hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, false>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
-                           a.wave_cand, a.wave_prefix, a.nw, a.mk, a.dbm, gtab, tspan);
+                           a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
 }
 
 template <typename WT, int K, bool LEAN>

@@ -175,7 +175,8 @@ __device__ __forceinline__ void sweep_supertile(uint4 v0, uint4 v1, uint4 v2, ui
 // wave keeps 4-8 KiB of HBM reads in flight while its VALU work runs.
 template <int H, int MODE, int BLOCK, bool PREFETCH>
 __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
-                                                 uint64_t n_full_strips, agh_dev_query q,
+                                                 uint64_t n_full_strips, uint32_t w_base,
+                                                 agh_dev_query q,
                                                  const uint8_t *__restrict__ ftab_g,
                                                  uint32_t *__restrict__ strip_prefix,
                                                  uint32_t *__restrict__ wave_totals,
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
     }
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const uint64_t w = (uint64_t)blockIdx.x * (BLOCK / WAVE) + wib;
+    // this launch sweeps the wave ranges w_base .. up to strip n_full_strips (a part of the text)
+    const uint64_t w = (uint64_t)w_base + (uint64_t)blockIdx.x * (BLOCK / WAVE) + wib;
     const uint64_t s0 = w * AGH_WAVE_STRIPS;
     if (s0 >= n_full_strips) return;
     uint64_t s1 = s0 + AGH_WAVE_STRIPS;
@@ -546,6 +548,44 @@ __global__ __launch_bounds__(256) void k_hashset_count(uint64_t *__restrict__ ta
 }
 
 // ---------------------------------------------------------------------------------------
+// segment cuts: inputs above the segment limit are cut where a record ends at a 16-byte aligned
+// offset (every kernel wants an aligned base).  One workgroup per nominal boundary walks back
+// from it, 256 aligned offsets (4 KiB) per round; cut[i] = the largest p <= bound[i], p > lo[i],
+// p % 16 == 0 with text[p-1] == delimiter, or 0 if there is none.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_find_cuts(const uint8_t *__restrict__ text,
+                                                   const uint64_t *__restrict__ bound,
+                                                   const uint64_t *__restrict__ lo,
+                                                   uint32_t delim, uint64_t *__restrict__ cut)
+{
+    __shared__ uint32_t best;
+    const uint64_t b = bound[blockIdx.x], l = lo[blockIdx.x];
+    uint64_t found = 0;
+    for (uint64_t base = b; base > l;) {
+        if (threadIdx.x == 0) best = 0xffffffffu;
+        __syncthreads();
+        const uint64_t back = 16ull * threadIdx.x;
+        if (base >= back && base - back > l && text[base - back - 1] == delim)
+            atomicMin(&best, threadIdx.x);
+        __syncthreads();
+        const uint32_t t = best;
+        __syncthreads();
+        if (t != 0xffffffffu) { found = base - 16ull * t; break; }
+        if (base < 4096ull + l) break;
+        base -= 4096ull;
+    }
+    if (threadIdx.x == 0) cut[blockIdx.x] = found;
+}
+
+void agh_launch_find_cuts(const void *text, const uint64_t *bound, const uint64_t *lo,
+                          uint32_t n_bounds, uint32_t delim, uint64_t *cut, hipStream_t st)
+{
+    if (!n_bounds) return;
+    hipLaunchKernelGGL(k_find_cuts, dim3(n_bounds), dim3(256), 0, st, (const uint8_t *)text, bound,
+                       lo, delim, cut);
+}
+
+// ---------------------------------------------------------------------------------------
 // bench support: read probe and synthetic corpus
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_read_probe(const uint4 *__restrict__ text,
@@ -659,18 +699,23 @@ void agh_launch_census_scan(const agh_sweep_args &a, bool with_cand, hipStream_t
 template <int H, int MODE>
 static void launch_sweep_hm(const agh_sweep_args &a, hipStream_t st)
 {
-    const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
-    const uint64_t n_waves = (n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+    const uint64_t n_full_all = a.n >> AGH_STRIP_SHIFT;
+    // a part [w_begin, w_end) of the wave ranges, or everything
+    const bool to_end = a.w_end == 0 || (uint64_t)a.w_end * AGH_WAVE_STRIPS >= n_full_all;
+    const uint64_t n_full = to_end ? n_full_all : (uint64_t)a.w_end * AGH_WAVE_STRIPS;
+    const uint64_t w_hi = (n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+    const uint64_t n_waves = w_hi > a.w_begin ? w_hi - a.w_begin : 0;
     if (a.ev_begin) (void)hipEventRecord(a.ev_begin, st);
     if (n_waves) {
         const uint32_t wpb = AGH_SWEEP_BLOCK / 64;
         const uint32_t blocks = (uint32_t)((n_waves + wpb - 1) / wpb);
         hipLaunchKernelGGL((k_sweep<H, MODE, AGH_SWEEP_BLOCK, true>), dim3(blocks),
-                           dim3(AGH_SWEEP_BLOCK), 0, st, (const uint4 *)a.text, n_full, a.q,
-                           a.ftab, a.strip_prefix, a.wave_totals, a.cand, a.wave_cand,
-                           a.counters, (const uint16_t *)a.dbm);
+                           dim3(AGH_SWEEP_BLOCK), 0, st, (const uint4 *)a.text, n_full,
+                           a.w_begin, a.q, a.ftab, a.strip_prefix, a.wave_totals, a.cand,
+                           a.wave_cand, a.counters, (const uint16_t *)a.dbm);
     }
     if (a.ev_end) (void)hipEventRecord(a.ev_end, st);
+    if (!to_end) return;                        // parts are lean: the tail belongs to the last one
     if (a.n & (AGH_STRIP - 1))
         hipLaunchKernelGGL((k_sweep_tail<H, MODE>), dim3(1), dim3(64), 0, st,
                            (const uint4 *)a.text, a.n, a.q, a.ftab, a.strip_prefix,

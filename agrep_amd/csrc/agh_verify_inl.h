@@ -31,6 +31,7 @@ __device__ __forceinline__ void mark_record(const agh_marks &mk, uint32_t r, uin
 __device__ __forceinline__ void lean_insert(const agh_marks &mk, uint64_t rec_start)
 {
     const uint64_t key = rec_start + 1;         // 0 = empty slot
+    mk.counters[AGH_C_ANYHIT] = 1u;             // -l scans stop at the first part with a hit
     uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & mk.hashset_mask;
     for (int probe = 0; probe < 64; ++probe) {
         const uint64_t old = atomicCAS((unsigned long long *)&mk.hashset[slot], 0ull,

@@ -16,6 +16,7 @@
  */
 #include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,13 +46,14 @@ static struct {
     int dlen;
     const char *pattern;
     const char *pattern_file;  /* -f  PAT_FILE */
+    int gpus;              /* --gpus N: shard every file over N GPUs (0: the plain one-GPU path) */
 } opt;
 
 static void die_usage(const char *msg)
 {
     fprintf(stderr, "%s: %s\n", Progname, msg);
     fprintf(stderr,
-            "usage: %s [-#cilnhsvyB] [-V0] [-d delim] [-e pattern | -f patternfile | pattern] [file ...]\n",
+            "usage: %s [--gpus N] [-#cilnhsvyB] [-V0] [-d delim] [-e pattern | -f patternfile | pattern] [file ...]\n",
             Progname);
     exit(2);
 }
@@ -92,9 +94,15 @@ static int parse_options(int argc, char **argv, char **files)
     opt.dlen = 1;
     for (i = 1; i < argc; i++) {
         char *a = argv[i];
-        if (a[0] == '-' && a[1] != '\0' && (opt.pattern == NULL || 1)) {
+        if (opt.pattern == NULL && strcmp(a, "--gpus") == 0) {   /* not a reference option: SURVEY 8e */
+            if (i + 1 >= argc || (opt.gpus = atoi(argv[++i])) < 1 || opt.gpus > 64)
+                die_usage("--gpus needs a device count in 1..64");
+            continue;
+        }
+        if (a[0] == '-' && a[1] != '\0') {
             char *p = a + 1;
             if (opt.pattern != NULL) {           /* after the pattern everything is a file */
+                if (nfiles >= MAX_FILES) die_usage("too many files");
                 files[nfiles++] = a;
                 continue;
             }
@@ -299,6 +307,210 @@ static long run_pass(agh_query *q, char **files, int nfiles, int print, int coun
     return total;
 }
 
+/* ---------------------------------------------------------------------------------------
+ * --gpus N: one process, N devices, one host thread per device.
+ *   -c / record output: every file is cut into N record-aligned shards (agh_shard_cuts_fd), GPU r
+ *       scans shard r (agh_scan_fd_range); the per-file count exec() prints (agrep.c:3444-3558)
+ *       is the RCCL sum of the shard counts (agh_reduce_counts_all); matched records are printed
+ *       shard after shard, i.e. in file order, record numbers offset by the shards in front.
+ *   -l: the files are dealt out to the GPUs (file f -> GPU f mod N), each scanned whole with the
+ *       early exit; the file list is the RCCL max of the per-GPU hit vectors
+ *       (agh_reduce_file_hits_all), printed in argument order.
+ * The queries are built per device by the same code as the one-GPU path.
+ * --------------------------------------------------------------------------------------- */
+typedef agh_query *(*query_builder)(void);
+
+struct gpu_task {
+    int rank, ngpus;
+    query_builder build;
+    char **files;
+    int nfiles;
+    int want_records;
+    /* results */
+    struct filehit *hits;       /* [nfiles]: this rank's shard of every file (-c / records) */
+    unsigned char *file_hit;    /* [nfiles]: -l */
+    int failed;
+    char err[512];
+};
+
+static int scan_range(agh_query *q, int fd, uint64_t b, uint64_t e, int want_records,
+                      struct filehit *out)
+{
+    size_t cap = 65536, total = 0;
+    unsigned inv = opt.INVERSE ? AGH_INVERT : 0u;
+    memset(out, 0, sizeof(*out));
+    if (!want_records)
+        return agh_scan_fd_range(q, fd, b, e, AGH_COUNT | inv, &out->res, NULL, 0);
+    out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
+    if (!out->matches) return -1;
+    if (agh_scan_fd_range(q, fd, b, e, inv, &out->res, out->matches, cap)) return -1;
+    if (out->res.truncated) {
+        free(out->matches);
+        cap = (size_t)out->res.n_matched + 16;
+        out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
+        if (!out->matches) return -1;
+        if (agh_rescan_staged(q, inv, &out->res, out->matches, cap)) return -1;
+    }
+    if (agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, NULL, 0, &total) == 0 && total == 0)
+        return 0;
+    out->bytes = (unsigned char *)malloc(total ? total : 1);
+    if (!out->bytes) return -1;
+    return agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, out->bytes, total, &total);
+}
+
+static void *gpu_worker(void *arg)
+{
+    struct gpu_task *t = (struct gpu_task *)arg;
+    agh_query *q;
+    int f;
+    if (agh_set_device(t->rank) || !(q = t->build())) {
+        t->failed = 1;
+        snprintf(t->err, sizeof(t->err), "GPU %d: %s", t->rank, agh_last_error());
+        return NULL;
+    }
+    for (f = 0; f < t->nfiles && !t->failed; f++) {
+        int fd;
+        if (opt.FILENAMEONLY && f % t->ngpus != t->rank) continue;     /* dealt to another GPU */
+        fd = open(t->files[f], O_RDONLY);
+        if (fd < 0) continue;                    /* reported once by the main thread */
+        if (opt.FILENAMEONLY) {
+            agh_result r;
+            if (agh_scan_fd(q, fd, AGH_FILENAMEONLY, &r, NULL, 0)) t->failed = 1;
+            else t->file_hit[f] = r.n_matched ? 1 : 0;
+        } else {
+            uint64_t cuts[65];
+            if (agh_shard_cuts_fd(fd, opt.delim, opt.dlen, t->ngpus, cuts) ||
+                scan_range(q, fd, cuts[t->rank], cuts[t->rank + 1], t->want_records, &t->hits[f]))
+                t->failed = 1;
+        }
+        if (t->failed) snprintf(t->err, sizeof(t->err), "%s: %s", t->files[f], agh_last_error());
+        close(fd);
+    }
+    agh_query_free(q);
+    return NULL;
+}
+
+static long run_multi_gpu(query_builder build, char **files, int nfiles, long *files_matched)
+{
+    const int G = opt.gpus;
+    const int want_records = !opt.COUNT && !opt.FILENAMEONLY && !opt.SILENT;
+    struct gpu_task *tasks = (struct gpu_task *)calloc((size_t)G, sizeof(*tasks));
+    pthread_t *th = (pthread_t *)calloc((size_t)G, sizeof(*th));
+    agh_comm *comms[64];
+    long total = 0;
+    int r, f;
+    if (nfiles == 0) die_usage("--gpus needs file arguments (stdin cannot be cut into shards)");
+    if (agh_device_count() < G) {
+        fprintf(stderr, "%s: --gpus %d but only %d HIP device(s) are visible\n", Progname, G, agh_device_count());
+        exit(2);
+    }
+    if (agh_comm_init_all(comms, G, NULL)) {
+        fprintf(stderr, "%s: RCCL: %s\n", Progname, agh_last_error());
+        exit(2);
+    }
+    for (r = 0; r < G; r++) {
+        tasks[r].rank = r;
+        tasks[r].ngpus = G;
+        tasks[r].build = build;
+        tasks[r].files = files;
+        tasks[r].nfiles = nfiles;
+        tasks[r].want_records = want_records;
+        tasks[r].hits = (struct filehit *)calloc((size_t)nfiles, sizeof(struct filehit));
+        tasks[r].file_hit = (unsigned char *)calloc((size_t)nfiles, 1);
+        pthread_create(&th[r], NULL, gpu_worker, &tasks[r]);
+    }
+    for (r = 0; r < G; r++) pthread_join(th[r], NULL);
+    for (r = 0; r < G; r++)
+        if (tasks[r].failed) { fprintf(stderr, "%s: %s\n", Progname, tasks[r].err); exit(2); }
+
+    if (opt.FILENAMEONLY) {                      /* the -l hit vector: RCCL max over the GPUs */
+        unsigned char *vec[64];
+        for (r = 0; r < G; r++) vec[r] = tasks[r].file_hit;
+        if (agh_reduce_file_hits_all(comms, G, vec, (size_t)nfiles)) {
+            fprintf(stderr, "%s: RCCL: %s\n", Progname, agh_last_error());
+            exit(2);
+        }
+    }
+    for (f = 0; f < nfiles; f++) {
+        uint64_t counts[64][2], host_sum = 0, rec_off = 0;
+        int fd = open(files[f], O_RDONLY);
+        if (fd < 0) {                            /* agrep.c:2952-2958 */
+            fprintf(stderr, "%s: '%s' no such file or directory\n", Progname, files[f]);
+            continue;
+        }
+        close(fd);
+        if (opt.FILENAMEONLY) {                  /* asearch.c:130-161 */
+            if (tasks[0].file_hit[f]) {
+                if (!opt.SILENT) printf("%s\n", files[f]);
+                (*files_matched)++;
+                total++;
+            }
+            continue;
+        }
+        for (r = 0; r < G; r++) {
+            counts[r][0] = tasks[r].hits[f].res.n_matched;
+            counts[r][1] = tasks[r].hits[f].res.n_records;
+            host_sum += counts[r][0];
+        }
+        if (agh_reduce_counts_all(comms, G, counts)) {   /* ncclAllReduce(sum) over the shard counts */
+            fprintf(stderr, "%s: RCCL: %s\n", Progname, agh_last_error());
+            exit(2);
+        }
+        if (counts[0][0] != host_sum) {
+            fprintf(stderr, "%s: internal error: RCCL sum %llu != host sum %llu\n", Progname,
+                    (unsigned long long)counts[0][0], (unsigned long long)host_sum);
+            exit(2);
+        }
+        if (!opt.SILENT) {
+            if (opt.COUNT) {                     /* agrep.c:3501-3556 */
+                if (nfiles > 1 && !opt.NOFILENAME)
+                    printf("%s: %llu\n", files[f], (unsigned long long)counts[0][0]);
+                else
+                    printf("%llu\n", (unsigned long long)counts[0][0]);
+            } else if (want_records) {
+                for (r = 0; r < G; r++) {        /* shard after shard = file order */
+                    struct filehit *h = &tasks[r].hits[f];
+                    uint64_t i;
+                    for (i = 0; i < h->res.n_stored; i++) h->matches[i].index += rec_off;
+                    print_records(h, files[f], nfiles > 1 && !opt.NOFILENAME);
+                    rec_off += h->res.n_records;
+                }
+            }
+        }
+        if (counts[0][0]) (*files_matched)++;
+        total += (long)counts[0][0];
+    }
+    for (r = 0; r < G; r++) {
+        for (f = 0; f < nfiles; f++) { free(tasks[r].hits[f].matches); free(tasks[r].hits[f].bytes); }
+        free(tasks[r].hits);
+        free(tasks[r].file_hit);
+        agh_comm_free(comms[r]);
+    }
+    free(tasks);
+    free(th);
+    return total;
+}
+
+/* query of the command line for the calling thread's device */
+static const unsigned char **g_multi_pats;
+static int *g_multi_lens;
+static int g_multi_n;
+
+static agh_query *build_cli_query(void)
+{
+    agh_query *q;
+    if (opt.pattern_file)
+        return agh_query_multi(g_multi_pats, g_multi_lens, g_multi_n, opt.NOUPPER, opt.delim, opt.dlen);
+    q = agh_query_literal((const unsigned char *)opt.pattern, (int)strlen(opt.pattern), opt.D,
+                          opt.NOUPPER, opt.delim, opt.dlen);
+    if (q && (opt.I || opt.S || opt.DD) &&
+        agh_query_set_costs(q, opt.I ? opt.I : 1, opt.S ? opt.S : 1, opt.DD ? opt.DD : 1)) {
+        agh_query_free(q);
+        return NULL;
+    }
+    return q;
+}
+
 int main(int argc, char **argv)
 {
     static char *files[MAX_FILES];
@@ -342,10 +554,17 @@ int main(int argc, char **argv)
             fprintf(stderr, "%s: no usable HIP device (this build has no CPU scan engine)\n", Progname);
             exit(2);
         }
-        q = agh_query_multi(pp, ll, (int)np, opt.NOUPPER, opt.delim, opt.dlen);
-        if (!q) { fprintf(stderr, "%s: %s\n", Progname, agh_last_error()); exit(2); }
-        total = run_pass(q, files, nfiles, 1, 0, &files_matched);
-        agh_query_free(q);
+        g_multi_pats = pp;
+        g_multi_lens = ll;
+        g_multi_n = (int)np;
+        if (opt.gpus) {
+            total = run_multi_gpu(build_cli_query, files, nfiles, &files_matched);
+        } else {
+            q = build_cli_query();
+            if (!q) { fprintf(stderr, "%s: %s\n", Progname, agh_last_error()); exit(2); }
+            total = run_pass(q, files, nfiles, 1, 0, &files_matched);
+            agh_query_free(q);
+        }
         if (opt.VERBOSE > 0 && !opt.SILENT) printf("Grand Total: %ld match(es) found.\n", total);
         return (int)total;
     }
@@ -359,15 +578,12 @@ int main(int argc, char **argv)
         exit(2);
     }
 
-    if (!opt.BESTMATCH) {
-        q = agh_query_literal((const unsigned char *)opt.pattern, m, opt.D, opt.NOUPPER,
-                              opt.delim, opt.dlen);
+    if (opt.gpus && opt.BESTMATCH) die_usage("--gpus does not combine with -B");
+    if (opt.gpus) {
+        total = run_multi_gpu(build_cli_query, files, nfiles, &files_matched);
+    } else if (!opt.BESTMATCH) {
+        q = build_cli_query();
         if (!q) { fprintf(stderr, "%s: %s\n", Progname, agh_last_error()); exit(2); }
-        if ((opt.I || opt.S || opt.DD) &&
-            agh_query_set_costs(q, opt.I ? opt.I : 1, opt.S ? opt.S : 1, opt.DD ? opt.DD : 1)) {
-            fprintf(stderr, "%s: %s\n", Progname, agh_last_error());
-            exit(2);
-        }
         total = run_pass(q, files, nfiles, 1, 0, &files_matched);
         agh_query_free(q);
     } else {

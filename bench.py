@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X agrep scanner.
 
-Metric (BASELINE.json): GB/s scanned (+ Mmatches/s), m=16 pattern, k=2, synthetic
-newline-delimited corpus resident in HBM.  A "step" is one complete -c scan of the rank's
-shard (sweep + verify + count, through the C-ABI agh_scan_device) followed, for N > 1, by the
-RCCL all-reduce of the per-rank counts.  Weak scaling: every rank owns `--gib` GiB (default 4 =
-BASELINE configs[1]) of the same deterministic corpus (disjoint page ranges).
+Metric (BASELINE.json): GB/s scanned + Mmatches/s, k in {0, 2}, m = 16, 64 GiB synthetic
+newline-delimited corpus at 1/2/4/8 GPUs.  STRONG scaling: the job is always the same 64 GiB
+(16 shards x 4 GiB of SURVEY 8d's generator, seed 12345); rank r of N owns the contiguous
+64/N GiB page range r (N = 8: 8 GiB per GPU = BASELINE configs[3]), resident in HBM before the
+timed region starts.  A "step" is one complete `-c` scan of the rank's range through the C-ABI
+(agh_scan_device: sweep + verify + count of every <= 8 GiB segment, one host sync) followed by
+the RCCL all-reduce of the counts through the C-ABI (agh_reduce_counts, N > 1).
 
-    python bench.py                     # 1 GPU, configs[1]
+    python bench.py                     # 1 GPU, the whole 64 GiB
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  k0           -- the same K steps timed the same way with k = 0 (the metric's other point)
   roofline     -- dominant kernel k_sweep<H>: algorithmic bytes (1 B per corpus byte) / its
-                  average launch duration, measured with HIP events recorded around the
-                  kernel on its own stream, against the 8 TB/s HBM peak
-  cpu_baseline -- the unmodified reference (oracle/_ref/agrep, 1 core) on a bounded sample of
-                  the same corpus, N=1 only
+                  average launch duration, HIP events recorded around every launch on the
+                  stream it is launched on, against the 8 TB/s HBM peak; `traffic` = HBM read
+                  bytes per launch from rocprofv3's FETCH_SIZE counter, measured in THIS run by
+                  a child process (or null)
+  cpu_baseline -- the unmodified reference (oracle/_ref/agrep, 1 core and all cores) on a
+                  bounded sample of the same corpus, N = 1 only
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -33,6 +41,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PATTERN = b"approximatematch"
 VARIANTS = (b"approximatematch", b"approximatematch", b"aproximatematch", b"approxXmatematch",
             b"approximatemmatcZ", b"apprximatemtch", b"appQoximRtematch")
+VARIANT_EDITS = (0, 0, 1, 1, 2, 2, 2)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 12345
 
@@ -106,8 +115,9 @@ def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes):
         return {"value": round(sample_bytes / 1e9 / dt, 4), "unit": "GB/s", "cores": 1,
                 **extra,
                 "kind": "reference",
-                "sample": "first %.2f GiB of the rank-0 shard, `agrep -V0 -%d -c %s` (sgrep.c:agrep() "
-                          "path), page cache warm, 1 process" % (sample_bytes / 2**30, k, PATTERN.decode()),
+                "sample": "shard 0 of 16 = the first %.2f GiB of the 64 GiB corpus, `agrep -V0 -%d -c %s` "
+                          "(sgrep.c:agrep() path), page cache warm, 1 process"
+                          % (sample_bytes / 2**30, k, PATTERN.decode()),
                 "seconds": round(dt, 3), "count": cnt,
                 "count_equals_gpu": bool(cnt == gpu_count_on_sample)}
     import _oracle as O                                        # the restatement as a port
@@ -120,15 +130,54 @@ def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes):
             "seconds": round(dt, 3), "count": int(cnt)}
 
 
+def measure_traffic(seg_gib, k, timeout_s):
+    """HBM read bytes of ONE k_sweep launch, measured now: a child process runs a few scans of
+    one segment of the same corpus under `rocprofv3 --pmc FETCH_SIZE` (its own pass, with
+    --kernel-trace only, as MI355X_MICROARCH.md prescribes); FETCH_SIZE is in KiB and counts the
+    128-byte requests of gfx950 as 64 bytes (the guide's correction: x 2).  None on any failure."""
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="agh_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(v, None)
+        cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p",
+               "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--total-gib", str(seg_gib),
+               "-k", str(k), "--steps", "3", "--warmup", "0"]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=timeout_s)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, "rocprofv3 pass failed (rc %d)" % r.returncode
+        vals = []
+        for row in csv.DictReader(open(files[0])):
+            if row.get("Counter_Name") == "FETCH_SIZE" and row.get("Kernel_Name", "").startswith("void k_sweep<"):
+                vals.append(float(row["Counter_Value"]))
+        if not vals:
+            return None, "no k_sweep rows in the counter file"
+        # one row per launch (the counter is summed over the XCDs by rocprofv3); drop nothing
+        per_launch = sum(vals) / len(vals)
+        return int(per_launch * 1024 * 2), "rocprofv3 --pmc FETCH_SIZE, %d launches of %g GiB, KiB x 1024 x 2" % (len(vals), seg_gib)
+    except Exception as e:                                      # never lose the headline over this
+        return None, "traffic pass failed: %s" % str(e)[:120]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--gib", type=float, default=4.0, help="corpus GiB per GPU")
+    ap.add_argument("--total-gib", type=float, default=64.0,
+                    help="corpus GiB of the whole job (BASELINE: 64), split evenly over the ranks")
     ap.add_argument("-k", type=int, default=2)
     ap.add_argument("--cpu-sample-gib", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 FETCH_SIZE pass")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
@@ -141,38 +190,40 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
     # Test hooks (1-GPU boxes): AGH_BENCH_BACKEND=gloo + AGH_BENCH_ONE_GPU=1 run all ranks on
-    # GPU 0 with the count reduction on CPU tensors -- exercises the multi-rank control flow.
+    # GPU 0 with the count reduction through torch/gloo (RCCL refuses two ranks on one device).
     backend = os.environ.get("AGH_BENCH_BACKEND", "nccl")
     if os.environ.get("AGH_BENCH_ONE_GPU") == "1":
         local_rank = 0
-    red_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     A.set_device(local_rank)
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # the C-ABI's own RCCL communicator: rank 0's unique id travels over torch.distributed
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(A.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            comm = A.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank)
         else:
             dist.init_process_group(backend)
 
-    n_pages = int(args.gib * (1 << 30)) // 4096
+    total_pages = int(args.total_gib * (1 << 30)) // 4096
+    first_page, n_pages = shard.shard_pages(total_pages, world, rank)
     n = n_pages * 4096
     text = torch.empty(n, dtype=torch.uint8, device="cuda")
-    first_page, my_pages = shard.shard_pages(n_pages * world, world, rank)
-    assert my_pages == n_pages
     planted = A.corpus_fill_device(text.data_ptr(), n_pages, first_page=first_page, seed=SEED,
                                    variants=VARIANTS, plant_period=500)
     torch.cuda.synchronize()
-    q = A.Query(PATTERN, args.k)
-    info = q.info()
-    agg = [0, 0]
 
-    def step():
-        # AGH_TIME_SWEEP: HIP events around k_sweep on the scan's stream, in every timed step
-        res = q.scan_device(text.data_ptr(), n, flags=A.COUNT | A.TIME_SWEEP, time_scan=False)
-        if world > 1:                                        # RCCL: the -c aggregate
-            agg[0], agg[1] = shard.reduce_counts(res.n_matched, res.n_records, device=red_dev)
-        return res
+    if args.pmc_child:                          # under rocprofv3 --pmc: a few scans, nothing else
+        with A.Query(PATTERN, args.k) as qc:
+            for _ in range(args.steps):
+                qc.scan_device(text.data_ptr(), n, flags=A.COUNT, time_sweep=False, time_scan=False)
+        torch.cuda.synchronize()
+        return
 
     def fence():
         torch.cuda.synchronize()
@@ -180,86 +231,124 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    fence()
-    t0 = time.perf_counter()
-    sweep_ms = 0.0
-    for _ in range(args.steps):
-        res = step()
-        sweep_ms += res.sweep_ms
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed_loop(q):
+        """W untimed + K timed steps; -> (seconds max over ranks, last result, sweep ms, sweep launches,
+        matched records of the whole job)"""
+        agg = [0, 0]
+
+        def step():
+            # AGH_TIME_SWEEP: HIP events around every k_sweep launch on the scan's stream
+            res = q.scan_device(text.data_ptr(), n, flags=A.COUNT | A.TIME_SWEEP, time_scan=False)
+            if world > 1:                       # the -c aggregate: ncclAllReduce through the C-ABI
+                if comm is not None:
+                    agg[0], agg[1] = comm.reduce_counts(res.n_matched, res.n_records)
+                else:
+                    agg[0], agg[1] = shard.reduce_counts(res.n_matched, res.n_records, device="cpu")
+            return res
+
+        for _ in range(args.warmup):
+            res = step()
+        fence()
+        t0 = time.perf_counter()
+        sweep_ms, launches = 0.0, 0
+        for _ in range(args.steps):
+            res = step()
+            sweep_ms += res.sweep_ms
+            launches += res.sweep_launches
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            matched_all = int(agg[0])
+        else:
+            matched_all = int(res.n_matched)
+        return elapsed, res, sweep_ms, launches, matched_all
+
+    q = A.Query(PATTERN, args.k)
+    info = q.info()
+    elapsed, res, sweep_ms, launches, matched_all = timed_loop(q)
+    q0 = A.Query(PATTERN, 0)
+    info0 = q0.info()
+    elapsed0, res0, sweep_ms0, launches0, matched0 = timed_loop(q0)
+
+    # planted records of the whole job (all ranks), by number of edits
+    pl = torch.tensor([int(x) for x in planted], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        matched_all = int(agg[0])
-    else:
-        matched_all = int(res.n_matched)
+        dist.all_reduce(pl, op=dist.ReduceOp.SUM)
+    pl = [int(x) for x in pl.tolist()]
+    planted_le = {kk: sum(c for c, e in zip(pl, VARIANT_EDITS) if e <= kk) for kk in (0, 1, 2)}
 
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        total_bytes = n * world
-        value = total_bytes / 1e9 / (elapsed / args.steps)
-        sweep_avg_ms = sweep_ms / args.steps
-        achieved = n / 1e6 / sweep_avg_ms                     # GB/s of the dominant kernel
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if abs(tj.get("bytes_per_launch_basis", 0) - n) < 1:
-                    traffic = tj.get("hbm_read_bytes_per_launch")
-            except Exception:
-                traffic = None
+        step_s = elapsed / args.steps
+        total_bytes = total_pages * 4096
+        value = total_bytes / 1e9 / step_s
+        per_launch_bytes = n * args.steps / max(launches, 1)
+        sweep_avg_ms = sweep_ms / max(launches, 1)
+        achieved = per_launch_bytes / 1e6 / sweep_avg_ms          # GB/s of the dominant kernel
         out = {
-            "metric": "GB/s scanned (k=2, m=16, -c count) + Mmatches/s",
+            "metric": "GB/s scanned + Mmatches/s, k in {0,2}, m=16, 64 GiB corpus (value: k=%d, -c count)" % args.k,
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: pattern 'approximatematch' (m=16), k=%d, "
-                                   "%.2f GiB of newline-delimited records per GPU resident in HBM, "
-                                   "count-only (-c)" % (args.k, args.gib),
-                       "bytes_per_gpu": n,
-                       "records_per_gpu": int(q.scan_device(text.data_ptr(), n).n_records),
-                       "sharding": "disjoint page ranges per rank, RCCL all-reduce of the counts",
+            "config": {"workload": "BASELINE metric config (configs[3] corpus): pattern 'approximatematch' (m=16), "
+                                   "k=%d, %.0f GiB of newline-delimited records in total = 16 shards x 4 GiB of "
+                                   "the SURVEY 8d generator, split evenly over %d GPU(s), resident in HBM, "
+                                   "count-only (-c)" % (args.k, args.total_gib, world),
+                       "total_bytes": total_bytes, "bytes_per_gpu": n,
+                       "segments_per_gpu": int(res.n_segments),
+                       "sharding": "contiguous page range per rank; the only exchange is the RCCL all-reduce of "
+                                   "the counts (agh_reduce_counts)" if world > 1 else "one GPU holds the whole corpus",
                        "engine": {1: "fullscan", 2: "q-gram sample filter + verify"}[res.engine],
                        "filter_sample": "q=%d bytes every h=%d bytes" % (info["filter_q"], info["filter_h"]),
                        "seed": SEED},
             "matched_records": matched_all,
-            "mmatches_per_s": round(matched_all / 1e6 / (elapsed / args.steps), 3),
-            "planted_records_rank0": int(sum(planted)),
+            "planted_records": planted_le[min(args.k, 2)],
+            "matched_equals_planted": bool(matched_all == planted_le[min(args.k, 2)]),
+            "mmatches_per_s": round(matched_all / 1e6 / step_s, 3),
+            "timed_region_s": round(elapsed, 4),
+            "lean_reruns_last_step": int(res.lean_reruns),
             "candidates_per_step_rank0": int(res.n_candidates),
+            "k0": {"value": round(total_bytes / 1e9 / (elapsed0 / args.steps), 2), "unit": "GB/s",
+                   "ms_per_step": round(elapsed0 / args.steps * 1e3, 4), "steps": args.steps,
+                   "matched_records": matched0, "planted_records": planted_le[0],
+                   "mmatches_per_s": round(matched0 / 1e6 / (elapsed0 / args.steps), 3),
+                   "filter_sample": "q=%d bytes every h=%d bytes" % (info0["filter_q"], info0["filter_h"]),
+                   "sweep_avg_launch_ms": round(sweep_ms0 / max(launches0, 1), 4)},
             "roofline": {"bound": "hbm", "kernel": "k_sweep<%d>" % info["filter_h"],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": n,
-                         "avg_launch_ms": round(sweep_avg_ms, 4)},
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                         "avg_launch_ms": round(sweep_avg_ms, 4), "launches_timed": int(launches),
+                         "whole_scan_frac": round(value / world / HBM_PEAK_GBPS, 4)},
         }
-        # secondary points of the metric: k = 0 and the streaming-read ceiling of this access pattern
-        q0 = A.Query(PATTERN, 0)
-        for _ in range(2):
-            q0.scan_device(text.data_ptr(), n, flags=A.COUNT)
-        t1 = time.perf_counter()
-        for _ in range(5):
-            r0 = q0.scan_device(text.data_ptr(), n, flags=A.COUNT)
-        torch.cuda.synchronize()
-        out["k0"] = {"value": round(n / 1e9 / ((time.perf_counter() - t1) / 5), 2), "unit": "GB/s",
-                     "matched_records_rank0": int(r0.n_matched)}
-        q0.close()
-        A.probe_read_ms(text.data_ptr(), n)
-        out["read_ceiling_gbps"] = round(n / 1e6 / min(A.probe_read_ms(text.data_ptr(), n) for _ in range(3)), 1)
+        A.probe_read_ms(text.data_ptr(), min(n, 8 << 30))
+        rn = min(n, 8 << 30)
+        out["read_ceiling_gbps"] = round(rn / 1e6 / min(A.probe_read_ms(text.data_ptr(), rn) for _ in range(3)), 1)
         if world == 1 and not args.no_cpu_baseline:
             sb = int(args.cpu_sample_gib * (1 << 30)) // 4096 * 4096
             sb = min(sb, n)
-            gpu_cnt = q.scan_device(text.data_ptr(), sb).n_matched
+            gpu_cnt = q.scan_device(text.data_ptr(), sb, flags=A.COUNT).n_matched
             out["cpu_baseline"] = cpu_baseline(text, n, args.k, int(gpu_cnt), sb)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     q.close()
+    q0.close()
+    if rank == 0:
+        if world == 1 and not args.no_traffic:
+            del text
+            torch.cuda.empty_cache()
+            seg_gib = per_launch_bytes / 2**30
+            tr, note = measure_traffic(seg_gib, args.k, 240)
+            out["roofline"]["traffic"] = tr
+            out["roofline"]["traffic_source"] = note
+            if tr:
+                out["roofline"]["traffic_over_algorithmic"] = round(tr / per_launch_bytes, 4)
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -80,6 +80,12 @@ typedef struct {
     double   device_ms;     /* AGH_TIME_SCAN: GPU time of the whole scan (hipEvent), excluding staging; else 0 */
     double   sweep_ms;      /* AGH_TIME_SWEEP (else 0): of which the k_sweep kernel launches (the kernel that reads every
                                byte), hipEvents recorded right around them on the scan stream */
+    uint32_t sweep_launches;/* AGH_TIME_SWEEP: number of k_sweep launches sweep_ms is the sum of */
+    uint32_t lean_reruns;   /* segments whose count-only (lean) scan gave up (a record start more than 64 KiB
+                               in front of a match, hash set full, candidate slices full) and were scanned
+                               again on the numbered pipeline: the result is exact, the time doubled */
+    uint32_t n_segments;    /* kernel sequences the text was cut into (<= 8 GiB each, at record boundaries) */
+    uint32_t reserved;
 } agh_result;
 
 /* ---- query construction ------------------------------------------------------------- */
@@ -162,6 +168,47 @@ int agh_fetch_records(agh_query *q, const agh_match *m, size_t n_matches, unsign
  * match_cap uint64) receives, unordered, one byte offset inside each matched record. */
 int agh_scan_device(agh_query *q, const void *dev_text, size_t len, void *stream,
                     unsigned flags, agh_result *res, void *dev_match_pos, size_t match_cap);
+
+/* ---- multi-GPU: records shard, the only exchange is the aggregate --------------------- */
+
+/* Records are independent (every engine resets at a delimiter, asearch.c:175-196), so G GPUs
+ * scan G record-aligned byte ranges with no data-path collective; what exec() prints per file
+ * (agrep.c:3444-3558: the -c count, the -l name) needs one tiny all-reduce, done here directly
+ * on RCCL (ncclAllReduce over xGMI).  RCCL is opened at the first call (dlopen), never before.
+ * Two ways to form the communicator:
+ *   one process per GPU:  rank 0 calls agh_comm_unique_id() and hands the 128 bytes to the other
+ *       ranks by any means (MPI, a file, torch.distributed); every rank then calls
+ *       agh_comm_init_rank() with its own device selected (agh_set_device);
+ *   one process, N GPUs:  agh_comm_init_all() (ncclCommInitAll), one communicator per device; the
+ *       *_all reductions run them as one RCCL group. */
+#define AGH_UNIQUE_ID_BYTES 128
+typedef struct agh_comm agh_comm;
+int agh_comm_unique_id(unsigned char id[AGH_UNIQUE_ID_BYTES]);
+agh_comm *agh_comm_init_rank(const unsigned char id[AGH_UNIQUE_ID_BYTES], int nranks, int rank);
+int agh_comm_init_all(agh_comm **comms, int ndev, const int *devices /* NULL: 0..ndev-1 */);
+int agh_comm_info(const agh_comm *c, int *rank, int *nranks, int *device);
+void agh_comm_free(agh_comm *c);
+
+/* counts[0] = n_matched, counts[1] = n_records of this rank's shard -> the sums over all ranks
+ * (ncclSum over uint64), identical on every rank: what -c prints for a sharded file. */
+int agh_reduce_counts(agh_comm *c, uint64_t counts[2]);
+int agh_reduce_counts_all(agh_comm *const *comms, int n, uint64_t (*counts)[2]);
+
+/* hits[f] != 0 iff this rank found a match in file f -> the OR over all ranks (ncclMax over
+ * bytes): the -l file list of files that were sharded or dealt out across ranks. */
+int agh_reduce_file_hits(agh_comm *c, unsigned char *hits, size_t n_files);
+int agh_reduce_file_hits_all(agh_comm *const *comms, int n, unsigned char *const *hits,
+                             size_t n_files);
+
+/* Record-aligned shards of a file (SURVEY 8e ownership rule: a record belongs to the range that
+ * holds its first byte): cuts[0] = 0 <= cuts[1] <= ... <= cuts[nranks] = file size, every inner
+ * cut placed just after the first delimiter at or after r * size / nranks.  fd must be seekable
+ * (pread).  delim/dlen as in agh_query_literal. */
+int agh_shard_cuts_fd(int fd, const unsigned char *delim, int dlen, int nranks, uint64_t *cuts);
+
+/* agh_scan_fd restricted to the byte range [begin, end) of a seekable file -- one rank's shard. */
+int agh_scan_fd_range(agh_query *q, int fd, uint64_t begin, uint64_t end, unsigned flags,
+                      agh_result *res, agh_match *matches, size_t cap);
 
 /* ---- device / bench support --------------------------------------------------------- */
 

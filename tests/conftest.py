@@ -14,6 +14,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "ref: needs the compiled reference under oracle/_ref")
 
 
+def _have_gpu():
+    """True iff libagrep_hip.so is built and sees a HIP device (no torch import needed)."""
+    try:
+        import agrep_amd
+        return agrep_amd.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests are skipped on a box without a HIP device (plain `pytest tests` stays
+    green on CPU); AGH_REQUIRE_GPU=1 (the GPU box) turns a missing device into failures."""
+    # strict on anything that looks like a GPU box: a broken build must fail there, not skip
+    if os.environ.get("AGH_REQUIRE_GPU") == "1" or os.path.exists("/dev/kfd"):
+        return
+    gpu_items = [it for it in items if "gpu" in it.keywords]
+    if not gpu_items or _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device / libagrep_hip.so (set AGH_REQUIRE_GPU=1 to fail instead)")
+    for it in gpu_items:
+        it.add_marker(skip)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _build_oracle():
     """The oracle is test infrastructure; build it on demand (gcc only)."""

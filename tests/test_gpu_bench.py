@@ -23,14 +23,18 @@ def _last_json(out):
 
 def test_bench_single_and_two_ranks():
     env = dict(os.environ)
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gib", "0.5", "--steps", "3",
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--total-gib", "0.5", "--steps", "3",
                           "--warmup", "1", "--cpu-sample-gib", "0.125"], stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     a = _last_json(one.stdout)
     for k in REQUIRED:
         assert k in a, k
-    assert a["n_gpus"] == 1 and a["scaling"] == "weak" and a["dtype"] == "u8" and a["vs_baseline"] is None
+    assert a["n_gpus"] == 1 and a["scaling"] == "strong" and a["dtype"] == "u8" and a["vs_baseline"] is None
+    assert a["matched_equals_planted"] is True and a["k0"]["matched_records"] == a["k0"]["planted_records"]
+    # traffic is measured in the run (rocprofv3 FETCH_SIZE pass of a child process) or null
+    tr = a["roofline"]["traffic"]
+    assert tr is None or 0.9 < tr / a["roofline"]["algorithmic_bytes_per_launch"] < 1.5, a["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(a["roofline"])
     assert a["roofline"]["bound"] == "hbm" and 0 < a["roofline"]["frac"] < 1
     cb = a["cpu_baseline"]
@@ -41,11 +45,12 @@ def test_bench_single_and_two_ranks():
     env.update(AGH_BENCH_BACKEND="gloo", AGH_BENCH_ONE_GPU="1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--gib", "0.25", "--steps", "3", "--warmup", "1"],
+                          "--gpus", "2", "--total-gib", "0.5", "--steps", "3", "--warmup", "1"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT)
     assert two.returncode == 0, two.stderr[-2000:]
     b = _last_json(two.stdout)
     assert b["n_gpus"] == 2 and b["cpu_baseline"] is None
-    # two shards of 0.25 GiB are the same bytes as the one 0.5 GiB corpus
-    assert b["matched_records"] == a["matched_records"]
+    # strong scaling: the same 0.5 GiB job, half of it per rank
+    assert b["matched_records"] == a["matched_records"] and b["matched_equals_planted"] is True
     assert b["config"]["bytes_per_gpu"] * 2 == a["config"]["bytes_per_gpu"]
+    assert b["config"]["total_bytes"] == a["config"]["total_bytes"] and b["scaling"] == "strong"

@@ -132,3 +132,56 @@ def test_cli_rejects_what_is_outside_the_hot_path(files):
               ["-9", "approximatematch", files[0]], ["-2", "ab", files[0]]):
         rc, out, err = _run(CLI, a)
         assert rc == 2 and err
+
+
+def _n_devices():
+    import agrep_amd
+    return agrep_amd.device_count()
+
+
+@pytest.mark.parametrize("args", [["-V0", "-2", "-c"], ["-2", "-c"], ["-V0", "-2"], ["-V0", "-n", "-i", "-2"],
+                                  ["-V0", "-1", "-l"], ["-2", "-l"], ["-V0", "-c"], ["-V0", "-h", "-2"]])
+def test_cli_multi_gpu_equals_single(files, args):
+    """--gpus N: every file cut into N record-aligned shards, one host thread + one
+    query per device, the -c sum / the -l hit vector reduced with RCCL inside the C-ABI
+    (agh_reduce_counts_all / agh_reduce_file_hits_all).  Output, order and exit status equal the
+    one-GPU run.  On a one-GPU box N = 1 still goes through ncclCommInitAll + ncclAllReduce."""
+    n_dev = _n_devices()
+    for g in sorted({1, min(2, n_dev), n_dev}):
+        for fl in (files[:1], files):
+            a = args + ["approximatematch"] + fl
+            rc_1, out_1, err_1 = _run(CLI, a)
+            rc_g, out_g, err_g = _run(CLI, ["--gpus", str(g)] + a)
+            assert err_g == b"", err_g[:500]
+            assert out_g == out_1, (g, a, out_g[:300], out_1[:300])
+            assert rc_g == rc_1
+
+
+def test_cli_multi_gpu_pattern_file(files, tmp_path):
+    pf = tmp_path / "pats.txt"
+    pf.write_bytes(b"approximatematch\naproximatematch\nzzzzqqqq\n")
+    for mode in (["-c"], ["-l"], []):
+        a = ["-V0"] + mode + ["-f", str(pf)] + files
+        rc_1, out_1, _ = _run(CLI, a)
+        rc_g, out_g, err_g = _run(CLI, ["--gpus", "1"] + a)
+        assert err_g == b"" and out_g == out_1 and rc_g == rc_1, (mode, out_g[:200], out_1[:200])
+
+
+def test_cli_q6_divergence_is_deliberate(tmp_path):
+    """Quirk Q6 (sgrep.c:226-236: TR[] folds ASCII case unconditionally on the k = 0 bm() path):
+    the reference's `agrep hello` also prints "Hello World".  This build does not reproduce it:
+    without -i a pattern is case-sensitive at every k (as the reference itself is at k > 0 and on
+    its bitap path), with -i both agree."""
+    f = tmp_path / "mixed.txt"
+    f.write_bytes(b"hello world\nHello World\nHELLO\nnothing here\n")
+    rc, out, err = _run(CLI, ["-V0", "hello", str(f)])
+    assert out == b"hello world\n" and err == b""
+    rc, out, err = _run(CLI, ["-V0", "-i", "hello", str(f)])
+    assert out == b"hello world\nHello World\nHELLO\n"
+    if os.path.exists(REF):
+        _, out_r, _ = _run(REF, ["-V0", "hello", str(f)])
+        assert out_r == b"hello world\nHello World\nHELLO\n"          # Q6, stated not emulated
+        _, out_n, _ = _run(REF, ["-V0", "-n", "hello", str(f)])          # bitap path: case-sensitive
+        assert out_n == b"1: hello world\n"
+        _, out_ri, _ = _run(REF, ["-V0", "-i", "hello", str(f)])
+        assert out_ri == out

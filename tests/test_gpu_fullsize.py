@@ -1,0 +1,173 @@
+"""Parity at the sizes BASELINE.json names (the driver runs these on the MI355X):
+
+  C2  m=16 k=2, 4 GiB: the MATCH SET -- sha256 over the matched records in file order -- equals
+      the lines the reference CLI prints for the same file (oracle/_ref/agrep -V0 -2 pat file),
+      through agh_scan_fd + agh_fetch_records (staging, numbered pipeline, device gather);
+  C3  m=48 k=3 -i, 16 GiB (two segments): matched == the planted 0..3-edit records, and the
+      filter engine == the full scan on the first 2 GiB (the reference rejects m > 29: anchored on
+      the planted set, SURVEY 8c "parity unpinned");
+  C5  1024 exact patterns, 8 GiB (one GPU's share of 32 GiB / 4 GPUs): matched == planted, and
+      == the oracle on a 16 MiB slice.
+
+Each test appends one JSON line to gpurun_out/fullsize.jsonl (evidence; copied to profiles/)."""
+import hashlib
+import json
+import os
+import random
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(O.REF_DIR, "agrep")
+
+
+def _log(rec):
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "fullsize.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/agrep not built")
+def test_c2_match_set_equals_reference_at_4gib():
+    import torch
+    import agrep_amd as A
+    n = 4 << 30
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    planted = A.corpus_fill_device(t.data_ptr(), n // 4096, seed=12345, variants=O.VARIANTS_C2, plant_period=500)
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(d, "agh_c2_%d.txt" % os.getpid())
+    try:
+        t.cpu().numpy().tofile(path)
+        del t
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        ref = subprocess.run([REF, "-V0", "-2", O.PATTERN_C2.decode(), path], stdout=subprocess.PIPE)
+        ref_s = time.time() - t0
+        ref_lines = ref.stdout.count(b"\n")
+        ref_sha = hashlib.sha256(ref.stdout).hexdigest()
+        with A.Query(O.PATTERN_C2, 2) as q:
+            fd = os.open(path, os.O_RDONLY)
+            try:
+                t0 = time.time()
+                res, ms = q.scan_fd(fd, cap=200000)
+                recs = q.fetch_records(ms)
+                gpu_s = time.time() - t0
+            finally:
+                os.close(fd)
+            h = hashlib.sha256()
+            for r in recs:
+                h.update(r + b"\n")
+            # the count-only pipelines on the same file: streaming -c and -l
+            fd = os.open(path, os.O_RDONLY)
+            try:
+                rc, _ = q.scan_fd(fd, flags=A.COUNT)
+                os.lseek(fd, 0, os.SEEK_SET)
+                rl, _ = q.scan_fd(fd, flags=A.FILENAMEONLY)
+            finally:
+                os.close(fd)
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+    _log({"test": "c2_match_set", "bytes": n, "reference_lines": ref_lines, "gpu_records": len(recs),
+          "sha256_reference": ref_sha, "sha256_gpu": h.hexdigest(), "planted": int(sum(planted)),
+          "reference_seconds": round(ref_s, 2), "gpu_file_to_records_seconds": round(gpu_s, 2),
+          "count_only_matched": int(rc.n_matched), "l_scan_bytes_read": int(rl.n_bytes)})
+    assert not res.truncated and res.n_matched == len(recs) == ref_lines == sum(planted)
+    assert h.hexdigest() == ref_sha, "matched records differ from the reference's printed lines"
+    assert [m[0] for m in ms] == sorted(m[0] for m in ms)                  # file order
+    assert rc.n_matched == res.n_matched
+    # -l stops reading at the first segment with a match (asearch.c:130-161)
+    assert rl.n_matched >= 1 and rl.n_bytes < n // 8, (rl.n_matched, rl.n_bytes)
+
+
+def test_c3_long_pattern_nocase_16gib():
+    import torch
+    import agrep_amd as A
+    rng = random.Random(48)
+    pat = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(48))
+    vs = [pat]
+    for edits in (1, 2, 3, 4):
+        v = bytearray(pat)
+        for _ in range(edits):
+            op, pos = rng.randint(0, 2), rng.randrange(4, len(v) - 4)
+            if op == 0:
+                v[pos] = ord("Q")
+            elif op == 1:
+                del v[pos]
+            else:
+                v.insert(pos, ord("Z"))
+        vs.append(bytes(v))
+    n = 16 << 30
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    planted = A.corpus_fill_device(t.data_ptr(), n // 4096, seed=9, variants=tuple(vs), plant_period=500,
+                                   upper_permille=500)
+    with A.Query(pat, 3, nocase=True) as q:
+        info = q.info()
+        rl = q.scan_device(t.data_ptr(), n, flags=A.COUNT)                  # lean pipeline, 2 segments
+        xs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            q.scan_device(t.data_ptr(), n, flags=A.COUNT, time_sweep=False, time_scan=False)
+            xs.append(time.perf_counter() - t0)
+        rn = q.scan_device(t.data_ptr(), n)                                 # numbered pipeline
+        r_full = q.scan_device(t.data_ptr(), 2 << 30, flags=A.FORCE_FULLSCAN)
+        r_filt = q.scan_device(t.data_ptr(), 2 << 30)
+        # a slice against the oracle's 64-bit-word automaton
+        sl = 8 << 20
+        host = t[:sl].cpu().numpy()
+        want = O.wm_count(pat, 3, host, nocase=True)[0]
+        got = q.scan_device(t.data_ptr(), sl).n_matched
+    want_all = int(sum(planted[:4]))
+    _log({"test": "c3_m48_k3_nocase_16gib", "bytes": n, "filter": info, "matched_lean": int(rl.n_matched),
+          "matched_numbered": int(rn.n_matched), "planted_0_to_3_edits": want_all,
+          "planted_4_edits": int(planted[4]), "segments": int(rl.n_segments), "lean_reruns": int(rl.lean_reruns),
+          "count_only_GBps": round(n / 1e9 / sorted(xs)[1], 1), "fullscan_2gib_matched": int(r_full.n_matched),
+          "filter_2gib_matched": int(r_filt.n_matched), "oracle_slice_matched": int(want)})
+    assert info["filter_h"] > 0 and rl.engine == A.ENGINE_FILTER and rl.n_segments == 2
+    assert rl.n_matched == rn.n_matched == want_all
+    assert r_full.engine == A.ENGINE_FULLSCAN and r_full.n_matched == r_filt.n_matched > 0
+    assert got == want
+
+
+def test_c5_1024_exact_patterns_8gib():
+    import torch
+    import agrep_amd as A
+    rng = random.Random(1024)
+    pats = set()
+    while len(pats) < 1024:
+        pats.add(bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(4, 12))))
+    pats = sorted(pats)
+    n = 8 << 30
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    planted = A.corpus_fill_device(t.data_ptr(), n // 4096, seed=5, variants=tuple(pats[:7]), plant_period=500)
+    q = A.Query.multi(pats)
+    try:
+        r = q.scan_device(t.data_ptr(), n, flags=A.COUNT)
+        xs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            q.scan_device(t.data_ptr(), n, flags=A.COUNT, time_sweep=False, time_scan=False)
+            xs.append(time.perf_counter() - t0)
+        sl = 16 << 20
+        host = t[:sl].cpu().numpy()
+        want = O.multi_exact_count(pats, host)[0]
+        got = q.scan_device(t.data_ptr(), sl, flags=A.COUNT).n_matched
+    finally:
+        q.close()
+    # random 4-byte patterns also occur by chance in 8 GiB of text: matched >= planted, and the
+    # oracle decides on the slice
+    _log({"test": "c5_1024_exact_8gib", "bytes": n, "matched": int(r.n_matched), "planted": int(sum(planted)),
+          "candidates": int(r.n_candidates), "count_only_GBps": round(n / 1e9 / sorted(xs)[1], 1),
+          "oracle_slice_matched": int(want), "gpu_slice_matched": int(got), "segments": int(r.n_segments)})
+    assert got == want
+    assert r.n_matched >= sum(planted) > 0
