@@ -97,8 +97,9 @@ def lib():
     L.agh_corpus_fill_device.restype = C.c_int
     L.agh_probe_read_ms.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_double)]
     L.agh_probe_read_ms.restype = C.c_int
-    L.agh_probe_variant_ms.argtypes = [vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_double)]
-    L.agh_probe_variant_ms.restype = C.c_int
+    if hasattr(L, "agh_probe_variant_ms"):      # diagnostics build only (make -C agrep_amd/csrc EXP=1)
+        L.agh_probe_variant_ms.argtypes = [vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_double)]
+        L.agh_probe_variant_ms.restype = C.c_int
     L.agh_scan_fd_range.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint, C.POINTER(Result),
                                     C.POINTER(Match), C.c_size_t]
     L.agh_scan_fd_range.restype = C.c_int

@@ -1914,17 +1914,10 @@ extern "C" int agh_corpus_fill_device(void *dev_out, uint64_t first_page, uint64
     return 0;
 }
 
-// Diagnostics: time one structural variant of the sweep (agh_exp.hip); exp < 0 = read probe.
-extern "C" int agh_probe_variant_ms(const void *dev_text, size_t len, void *stream, int exp,
-                                    double *ms);
-
-extern "C" int agh_probe_read_ms(const void *dev_text, size_t len, void *stream, double *ms)
-{
-    return agh_probe_variant_ms(dev_text, len, stream, -1, ms);
-}
-
-extern "C" int agh_probe_variant_ms(const void *dev_text, size_t len, void *stream, int exp,
-                                    double *ms)
+// Streaming-read ceiling of the sweep's access pattern (bench support).  With -DAGH_WITH_EXP
+// (make EXP=1) the library also carries the structural A/B variants of the sweep (agh_exp.hip)
+// behind agh_probe_variant_ms -- diagnostics, not part of the product ABI or its header.
+static int probe_ms(const void *dev_text, size_t len, void *stream, int exp, double *ms)
 {
     hipStream_t st = (hipStream_t)stream;
     uint32_t *d_c = nullptr;
@@ -1934,8 +1927,12 @@ extern "C" int agh_probe_variant_ms(const void *dev_text, size_t len, void *stre
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     HIP_TRY(hipEventRecord(a, st));
-    if (exp < 0) agh_launch_read_probe(dev_text, len, d_c, st);
-    else agh_launch_exp(exp, dev_text, len, d_c, st);
+#ifdef AGH_WITH_EXP
+    if (exp >= 0) agh_launch_exp(exp, dev_text, len, d_c, st);
+    else
+#endif
+        agh_launch_read_probe(dev_text, len, d_c, st);
+    (void)exp;
     HIP_TRY(hipEventRecord(b, st));
     HIP_TRY(hipStreamSynchronize(st));
     float f = 0;
@@ -1946,3 +1943,16 @@ extern "C" int agh_probe_variant_ms(const void *dev_text, size_t len, void *stre
     (void)hipFree(d_c);
     return 0;
 }
+
+extern "C" int agh_probe_read_ms(const void *dev_text, size_t len, void *stream, double *ms)
+{
+    return probe_ms(dev_text, len, stream, -1, ms);
+}
+
+#ifdef AGH_WITH_EXP
+extern "C" int agh_probe_variant_ms(const void *dev_text, size_t len, void *stream, int exp,
+                                    double *ms)
+{
+    return probe_ms(dev_text, len, stream, exp, ms);
+}
+#endif

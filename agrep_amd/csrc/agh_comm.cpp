@@ -11,6 +11,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <fcntl.h>
+#include <stdlib.h>
+#include <unistd.h>
+
 #include <mutex>
 
 #include "../../include/agrep_hip.h"
@@ -83,6 +87,31 @@ int need_rccl()
 }
 }   // namespace
 
+// RCCL 2.27 prints a version banner on STDOUT when the first communicator is created.  A scan
+// library must not write to its caller's stdout (agrep's stdout is the match list), so fd 1
+// points at /dev/null while a communicator is being created (AGH_RCCL_BANNER=1 keeps it).
+struct stdout_silencer {
+    int saved = -1;
+    stdout_silencer()
+    {
+        const char *e = getenv("AGH_RCCL_BANNER");
+        if (e && e[0] == '1') return;
+        fflush(stdout);                         // the caller's pending output goes where it belongs
+        const int nul = open("/dev/null", O_WRONLY);
+        if (nul < 0) return;
+        saved = dup(1);
+        if (saved >= 0) (void)dup2(nul, 1);
+        close(nul);
+    }
+    ~stdout_silencer()
+    {
+        if (saved < 0) return;
+        fflush(stdout);                         // the banner, if it was buffered
+        (void)dup2(saved, 1);
+        close(saved);
+    }
+};
+
 #define NCCL_TRY(expr)                                                                     \
     do {                                                                                   \
         ncclResult_t r__ = (expr);                                                         \
@@ -150,7 +179,11 @@ extern "C" agh_comm *agh_comm_init_rank(const unsigned char id[AGH_UNIQUE_ID_BYT
     c->nranks = nranks;
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
-    ncclResult_t r = R.CommInitRank(&c->comm, nranks, u, rank);
+    ncclResult_t r;
+    {
+        stdout_silencer quiet;
+        r = R.CommInitRank(&c->comm, nranks, u, rank);
+    }
     if (r != ncclSuccess) {
         cfail("ncclCommInitRank failed: %s", R.GetErrorString(r));
         delete c;
@@ -166,7 +199,11 @@ extern "C" int agh_comm_init_all(agh_comm **comms, int ndev, const int *devices)
     ncclComm_t raw[64];
     int devs[64];
     for (int i = 0; i < ndev; ++i) devs[i] = devices ? devices[i] : i;
-    NCCL_TRY(R.CommInitAll(raw, ndev, devs));
+    {
+        stdout_silencer quiet;
+        ncclResult_t r = R.CommInitAll(raw, ndev, devs);
+        if (r != ncclSuccess) return cfail("ncclCommInitAll failed: %s", R.GetErrorString(r));
+    }
     for (int i = 0; i < ndev; ++i) {
         comms[i] = new agh_comm();
         comms[i]->comm = raw[i];

@@ -229,8 +229,6 @@ int agh_corpus_fill_device(void *dev_out, uint64_t first_page, uint64_t n_pages,
 /* Streaming-read ceiling probe: reads len bytes with the same 16 B/lane access pattern as
  * the sweep kernel and no arithmetic beyond a checksum; returns the kernel time in ms. */
 int agh_probe_read_ms(const void *dev_text, size_t len, void *stream, double *ms);
-/* Diagnostics: the same for one structural variant of the sweep (csrc/agh_exp.hip). */
-int agh_probe_variant_ms(const void *dev_text, size_t len, void *stream, int exp, double *ms);
 
 const char *agh_last_error(void);
 const char *agh_version(void);
