@@ -1,4 +1,4 @@
-"""Attribute the gap between the read probe and the sweep: structural variants, interleaved."""
+"""(needs the diagnostics build: make -C agrep_amd/csrc EXP=1.)  Attribute the gap between the read probe and the sweep: structural variants, interleaved."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
