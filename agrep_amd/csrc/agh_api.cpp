@@ -146,6 +146,55 @@ struct agh_query {
 static bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
 static bool is_lower(int c) { return c >= 'a' && c <= 'z'; }
 
+// Bytes a pattern position accepts (its class, maskgen.c:86-135; one byte for a literal, a
+// case pair under -i).
+static std::vector<uint8_t> position_members(const agh_query *q, int p)
+{
+    std::vector<uint8_t> v;
+    for (int c = 0; c < 256; ++c)
+        if ((q->mask[c] >> p) & 1) v.push_back((uint8_t)c);
+    return v;
+}
+
+static bool is_case_pair(const std::vector<uint8_t> &v)
+{
+    return v.size() == 2 && is_upper(v[0]) && v[1] == v[0] + 32;
+}
+
+// Distinct bytes of a position as the sample filter sees them: with folding (OR 0x20 on both
+// sides) several members collapse into one.
+static std::vector<uint8_t> folded_members(const std::vector<uint8_t> &v, bool fold)
+{
+    bool seen[256] = {false};
+    std::vector<uint8_t> out;
+    for (uint8_t c : v) {
+        const uint8_t f = fold ? (uint8_t)(c | 0x20u) : c;
+        if (!seen[f]) { seen[f] = true; out.push_back(f); }
+    }
+    return out;
+}
+
+#define AGH_CLASS_MAX 40        // largest class a sampled position may have ([a-z], [0-9a-z] ...)
+#define AGH_GRAMS_MAX 2048      // expanded q-grams of one query (32 Ki table slots: <= 6 % full)
+
+// Every concrete q-gram of the pattern window [i, i + fq): the cartesian product of the
+// positions' (folded) members.  fn(sample) is called once per gram.
+template <typename F>
+static void for_each_gram(const agh_query *q, int i, bool fold, F fn)
+{
+    std::vector<uint8_t> mem[4];
+    for (int t = 0; t < q->fq; ++t) mem[t] = folded_members(position_members(q, i + t), fold);
+    size_t idx[4] = {0, 0, 0, 0};
+    for (;;) {
+        uint32_t s = 0;
+        for (int t = 0; t < q->fq; ++t) s |= (uint32_t)mem[t][idx[t]] << (8 * t);
+        fn((s & q->qmask) | q->fold);
+        int t = 0;
+        while (t < q->fq && ++idx[t] == mem[t].size()) idx[t++] = 0;
+        if (t == q->fq) break;
+    }
+}
+
 // Choose the q-gram sample shape: samples of q bytes at every multiple of h bytes.  Lossless
 // iff an occurrence (>= m-k text bytes) always contains >= k+1 whole samples, because k errors
 // can spoil at most k disjoint samples:  floor((m - k - q + 1) / h) >= k + 1.
@@ -155,50 +204,56 @@ static void choose_filter(agh_query *q)
     q->qmask = q->fold = 0;
     q->run_a = 0;
     q->run_len = 0;
-    // The samples come from the longest run of positions that are a single byte or an ASCII
-    // case pair.  For a literal pattern that is the whole pattern; for -w / -x / [class]
-    // patterns it is the literal core: an occurrence of the pattern with <= k errors contains
-    // an occurrence of the core with <= k errors, so the lemma applies with the core's length.
-    bool any_pair = false, any_single_letter = false;
-    int best_a = 0, best_len = 0, cur_a = 0, cur_len = 0;
-    for (int p = 0; p <= q->m; ++p) {
-        bool lit = false;
-        if (p < q->m) {
-            int members = 0, lo = -1;
-            for (int c = 0; c < 256; ++c)
-                if ((q->mask[c] >> p) & 1) { ++members; if (lo < 0) lo = c; }
-            if (members == 1) lit = true;
-            else if (members == 2 && is_upper(lo) && ((q->mask[lo + 32] >> p) & 1)) lit = true;
-        }
-        if (lit) {
-            if (!cur_len) cur_a = p;
-            ++cur_len;
-        } else {
-            if (cur_len > best_len) { best_len = cur_len; best_a = cur_a; }
-            cur_len = 0;
-        }
+    // The samples come from a run of positions with SMALL classes: a single byte, an ASCII case
+    // pair, or a class of at most AGH_CLASS_MAX bytes ([xyz], [0-9], [a-z]) whose q-grams are
+    // enumerated (a sample that lies inside an error-free stretch of an occurrence equals one
+    // concrete choice of the classes' members).  For -w / -x / <exact> / wide-class patterns the
+    // run is a core of the pattern: an occurrence of the pattern with <= k errors contains an
+    // occurrence of the core with <= k errors, so the lemma applies with the core's length.
+    // Among all runs the one that allows the cheapest sample shape wins, ties by fewer grams.
+    std::vector<size_t> width((size_t)q->m);
+    bool any_pair = false;
+    for (int p = 0; p < q->m; ++p) {
+        const std::vector<uint8_t> v = position_members(q, p);
+        if (is_case_pair(v)) any_pair = true;
     }
-    for (int p = best_a; p < best_a + best_len; ++p) {
-        int members = 0, lo = -1;
-        for (int c = 0; c < 256; ++c)
-            if ((q->mask[c] >> p) & 1) { ++members; if (lo < 0) lo = c; }
-        if (members == 2) any_pair = true;
-        else if (is_upper(lo) || is_lower(lo)) any_single_letter = true;
+    for (int p = 0; p < q->m; ++p) {
+        const std::vector<uint8_t> v = folded_members(position_members(q, p), any_pair);
+        width[(size_t)p] = v.size();
     }
-    (void)any_single_letter;    // folding a single-case letter only widens the candidate set
     static const int hs[3] = {16, 8, 4};
-    for (int i = 0; i < 3; ++i) {
-        int h = hs[i];
-        int qmax = best_len - q->k + 1 - h * (q->k + 1);
-        if (qmax > 4) qmax = 4;
-        if (qmax > h) qmax = h;
-        if (qmax >= 3) {
-            q->fq = qmax;
-            q->fh = h;
-            break;
+    int best_h = 0, best_q = 0, best_a = 0, best_len = 0;
+    double best_grams = 0;
+    for (int a = 0; a < q->m; ++a) {
+        for (int len = 3; a + len <= q->m; ++len) {
+            if (width[(size_t)(a + len - 1)] == 0 || width[(size_t)(a + len - 1)] > AGH_CLASS_MAX) break;
+            bool ok = true;
+            for (int p = a; p < a + len && ok; ++p) ok = width[(size_t)p] >= 1 && width[(size_t)p] <= AGH_CLASS_MAX;
+            if (!ok) break;
+            for (int i = 0; i < 3; ++i) {
+                const int h = hs[i];
+                int qmax = len - q->k + 1 - h * (q->k + 1);
+                if (qmax > 4) qmax = 4;
+                if (qmax > h) qmax = h;
+                if (qmax < 3) continue;
+                double grams = 0;
+                for (int g = a; g + qmax <= a + len; ++g) {
+                    double prod = 1;
+                    for (int t = 0; t < qmax; ++t) prod *= (double)width[(size_t)(g + t)];
+                    grams += prod;
+                }
+                if (grams > AGH_GRAMS_MAX) continue;
+                // larger stride first (fewer probes per 16 bytes), then longer samples, then fewer grams
+                const bool better = h > best_h || (h == best_h && qmax > best_q) ||
+                                    (h == best_h && qmax == best_q && grams < best_grams);
+                if (better) { best_h = h; best_q = qmax; best_a = a; best_len = len; best_grams = grams; }
+                break;                          // smaller strides of the same run are never better
+            }
         }
     }
-    if (!q->fq) return;
+    if (!best_h) return;
+    q->fq = best_q;
+    q->fh = best_h;
     q->run_a = best_a;
     q->run_len = best_len;
     q->qmask = q->fq == 4 ? 0xffffffffu : ((1u << (8 * q->fq)) - 1u);
@@ -231,23 +286,8 @@ static int upload_tables(agh_query *q)
     }
     if (q->fq) {
         std::vector<uint8_t> tab(AGH_FT_SIZE, 0);
-        // one representative byte per position (lower-case member when folding)
-        unsigned char rep[AGH_MAX_PATTERN];
-        for (int p = 0; p < q->m; ++p) {
-            int lo = -1;
-            for (int c = 0; c < 256; ++c)
-                if ((q->mask[c] >> p) & 1) { lo = c; break; }
-            rep[p] = (unsigned char)lo;
-        }
-        const int run_end = q->run_a + q->run_len;          // grams of the literal run only
-        for (int i = q->run_a; i + q->fq <= run_end; ++i) {
-            uint32_t s = 0;
-            for (int t = 0; t < q->fq; ++t) s |= (uint32_t)rep[i + t] << (8 * t);
-            s = (s & q->qmask) | q->fold;
-            tab[q->fq == 4 ? agh_sample_hash_q4(s) : agh_sample_hash_q3(s)] = 1;
-        }
-        HIP_TRY(hipMalloc((void **)&q->d_ftab, AGH_FT_SIZE));
-        HIP_TRY(hipMemcpy(q->d_ftab, tab.data(), AGH_FT_SIZE, hipMemcpyHostToDevice));
+        const bool fold = q->fold != 0;
+        const int run_end = q->run_a + q->run_len;          // grams of the sampled run only
         // Per hash slot: which gram sits there and where in the pattern it occurs -- the lean
         // verifier drops hash false positives before running the automaton and, knowing the
         // gram's offset o, walks [j-o-k, j-o+m+k) instead of the offset-blind window.
@@ -255,20 +295,22 @@ static int upload_tables(agh_query *q)
         //   (two different grams share the slot, or offsets too far apart) -> full window
         std::vector<uint64_t> gt(AGH_FT_SIZE, AGH_GT_AMBIGUOUS);
         std::vector<char> used(AGH_FT_SIZE, 0);
-        for (int i = q->run_a; i + q->fq <= run_end; ++i) {
-            uint32_t s = 0;
-            for (int t = 0; t < q->fq; ++t) s |= (uint32_t)rep[i + t] << (8 * t);
-            s = (s & q->qmask) | q->fold;
-            const uint32_t h = q->fq == 4 ? agh_sample_hash_q4(s) : agh_sample_hash_q3(s);
-            if (!used[h]) {
-                used[h] = 1;
-                gt[h] = (uint64_t)s | ((uint64_t)i << 32) | ((uint64_t)i << 40);
-            } else if (!(gt[h] & AGH_GT_AMBIGUOUS) && (uint32_t)gt[h] == s) {
-                gt[h] = (gt[h] & ~((uint64_t)0xff << 40)) | ((uint64_t)i << 40);   // last offset
-            } else {
-                gt[h] = AGH_GT_AMBIGUOUS;
-            }
-        }
+        for (int i = q->run_a; i + q->fq <= run_end; ++i)
+            for_each_gram(q, i, fold, [&](uint32_t s) {
+                const uint32_t h = q->fq == 4 ? agh_sample_hash_q4(s) : agh_sample_hash_q3(s);
+                tab[h] = 1;
+                if (!used[h]) {
+                    used[h] = 1;
+                    gt[h] = (uint64_t)s | ((uint64_t)i << 32) | ((uint64_t)i << 40);
+                } else if (!(gt[h] & AGH_GT_AMBIGUOUS) && (uint32_t)gt[h] == s) {
+                    if ((uint32_t)i > (uint32_t)((gt[h] >> 40) & 0xff))
+                        gt[h] = (gt[h] & ~((uint64_t)0xff << 40)) | ((uint64_t)i << 40);   // last offset
+                } else {
+                    gt[h] = AGH_GT_AMBIGUOUS;
+                }
+            });
+        HIP_TRY(hipMalloc((void **)&q->d_ftab, AGH_FT_SIZE));
+        HIP_TRY(hipMemcpy(q->d_ftab, tab.data(), AGH_FT_SIZE, hipMemcpyHostToDevice));
         q->gram_spread = 0;
         for (uint32_t h = 0; h < AGH_FT_SIZE; ++h) {
             if (!used[h] || (gt[h] & AGH_GT_AMBIGUOUS)) continue;

@@ -179,7 +179,7 @@ static int run_scan(agh_query *q, const struct text_src *src, const unsigned cha
             return shim_fail(agh_last_error());
         }
         /* does the text open with the delimiter?  (-d: asearch.c:79-84 starts counting at -1) */
-        if (DELIMITER && text_len >= (uint64_t)dlen) {
+        if (DELIMITER && text_len >= (uint64_t)dlen && ms[0].start > 0) {
             size_t got = 0;
             head.start = 0;
             head.end = (uint64_t)dlen;
@@ -187,29 +187,40 @@ static int run_scan(agh_query *q, const struct text_src *src, const unsigned cha
             if (agh_fetch_records(q, &head, 1, first, sizeof(first), &got) == 0 && got == (size_t)dlen)
                 lead_delim = memcmp(first, delim, (size_t)dlen) == 0;
         }
-        for (i = 0; i < res.n_stored && rc == 0; i++) {
-            const size_t wlen = (size_t)(wide[i].end - wide[i].start);
-            const size_t pre = (size_t)(ms[i].start - wide[i].start);        /* 0 or dlen */
-            const size_t body = (size_t)(ms[i].end - ms[i].start);
-            const size_t post = wlen - pre - body;
-            /* own copy: room for the delimiter the reference appends at end of input
-             * (asearch.c:87-91) and for the byte output() may look at behind it */
-            unsigned char *rec = (unsigned char *)malloc(wlen + (size_t)dlen + 2);
-            int i1 = 0, i2, j;
-            if (!rec) { rc = shim_fail("out of memory"); break; }
-            memcpy(rec, bytes + off, wlen);
-            if (post < (size_t)dlen) memcpy(rec + pre + body, delim, (size_t)dlen);
-            rec[pre + body + (size_t)dlen] = '\0';
-            i2 = (int)(pre + body) - 1;
-            j = (int)ms[i].index + 1 - lead_delim;      /* delimiters seen when the record closes */
-            CurrentByteOffset = (int)(ms[i].end + 1);
-            TRUNCATE = 0;
-            if (-1 == output(rec, i1, i2, j)) rc = -1;
-            free(rec);
-            off += wlen;
-            if ((LIMITOUTPUT > 0 && LIMITOUTPUT <= num_of_matched) ||
-                (LIMITPERFILE > 0 && LIMITPERFILE <= num_of_matched - prev_num_of_matched))
-                break;                                  /* asearch.c:171-175 */
+        /* What asearch.c hands to output(): the buffer holds the delimiter in front of the record
+         * (lasti points at it), the record, and the delimiter behind it; j = delimiters seen when
+         * the record closes.  File mode feeds a virtual '\n' first (buffer[Max_record-1],
+         * asearch.c:69-78): when the delimiter IS "\n" that byte closes an empty record, so j runs
+         * one ahead and even the first record has a delimiter in front of it; with any other
+         * delimiter the first record starts at the first text byte and, if the text opens with the
+         * delimiter, counting starts at -1 (asearch.c:79-84). */
+        {
+            const int virt = dlen == 1 && delim[0] == '\n';
+            for (i = 0; i < res.n_stored && rc == 0; i++) {
+                const size_t wlen = (size_t)(wide[i].end - wide[i].start);
+                const size_t pre = (size_t)(ms[i].start - wide[i].start);      /* 0 or dlen */
+                const size_t body = (size_t)(ms[i].end - ms[i].start);
+                const size_t post = wlen - pre - body;
+                const size_t vpre = (pre == 0 && virt) ? 1 : 0;                 /* the virtual '\n' */
+                unsigned char *rec = (unsigned char *)malloc(wlen + (size_t)dlen + 4);
+                int i2, j;
+                if (!rec) { rc = shim_fail("out of memory"); break; }
+                if (vpre) rec[0] = '\n';
+                memcpy(rec + vpre, bytes + off, wlen);
+                /* the delimiter the reference appends at end of input (asearch.c:87-91) */
+                if (post < (size_t)dlen) memcpy(rec + vpre + pre + body, delim, (size_t)dlen);
+                rec[vpre + pre + body + (size_t)dlen] = '\0';
+                i2 = (int)(vpre + pre + body) - 1;
+                j = (int)ms[i].index + 1 + virt - ((DELIMITER && lead_delim) ? 1 : 0);
+                CurrentByteOffset = (int)(ms[i].end + 1);
+                TRUNCATE = 0;
+                if (-1 == output(rec, 0, i2, j)) rc = -1;
+                free(rec);
+                off += wlen;
+                if ((LIMITOUTPUT > 0 && LIMITOUTPUT <= num_of_matched) ||
+                    (LIMITPERFILE > 0 && LIMITPERFILE <= num_of_matched - prev_num_of_matched))
+                    break;                              /* asearch.c:171-175 */
+            }
         }
         free(wide);
     }

@@ -584,3 +584,34 @@ def test_general_queries_take_the_filter_path(agh):
             assert res.engine == agh.ENGINE_FILTER
             assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want and lean.n_matched == want[0]
         q.close()
+
+
+def test_class_patterns_keep_the_sample_filter(agh):
+    """A [class] inside the pattern no longer sends the query to the full scan: the q-grams of
+    small classes are enumerated into the sample table (choose_filter / for_each_gram).  The
+    reference's own maskgen tables in, filter engine == full scan == oracle out."""
+    variants = (b"apprxximatematch", b"approximatematch", b"approxammatematch", b"approxmmatemmatch",
+                b"aprroximatematch", b"approxzmatematch", b"apprximatematch")
+    text = O.corpus(2048, seed=21, variants=variants, plant_period=9)[0].tobytes()
+    seen = 0
+    for case in _golden("pattern_language.json"):
+        if case["pattern"] not in ("appr[ox]ximatematch", "approx[a-m]matematch"):
+            continue
+        t = case["tables"]
+        M = t["D_endpos"].bit_length()
+        q = agh.Query.from_maskgen(t["Mask"], t["Init0"], t["Init1"], t["NO_ERR_MASK"], t["endposition"],
+                                   t["D_endpos"], M, b"\n", case["k"], t["AND"])
+        info = q.info()
+        assert info["filter_h"] > 0 and info["filter_q"] >= 3, (case["pattern"], info)
+        assert (info["m"] - case["k"] - info["filter_q"] + 1) // info["filter_h"] >= case["k"] + 1
+        want = O.asearch_tables(O.tables_from_golden(t, M), case["k"], text, cap=400000)
+        res, ms = q.scan_buffer(text, cap=400000)
+        full, ms_f = q.scan_buffer(text, cap=400000, flags=agh.FORCE_FULLSCAN)
+        lean, _ = q.scan_buffer(text, flags=agh.COUNT)
+        assert res.engine == agh.ENGINE_FILTER and full.engine == agh.ENGINE_FULLSCAN
+        assert want[0] > 1000
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want == (full.n_matched, [(s, e) for s, e, _ in ms_f])
+        assert lean.n_matched == want[0]
+        q.close()
+        seen += 1
+    assert seen == 2

@@ -1,0 +1,107 @@
+"""Link-level drop-in: oracle/_ref/agrep_gpu = the reference's UNMODIFIED front-end objects
+(option parsing, preprocess, maskgen, checksg, exec, output) linked with
+agrep_amd/host/ref_shim.c in place of bitap.o / sgrep.o / newmgrep.o / asearch.o / asearch1.o
+(oracle/Makefile target ref_gpu).  The same command lines through the all-CPU reference binary
+and through the GPU-engined one must print the same bytes and exit with the same status."""
+import os
+import subprocess
+
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(O.REF_DIR, "agrep")
+GPU = os.path.join(O.REF_DIR, "agrep_gpu")
+
+needs = pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(GPU)),
+                           reason="oracle/_ref/agrep and agrep_gpu not built (make -C oracle ref ref_gpu)")
+
+
+def _run(exe, args, stdin=None):
+    p = subprocess.run([exe] + args, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return p.returncode, p.stdout, p.stderr
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("shim")
+    out = []
+    for i, (pages, period) in enumerate(((24, 30), (8, 11), (4, 1000000))):
+        text, _ = O.corpus(pages, seed=100 + i, variants=O.VARIANTS_C2, plant_period=period)
+        p = d / ("f%d.txt" % i)
+        p.write_bytes(text.tobytes())
+        out.append(str(p))
+    return out
+
+
+def _same(args, files_):
+    rc_r, out_r, err_r = _run(REF, args + files_)
+    rc_g, out_g, err_g = _run(GPU, args + files_)
+    assert out_g == out_r, (args, out_g[:400], out_r[:400], err_g[:300])
+    assert rc_g == rc_r, (args, rc_g, rc_r, err_g[:300])
+
+
+@needs
+@pytest.mark.parametrize("args", [
+    # sgrep() seam (simple pattern): k > 0 and k = 0
+    ["-V0", "-2", "-c"], ["-2", "-c"], ["-V0", "-2"], ["-2"], ["-V0", "-1", "-l"], ["-2", "-l"],
+    ["-V0", "-2", "-h"], ["-V0", "-c"], ["-V0", "-s", "-2"], ["-V0", "-1"], ["-V0"],
+    # bitap() seam (maskgen tables): -i, -n, costs, k = 0 with -n
+    ["-V0", "-i", "-2"], ["-V0", "-i", "-n", "-2"], ["-V0", "-3", "-ci"], ["-V0", "-n"],
+    ["-V0", "-I2", "-c", "-2"], ["-V0", "-D2", "-S2", "-2"], ["-V0", "-n", "-8", "-c"],
+    ["-V0", "-i", "-2", "-l"], ["-V0", "-y", "-n", "-1"],
+])
+def test_reference_front_end_on_gpu_engines(files, args):
+    for fl in (files[:1], files):
+        _same(args + ["approximatematch"], fl)
+
+
+@needs
+@pytest.mark.parametrize("pattern,args", [
+    ("appro[xyz]imatematch", ["-V0", "-2"]),                # class -> maskgen tables
+    ("appro[a-z]imatematch", ["-V0", "-1", "-c"]),
+    ("approximate#match", ["-V0", "-c"]),                   # wildcard -> table engine
+    ("approx;match", ["-V0", "-c"]),                        # AND
+    ("zzzzzz,approximatematch", ["-V0", "-c"]),             # OR
+    ("<approx>imatematch", ["-V0", "-2", "-c"]),            # no errors inside <>
+    ("match", ["-V0", "-w", "-c", "-1"]),                   # -w with errors: maskgen path
+    ("approximatematch", ["-V0", "-w", "-n"]),
+    ("^the", ["-V0", "-c"]),                                # anchors
+    ("ing$", ["-V0", "-c", "-1"]),
+    ("approximatematch", ["-V0", "-v", "-i", "-c", "-2"]),  # -v on the asearch path
+])
+def test_pattern_language_through_the_shim(files, pattern, args):
+    for fl in (files[:1], files[:2]):
+        _same(args + [pattern], fl)
+
+
+@needs
+@pytest.mark.parametrize("delim", [";", "e ", "$$"])
+def test_delimiters_through_the_shim(files, tmp_path, delim):
+    text = open(files[1], "rb").read()[:60000].replace(b"\n\n", b"\n")
+    f = tmp_path / "d.txt"
+    f.write_bytes(text)
+    for args in (["-V0", "-d", delim, "-2", "-c"], ["-V0", "-d", delim, "-i", "-2"], ["-V0", "-d", delim, "-2"],
+                 ["-V0", "-d", delim, "-i", "-n", "-1"]):
+        _same(args + ["approximatematch"], [str(f)])
+
+
+@needs
+def test_pattern_file_through_the_shim(files, tmp_path):
+    pf = tmp_path / "pats.txt"
+    pf.write_bytes(b"approximatematch\naproximatematch\nzzzzqqqq\n")
+    for mode in (["-c"], ["-l"], []):
+        _same(["-V0"] + mode + ["-f", str(pf)], files)
+
+
+@needs
+def test_stdin_and_missing_file(files):
+    data = open(files[1], "rb").read()
+    for args in (["-V0", "-2", "-c", "approximatematch"], ["-V0", "-i", "-1", "approximatematch"]):
+        rc_r, out_r, _ = _run(REF, args, stdin=data)
+        rc_g, out_g, err_g = _run(GPU, args, stdin=data)
+        assert (rc_g, out_g) == (rc_r, out_r), (args, err_g[:300])
+    _same(["-V0", "-2", "-c", "approximatematch", "/nonexistent/file"], files[:1])
