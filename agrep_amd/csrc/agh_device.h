@@ -87,12 +87,20 @@ AGH_HD uint32_t agh_sample_hash_q4(uint32_t s)
     uint32_t p = t * 0x9E3779u;              // 24 x 24 -> low 32 bits (v_mul_u32_u24)
     return (p >> 14) & (AGH_FT_SIZE - 1u);
 }
-// 18-bit variants for the multi-pattern bit table (same multipliers, more result bits).
+// 18-bit variant for the multi-pattern bit table, probed at EVERY text position (16 probes per
+// 16 bytes), so every instruction counts: one shift + one v_mad_u32_u24 (the 24-bit multiply
+// ignores the top byte by itself; the shifted copy folds it back in through the addend).
+AGH_HD uint32_t agh_sample_prod18_q4(uint32_t s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(s, 0x9E3779u) + (s >> 13);
+#else
+    return (s & 0xffffffu) * 0x9E3779u + (s >> 13);
+#endif
+}
 AGH_HD uint32_t agh_sample_hash18_q4(uint32_t s)
 {
-    uint32_t t = (s ^ (s >> 11)) & 0xffffffu;
-    uint32_t p = t * 0x9E3779u;
-    return (p >> 14) & ((1u << AGH_MP_BITS) - 1u);
+    return (agh_sample_prod18_q4(s) >> 14) & ((1u << AGH_MP_BITS) - 1u);
 }
 // second, independent 18-bit hash of a 4-byte prefix: the multi-pattern bit table is a Bloom
 // filter with two probes when q == 4 (the second probe runs only on first-level hits)

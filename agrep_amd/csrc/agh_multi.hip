@@ -29,10 +29,14 @@ template <int MODE>   // bit 0: fold case, bit 1: q == 4, bit 2: lean (no census
 __device__ __forceinline__ uint32_t probe_bit(uint32_t g, const agh_dev_query &q,
                                               const uint32_t *tab)
 {
-    uint32_t h;
-    if (MODE & 2) h = agh_sample_hash18_q4((MODE & 1) ? (g | q.fold) : g);
-    else h = agh_sample_hash18_q3((MODE & 1) ? ((g & q.qmask) | q.fold) : (g & q.qmask));
-    return (tab[h >> 5] >> (h & 31u)) & 1u;
+    // the table read as bytes: byte index = hash >> 3 (one v_bfe of the product), bit = hash & 7
+    const uint8_t *tab8 = reinterpret_cast<const uint8_t *>(tab);
+    if (MODE & 2) {
+        const uint32_t p = agh_sample_prod18_q4((MODE & 1) ? (g | q.fold) : g);
+        return ((uint32_t)tab8[p >> 17] >> ((p >> 14) & 7u)) & 1u;
+    }
+    const uint32_t h = agh_sample_hash18_q3((MODE & 1) ? ((g & q.qmask) | q.fold) : (g & q.qmask));
+    return ((uint32_t)tab8[h >> 3] >> (h & 7u)) & 1u;
 }
 
 // all 16 byte positions of one 16-byte chunk (nx = the 4 bytes that follow it)

@@ -114,6 +114,41 @@ static int print_filename(void)
     return 0;
 }
 
+/* What asearch.c hands to output() (asearch.c:162: output(buffer, lasti, i - D_length - 1, j)): the
+ * buffer holds the delimiter in front of the record (lasti points at it), the record, and the
+ * delimiter behind it; j = delimiters seen when the record closes.  File mode feeds a virtual
+ * '\n' first (buffer[Max_record-1], asearch.c:69-78): when the delimiter IS "\n" that byte closes
+ * an empty record, so j runs one ahead and even the first record has a delimiter in front of it;
+ * with any other delimiter the first record starts at the first text byte and, if the text opens
+ * with the delimiter, counting starts at -1 (asearch.c:79-84).
+ * wide = text[start - pre, end + post): pre is 0 or dlen, post <= dlen.  Returns 0, -1 (error) or
+ * 1 (an output limit of -L was reached: stop, asearch.c:171-175). */
+static int emit_one(const unsigned char *wide, size_t wlen, size_t pre, size_t body, uint64_t index,
+                    uint64_t end_off, const unsigned char *delim, int dlen, int lead_delim)
+{
+    const int virt = dlen == 1 && delim[0] == '\n';
+    const size_t post = wlen - pre - body;
+    const size_t vpre = (pre == 0 && virt) ? 1 : 0;     /* the virtual '\n' */
+    unsigned char *rec = (unsigned char *)malloc(wlen + (size_t)dlen + 4);
+    int i2, j, rc = 0;
+    if (!rec) return shim_fail("out of memory");
+    if (vpre) rec[0] = '\n';
+    memcpy(rec + vpre, wide, wlen);
+    /* the delimiter the reference appends at end of input (asearch.c:87-91) */
+    if (post < (size_t)dlen) memcpy(rec + vpre + pre + body, delim, (size_t)dlen);
+    rec[vpre + pre + body + (size_t)dlen] = '\0';
+    i2 = (int)(vpre + pre + body) - 1;
+    j = (int)index + 1 + virt - ((DELIMITER && lead_delim) ? 1 : 0);
+    CurrentByteOffset = (int)(end_off + 1);
+    TRUNCATE = 0;
+    if (-1 == output(rec, 0, i2, j)) rc = -1;
+    free(rec);
+    if (rc == 0 && ((LIMITOUTPUT > 0 && LIMITOUTPUT <= num_of_matched) ||
+                    (LIMITPERFILE > 0 && LIMITPERFILE <= num_of_matched - prev_num_of_matched)))
+        rc = 1;
+    return rc;
+}
+
 /* ---- one scan: count / -l / records through output() ------------------------------------ */
 struct text_src {
     int fd;                     /* >= 0: file / pipe; -1: memory */
@@ -187,40 +222,12 @@ static int run_scan(agh_query *q, const struct text_src *src, const unsigned cha
             if (agh_fetch_records(q, &head, 1, first, sizeof(first), &got) == 0 && got == (size_t)dlen)
                 lead_delim = memcmp(first, delim, (size_t)dlen) == 0;
         }
-        /* What asearch.c hands to output(): the buffer holds the delimiter in front of the record
-         * (lasti points at it), the record, and the delimiter behind it; j = delimiters seen when
-         * the record closes.  File mode feeds a virtual '\n' first (buffer[Max_record-1],
-         * asearch.c:69-78): when the delimiter IS "\n" that byte closes an empty record, so j runs
-         * one ahead and even the first record has a delimiter in front of it; with any other
-         * delimiter the first record starts at the first text byte and, if the text opens with the
-         * delimiter, counting starts at -1 (asearch.c:79-84). */
-        {
-            const int virt = dlen == 1 && delim[0] == '\n';
-            for (i = 0; i < res.n_stored && rc == 0; i++) {
-                const size_t wlen = (size_t)(wide[i].end - wide[i].start);
-                const size_t pre = (size_t)(ms[i].start - wide[i].start);      /* 0 or dlen */
-                const size_t body = (size_t)(ms[i].end - ms[i].start);
-                const size_t post = wlen - pre - body;
-                const size_t vpre = (pre == 0 && virt) ? 1 : 0;                 /* the virtual '\n' */
-                unsigned char *rec = (unsigned char *)malloc(wlen + (size_t)dlen + 4);
-                int i2, j;
-                if (!rec) { rc = shim_fail("out of memory"); break; }
-                if (vpre) rec[0] = '\n';
-                memcpy(rec + vpre, bytes + off, wlen);
-                /* the delimiter the reference appends at end of input (asearch.c:87-91) */
-                if (post < (size_t)dlen) memcpy(rec + vpre + pre + body, delim, (size_t)dlen);
-                rec[vpre + pre + body + (size_t)dlen] = '\0';
-                i2 = (int)(vpre + pre + body) - 1;
-                j = (int)ms[i].index + 1 + virt - ((DELIMITER && lead_delim) ? 1 : 0);
-                CurrentByteOffset = (int)(ms[i].end + 1);
-                TRUNCATE = 0;
-                if (-1 == output(rec, 0, i2, j)) rc = -1;
-                free(rec);
-                off += wlen;
-                if ((LIMITOUTPUT > 0 && LIMITOUTPUT <= num_of_matched) ||
-                    (LIMITPERFILE > 0 && LIMITPERFILE <= num_of_matched - prev_num_of_matched))
-                    break;                              /* asearch.c:171-175 */
-            }
+        for (i = 0; i < res.n_stored && rc == 0; i++) {
+            const size_t wlen = (size_t)(wide[i].end - wide[i].start);
+            rc = emit_one(bytes + off, wlen, (size_t)(ms[i].start - wide[i].start),
+                          (size_t)(ms[i].end - ms[i].start), ms[i].index, ms[i].end, delim, dlen, lead_delim);
+            off += wlen;
+            if (rc == 1) { rc = 0; break; }             /* -L limits reached */
         }
         free(wide);
     }
@@ -418,7 +425,94 @@ int prepf(int mfp, unsigned char *mbuf, int mlen)
     return 0;
 }
 
-int mgrep(int fd)
+/* Boolean patterns: agrep_search turns "a;b" / "a,b" into a multi-pattern search whose terminals
+ * come through prepf() and whose operator arrives as mgrep()'s second argument (asplit.c, the call
+ * at agrep.c:3357: mgrep(fd, AParse)).  OR = any terminal = the multi-pattern query.  AND = every
+ * terminal somewhere in the record (newmgrep.c:903-905): one exact scan per terminal, the record
+ * lists intersected here.  Parse TREES (parentheses, mixed operators) stay with the CPU. */
+#define AND_EXP 0x1             /* agrep.h:144 */
+extern int AComplexBoolean;
+
+static int mgrep_all_terminals(int fd, const unsigned char *delim, int dlen)
+{
+    struct text_src src;
+    unsigned char *own = NULL;
+    const unsigned char *text;
+    size_t len = 0, cap = 0;
+    agh_match *cur = NULL, *ms = NULL;
+    size_t ncur = 0;
+    int t, rc = 0, lead_delim;
+    text_of(fd, &src);
+    if (fd >= 0) {                                      /* every terminal scans the same bytes */
+        for (;;) {
+            ssize_t r;
+            if (len == cap) {
+                cap = cap ? cap * 2 : (1u << 20);
+                own = (unsigned char *)realloc(own, cap);
+                if (!own) return shim_fail("out of memory");
+            }
+            r = read(fd, own + len, cap - len);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) break;
+            len += (size_t)r;
+        }
+        text = own;
+    } else {
+        text = src.mem;
+        len = src.mem_len;
+    }
+    for (t = 0; t < g_mn && rc == 0; t++) {
+        agh_query *q = agh_query_literal(g_mp[t], g_ml[t], 0, NOUPPER, delim, dlen);
+        agh_result res;
+        size_t mcap = 65536, a, b, w;
+        if (!q) { rc = shim_fail(agh_last_error()); break; }
+        for (;;) {
+            free(ms);
+            ms = (agh_match *)malloc(mcap * sizeof(*ms));
+            if (!ms || agh_scan_buffer(q, text, len, 0, &res, ms, mcap)) { rc = shim_fail(ms ? agh_last_error() : "out of memory"); break; }
+            if (!res.truncated) break;
+            mcap = (size_t)res.n_matched + 16;
+        }
+        agh_query_free(q);
+        if (rc) break;
+        if (t == 0) {
+            cur = ms;
+            ncur = (size_t)res.n_stored;
+            ms = NULL;
+        } else {                                        /* both lists are in file order */
+            for (a = b = w = 0; a < ncur && b < (size_t)res.n_stored;) {
+                if (cur[a].start == ms[b].start) { cur[w++] = cur[a]; a++; b++; }
+                else if (cur[a].start < ms[b].start) a++;
+                else b++;
+            }
+            ncur = w;
+        }
+    }
+    free(ms);
+    if (rc == 0) {
+        if (COUNT) {
+            num_of_matched += (int)ncur;
+        } else if (FILENAMEONLY && (NEW_FILE || !POST_FILTER)) {
+            if (ncur) rc = print_filename();
+        } else {
+            size_t i;
+            lead_delim = DELIMITER && len >= (size_t)dlen && memcmp(text, delim, (size_t)dlen) == 0;
+            for (i = 0; i < ncur && rc == 0; i++) {
+                const uint64_t ws = cur[i].start >= (uint64_t)dlen ? cur[i].start - (uint64_t)dlen : 0;
+                const uint64_t we = cur[i].end + (uint64_t)dlen <= len ? cur[i].end + (uint64_t)dlen : len;
+                rc = emit_one(text + ws, (size_t)(we - ws), (size_t)(cur[i].start - ws),
+                              (size_t)(cur[i].end - cur[i].start), cur[i].index, cur[i].end, delim, dlen,
+                              lead_delim);
+                if (rc == 1) { rc = 0; break; }
+            }
+        }
+    }
+    free(cur);
+    free(own);
+    return rc;
+}
+
+int mgrep(int fd, void *AParse)
 {
     const unsigned char *delim = (const unsigned char *)"\n";
     int dlen = 1;
@@ -429,6 +523,12 @@ int mgrep(int fd)
     if (DELIMITER) {
         delim = D_pattern;
         dlen = D_length;
+    }
+    if (AParse != NULL) {
+        if (AComplexBoolean)
+            return shim_fail("boolean patterns with parentheses / mixed operators are not served by the GPU engines");
+        if (INVERSE) return shim_fail("-v with a boolean pattern is not served by the GPU engines");
+        if ((long)AParse & AND_EXP) return mgrep_all_terminals(fd, delim, dlen);
     }
     if (!g_mq || g_mq_i != NOUPPER || g_mq_dlen != dlen || memcmp(delim, g_mq_delim, (size_t)dlen)) {
         if (g_mq) agh_query_free(g_mq);

@@ -64,7 +64,10 @@ def test_reference_front_end_on_gpu_engines(files, args):
     ("appro[xyz]imatematch", ["-V0", "-2"]),                # class -> maskgen tables
     ("appro[a-z]imatematch", ["-V0", "-1", "-c"]),
     ("approximate#match", ["-V0", "-c"]),                   # wildcard -> table engine
-    ("approx;match", ["-V0", "-c"]),                        # AND
+    ("approx;match", ["-V0", "-c"]),                        # AND: terminals through prepf/mgrep
+    ("approx;match", ["-V0"]),
+    ("approx;match", ["-V0", "-1", "-c"]),                  # AND with errors: maskgen's AND tables
+    ("zzzzzz,approx", ["-V0", "-l"]),
     ("zzzzzz,approximatematch", ["-V0", "-c"]),             # OR
     ("<approx>imatematch", ["-V0", "-2", "-c"]),            # no errors inside <>
     ("match", ["-V0", "-w", "-c", "-1"]),                   # -w with errors: maskgen path
@@ -81,11 +84,21 @@ def test_pattern_language_through_the_shim(files, pattern, args):
 @needs
 @pytest.mark.parametrize("delim", [";", "e ", "$$"])
 def test_delimiters_through_the_shim(files, tmp_path, delim):
-    text = open(files[1], "rb").read()[:60000].replace(b"\n\n", b"\n")
+    """-d: records separated by the delimiter, printed with it in front (OUTTAIL off) -- placement,
+    -n numbering and the leading-delimiter rule are output()'s, the record set is the GPU's.
+    The sgrep path's -c double-counts a record with two occurrences (quirk Q4, sgrep.c:1187-1193;
+    not reproduced), so its count is compared only where every record holds one occurrence."""
+    text = open(files[1], "rb").read()[:60000]
+    raw = {";": b";", "e ": b"e ", "$$": b"\n\n"}[delim]
+    if delim != "e ":
+        text = text.replace(b"\n", raw)               # one occurrence per record, as with newlines
     f = tmp_path / "d.txt"
     f.write_bytes(text)
-    for args in (["-V0", "-d", delim, "-2", "-c"], ["-V0", "-d", delim, "-i", "-2"], ["-V0", "-d", delim, "-2"],
-                 ["-V0", "-d", delim, "-i", "-n", "-1"]):
+    matrix = [["-V0", "-d", delim, "-i", "-2", "-c"], ["-V0", "-d", delim, "-i", "-2"], ["-V0", "-d", delim, "-2"],
+              ["-V0", "-d", delim, "-i", "-n", "-1"], ["-V0", "-d", delim, "-1", "-l"]]
+    if delim != "e ":
+        matrix.append(["-V0", "-d", delim, "-2", "-c"])
+    for args in matrix:
         _same(args + ["approximatematch"], [str(f)])
 
 
