@@ -21,10 +21,13 @@
 // q-gram filter table: one byte per hash bucket, resident in LDS (32 KiB / workgroup).
 #define AGH_FT_BITS 15
 #define AGH_FT_SIZE (1u << AGH_FT_BITS)
-// Full-scan kernel: bytes per lane chunk and lanes per workgroup (tile = 64 KiB in LDS).
-#define AGH_FS_CHUNK 256u
+// Full-scan kernel: bytes per lane chunk (= one census strip), bytes per lane per refill of the
+// per-wave LDS ring, the ring's row stride (+16 B keeps the b128 reads conflict-free), lanes per
+// workgroup.
+#define AGH_FS_CHUNK 1024u
+#define AGH_FS_ROUND 64u
+#define AGH_FS_ROW (AGH_FS_ROUND + 16u)
 #define AGH_FS_THREADS 256u
-#define AGH_FS_SLOT (AGH_FS_CHUNK + 16u)   // LDS stride per chunk: +16 B keeps b128 reads conflict-free
 
 enum agh_counter {
     AGH_C_CAND = 0,      // candidate windows emitted by the filter

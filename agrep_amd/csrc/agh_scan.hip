@@ -86,6 +86,17 @@ __device__ __forceinline__ void fullscan_piece(uint4 v, const WT *lmask, WT fina
 }
 
 // GEN: the general automaton (non-unit costs / <exact> segments) instead of the unit-cost one.
+//
+// Data feeding.  The automaton is serial over bytes, so the parallelism is one CHUNK per lane
+// (AGH_FS_CHUNK = 1 KiB = one census strip; a wave owns a 64 KiB tile), and every lane needs ITS
+// next bytes while a coalesced load hands consecutive bytes to consecutive lanes.  The transpose
+// goes through a small per-wave LDS ring: each round the wave gathers the next 64 bytes of all 64
+// chunks with four dwordx4 loads (4 lanes x 16 B per chunk: 64-byte segments, every text byte
+// fetched once), writes them into the ring, and every lane reads back its own 64 bytes (row
+// stride 80 B: conflict-free b128 reads).  The next round's loads are in flight while the current
+// 64 bytes run through the automaton.  5 KiB of LDS per wave -> 7 workgroups per CU instead of
+// the 2 a 64 KiB tile allowed, and the warm-up replay (m+k+1 bytes of halo per chunk)
+// is 8 % of a 1 KiB chunk instead of 31 % of a 256-byte one.
 template <typename WT, int K, bool MB, bool GEN>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q,
@@ -93,18 +104,18 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
     const uint32_t *__restrict__ wave_prefix, uint32_t n_strips, agh_marks mk,
     const uint64_t *__restrict__ dbm)
 {
-    // slot 0 = the 256 bytes in front of the tile (warm-up halo), slots 1..256 = lane chunks
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    WT *lmask = reinterpret_cast<WT *>(lds);
-    uint8_t *tile = lds + 256 * sizeof(WT);
+    __shared__ WT lmask[256];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * WAVE * AGH_FS_ROW];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
     __syncthreads();
 
-    const uint64_t tile_bytes = (uint64_t)AGH_FS_THREADS * AGH_FS_CHUNK;
+    const int lane = lane_id();
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    uint8_t *ring = ring_all + wib * (WAVE * AGH_FS_ROW);
+    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_FS_CHUNK;
     const uint64_t n_tiles = (n + tile_bytes - 1) / tile_bytes;
     const uint32_t total_delims = mk.counters[AGH_C_NDELIM];
     const WT finalbit = (WT)1 << (q.m - 1);
-    const uint32_t dd = q.delim * 0x01010101u;
     const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
     const uint64_t n16 = (n + 15) & ~(uint64_t)15;
     const uint32_t warm = ((uint32_t)(q.m + q.k + 1) + 15u) & ~15u;   // <= 80 bytes
@@ -114,107 +125,106 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
     RF.reset();
     const uint32_t rf_hit = RF.template step_q<GEN>(lmask[q.delim], finalbit, q) ? 1u : 0u;
 
-    for (uint64_t tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
-        const uint64_t t0 = tix * tile_bytes;
-        __syncthreads();
-        // cooperative, coalesced global -> LDS of 257 chunks (halo + tile), 16 B pieces
-        for (uint32_t pc = threadIdx.x; pc < (AGH_FS_THREADS + 1) * (AGH_FS_CHUNK / 16);
-             pc += AGH_FS_THREADS) {
-            const uint32_t slot = pc / (AGH_FS_CHUNK / 16), sub = pc % (AGH_FS_CHUNK / 16);
-            const int64_t g = (int64_t)t0 - (int64_t)AGH_FS_CHUNK + (int64_t)pc * 16;
-            uint4 v = make_uint4(fill4, fill4, fill4, fill4);
-            if (g >= 0 && (uint64_t)g < n16) v = ld_stream(reinterpret_cast<const uint4 *>(text + g));
-            *reinterpret_cast<uint4 *>(tile + slot * AGH_FS_SLOT + sub * 16) = v;
-        }
-        __syncthreads();
+    // my part of the cooperative gather: 16 bytes of chunk (lane / 4 + 16 i), i = 0..3
+    const uint32_t seg_lo = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
+    uint8_t *ring_w = ring + seg_lo * AGH_FS_ROW + part * 16u;
+    const uint8_t *ring_r = ring + (uint32_t)lane * AGH_FS_ROW;
 
-        const uint64_t cs = t0 + (uint64_t)threadIdx.x * AGH_FS_CHUNK;
-        const uint8_t *mine = tile + (threadIdx.x + 1) * AGH_FS_SLOT;
-        uint32_t my_delims = 0;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (AGH_FS_THREADS / WAVE) + wib; tile < n_tiles;
+         tile += (uint64_t)gridDim.x * (AGH_FS_THREADS / WAVE)) {
+        const uint64_t t0 = tile * tile_bytes;
+        const uint64_t cs = t0 + (uint64_t)lane * AGH_FS_CHUNK;
+        const bool mine = cs < n;
         uint64_t ce = cs + AGH_FS_CHUNK;
         if (ce > n) ce = n;
-        if (cs < n && MB) {
-            my_delims = dbm_count(dbm, cs, ce);
-        } else if (cs < n) {
-            const uint32_t len = (uint32_t)(ce - cs);
-            for (uint32_t i = 0; i < (len >> 4); ++i)
-                my_delims += delims_in(*reinterpret_cast<const uint4 *>(mine + i * 16), dd);
-            if (len & 15u)
-                my_delims += delims_in(
-                    mask_tail(*reinterpret_cast<const uint4 *>(mine + (len & ~15u)),
-                              (int)(len & 15u), fill4), dd);
-        }
-        // delimiters of the preceding chunks of my 1 KiB strip (4 lanes per strip)
-        uint32_t before = 0;
-        {
-            const int l4 = (int)(threadIdx.x & 3u);
-            uint32_t v1 = (uint32_t)__shfl_up((int)my_delims, 1, 4);
-            uint32_t v2 = (uint32_t)__shfl_up((int)my_delims, 2, 4);
-            uint32_t v3 = (uint32_t)__shfl_up((int)my_delims, 3, 4);
-            if (l4 >= 1) before += v1;
-            if (l4 >= 2) before += v2;
-            if (l4 >= 3) before += v3;
-        }
-        if (cs >= n) continue;
+        const uint32_t len = mine ? (uint32_t)(ce - cs) : 0u;
+        auto gather = [&](uint32_t r, uint4 (&g)[4]) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint64_t a = t0 + (uint64_t)(seg_lo + 16u * i) * AGH_FS_CHUNK + r * AGH_FS_ROUND + part * 16u;
+                g[i] = a < n16 ? ld_stream(reinterpret_cast<const uint4 *>(text + a))
+                               : make_uint4(fill4, fill4, fill4, fill4);
+            }
+        };
+        uint4 g[4];
+        gather(0, g);
 
-        const uint64_t strip = cs >> AGH_STRIP_SHIFT;
-        uint32_t rec = (strip < n_strips)
-                           ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] + before
-                           : total_delims;
-
+        uint32_t rec = 0;
         Automaton<WT, K> A;
         A.reset();
         uint32_t seen = 0;
-        if (cs == 0) {
-            A.template step_q<GEN>(lmask[q.head_byte], finalbit, q); // asearch.c:69-78
-        } else {
-            // rebuild the state from the m+k+1 (rounded to 16) bytes in front of the chunk
-            const uint8_t *halo = tile + threadIdx.x * AGH_FS_SLOT + (AGH_FS_CHUNK - warm);
-            for (uint32_t t = 0; t < warm / 16; ++t) {
-                uint32_t h16 = 0, d16 = 0;
-                if (MB) d16 = (uint32_t)dbm_bits64(dbm, cs - warm + 16u * t) & 0xffffu;
-                fullscan_piece<WT, K, MB, GEN>(*reinterpret_cast<const uint4 *>(halo + 16 * t),
-                                               lmask, finalbit, q, RF, rf_hit, A, seen, h16, d16);
+        if (mine) {
+            const uint64_t strip = cs >> AGH_STRIP_SHIFT;       // chunk == strip
+            rec = strip < n_strips ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] : total_delims;
+            if (cs == 0) {
+                A.template step_q<GEN>(lmask[q.head_byte], finalbit, q); // asearch.c:69-78
+            } else {
+                // rebuild the state from the m+k+1 (rounded to 16) bytes in front of the chunk
+                for (uint32_t t = 0; t < warm / 16; ++t) {
+                    uint32_t h16 = 0, d16 = 0;
+                    if (MB) d16 = (uint32_t)dbm_bits64(dbm, cs - warm + 16u * t) & 0xffffu;
+                    fullscan_piece<WT, K, MB, GEN>(
+                        *reinterpret_cast<const uint4 *>(text + cs - warm + 16u * t), lmask, finalbit, q,
+                        RF, rf_hit, A, seen, h16, d16);
+                }
+                seen = 0;                       // matches before cs belong to the previous lane
             }
-            seen = 0;                           // matches before cs belong to the previous lane
         }
-        const uint32_t len = (uint32_t)(ce - cs);
-        const uint32_t full = len >> 4;
-        for (uint32_t t = 0; t < full; ++t) {
-            uint32_t h16 = 0, d16 = 0;
-            if (MB) d16 = (uint32_t)dbm_bits64(dbm, cs + 16u * t) & 0xffffu;
-            fullscan_piece<WT, K, MB, GEN>(*reinterpret_cast<const uint4 *>(mine + 16 * t), lmask,
-                                           finalbit, q, RF, rf_hit, A, seen, h16, d16);
-            uint32_t ev = h16 | (rf_hit ? d16 : 0u);
-            while (ev) {                        // rare: a record matched in this piece
-                const uint32_t b = (uint32_t)__ffs((int)ev) - 1u;
-                ev &= ev - 1u;
-                const uint32_t below = (uint32_t)__popc(d16 & ((1u << b) - 1u));
-                if ((h16 >> b) & 1u) mark_record(mk, rec + below, cs + 16u * t + b);
-                if (rf_hit && ((d16 >> b) & 1u)) mark_record(mk, rec + below + 1u, cs + 16u * t + b + 1u);
-            }
-            rec += (uint32_t)__popc(d16);
-        }
-        bool seenb = seen != 0;
-        for (uint32_t i = full * 16; i < len; ++i) {     // the last, partial piece of the text
-            const uint32_t c = mine[i];
-            bool hit = A.template step_q<GEN>(lmask[c], finalbit, q);
-            if (hit && !seenb) {
-                seenb = true;
-                mark_record(mk, rec, cs + i);
-            }
-            if (MB ? dbm_bit(dbm, cs + i) != 0 : c == q.delim) {
-                A.reset();
-                ++rec;
-                seenb = false;
-                if (A.template step_q<GEN>(lmask[c], finalbit, q)) {
-                    seenb = true;
-                    mark_record(mk, rec, cs + i + 1);
+        bool seenb = false;
+        for (uint32_t r = 0; r < AGH_FS_CHUNK / AGH_FS_ROUND; ++r) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i)
+                *reinterpret_cast<uint4 *>(ring_w + 16u * i * AGH_FS_ROW) = g[i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the whole wave's rows are in
+            __builtin_amdgcn_wave_barrier();
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const uint4 *>(ring_r + 16u * p);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next round overwrites
+            __builtin_amdgcn_wave_barrier();
+            if (r + 1 < AGH_FS_CHUNK / AGH_FS_ROUND) gather(r + 1, g);   // in flight during the walk
+#pragma unroll
+            for (uint32_t p = 0; p < 4; ++p) {
+                const uint32_t off = r * AGH_FS_ROUND + 16u * p;
+                if (off + 16u <= len) {
+                    uint32_t h16 = 0, d16 = 0;
+                    if (MB) d16 = (uint32_t)dbm_bits64(dbm, cs + off) & 0xffffu;
+                    fullscan_piece<WT, K, MB, GEN>(v[p], lmask, finalbit, q, RF, rf_hit, A, seen, h16, d16);
+                    uint32_t ev = h16 | (rf_hit ? d16 : 0u);
+                    while (ev) {                        // rare: a record matched in this piece
+                        const uint32_t b = (uint32_t)__ffs((int)ev) - 1u;
+                        ev &= ev - 1u;
+                        const uint32_t below = (uint32_t)__popc(d16 & ((1u << b) - 1u));
+                        if ((h16 >> b) & 1u) mark_record(mk, rec + below, cs + off + b);
+                        if (rf_hit && ((d16 >> b) & 1u)) mark_record(mk, rec + below + 1u, cs + off + b + 1u);
+                    }
+                    rec += (uint32_t)__popc(d16);
+                } else if (off < len) {                 // the last, partial piece of the text
+                    const uint32_t dws[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+                    seenb = seen != 0;
+                    for (uint32_t i = 0; off + i < len; ++i) {
+                        const uint32_t c = (dws[i >> 2] >> (8u * (i & 3u))) & 0xffu;
+                        const bool hit = A.template step_q<GEN>(lmask[c], finalbit, q);
+                        if (hit && !seenb) {
+                            seenb = true;
+                            mark_record(mk, rec, cs + off + i);
+                        }
+                        if (MB ? dbm_bit(dbm, cs + off + i) != 0 : c == q.delim) {
+                            A.reset();
+                            ++rec;
+                            seenb = false;
+                            if (A.template step_q<GEN>(lmask[c], finalbit, q)) {
+                                seenb = true;
+                                mark_record(mk, rec, cs + off + i + 1);
+                            }
+                        }
+                    }
+                    seen = seenb ? 1u : 0u;
                 }
             }
         }
-        if (ce == n && q.tail_virtual)          // asearch.c:87-91
-            feed_virtual_tail<WT, K, false, GEN>(text, n, q, lmask, dbm, A, seenb, rec, 0, mk);
+        if (mine && ce == n && q.tail_virtual)          // asearch.c:87-91
+            feed_virtual_tail<WT, K, false, GEN>(text, n, q, lmask, dbm, A, seen != 0, rec, 0, mk);
     }
 }
 
@@ -361,13 +371,13 @@ static void launch_verify_t(const agh_scan_args &a, hipStream_t st)
 template <typename WT, int K>
 static void launch_fullscan_t(const agh_scan_args &a, hipStream_t st)
 {
-    const uint64_t tile_bytes = (uint64_t)AGH_FS_THREADS * AGH_FS_CHUNK;
-    uint64_t n_tiles = (a.n + tile_bytes - 1) / tile_bytes;
+    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_FS_CHUNK;          // one wave, 64 KiB
+    const uint64_t n_tiles = (a.n + tile_bytes - 1) / tile_bytes;
     if (!n_tiles) return;
-    uint32_t blocks = n_tiles > 65536 ? 65536u : (uint32_t)n_tiles;
-    const size_t lds = 256 * sizeof(WT) + (size_t)(AGH_FS_THREADS + 1) * AGH_FS_SLOT;
+    const uint64_t want = (n_tiles + (AGH_FS_THREADS / WAVE) - 1) / (AGH_FS_THREADS / WAVE);
+    const uint32_t blocks = want > 16384 ? 16384u : (uint32_t)want;    // grid-stride beyond that
 #define AGH_FS_LAUNCH(MBV, GENV)                                                              \
-    hipLaunchKernelGGL((k_fullscan<WT, K, MBV, GENV>), dim3(blocks), dim3(AGH_FS_THREADS), lds,  \
+    hipLaunchKernelGGL((k_fullscan<WT, K, MBV, GENV>), dim3(blocks), dim3(AGH_FS_THREADS), 0,    \
                        st, (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask,                \
                        a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm)
     const bool mbv = a.q.dlen > 1, genv = a.general != 0;

@@ -39,7 +39,7 @@
 extern unsigned Mask[], Init[], Init1, NO_ERR_MASK, endposition, D_endpos;
 extern int AND, REGEX, JUMP, I, S, DD, INVERSE, NOUPPER, COUNT, FILENAMEONLY, SILENT, DELIMITER,
     OUTTAIL, LINENUM, WORDBOUND, WHOLELINE, LIMITOUTPUT, LIMITPERFILE, NEW_FILE, POST_FILTER,
-    EXITONERROR, CurrentByteOffset, TRUNCATE, D_length, CONSTANT;
+    EXITONERROR, CurrentByteOffset, TRUNCATE, D_length, CONSTANT, FIRSTOUTPUT;
 extern int num_of_matched, prev_num_of_matched;
 extern unsigned char D_pattern[], CurrentFileName[], Progname[];
 extern FILE *agrep_finalfp;
@@ -352,6 +352,8 @@ int sgrep(unsigned char *in_pat, int in_m, int fd, int D, int samepattern)
         memcpy(g_sq_delim, delim, (size_t)dlen);
         g_sq_m = m; g_sq_D = D; g_sq_i = NOUPPER; g_sq_dlen = dlen;
     }
+    /* s_output() (sgrep.c:1274-1483) has no "eat the first newline" step: keep output()'s off */
+    FIRSTOUTPUT = 0;
     text_of(fd, &src);
     return run_scan(g_sq, &src, delim, dlen);
 }
@@ -528,6 +530,7 @@ int mgrep(int fd, void *AParse)
         if (AComplexBoolean)
             return shim_fail("boolean patterns with parentheses / mixed operators are not served by the GPU engines");
         if (INVERSE) return shim_fail("-v with a boolean pattern is not served by the GPU engines");
+        FIRSTOUTPUT = 0;
         if ((long)AParse & AND_EXP) return mgrep_all_terminals(fd, delim, dlen);
     }
     if (!g_mq || g_mq_i != NOUPPER || g_mq_dlen != dlen || memcmp(delim, g_mq_delim, (size_t)dlen)) {
@@ -538,6 +541,7 @@ int mgrep(int fd, void *AParse)
         g_mq_dlen = dlen;
         memcpy(g_mq_delim, delim, (size_t)dlen);
     }
+    FIRSTOUTPUT = 0;                                    /* as in sgrep(): s_output's behaviour */
     text_of(fd, &src);
     return run_scan(g_mq, &src, delim, dlen);
 }
