@@ -140,7 +140,7 @@ struct agh_query {
     int npat = 0;
     void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_off = nullptr,
          *d_mp_pool = nullptr, *d_mp_owner = nullptr, *d_mp_po = nullptr, *d_mp_olen = nullptr,
-         *d_mp_omask = nullptr;
+         *d_mp_omask = nullptr, *d_mp_info = nullptr;
 };
 
 static bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
@@ -631,11 +631,18 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
         }
     }
     off[npc] = (uint32_t)pool.size();
+    pool.resize(pool.size() + 16, 0);           // the exact verifier reads 16 bytes at any entry
+    if (pool.size() >= (1u << 24)) return fail("pattern set too large (%zu bytes)", pool.size());
     for (uint32_t b = 0; b < NB; ++b) bstart[b + 1] += bstart[b];
+    std::vector<uint32_t> info(npc ? npc : 1, 0u);
     {
         std::vector<uint32_t> fill(bstart.begin(), bstart.end() - 1);
         for (int i = 0; i < npc; ++i)
-            if (usable[i]) items[fill[bucket_of[i]]++] = (uint32_t)i;
+            if (usable[i]) {
+                const uint32_t at = fill[bucket_of[i]]++;
+                items[at] = (uint32_t)i;
+                info[at] = (off[i] << 8) | (uint32_t)pcs[i].len;
+            }
     }
     // per-pattern position masks for the verifying automaton (as agh_query_literal builds them)
     std::vector<uint32_t> omask;
@@ -662,7 +669,8 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
         up(&q->d_mp_owner, piece_owner.data(), piece_owner.size() * 4) ||
         up(&q->d_mp_po, piece_po.data(), piece_po.size()) ||
         up(&q->d_mp_olen, owner_len.data(), owner_len.size()) ||
-        up(&q->d_mp_omask, omask.data(), omask.size() * 4))
+        up(&q->d_mp_omask, omask.data(), omask.size() * 4) ||
+        up(&q->d_mp_info, info.data(), info.size() * 4))
         return -1;
     return 0;
 }
@@ -758,6 +766,7 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_mp_po) (void)hipFree(q->d_mp_po);
     if (q->d_mp_olen) (void)hipFree(q->d_mp_olen);
     if (q->d_mp_omask) (void)hipFree(q->d_mp_omask);
+    if (q->d_mp_info) (void)hipFree(q->d_mp_info);
     if (q->d_counters) (void)hipFree(q->d_counters);
     if (q->d_chunk_totals) (void)hipFree(q->d_chunk_totals);
     if (q->h_counters) (void)hipHostFree(q->h_counters);
@@ -823,6 +832,7 @@ static agh_multi_dev multi_dev(const agh_query *q)
     m.piece_po = (const uint8_t *)q->d_mp_po;
     m.owner_len = (const uint8_t *)q->d_mp_olen;
     m.owner_mask = (const uint32_t *)q->d_mp_omask;
+    m.item_info = (const uint32_t *)q->d_mp_info;
     return m;
 }
 

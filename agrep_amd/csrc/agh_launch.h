@@ -99,6 +99,7 @@ struct agh_multi_dev {
     const uint8_t *piece_po;
     const uint8_t *owner_len;
     const uint32_t *owner_mask;
+    const uint32_t *item_info;     // (pool offset << 8) | length per bucket item
 };
 void agh_launch_sweep_multi(const agh_sweep_args &a, const agh_multi_dev &m, const agh_marks &mk,
                             bool inl, hipStream_t st);

@@ -21,6 +21,8 @@ struct agh_multi_tables {
     const uint8_t *piece_po;       // its offset inside that pattern
     const uint8_t *owner_len;      // pattern lengths (<= 32)
     const uint32_t *owner_mask;    // [pattern][256] position masks (bit p-1 = position p)
+    const uint32_t *item_info;     // per bucket item: (pool offset << 8) | length -- saves the exact
+                                   // verifier two dependent loads (bucket_items -> pat_off -> pool)
 };
 
 #define AGH_MP_WORDS ((1u << AGH_MP_BITS) / 32u)
@@ -99,27 +101,59 @@ __device__ __forceinline__ void emit_positions(uint32_t hits16, uint64_t strip, 
     }
 }
 
-// Does any pattern occur at text position j?  Walks the bucket of patterns sharing the prefix.
+// ASCII upper -> lower in four bytes at once (newmgrep.c: tr[] folds case under -i).
+__device__ __forceinline__ uint32_t swar_lower(uint32_t t)
+{
+    const uint32_t x = t & 0x7f7f7f7fu;
+    const uint32_t ge = x + 0x3f3f3f3fu;            // bit 7 of a byte <=> byte >= 'A'
+    const uint32_t gt = x + 0x25252525u;            // bit 7 <=> byte > 'Z'
+    return t | (((ge & ~gt & ~t) & 0x80808080u) >> 2);
+}
+
+// Does any pattern occur at text position j?  Walks the bucket of patterns sharing the prefix;
+// the text window is fetched once (16 unaligned bytes), patterns of up to 16 bytes are compared
+// as four masked dwords (the pool is padded so that 16 bytes can always be read).
 __device__ __forceinline__ bool multi_match_at(const uint8_t *__restrict__ text, uint64_t n,
                                                const agh_dev_query &q, const agh_multi_tables &mt,
                                                uint64_t j)
 {
-    const uint32_t fold = q.fold ? 0x20u : 0u;
-    uint32_t g = 0;                              // the q-byte prefix at j
-    for (uint32_t t = 0; t < (uint32_t)q.fq && j + t < n; ++t) g |= (uint32_t)text[j + t] << (8 * t);
-    g = (g & q.qmask) | q.fold;
+    const bool fold = q.fold != 0;
+    const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    uint32_t tw[4];
+    if (j + 16 <= n16) {
+        const u32x4_u v = *reinterpret_cast<const u32x4_u *>(text + j);
+        tw[0] = v[0]; tw[1] = v[1]; tw[2] = v[2]; tw[3] = v[3];
+    } else {                                        // the last bytes of the text
+        tw[0] = tw[1] = tw[2] = tw[3] = 0;
+        for (uint32_t t = 0; t < 16 && j + t < n; ++t) tw[t >> 2] |= (uint32_t)text[j + t] << (8 * (t & 3));
+    }
+    const uint32_t g = (tw[0] & q.qmask) | q.fold;  // the q-byte prefix at j
+    if (fold) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) tw[d] = swar_lower(tw[d]);
+    }
     const uint32_t b = agh_mp_bucket(g);
     for (uint32_t it = mt.bucket_start[b]; it < mt.bucket_start[b + 1]; ++it) {
-        const uint32_t p = mt.bucket_items[it];
-        const uint32_t o = mt.pat_off[p], len = mt.pat_off[p + 1] - o;
+        const uint32_t info = mt.item_info[it];
+        const uint32_t o = info >> 8, len = info & 0xffu;
         if (j + len > n) continue;
-        uint32_t t = 0;
-        for (; t < len; ++t) {
+        const u32x4_u pv = *reinterpret_cast<const u32x4_u *>(mt.pool + o);
+        const uint32_t head = len < 16u ? len : 16u;
+        uint32_t diff = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+            const uint32_t nb = head > 4u * d ? head - 4u * d : 0u;      // bytes of this dword in play
+            const uint32_t m = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+            diff |= (tw[d] ^ pv[d]) & m;
+        }
+        if (diff) continue;
+        uint32_t t = 16;
+        for (; t < len; ++t) {                      // patterns longer than 16 bytes: the rest
             uint32_t c = text[j + t];
-            if (fold && c >= 'A' && c <= 'Z') c += 32u;          // newmgrep.c: tr[] folds case
+            if (fold && c >= 'A' && c <= 'Z') c += 32u;
             if (c != mt.pool[o + t]) break;
         }
-        if (t == len) return true;
+        if (t >= len) return true;
     }
     return false;
 }
@@ -462,6 +496,7 @@ static void launch_sweep_multi_m(const agh_sweep_args &a, const agh_multi_dev &m
     mt.piece_po = m.piece_po;
     mt.owner_len = m.owner_len;
     mt.owner_mask = m.owner_mask;
+    mt.item_info = m.item_info;
     if (n_waves && inl)
         hipLaunchKernelGGL((k_sweep_multi<MODE, true>), dim3((uint32_t)((n_waves + 3) / 4)),
                            dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,
@@ -513,6 +548,7 @@ void agh_launch_verify_multi(const agh_scan_args &a, const agh_multi_dev &m, boo
     mt.piece_po = m.piece_po;
     mt.owner_len = m.owner_len;
     mt.owner_mask = m.owner_mask;
+    mt.item_info = m.item_info;
     const uint32_t blocks = (a.nw + 3u) / 4u;
     if (!blocks) return;
     if (lean)

@@ -254,6 +254,21 @@ static void text_of(int fd, struct text_src *src)
     }
 }
 
+/* The simple-pattern engines print through s_output() (sgrep.c:1274-1483) in the reference: the
+ * record with its delimiter where -d puts it, no "eat the first newline" step.  output() does the
+ * same once it sees the state bitap() would have left: D_length = the delimiter's real length
+ * (the sgrep path keeps 2 for the default "\n; ", agrep.c:378) and FIRSTOUTPUT already spent. */
+static int run_simple(agh_query *q, const struct text_src *src, const unsigned char *delim, int dlen)
+{
+    const int saved = D_length;
+    int rc;
+    FIRSTOUTPUT = 0;
+    if (!DELIMITER) D_length = 1;
+    rc = run_scan(q, src, delim, dlen);
+    D_length = saved;
+    return rc;
+}
+
 /* ---- bitap(): maskgen()'s tables, unchanged -------------------------------------------- */
 static agh_query *g_bq;
 static unsigned g_bq_sum;
@@ -352,10 +367,8 @@ int sgrep(unsigned char *in_pat, int in_m, int fd, int D, int samepattern)
         memcpy(g_sq_delim, delim, (size_t)dlen);
         g_sq_m = m; g_sq_D = D; g_sq_i = NOUPPER; g_sq_dlen = dlen;
     }
-    /* s_output() (sgrep.c:1274-1483) has no "eat the first newline" step: keep output()'s off */
-    FIRSTOUTPUT = 0;
     text_of(fd, &src);
-    return run_scan(g_sq, &src, delim, dlen);
+    return run_simple(g_sq, &src, delim, dlen);
 }
 
 /* ---- prepf() / mgrep(): -f pattern files ------------------------------------------------ */
@@ -530,8 +543,15 @@ int mgrep(int fd, void *AParse)
         if (AComplexBoolean)
             return shim_fail("boolean patterns with parentheses / mixed operators are not served by the GPU engines");
         if (INVERSE) return shim_fail("-v with a boolean pattern is not served by the GPU engines");
-        FIRSTOUTPUT = 0;
-        if ((long)AParse & AND_EXP) return mgrep_all_terminals(fd, delim, dlen);
+        if ((long)AParse & AND_EXP) {
+            const int saved = D_length;
+            int rc;
+            FIRSTOUTPUT = 0;
+            if (!DELIMITER) D_length = 1;
+            rc = mgrep_all_terminals(fd, delim, dlen);
+            D_length = saved;
+            return rc;
+        }
     }
     if (!g_mq || g_mq_i != NOUPPER || g_mq_dlen != dlen || memcmp(delim, g_mq_delim, (size_t)dlen)) {
         if (g_mq) agh_query_free(g_mq);
@@ -541,7 +561,6 @@ int mgrep(int fd, void *AParse)
         g_mq_dlen = dlen;
         memcpy(g_mq_delim, delim, (size_t)dlen);
     }
-    FIRSTOUTPUT = 0;                                    /* as in sgrep(): s_output's behaviour */
     text_of(fd, &src);
-    return run_scan(g_mq, &src, delim, dlen);
+    return run_simple(g_mq, &src, delim, dlen);
 }
