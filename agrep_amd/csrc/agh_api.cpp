@@ -1011,6 +1011,58 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         // fall through: the numbered pipeline is exact for every input
     }
 
+    // ---- lean full scan: count-only scans of a query without a filter ------------------------
+    // The same record identity (hash set of record starts) lets the automaton-over-every-byte
+    // engine skip the census sweep: one pass over the text instead of two.
+    const bool lean_fs_ok = !want_filter && !q->table && !multi && !d_match_pos && !invert &&
+                            (flags & (AGH_COUNT | AGH_FILENAMEONLY)) && !(flags & AGH_FORCE_NUMBERED) &&
+                            !lean_rerun;
+    if (lean_fs_ok) {
+        uint64_t slots = 1u << 17;
+        if (!q->hashset_slots_hint) while (slots < (n >> 13) && slots < (1u << 26)) slots <<= 1;
+        while (slots < q->hashset_slots_hint) slots <<= 1;
+        {
+            const size_t cap_before = q->hashset.cap;
+            if (q->hashset.ensure(slots * sizeof(uint64_t))) return -1;
+            if (q->hashset.cap != cap_before || q->hashset_dirty)
+                HIP_TRY(hipMemsetAsync(q->hashset.p, 0, q->hashset.cap, st));
+            q->hashset_dirty = true;
+        }
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev0, st));
+        HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+        agh_scan_args va;
+        memset(&va, 0, sizeof(va));
+        va.text = d_text;
+        va.n = n;
+        va.q = dq;
+        va.mask = q->d_mask;
+        va.wide = q->wide;
+        va.general = q->general;
+        va.dbm = d_dbm;
+        va.mk.counters = q->d_counters;
+        va.mk.hashset = (uint64_t *)q->hashset.p;
+        va.mk.hashset_mask = (uint32_t)(slots - 1);
+        agh_launch_fullscan(va, st);
+        agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8), nullptr, 0u,
+                                 q->d_counters, st);
+        HIP_TRY(hipGetLastError());
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev1, st));
+        HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        q->hashset_dirty = false;
+        if (!q->h_counters[AGH_C_LEAN_FALLBACK]) {
+            if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
+            out->matched = q->h_counters[AGH_C_MATCHED];
+            out->records = 0;
+            out->engine = AGH_ENGINE_FULLSCAN;
+            q->hashset_slots_hint = 4ull * out->matched;
+            return 0;
+        }
+        q->hashset_slots_hint = 8ull * (q->h_counters[AGH_C_MATCHED] + 1024);
+        lean_rerun = 1;                         // numbered pipeline below: exact for every input
+    }
+
     // Optimistic single-sync pipeline: the record bitmap is sized from a hint (the previous
     // scan of this query, or one record per 32 bytes) and everything -- census/filter sweep,
     // prefix scan, verify or full scan, population count -- is queued back to back.  The host

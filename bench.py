@@ -141,7 +141,7 @@ def measure_traffic(seg_gib, k, timeout_s):
     d = tempfile.mkdtemp(prefix="agh_pmc_", dir="/tmp")
     try:
         env = dict(os.environ, TMPDIR="/tmp")
-        for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "AGH_BENCH_FORCE_DIST"):
             env.pop(v, None)
         cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p",
                "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--total-gib", str(seg_gib),
@@ -197,8 +197,14 @@ def main():
     torch.cuda.set_device(local_rank)
     A.set_device(local_rank)
     comm = None
-    if world > 1:
+    # AGH_BENCH_FORCE_DIST=1 (test hook): take the multi-rank code path -- process group, the C-ABI's
+    # own RCCL communicator, the all-reduce in every step -- even with a single rank
+    dist_on = world > 1 or os.environ.get("AGH_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             # the C-ABI's own RCCL communicator: rank 0's unique id travels over torch.distributed
@@ -227,7 +233,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -239,7 +245,7 @@ def main():
         def step():
             # AGH_TIME_SWEEP: HIP events around every k_sweep launch on the scan's stream
             res = q.scan_device(text.data_ptr(), n, flags=A.COUNT | A.TIME_SWEEP, time_scan=False)
-            if world > 1:                       # the -c aggregate: ncclAllReduce through the C-ABI
+            if dist_on:                         # the -c aggregate: ncclAllReduce through the C-ABI
                 if comm is not None:
                     agg[0], agg[1] = comm.reduce_counts(res.n_matched, res.n_records)
                 else:
@@ -257,7 +263,7 @@ def main():
             launches += res.sweep_launches
         fence()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
@@ -275,7 +281,7 @@ def main():
 
     # planted records of the whole job (all ranks), by number of edits
     pl = torch.tensor([int(x) for x in planted], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
+    if dist_on:
         dist.all_reduce(pl, op=dist.ReduceOp.SUM)
     pl = [int(x) for x in pl.tolist()]
     planted_le = {kk: sum(c for c, e in zip(pl, VARIANT_EDITS) if e <= kk) for kk in (0, 1, 2)}
@@ -301,6 +307,8 @@ def main():
                        "segments_per_gpu": int(res.n_segments),
                        "sharding": "contiguous page range per rank; the only exchange is the RCCL all-reduce of "
                                    "the counts (agh_reduce_counts)" if world > 1 else "one GPU holds the whole corpus",
+                       "count_reduction": ("agh_reduce_counts (RCCL ncclAllReduce inside the C-ABI)" if comm is not None
+                                           else ("torch.distributed/" + backend if dist_on else "none (one rank)")),
                        "engine": {1: "fullscan", 2: "q-gram sample filter + verify"}[res.engine],
                        "filter_sample": "q=%d bytes every h=%d bytes" % (info["filter_q"], info["filter_h"]),
                        "seed": SEED},
@@ -349,7 +357,7 @@ def main():
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

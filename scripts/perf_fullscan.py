@@ -25,8 +25,11 @@ for k in (0, 1, 2, 3):
     with A.Query(B.PATTERN, k) as q:
         ms, r = med(q, A.FORCE_FULLSCAN)
         ms_f, r_f = med(q, 0)
-        print("fullscan m=16 k=%d: %.3f ms  %.0f GB/s  matched %d   (filter engine: %.3f ms %.0f GB/s matched %d)"
-              % (k, ms, n / 1e6 / ms, r.n_matched, ms_f, n / 1e6 / ms_f, r_f.n_matched), flush=True)
+        ms_l, r_l = med(q, A.FORCE_FULLSCAN | A.COUNT)
+        print("fullscan m=16 k=%d: %.3f ms  %.0f GB/s  matched %d | count-only (no census): %.3f ms  %.0f GB/s  matched %d "
+              "reruns %d | (filter engine: %.3f ms %.0f GB/s matched %d)"
+              % (k, ms, n / 1e6 / ms, r.n_matched, ms_l, n / 1e6 / ms_l, r_l.n_matched, r_l.lean_reruns,
+                 ms_f, n / 1e6 / ms_f, r_f.n_matched), flush=True)
 with A.Query(b"approximatematchapproximatematchapproximatemat", 3, nocase=True) as q:
     ms, r = med(q, A.FORCE_FULLSCAN, 3)
     print("fullscan m=46 k=3 -i (64-bit words): %.3f ms  %.0f GB/s  matched %d" % (ms, n / 1e6 / ms, r.n_matched), flush=True)

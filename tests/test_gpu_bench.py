@@ -54,3 +54,17 @@ def test_bench_single_and_two_ranks():
     assert b["matched_records"] == a["matched_records"] and b["matched_equals_planted"] is True
     assert b["config"]["bytes_per_gpu"] * 2 == a["config"]["bytes_per_gpu"]
     assert b["config"]["total_bytes"] == a["config"]["total_bytes"] and b["scaling"] == "strong"
+
+
+def test_bench_rccl_code_path_with_one_rank():
+    """The nccl branch of bench.py end to end on the one GPU there is: torch.distributed over RCCL,
+    rank 0's ncclUniqueId broadcast, the C-ABI's own communicator (agh_comm_init_rank) and
+    agh_reduce_counts (ncclAllReduce) in every timed step -- with a world of one rank."""
+    env = dict(os.environ, AGH_BENCH_FORCE_DIST="1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--total-gib", "0.5", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-traffic"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = _last_json(r.stdout)
+    assert a["config"]["count_reduction"].startswith("agh_reduce_counts")
+    assert a["matched_equals_planted"] is True and a["n_gpus"] == 1

@@ -48,6 +48,11 @@ def _check(agh, pat, k, text, nocase=False):
         res_n, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
     assert res_c.n_matched == want[0], ("lean", pat, k, nocase)
     assert res_n.n_matched == want[0] and res_n.n_records == res.n_records
+    # ... and so does the count-only full scan (no census pass in front of k_fullscan)
+    with agh.Query(pat, k, nocase=nocase) as q:
+        res_lf, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_FULLSCAN)
+    assert res_lf.n_matched == want[0], ("lean fullscan", pat, k, nocase)
+    assert res_lf.engine == (agh.ENGINE_FULLSCAN if tb else 0)
     # record numbers are consistent with the record starts
     nl = np.frombuffer(tb, dtype=np.uint8) == 10
     for (s, e), i in zip(recs[:50], idx[:50]):
