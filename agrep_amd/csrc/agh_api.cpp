@@ -334,7 +334,10 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
 static int attach_piece_engine(agh_query *q)
 {
     if (q->fq || q->general || q->table || q->dlen != 1 || q->m > 32 || q->m <= q->k) return 0;
-    if (q->m / (q->k + 1) < 2) return 0;            // 1-byte pieces select nothing
+    // Pieces of 1-2 bytes select next to nothing (a 2-byte piece hits every ~500th position of
+    // English-like text: 10-25 M candidates per 4 GiB): the census-free full scan is faster then
+    // (scripts/perf_short.py: 'approxim' k=2 1.06 vs 1.54 TB/s, 'match' k=1 1.33 vs 1.98).
+    if (q->m / (q->k + 1) < 3) return 0;
     unsigned char pat[32];
     bool any_pair = false, any_single_letter = false;
     for (int p = 0; p < q->m; ++p) {
@@ -1014,7 +1017,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     // ---- lean full scan: count-only scans of a query without a filter ------------------------
     // The same record identity (hash set of record starts) lets the automaton-over-every-byte
     // engine skip the census sweep: one pass over the text instead of two.
-    const bool lean_fs_ok = !want_filter && !q->table && !multi && !d_match_pos && !invert &&
+    const bool lean_fs_ok = !want_filter && !multi && !d_match_pos && !invert &&
                             (flags & (AGH_COUNT | AGH_FILENAMEONLY)) && !(flags & AGH_FORCE_NUMBERED) &&
                             !lean_rerun;
     if (lean_fs_ok) {
@@ -1042,7 +1045,10 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.counters = q->d_counters;
         va.mk.hashset = (uint64_t *)q->hashset.p;
         va.mk.hashset_mask = (uint32_t)(slots - 1);
-        agh_launch_fullscan(va, st);
+        va.table = q->table;
+        va.tab = q->tab;
+        if (q->table) agh_launch_tablescan(va, st);
+        else agh_launch_fullscan(va, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8), nullptr, 0u,
                                  q->d_counters, st);
         HIP_TRY(hipGetLastError());

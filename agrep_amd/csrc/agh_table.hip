@@ -6,12 +6,12 @@
 // record closes, asearch.c:119-128).
 //
 // Parallel over records instead of over bytes: a lane owns the records whose first byte lies
-// in its 256-byte chunk and runs each of them from its start (reset + re-fed delimiter,
+// in its 1 KiB chunk and runs each of them from its start (reset + re-fed delimiter,
 // asearch.c:175-186) to the delimiter that closes it, wherever that is.  Record numbers come
-// from the same delimiter census the full scan uses.
+// from the same delimiter census the full scan uses (count-only scans need neither).
 #include "agh_verify_inl.h"
 
-#define AGH_TS_CHUNK 256u
+#define AGH_TS_CHUNK 256u       // k_unmatched: bytes per lane
 
 template <int K>
 struct TableAutomaton {
@@ -50,100 +50,140 @@ struct TableAutomaton {
     }
 };
 
-template <int K>
-__global__ __launch_bounds__(256) void k_tablescan(const uint8_t *__restrict__ text, uint64_t n,
-                                                   agh_dev_query q, agh_dev_tables T,
-                                                   const uint32_t *__restrict__ mask_g,
-                                                   const uint32_t *__restrict__ strip_prefix,
-                                                   const uint32_t *__restrict__ wave_prefix,
-                                                   uint32_t n_strips, agh_marks mk)
+// Text feeding as in k_fullscan (agh_fullscan.hip): a lane's chunk is one 1 KiB census strip, a wave
+// owns a 64 KiB tile and gathers the next 64 bytes of all 64 chunks per round (64-byte segments,
+// four dwordx4 loads) through a 5 KiB per-wave LDS ring.  A lane runs the records that START in its
+// chunk, so after the 16 rounds it walks on alone (plain loads, the neighbour's chunk is in L2) to
+// the delimiter that closes its last record.
+// LEAN (count-only): no census pass in front -- a record is identified by the offset of its first
+// byte, which the owning lane knows exactly, and goes into the hash set of record starts.
+template <int K, bool LEAN>
+__global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
+    const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
+    const uint32_t *__restrict__ mask_g, const uint32_t *__restrict__ strip_prefix,
+    const uint32_t *__restrict__ wave_prefix, uint32_t n_strips, agh_marks mk)
 {
     __shared__ uint32_t lmask[256];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * WAVE * AGH_FS_ROW];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
     __syncthreads();
-    const uint64_t n_chunks = (n + AGH_TS_CHUNK - 1) / AGH_TS_CHUNK;
-    const uint32_t dd = q.delim * 0x01010101u;
+    const int lane = lane_id();
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    uint8_t *ring = ring_all + wib * (WAVE * AGH_FS_ROW);
+    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_FS_CHUNK;
+    const uint64_t n_tiles = (n + tile_bytes - 1) / tile_bytes;
     const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
+    const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    const uint32_t seg_lo = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
+    uint8_t *ring_w = ring + seg_lo * AGH_FS_ROW + part * 16u;
+    const uint8_t *ring_r = ring + (uint32_t)lane * AGH_FS_ROW;
 
-    for (uint64_t base = (uint64_t)blockIdx.x * 256u; base < n_chunks;
-         base += (uint64_t)gridDim.x * 256u) {
-        const uint64_t cs = (base + threadIdx.x) * AGH_TS_CHUNK;
-        uint64_t ce = cs + AGH_TS_CHUNK;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (AGH_FS_THREADS / WAVE) + wib; tile < n_tiles;
+         tile += (uint64_t)gridDim.x * (AGH_FS_THREADS / WAVE)) {
+        const uint64_t t0 = tile * tile_bytes;
+        const uint64_t cs = t0 + (uint64_t)lane * AGH_FS_CHUNK;
+        const bool mine = cs < n;
+        uint64_t ce = cs + AGH_FS_CHUNK;
         if (ce > n) ce = n;
-        // delimiters of my chunk, and of the chunks of my 1 KiB strip in front of it
-        uint32_t my_delims = 0;
-        if (cs < n) {
-            const uint32_t len = (uint32_t)(ce - cs);
-            for (uint32_t i = 0; i < (len >> 4); ++i)
-                my_delims += delims_in(*reinterpret_cast<const uint4 *>(text + cs + i * 16), dd);
-            if (len & 15u)
-                my_delims += delims_in(
-                    mask_tail(*reinterpret_cast<const uint4 *>(text + cs + (len & ~15u)),
-                              (int)(len & 15u), fill4), dd);
-        }
-        uint32_t before = 0;
-        {
-            const int l4 = (int)(threadIdx.x & 3u);
-            uint32_t v1 = (uint32_t)__shfl_up((int)my_delims, 1, 4);
-            uint32_t v2 = (uint32_t)__shfl_up((int)my_delims, 2, 4);
-            uint32_t v3 = (uint32_t)__shfl_up((int)my_delims, 3, 4);
-            if (l4 >= 1) before += v1;
-            if (l4 >= 2) before += v2;
-            if (l4 >= 3) before += v3;
-        }
-        if (cs >= n) continue;
-        if (cs != 0 && my_delims == 0) continue;            // no record starts in my chunk
+        const uint32_t len = mine ? (uint32_t)(ce - cs) : 0u;
+        auto gather = [&](uint32_t r, uint4 (&g)[4]) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint64_t a = t0 + (uint64_t)(seg_lo + 16u * i) * AGH_FS_CHUNK + r * AGH_FS_ROUND + part * 16u;
+                g[i] = a < n16 ? ld_stream(reinterpret_cast<const uint4 *>(text + a))
+                               : make_uint4(fill4, fill4, fill4, fill4);
+            }
+        };
+        uint4 g[4];
+        gather(0, g);
 
-        const uint64_t strip = cs >> AGH_STRIP_SHIFT;
-        // number of the record that contains byte cs
-        uint32_t rec = (strip < n_strips)
-                           ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] + before
-                           : 0u;
+        // number of the record that contains byte cs (chunk == strip)
+        uint32_t rec = 0;
+        if (mine && !LEAN) {
+            const uint64_t strip = cs >> AGH_STRIP_SHIFT;
+            rec = strip < n_strips ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] : 0u;
+        }
+        uint64_t rstart = 0;                    // first byte of the record being run (once active)
         TableAutomaton<K> A;
         A.reset(T);
-        bool active = false;
-        if (cs == 0) {
+        bool active = false, done = !mine;
+        if (mine && cs == 0) {
             (void)A.feed(lmask[q.head_byte], T);            // asearch.c:69-78 (never a hit: host check)
             active = true;
         }
-        bool done = false;
-        for (uint64_t p0 = cs; !done; p0 += 16) {
-            if (p0 >= n) break;
-            const uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
-            const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+        auto step = [&](uint32_t c, uint64_t pos) {
+            const uint32_t r = A.feed(lmask[c], T);
+            if (r & 1u) {
+                if (active && (r & 2u)) {
+                    if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, pos);
+                }
+                if (pos >= ce) done = true;     // that closed my last record
+                active = true;
+                ++rec;
+                rstart = pos + 1;
+            }
+        };
+        for (uint32_t r = 0; r < AGH_FS_CHUNK / AGH_FS_ROUND; ++r) {
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const uint64_t pos = p0 + (uint32_t)b;
-                if (!done && pos < n) {
-                    const uint32_t c = (dws[b >> 2] >> (8 * (b & 3))) & 0xffu;
-                    const uint32_t r = A.feed(lmask[c], T);
-                    if (r & 1u) {
-                        if (active && (r & 2u)) mark_record(mk, rec, pos);
-                        if (pos >= ce) done = true;        // that closed my last record
-                        active = true;
-                        ++rec;
-                    }
+            for (uint32_t i = 0; i < 4; ++i)
+                *reinterpret_cast<uint4 *>(ring_w + 16u * i * AGH_FS_ROW) = g[i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const uint4 *>(ring_r + 16u * p);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (r + 1 < AGH_FS_CHUNK / AGH_FS_ROUND) gather(r + 1, g);
+#pragma unroll
+            for (uint32_t p = 0; p < 4; ++p) {
+                const uint32_t off = r * AGH_FS_ROUND + 16u * p;
+                const uint32_t dws[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+                if (off + 16u <= len) {
+#pragma unroll
+                    for (uint32_t b = 0; b < 16; ++b)
+                        step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, cs + off + b);
+                } else if (off < len) {
+                    for (uint32_t b = 0; off + b < len; ++b)
+                        step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, cs + off + b);
                 }
             }
         }
+        if (!active) done = true;               // no record starts in my chunk
+        // on alone to the delimiter that closes my last record (ce is 16-byte aligned unless ce == n)
+        for (uint64_t p0 = ce; !done && p0 < n; p0 += 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
+            const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t b = 0; b < 16 && !done && p0 + b < n; ++b)
+                step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, p0 + b);
+        }
         if (!done && active && q.tail_virtual) {            // asearch.c:87-91
             const uint32_t r = A.feed(lmask[q.delim], T);
-            if ((r & 3u) == 3u) mark_record(mk, rec, n);
+            if ((r & 3u) == 3u) {
+                if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
+            }
         }
     }
 }
 
 void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
 {
-    const uint64_t n_chunks = (a.n + AGH_TS_CHUNK - 1) / AGH_TS_CHUNK;
-    if (!n_chunks) return;
-    uint64_t want = (n_chunks + 255) / 256;
-    const uint32_t blocks = want > 65536 ? 65536u : (uint32_t)want;
+    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_FS_CHUNK;
+    const uint64_t n_tiles = (a.n + tile_bytes - 1) / tile_bytes;
+    if (!n_tiles) return;
+    const uint64_t want = (n_tiles + (AGH_FS_THREADS / WAVE) - 1) / (AGH_FS_THREADS / WAVE);
+    const uint32_t blocks = want > 16384 ? 16384u : (uint32_t)want;
+    const bool lean = a.mk.hashset != nullptr;  // count-only: hash set of record starts, no census
 #define AGH_CASE(KK)                                                                          \
     case KK:                                                                                  \
-        hipLaunchKernelGGL((k_tablescan<KK>), dim3(blocks), dim3(256), 0, st,                 \
-                           (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                           a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);                  \
+        if (lean)                                                                             \
+            hipLaunchKernelGGL((k_tablescan<KK, true>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
+                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);              \
+        else                                                                                  \
+            hipLaunchKernelGGL((k_tablescan<KK, false>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
+                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);              \
         break;
     switch (a.q.k) {
         AGH_CASE(0) AGH_CASE(1) AGH_CASE(2) AGH_CASE(3) AGH_CASE(4)

@@ -84,6 +84,9 @@ def test_reference_front_end_on_gpu_engines(files, args):
     ("^the", ["-V0", "-c"]),                                # anchors
     ("ing$", ["-V0", "-c", "-1"]),
     ("approximatematch", ["-V0", "-v", "-i", "-c", "-2"]),  # -v on the asearch path
+    ("aprxmtch", ["-V0", "-p", "-c"]),                      # -p: I = 0, every position sticky (bitap.c:123)
+    ("aprxmtch", ["-V0", "-p", "-1", "-c"]),
+    ("aqz", ["-V0", "-p"]),
 ])
 def test_pattern_language_through_the_shim(files, pattern, args):
     for fl in (files[:1], files[:2]):
