@@ -35,6 +35,54 @@ __device__ __forceinline__ void fullscan_piece(uint4 v, const WT *lmask, WT fina
     d16 = d;
 }
 
+// The common case made cheap: unit costs, a one-byte delimiter that is not a member of any pattern
+// position (Mask[delim] == 0 -- literal patterns cannot hold the record delimiter).  Then the
+// state right after a boundary is R_e = 2^e - 1 (level e has its e leading deletions, nothing
+// else), and the ordinary step on the delimiter byte (CM = 0) already produces a superset of it:
+// R_e' = R_(e-1) | ((R_(e-1) | R_(e-1)') << 1 | 1) >= 2^e - 1.  So the boundary is one AND per level
+// with (kb | 2^e - 1), kb = 0 for the delimiter byte and ~0 otherwise, read from LDS together with
+// the byte's mask (one b64 / b128 lookup) and folded into the step by v_bitop3: no compare, no
+// select, no branch.  Matches are not located here: the piece only ORs up the top level; a piece
+// whose OR reaches the final bit (one in thousands) is replayed by the exact path from the state
+// saved at its start.  17-18 VALU instructions per byte at k = 2 instead of 31.
+template <typename WT>
+struct MaskKill {
+    WT cm, kb;
+};
+
+template <typename WT, int K>
+__device__ __forceinline__ WT fullscan_piece_fast(uint4 v, const MaskKill<WT> *tab, Automaton<WT, K> &A)
+{
+    const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+    WT any = 0;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const uint32_t byte = (dws[b >> 2] >> (8 * (b & 3))) & 0xffu;
+        const MaskKill<WT> e = tab[byte];
+        WT po = A.R[0];
+        WT pn = ((po << 1) | (WT)1) & e.cm;
+        A.R[0] = pn;
+#pragma unroll
+        for (int l = 1; l <= K; ++l) {
+            const WT cur = A.R[l];
+            const WT ne = ((((cur << 1) | (WT)1) & e.cm) | po | (((po | pn) << 1) | (WT)1)) &
+                          (e.kb | (((WT)1 << l) - (WT)1));
+            po = cur;
+            pn = ne;
+            A.R[l] = ne;
+        }
+        any |= A.R[K];
+    }
+    return any;
+}
+
+// 0x80 in every byte of w that equals the delimiter (dd = delimiter in all four bytes)
+__device__ __forceinline__ uint32_t delim_bits(uint32_t w, uint32_t dd)
+{
+    const uint32_t x = w ^ dd;
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+}
+
 // GEN: the general automaton (non-unit costs / <exact> segments) instead of the unit-cost one.
 //
 // Data feeding.  The automaton is serial over bytes, so the parallelism is one CHUNK per lane
@@ -58,9 +106,17 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
     const uint64_t *__restrict__ dbm)
 {
     __shared__ WT lmask[256];
+    __shared__ MaskKill<WT> ktab[(MB || GEN) ? 1 : 256];
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * WAVE * AGH_FS_ROW];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
+    if (!MB && !GEN) {
+        ktab[threadIdx.x].cm = mask_g[threadIdx.x];
+        ktab[threadIdx.x].kb = threadIdx.x == q.delim ? (WT)0 : ~(WT)0;
+    }
     __syncthreads();
+    // the cheap boundary handling applies (see fullscan_piece_fast); uniform over the grid
+    const bool fastd = !MB && !GEN && lmask[q.delim & 0xffu] == (WT)0;
+    const uint32_t dd = q.delim * 0x01010101u;
 
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
@@ -147,6 +203,30 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
             for (uint32_t p = 0; p < 4; ++p) {
                 const uint32_t off = r * AGH_FS_ROUND + 16u * p;
                 if (off + 16u <= len) {
+                    bool exact = true;
+                    if (!MB && !GEN && fastd) {
+                        const Automaton<WT, K> at_start = A;
+                        const WT any = fullscan_piece_fast<WT, K>(v[p], ktab, A);
+                        if (any & finalbit) {
+                            A = at_start;               // rare: a match ends in this piece -> exact replay
+                        } else {
+                            exact = false;
+                            const uint32_t z0 = delim_bits(v[p].x, dd), z1 = delim_bits(v[p].y, dd);
+                            const uint32_t z2 = delim_bits(v[p].z, dd), z3 = delim_bits(v[p].w, dd);
+                            if (z0 | z1 | z2 | z3) {
+                                seen = 0;               // the open record starts inside this piece
+                                if (LEAN) {
+                                    // one past the last delimiter of the piece
+                                    const uint32_t zl = z3 ? z3 : (z2 ? z2 : (z1 ? z1 : z0));
+                                    const uint32_t dwi = z3 ? 3u : (z2 ? 2u : (z1 ? 1u : 0u));
+                                    rstart = cs + off + 4u * dwi + ((31u - (uint32_t)__clz((int)zl)) >> 3) + 1u;
+                                } else {
+                                    rec += (uint32_t)(__popc(z0) + __popc(z1) + __popc(z2) + __popc(z3));
+                                }
+                            }
+                        }
+                    }
+                    if (exact) {
                     uint32_t h16 = 0, d16 = 0;
                     if (MB) d16 = (uint32_t)dbm_bits64(dbm, cs + off) & 0xffffu;
                     fullscan_piece<WT, K, MB, GEN>(v[p], lmask, finalbit, q, RF, rf_hit, A, seen, h16, d16);
@@ -171,6 +251,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
                         if (d16) rstart = cs + off + (32u - (uint32_t)__clz((int)d16));
                     } else {
                         rec += (uint32_t)__popc(d16);
+                    }
                     }
                 } else if (off < len) {                 // the last, partial piece of the text
                     const uint32_t dws[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
