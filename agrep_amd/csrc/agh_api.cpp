@@ -843,6 +843,7 @@ static agh_multi_dev multi_dev(const agh_query *q)
 // one segment (<= AGH_SEG_MAX bytes) resident in HBM
 // ---------------------------------------------------------------------------------------
 static const uint64_t AGH_SEG_MAX_DEFAULT = (uint64_t)8 << 30;   // nominal segment (plan_segments)
+static const uint64_t AGH_LEAN_SEG_MAX = (uint64_t)64 << 30;     // lean scans: one launch per 64 GiB
 // lean pipeline defaults (lean_run): part size in MiB (0: one launch per segment) and whether the
 // verifier runs on a second stream; AGH_PART_MB / AGH_OVERLAP override (A/B runs)
 #define AGH_PART_MB_DEFAULT 0
@@ -1252,11 +1253,15 @@ static uint64_t seg_nominal(const agh_query *q)
 }
 
 static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, hipStream_t st,
-                         std::vector<uint64_t> *cuts)
+                         std::vector<uint64_t> *cuts, bool lean)
 {
     cuts->clear();
     cuts->push_back(0);
-    const uint64_t nominal = seg_nominal(q);
+    // Lean (count-only) scans of a single pattern carry 64-bit dword indices in their candidate
+    // entries and need no record numbers, so ONE kernel sequence covers up to 64 GiB (bounded only by
+    // the candidate slices: 1/8 of the text); everything else is limited by 32-bit indices.
+    uint64_t nominal = seg_nominal(q);
+    if (lean && !getenv("AGH_SEG_MAX_MB")) nominal = AGH_LEAN_SEG_MAX;
     if (len > nominal) {
         if (q->dlen > 1)
             return fail("multi-byte delimiters: inputs above the %llu-byte segment limit are not "
@@ -1321,6 +1326,9 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                         unsigned flags, uint32_t head_byte, int tail_virtual,
                         uint64_t *d_match_pos, uint32_t *d_match_rec, uint32_t match_cap,
                         seg_result *out);
+static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
+                            unsigned flags, agh_result *res, uint64_t *d_match_pos,
+                            uint32_t *d_match_rec, size_t match_cap, bool is_first, bool is_last);
 
 static int get_events(std::vector<hipEvent_t> &pool, size_t want, unsigned evflags)
 {
@@ -1517,16 +1525,17 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
             max_matched = std::max<uint64_t>(max_matched, h[AGH_C_MATCHED]);
             continue;
         }
-        // exact for every input: the numbered pipeline on the whole segment
+        // exact for every input: the numbered pipeline on the whole segment (in pieces of its own
+        // size limit)
         max_matched = std::max<uint64_t>(max_matched, 2ull * (h[AGH_C_MATCHED] + 1024));
-        seg_result sr;
-        if (scan_segment(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED,
-                         (i == 0 && is_first) ? '\n' : q->delim[0], i == nseg - 1 && is_last, nullptr,
-                         nullptr, 0, &sr))
+        q->hashset_slots_hint = 4ull * max_matched;
+        agh_result rr;
+        if (scan_device_impl(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED, &rr,
+                             nullptr, nullptr, 0, i == 0 && is_first, i == nseg - 1 && is_last))
             return -1;
         if (jobs[i].done_early) res->n_bytes = cuts[i + 1];    // the rerun read the whole segment
-        res->n_matched += sr.matched;
-        res->n_candidates += sr.candidates;
+        res->n_matched += rr.n_matched;
+        res->n_candidates += rr.n_candidates;
         res->lean_reruns += 1;
     }
     res->n_segments = (uint32_t)queued;
@@ -1536,8 +1545,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
 
 static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
                             unsigned flags, agh_result *res, uint64_t *d_match_pos,
-                            uint32_t *d_match_rec, size_t match_cap, bool is_first = true,
-                            bool is_last = true)
+                            uint32_t *d_match_rec, size_t match_cap, bool is_first, bool is_last)
 {
     if (!q || !res) return fail("null argument");
     memset(res, 0, sizeof(*res));
@@ -1546,9 +1554,9 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
     if (((uintptr_t)dev_text & 15u) != 0) return fail("device text must be 16-byte aligned");
     const unsigned char *base = (const unsigned char *)dev_text;
     std::vector<uint64_t> cuts;
-    if (plan_segments(q, base, len, st, &cuts)) return -1;
-    if (lean_pipeline_ok(q, flags, d_match_pos != nullptr))
-        return lean_run(q, base, cuts, st, flags, res, is_first, is_last);
+    const bool lean = lean_pipeline_ok(q, flags, d_match_pos != nullptr);
+    if (plan_segments(q, base, len, st, &cuts, lean)) return -1;
+    if (lean) return lean_run(q, base, cuts, st, flags, res, is_first, is_last);
     for (size_t i = 0; i + 1 < cuts.size(); ++i) {
         const uint64_t off = cuts[i], end = cuts[i + 1];
         seg_result sr;
@@ -1592,7 +1600,7 @@ extern "C" int agh_scan_device(agh_query *q, const void *dev_text, size_t len, v
                                size_t match_cap)
 {
     return scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res,
-                            (uint64_t *)dev_match_pos, nullptr, dev_match_pos ? match_cap : 0);
+                            (uint64_t *)dev_match_pos, nullptr, dev_match_pos ? match_cap : 0, true, true);
 }
 
 // Matches of the text staged in q->staging: bounds computed on the device, sorted into file
@@ -1641,7 +1649,7 @@ static int scan_staged(agh_query *q, uint64_t len, unsigned flags, agh_result *r
         d_rec = (uint32_t *)q->match_rec.p;
     }
     q->staged_len = len;
-    if (scan_device_impl(q, q->staging.p, len, nullptr, flags, res, d_pos, d_rec, cap)) return -1;
+    if (scan_device_impl(q, q->staging.p, len, nullptr, flags, res, d_pos, d_rec, cap, true, true)) return -1;
     return d_pos ? collect_matches(q, len, res, matches) : 0;
 }
 

@@ -101,8 +101,10 @@ __device__ __forceinline__ void emit_candidates_to(uint32_t hits, uint64_t s,
             for (int j = 0; j < lane; ++j) t &= t - 1;
             int b = __ffs((int)t) - 1;
             int u = b >> 2;
-            uint32_t dw = (uint32_t)(((s + (uint64_t)u) * 64u + (uint64_t)l) * 4u +
-                                     (uint64_t)(b & 3));
+            // dword index of the sample: < 2^32 inside a numbered segment (<= 16 GiB), where the
+            // upper half carries the record count; lean sweeps (r == 0) use all 64 bits, so one
+            // launch can cover any text length
+            const uint64_t dw = ((s + (uint64_t)u) * 64u + (uint64_t)l) * 4u + (uint64_t)(b & 3);
             uint32_t r = u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3));
             cq[qn + (uint32_t)lane] = ((uint64_t)r << 32) | dw;
         }

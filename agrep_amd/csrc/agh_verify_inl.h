@@ -322,7 +322,7 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
                                                  uint32_t wave_base)
 {
     constexpr int NMW = (NCH * 16 + 63) / 64;           // 64-bit words per position mask
-    const uint64_t j = (ent & 0xffffffffull) * 4u;
+    const uint64_t j = LEAN ? ent * 4u : (ent & 0xffffffffull) * 4u;   // lean entries: 64-bit dword index
     if (j >= c.n) return;
     const uint32_t rc_anchor = LEAN ? 0u : wave_base + (uint32_t)(ent >> 32);  // record no. at anchor
     const uint64_t anchor = j & ~(uint64_t)15;                           // sample's chunk start

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Everything DESIGN.md quotes, in one GPU call:  scripts/evidence_run.sh r02
+set -u
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
+cd $R
+mkdir -p gpurun_out
+python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/${TAG}_bench_line.json
+scripts/profile_configs.sh $TAG > gpurun_out/${TAG}_profile_configs.log 2>&1
+scripts/pmc_passes.sh pmc_${TAG}_fullc 2 2 fullc > gpurun_out/${TAG}_pmc_fullc.log 2>&1
+scripts/pmc_passes.sh pmc_${TAG}_lean 8 2 lean > gpurun_out/${TAG}_pmc_lean.log 2>&1
+python scripts/pmc_summary.py pmc_${TAG}_fullc k_fullscan 2147483648 gpurun_out/${TAG}_pmc_fullscan.json "prof_k2.py 2 GiB, k=2, count-only full scan (AGH_FORCE_FULLSCAN|AGH_COUNT)"
+python scripts/pmc_summary.py pmc_${TAG}_lean "k_sweep<4" 8589934592 gpurun_out/${TAG}_pmc_sweep.json "prof_k2.py 8 GiB, k=2, count-only (the headline kernel sequence on one segment)"
+python scripts/perf_multi.py 4 2>&1 | tail -7 > gpurun_out/${TAG}_perf_multi.log
+python scripts/perf_short.py 2>&1 | tail -9 > gpurun_out/${TAG}_perf_piece_engine.log
+ls gpurun_out | grep "^${TAG}_" | head -40

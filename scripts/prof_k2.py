@@ -10,7 +10,7 @@ import _oracle as O
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 mode = sys.argv[3] if len(sys.argv) > 3 else "lean"
-flags = {"full": A.FORCE_FULLSCAN, "numbered": 0, "lean": A.COUNT}[mode]
+flags = {"full": A.FORCE_FULLSCAN, "fullc": A.FORCE_FULLSCAN | A.COUNT, "numbered": 0, "lean": A.COUNT}[mode]
 n = int(gib * (1 << 30))
 t = torch.empty(n, dtype=torch.uint8, device='cuda')
 A.corpus_fill_device(t.data_ptr(), n // 4096, seed=12345, variants=O.VARIANTS_C2, plant_period=500)
