@@ -319,7 +319,8 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
         ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);
         if (__ballot(hits != 0)) {
             uint32_t rc[4];
-            rc[0] = before + 128u * (uint32_t)lane - (sc0 - a0);
+            // lean entries are 64-bit dword indices: the record-count half must stay zero
+            rc[0] = (MODE & 4) ? 0u : before + 128u * (uint32_t)lane - (sc0 - a0);
             rc[1] = rc[2] = rc[3] = 0;
             emit_candidates(hits, s, rc, cq, qn, cand + w * AGH_SLICE_CAP, ncand, counters);
             if (qn) flush_candidates(cq, qn, qn, cand + w * AGH_SLICE_CAP, ncand, counters);
