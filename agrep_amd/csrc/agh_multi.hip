@@ -272,6 +272,127 @@ __device__ __noinline__ void multi_approx_at(const uint8_t *__restrict__ text, u
     }
 }
 
+// ---- the same with the number of errors known at compile time (k_verify_multi<LEAN, K>) --------
+// What made the run-time version slow: eight predicated levels per byte whatever k is, one
+// dependent global load (the pattern's mask of the text byte) in front of every automaton step,
+// byte-wise piece compares.  Here the piece is compared as masked dwords against the window that is
+// fetched once, the automaton has exactly K+1 levels, and the masks of 16 text bytes are fetched
+// together (16 independent loads in flight) before the 16 steps run out of registers.
+template <bool LEAN, int K>
+__device__ __forceinline__ void approx_window_k(const uint8_t *__restrict__ text, uint64_t n,
+                                                const agh_dev_query &q,
+                                                const uint32_t *__restrict__ pmask, uint32_t m,
+                                                uint64_t ws, uint64_t we, uint64_t anchor,
+                                                uint32_t rc_anchor, const agh_marks &mk)
+{
+    const uint32_t finalbit = 1u << (m - 1);
+    const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    uint32_t rec = 0;
+    uint64_t rstart = 0;
+    if (LEAN) {
+        rstart = lean_record_start(text, ws, q.delim, mk);
+        if (rstart == ~0ull) return;
+    } else {
+        uint32_t back = 0;                      // delimiters in [ws, anchor)
+        for (uint64_t i = ws; i < anchor; ++i) back += (text[i] == q.delim);
+        rec = rc_anchor - back;
+    }
+    Automaton<uint32_t, K> A;
+    A.reset();
+    bool seen = false;
+    if (ws == 0) A.step(pmask[q.head_byte], finalbit);
+    for (uint64_t i0 = ws; i0 < we; i0 += 16) {
+        const uint32_t nb = we - i0 < 16 ? (uint32_t)(we - i0) : 16u;
+        uint32_t dws[4] = {0u, 0u, 0u, 0u};
+        if (i0 + 16 <= n16) {
+            const u32x4_u v = *reinterpret_cast<const u32x4_u *>(text + i0);
+            dws[0] = v[0]; dws[1] = v[1]; dws[2] = v[2]; dws[3] = v[3];
+        } else {
+            for (uint32_t t = 0; t < nb; ++t) dws[t >> 2] |= (uint32_t)text[i0 + t] << (8 * (t & 3));
+        }
+        uint32_t cms[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) cms[t] = pmask[(dws[t >> 2] >> (8 * (t & 3))) & 0xffu];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if ((uint32_t)t < nb) {
+                const uint32_t c = (dws[t >> 2] >> (8 * (t & 3))) & 0xffu;
+                if (A.step(cms[t], finalbit) && !seen) {
+                    seen = true;
+                    if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, i0 + t);
+                }
+                if (c == q.delim) {
+                    A.reset();
+                    ++rec;
+                    rstart = i0 + t + 1;
+                    seen = false;
+                    A.step(cms[t], finalbit);   // patterns never hold the delimiter byte
+                }
+            }
+        }
+    }
+    if (we == n && q.tail_virtual) {            // asearch.c:87-91
+        if (A.step(pmask[q.delim], finalbit) && !seen) {
+            if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
+        }
+    }
+}
+
+template <bool LEAN, int K>
+__device__ __forceinline__ void multi_approx_at_k(const uint8_t *__restrict__ text, uint64_t n,
+                                                  const agh_dev_query &q, const agh_multi_tables &mt,
+                                                  uint64_t j, uint32_t rc_chunk, const agh_marks &mk)
+{
+    const bool fold = q.fold != 0;
+    const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    uint32_t tw[4];
+    if (j + 16 <= n16) {
+        const u32x4_u v = *reinterpret_cast<const u32x4_u *>(text + j);
+        tw[0] = v[0]; tw[1] = v[1]; tw[2] = v[2]; tw[3] = v[3];
+    } else {
+        tw[0] = tw[1] = tw[2] = tw[3] = 0;
+        for (uint32_t t = 0; t < 16 && j + t < n; ++t) tw[t >> 2] |= (uint32_t)text[j + t] << (8 * (t & 3));
+    }
+    const uint32_t g = (tw[0] & q.qmask) | q.fold;
+    if (fold) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) tw[d] = swar_lower(tw[d]);
+    }
+    const uint32_t b = agh_mp_bucket(g);
+    for (uint32_t it = mt.bucket_start[b]; it < mt.bucket_start[b + 1]; ++it) {
+        const uint32_t info = mt.item_info[it];
+        const uint32_t o = info >> 8, len = info & 0xffu;
+        if (j + len > n) continue;
+        const u32x4_u pv = *reinterpret_cast<const u32x4_u *>(mt.pool + o);
+        const uint32_t head = len < 16u ? len : 16u;
+        uint32_t diff = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+            const uint32_t nb = head > 4u * d ? head - 4u * d : 0u;
+            const uint32_t mk4 = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+            diff |= (tw[d] ^ pv[d]) & mk4;
+        }
+        if (diff) continue;
+        uint32_t t = 16;
+        for (; t < len; ++t) {
+            uint32_t c = text[j + t];
+            if (fold && c >= 'A' && c <= 'Z') c += 32u;
+            if (c != mt.pool[o + t]) break;
+        }
+        if (t < len) continue;
+        const uint32_t pc = mt.bucket_items[it];
+        const uint32_t owner = mt.piece_owner[pc], po = mt.piece_po[pc], m = mt.owner_len[owner];
+        const uint64_t anchor = j & ~(uint64_t)15;          // rc_chunk = delimiters in front of it
+        const uint64_t back = (uint64_t)po + K;
+        uint64_t ws = j > back ? j - back : 0;
+        if (ws > anchor) ws = anchor;
+        uint64_t we = j + (m - po) + K;
+        if (we > n) we = n;
+        approx_window_k<LEAN, K>(text, n, q, mt.owner_mask + (size_t)owner * 256u, m, ws, we, anchor,
+                                 rc_chunk, mk);
+    }
+}
+
 // A verified occurrence at j: count its record once.
 template <bool LEAN>
 __device__ __forceinline__ void multi_mark(const uint8_t *__restrict__ text, const agh_dev_query &q,
@@ -453,7 +574,8 @@ __global__ __launch_bounds__(64) void k_sweep_multi_tail(const uint4 *__restrict
 }
 
 // One lane per candidate position: walk the bucket of patterns with that prefix, compare.
-template <bool LEAN>
+// K = 0: exact patterns; K = 1..8: -f with K errors (the candidate is a verbatim piece).
+template <bool LEAN, int K>
 __global__ __launch_bounds__(256) void k_verify_multi(const uint8_t *__restrict__ text,
                                                       uint64_t n, agh_dev_query q,
                                                       agh_multi_tables mt,
@@ -471,7 +593,7 @@ __global__ __launch_bounds__(256) void k_verify_multi(const uint8_t *__restrict_
         const uint64_t ent = slice[ci];
         const uint64_t j = ent & 0xffffffffull;
         if (j >= n) continue;
-        if (q.k) multi_approx_at<LEAN>(text, n, q, mt, j, wp + (uint32_t)(ent >> 32), mk);
+        if (K) multi_approx_at_k<LEAN, K>(text, n, q, mt, j, wp + (uint32_t)(ent >> 32), mk);
         else if (multi_match_at(text, n, q, mt, j)) multi_mark<LEAN>(text, q, mk, j, wp + (uint32_t)(ent >> 32));
     }
 }
@@ -551,12 +673,16 @@ void agh_launch_verify_multi(const agh_scan_args &a, const agh_multi_dev &m, boo
     mt.item_info = m.item_info;
     const uint32_t blocks = (a.nw + 3u) / 4u;
     if (!blocks) return;
-    if (lean)
-        hipLaunchKernelGGL((k_verify_multi<true>), dim3(blocks), dim3(256), 0, st,
-                           (const uint8_t *)a.text, a.n, a.q, mt, a.cand, a.wave_cand,
-                           a.wave_prefix, a.nw, a.mk);
-    else
-        hipLaunchKernelGGL((k_verify_multi<false>), dim3(blocks), dim3(256), 0, st,
-                           (const uint8_t *)a.text, a.n, a.q, mt, a.cand, a.wave_cand,
-                           a.wave_prefix, a.nw, a.mk);
+#define AGH_VM(LEANV, KK)                                                                     \
+    hipLaunchKernelGGL((k_verify_multi<LEANV, KK>), dim3(blocks), dim3(256), 0, st,           \
+                       (const uint8_t *)a.text, a.n, a.q, mt, a.cand, a.wave_cand,            \
+                       a.wave_prefix, a.nw, a.mk)
+#define AGH_VM_CASE(KK) case KK: if (lean) AGH_VM(true, KK); else AGH_VM(false, KK); break;
+    switch (a.q.k) {
+        AGH_VM_CASE(0) AGH_VM_CASE(1) AGH_VM_CASE(2) AGH_VM_CASE(3) AGH_VM_CASE(4)
+        AGH_VM_CASE(5) AGH_VM_CASE(6) AGH_VM_CASE(7) AGH_VM_CASE(8)
+    default: break;
+    }
+#undef AGH_VM_CASE
+#undef AGH_VM
 }

@@ -10,11 +10,19 @@ import _oracle as O
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 mode = sys.argv[3] if len(sys.argv) > 3 else "lean"
-flags = {"full": A.FORCE_FULLSCAN, "fullc": A.FORCE_FULLSCAN | A.COUNT, "numbered": 0, "lean": A.COUNT}[mode]
+flags = {"full": A.FORCE_FULLSCAN, "fullc": A.FORCE_FULLSCAN | A.COUNT, "numbered": 0, "lean": A.COUNT, "multi": A.COUNT}[mode]
 n = int(gib * (1 << 30))
 t = torch.empty(n, dtype=torch.uint8, device='cuda')
 A.corpus_fill_device(t.data_ptr(), n // 4096, seed=12345, variants=O.VARIANTS_C2, plant_period=500)
-q = A.Query(O.PATTERN_C2, k)
+if mode == "multi":                      # the config-5 pattern set (1024 patterns of 4..12 bytes)
+    import random
+    rng = random.Random(1024)
+    pats = set()
+    while len(pats) < 1024:
+        pats.add(bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(4, 12))))
+    q = A.Query.multi(sorted(pats), k=k)
+else:
+    q = A.Query(O.PATTERN_C2, k)
 for it in range(6):
     r = q.scan_device(t.data_ptr(), n, flags=flags)
 print("k", k, "matched", r.n_matched, "cand", r.n_candidates, "dev_ms %.3f sweep_ms %.3f" % (r.device_ms, r.sweep_ms))
