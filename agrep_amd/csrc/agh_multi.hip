@@ -35,10 +35,11 @@ __device__ __forceinline__ uint32_t probe_bit(uint32_t g, const agh_dev_query &q
     const uint8_t *tab8 = reinterpret_cast<const uint8_t *>(tab);
     if (MODE & 2) {
         const uint32_t p = agh_sample_prod18_q4((MODE & 1) ? (g | q.fold) : g);
-        return ((uint32_t)tab8[p >> 17] >> ((p >> 14) & 7u)) & 1u;
+        // v_bfe with a register offset: one instruction for (byte >> bit) & 1
+        return __builtin_amdgcn_ubfe((uint32_t)tab8[p >> 17], (p >> 14) & 7u, 1u);
     }
     const uint32_t h = agh_sample_hash18_q3((MODE & 1) ? ((g & q.qmask) | q.fold) : (g & q.qmask));
-    return ((uint32_t)tab8[h >> 3] >> (h & 7u)) & 1u;
+    return __builtin_amdgcn_ubfe((uint32_t)tab8[h >> 3], h & 7u, 1u);
 }
 
 // all 16 byte positions of one 16-byte chunk (nx = the 4 bytes that follow it)
@@ -52,7 +53,7 @@ __device__ __forceinline__ uint32_t probe_chunk(uint4 v, uint32_t nx, const agh_
     for (int p = 0; p < 16; ++p) {
         const int d = p >> 2, sh = p & 3;
         const uint32_t g = sh ? __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh) : w[d];
-        hits |= probe_bit<MODE>(g, q, tab) << p;
+        hits = (probe_bit<MODE>(g, q, tab) << p) | hits;       // v_lshl_or_b32
     }
     if ((MODE & 2) && __ballot(hits != 0)) {
         // q == 4: the table is a two-probe Bloom filter.  First-level hits (0.4-0.8 % of all
