@@ -620,3 +620,57 @@ def test_class_patterns_keep_the_sample_filter(agh):
         q.close()
         seen += 1
     assert seen == 2
+
+
+def test_streaming_count_scans_carry_records_across_segments(agh, tmp_path):
+    """Count-only file scans stream through one device segment (agh_scan_fd -> stream_scan): the
+    segment is cut after the last delimiter that has arrived and the unfinished record opens the
+    next one (fill_buf's residue carry, sgrep.c:465-471).  An 80 MiB input whose 32 MiB read chunks
+    end in the middle of records, from a file, from a pipe, with and without a trailing newline,
+    and -l stopping early -- always the count of the whole-file scan."""
+    import threading
+    body, planted = O.corpus(20480, seed=77, variants=O.VARIANTS_C2, plant_period=40)      # 80 MiB
+    head = b"x" * 1234 + b" approximatematch at the very top\n"
+    for tail in (b"", b"and a last record without a newline: aproximatematch"):
+        data = head + body.tobytes() + tail
+        f = tmp_path / "stream.txt"
+        f.write_bytes(data)
+        with agh.Query(O.PATTERN_C2, 2) as q:
+            fd = os.open(str(f), os.O_RDONLY)
+            try:
+                whole, ms = q.scan_fd(fd, cap=200000)                      # staged as one piece
+                os.lseek(fd, 0, os.SEEK_SET)
+                os.environ["AGH_STREAM_SEG_MB"] = "1"                      # a segment per read chunk
+                try:
+                    st, _ = q.scan_fd(fd, flags=agh.COUNT)
+                    os.lseek(fd, 0, os.SEEK_SET)
+                    st_l, _ = q.scan_fd(fd, flags=agh.FILENAMEONLY)
+                finally:
+                    del os.environ["AGH_STREAM_SEG_MB"]
+                os.lseek(fd, 0, os.SEEK_SET)
+                one, _ = q.scan_fd(fd, flags=agh.COUNT)                    # default 1 GiB segment
+            finally:
+                os.close(fd)
+            want = int(sum(planted)) + 1 + (1 if tail else 0)
+            assert whole.n_matched == len(ms) == want
+            assert st.n_matched == want and st.n_segments >= 3 and st.n_bytes == len(data)
+            assert one.n_matched == want
+            assert st_l.n_matched >= 1 and st_l.n_bytes < len(data)         # stopped at the first hit
+            # the same bytes through a pipe (no size known in advance, short reads)
+            r, w = os.pipe()
+
+            def feed():
+                mv = memoryview(data)
+                for i in range(0, len(mv), 1 << 20):
+                    os.write(w, mv[i:i + (1 << 20)])
+                os.close(w)
+            th = threading.Thread(target=feed)
+            th.start()
+            os.environ["AGH_STREAM_SEG_MB"] = "1"
+            try:
+                pp, _ = q.scan_fd(r, flags=agh.COUNT)
+            finally:
+                del os.environ["AGH_STREAM_SEG_MB"]
+                th.join()
+                os.close(r)
+            assert pp.n_matched == want and pp.n_bytes == len(data)
