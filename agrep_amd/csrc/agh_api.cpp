@@ -143,6 +143,9 @@ struct agh_query {
          *d_mp_omask = nullptr, *d_mp_info = nullptr;
 };
 
+// delimiter ends come from the delimiter bitmap: several bytes, or one letter under -i
+static bool q_mb(const agh_query *q) { return q->dlen > 1 || q->delim_fold; }
+
 static bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
 static bool is_lower(int c) { return c >= 'a' && c <= 'z'; }
 
@@ -333,7 +336,7 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
 // it the multi-pattern engine with its k+1 pieces as entries (agh_multi.hip).
 static int attach_piece_engine(agh_query *q)
 {
-    if (q->fq || q->general || q->table || q->dlen != 1 || q->m > 32 || q->m <= q->k) return 0;
+    if (q->fq || q->general || q->table || q_mb(q) || q->m > 32 || q->m <= q->k) return 0;
     // Pieces of 1-2 bytes select next to nothing (a 2-byte piece hits every ~500th position of
     // English-like text: 10-25 M candidates per 4 GiB): the census-free full scan is faster then
     // (scripts/perf_short.py: 'approxim' k=2 1.06 vs 1.54 TB/s, 'match' k=1 1.33 vs 1.98).
@@ -399,13 +402,9 @@ extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, 
     }
     bool delim_letters = false;
     for (int i = 0; i < dlen; ++i) delim_letters = delim_letters || is_upper(delim[i]) || is_lower(delim[i]);
-    if (nocase && delim_letters && dlen == 1) {
-        // maskgen.c:259-266 aliases the upper-case rows of Mask[] for the delimiter positions
-        // too: under -i "X" would end a record of -d x.  The kernels compare a single-byte
-        // delimiter verbatim (multi-byte delimiters go through delim_class, which folds).
-        fail("-i together with a letter as the delimiter is not supported");
-        return nullptr;
-    }
+    // -i with letters in the delimiter: maskgen.c:259-266 aliases the upper-case rows of Mask[] for
+    // the delimiter positions too ("X" ends a record of -d x); such delimiters go through the
+    // delimiter bitmap (delim_class folds), whatever their length
     agh_query *q = new agh_query();
     q->m = m;
     q->k = D;
@@ -532,10 +531,9 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
         for (int c = 0; c < 256; ++c)
             if ((Mask[c] >> (M - p)) & 1u) { ++members; if (lo < 0) lo = c; }
         const bool pair = members == 2 && is_upper(lo) && ((Mask[lo + 32] >> (M - p)) & 1u);
-        if (pair && D_length > 1) { delim_fold = true; continue; }
+        if (pair) { delim_fold = true; continue; }
         if (members != 1) {
-            fail("delimiter position %d matches %d different bytes (-i with a letter as a "
-                 "single-byte delimiter is not supported)", p, members);
+            fail("delimiter position %d matches %d different bytes", p, members);
             return nullptr;
         }
     }
@@ -689,6 +687,10 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
     if (!pats || !lens || npat < 1) { fail("no patterns"); return nullptr; }
     if (!delim || dlen != 1) {
         fail("multi-pattern scans support single-byte delimiters only");
+        return nullptr;
+    }
+    if (nocase && (is_upper(delim[0]) || is_lower(delim[0]))) {
+        fail("-f: -i together with a letter as the delimiter is not supported");
         return nullptr;
     }
     if (D < 0 || D > AGH_MAX_ERRORS) { fail("number of errors %d outside 0..%d", D, AGH_MAX_ERRORS); return nullptr; }
@@ -869,7 +871,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const bool invert = (flags & AGH_INVERT) != 0;
     const bool invert_list = invert && d_match_pos != nullptr;
     if (invert_list && q->multi) return fail("-v with record output is not supported for pattern files");
-    if (invert_list && q->dlen > 1) return fail("-v with record output supports single-byte delimiters only");
+    if (invert_list && q_mb(q)) return fail("-v with record output supports single-byte delimiters only");
     const bool pe = q->piece_single && !q->general && !(flags & AGH_FORCE_FULLSCAN) && !invert_list;
     const bool multi = q->multi || pe;
     const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
@@ -879,7 +881,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     if (multi && (flags & AGH_FORCE_FULLSCAN))
         return fail("multi-pattern queries have no full-scan engine");
     const bool want_filter = (q->fq > 0 || pe) && !(flags & AGH_FORCE_FULLSCAN) && !q->table && !invert_list &&
-                             !(q->general && (q->dlen > 1 || pe));   // general verify: 1-byte delimiters
+                             !(q->general && (q_mb(q) || pe));   // general verify: 1-byte delimiters
     if (!want_filter && (flags & AGH_FORCE_FILTER))
         return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
     if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
@@ -897,6 +899,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     memset(dq.dbytes, 0, sizeof(dq.dbytes));
     memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
     dq.dfold = q->delim_fold ? 1u : 0u;
+    dq.mb = q_mb(q) ? 1u : 0u;
     dq.fq = pe ? q->pe_fq : q->fq;
     dq.fh = pe ? 1 : q->fh;
     dq.qmask = pe ? q->pe_qmask : q->qmask;
@@ -910,7 +913,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
 
     // ---- multi-byte delimiter: mark where (selected) delimiter occurrences end --------------
     const uint64_t *d_dbm = nullptr;
-    if (q->dlen > 1) {
+    if (q_mb(q)) {
         const uint64_t n_words = (n + 63) / 64 + 4;     // readers may touch a few words past n
         if (q->dbm.ensure(n_words * sizeof(uint64_t))) return -1;
         HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
@@ -1263,7 +1266,7 @@ static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, 
     uint64_t nominal = seg_nominal(q);
     if (lean && !getenv("AGH_SEG_MAX_MB")) nominal = AGH_LEAN_SEG_MAX;
     if (len > nominal) {
-        if (q->dlen > 1)
+        if (q_mb(q))
             return fail("multi-byte delimiters: inputs above the %llu-byte segment limit are not "
                         "supported yet", (unsigned long long)nominal);
         const uint64_t nb = (len - 1) / nominal;        // boundaries strictly inside the text
@@ -1317,7 +1320,7 @@ static uint64_t env_mb(const char *name, uint64_t dflt_mb)
 static bool lean_pipeline_ok(const agh_query *q, unsigned flags, bool want_list)
 {
     const bool invert = (flags & AGH_INVERT) != 0;
-    return q->fq > 0 && !q->multi && !q->table && q->dlen == 1 && !want_list && !invert &&
+    return q->fq > 0 && !q->multi && !q->table && !q_mb(q) && !want_list && !invert &&
            (flags & (AGH_COUNT | AGH_FILENAMEONLY)) &&
            !(flags & (AGH_FORCE_FULLSCAN | AGH_FORCE_NUMBERED)) && !q->general;
 }
@@ -1393,6 +1396,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     memset(dq.dbytes, 0, sizeof(dq.dbytes));
     dq.dbytes[0] = q->delim[0];
     dq.dfold = 0;
+    dq.mb = 0;
     dq.fq = q->fq;
     dq.fh = q->fh;
     dq.qmask = q->qmask;
@@ -1617,6 +1621,7 @@ static int collect_matches(agh_query *q, uint64_t len, const agh_result *res, ag
     dq.dlen = (uint32_t)q->dlen;
     memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
     dq.dfold = q->delim_fold ? 1u : 0u;
+    dq.mb = q_mb(q) ? 1u : 0u;
     agh_launch_match_bounds(q->staging.p, len, dq, (const uint64_t *)q->dbm.p,
                             (const uint64_t *)q->match_pos.p, (uint32_t)ns,
                             (uint64_t *)q->match_start.p, (uint64_t *)q->match_end.p, nullptr);
@@ -1874,7 +1879,7 @@ static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, u
     fd_reader rd;
     if (rd.open_fd(fd, with_range, begin, end)) return -1;
     const bool count_only = (flags & (AGH_COUNT | AGH_FILENAMEONLY)) && !(matches && cap);
-    if (count_only && q->dlen == 1 && env_mb("AGH_STREAM", 1) != 0)
+    if (count_only && !q_mb(q) && env_mb("AGH_STREAM", 1) != 0)
         return stream_scan(q, rd, flags, res);
 
     // records wanted: the whole input is staged, then scanned (agh_fetch_records gathers from it)

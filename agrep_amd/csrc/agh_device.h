@@ -58,7 +58,8 @@ struct agh_dev_query {
     uint32_t delim;     // the delimiter byte (last byte of a multi-byte delimiter)
     uint32_t dlen;      // delimiter length in bytes; > 1: delimiter ends come from the bitmap
     uint8_t dbytes[8];  // the delimiter
-    uint32_t dfold;     // 1: delimiter bytes match case-insensitively (multi-byte delimiters, -i)
+    uint32_t dfold;     // 1: delimiter bytes match case-insensitively (-i with letters in the delimiter)
+    uint32_t mb;        // 1: delimiter ends come from the delimiter bitmap (dlen > 1, or a folded letter)
     int32_t fq;         // filter: sample length in bytes (1..4), 0 = no filter
     int32_t fh;         // filter: sample stride in bytes (4, 8 or 16)
     uint32_t qmask;     // low fq bytes

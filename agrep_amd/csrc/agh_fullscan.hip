@@ -306,7 +306,7 @@ static void launch_fullscan_t(const agh_scan_args &a, hipStream_t st)
     hipLaunchKernelGGL((k_fullscan<WT, K, MBV, GENV, LEANV>), dim3(blocks), dim3(AGH_FS_THREADS), \
                        0, st, (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask,             \
                        a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm)
-    const bool mbv = a.q.dlen > 1, genv = a.general != 0, leanv = a.mk.hashset != nullptr;
+    const bool mbv = a.q.mb != 0, genv = a.general != 0, leanv = a.mk.hashset != nullptr;
     if (leanv) {                                // count-only: hash set of record starts, no census
         if (mbv && genv) AGH_FS_LAUNCH(true, true, true);
         else if (mbv) AGH_FS_LAUNCH(true, false, true);

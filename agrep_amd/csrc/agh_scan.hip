@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_match_bounds(const uint8_t *__restrict_
     uint64_t e = pos[i];
     if (e > n) e = n;
     uint64_t s = e, en = e;
-    if (q.dlen > 1) {
+    if (q.mb) {
         // record = (end of the last delimiter in front of e, start of the next delimiter]
         const int64_t d = dbm_prev(dbm, e, ~0ull);
         s = d >= 0 ? (uint64_t)d + 1 : 0;
@@ -151,7 +151,7 @@ static void launch_verify_n(const agh_scan_args &a, const uint64_t *gtab, uint32
         hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, true>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
                            a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
-    else if (a.q.dlen > 1)
+    else if (a.q.mb)
         hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, true, false>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
                            a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);

@@ -733,7 +733,7 @@ static void launch_sweep_t(const agh_sweep_args &a, hipStream_t st)
 {
     // lean sweeps never look at delimiters, so bit 3 only matters for census sweeps
     const int mode = (a.q.fold ? 1 : 0) | (a.q.fq == 4 ? 2 : 0) | (a.lean ? 4 : 0) |
-                     ((a.q.dlen > 1 && !a.lean) ? 8 : 0);
+                     ((a.q.mb && !a.lean) ? 8 : 0);
     switch (mode) {
     case 0: launch_sweep_hm<H, 0>(a, st); break;
     case 1: launch_sweep_hm<H, 1>(a, st); break;
@@ -754,7 +754,7 @@ void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st)
 {
     switch (H) {
     case 0:
-        if (a.q.dlen > 1) launch_sweep_hm<0, 8>(a, st);
+        if (a.q.mb) launch_sweep_hm<0, 8>(a, st);
         else launch_sweep_hm<0, 0>(a, st);
         break;
     case 4: launch_sweep_t<4>(a, st); break;

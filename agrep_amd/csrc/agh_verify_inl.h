@@ -230,7 +230,7 @@ __device__ __noinline__ void verify_window_slow(const uint8_t *__restrict__ text
                                                 uint32_t rc_anchor, const agh_marks &mk)
 {
     const WT finalbit = (WT)1 << (q.m - 1);
-    const bool mb = q.dlen > 1;
+    const bool mb = q.mb != 0;
     uint32_t rec = 0;
     uint64_t rstart = 0;                        // LEAN: first byte of the current record
     if (LEAN) {

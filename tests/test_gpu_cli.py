@@ -185,3 +185,17 @@ def test_cli_q6_divergence_is_deliberate(tmp_path):
         assert out_n == b"1: hello world\n"
         _, out_ri, _ = _run(REF, ["-V0", "-i", "hello", str(f)])
         assert out_ri == out
+
+
+@needs_ref
+def test_cli_nocase_letter_delimiter(tmp_path):
+    """-i -d q ('Q' ends a record too, maskgen.c:259-266): counts equal the reference's (record
+    placement under -d is the reference's own output(): tests/test_gpu_refshim.py)."""
+    t, _ = O.corpus(16, seed=9, variants=O.VARIANTS_C2, plant_period=7, upper_permille=300)
+    f = tmp_path / "dq.txt"
+    f.write_bytes(t.tobytes().replace(b"\n", b"q"))
+    for args in (["-V0", "-i", "-d", "q", "-2", "-c"], ["-V0", "-i", "-d", "q", "-1", "-c"], ["-V0", "-i", "-d", "q", "-c"]):
+        a = args + ["approximatematch", str(f)]
+        rc_r, out_r, _ = _run(REF, a)
+        rc_g, out_g, err_g = _run(CLI, a)
+        assert (rc_g, out_g) == (rc_r, out_r), (a, out_g[:200], out_r[:200], err_g[:200])

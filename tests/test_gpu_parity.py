@@ -674,3 +674,33 @@ def test_streaming_count_scans_carry_records_across_segments(agh, tmp_path):
                 th.join()
                 os.close(r)
             assert pp.n_matched == want and pp.n_bytes == len(data)
+
+
+def test_nocase_with_a_letter_as_delimiter(agh):
+    """-i -d q: maskgen.c:259-266 aliases the upper-case rows of Mask[] for the delimiter position
+    too, so 'Q' ends a record as well.  One-byte delimiters that fold go through the delimiter
+    bitmap like the multi-byte ones; all engines against the oracle (== the reference, checked on
+    CPU: 57 / 83 records at k = 1 / 2 on this text)."""
+    t, _ = O.corpus(16, seed=9, variants=O.VARIANTS_C2, plant_period=7, upper_permille=300)
+    text = t.tobytes().replace(b"\n", b"q")
+    assert text.count(b"Q") > 100
+    for k, ref_count in ((1, 57), (2, 83), (0, None)):
+        want = O.asearch(O.PATTERN_C2, k, text, delim=b"q", nocase=True, cap=100000)
+        if ref_count is not None:
+            assert want[0] == ref_count
+        for flags in (0, agh.FORCE_FULLSCAN):
+            res, recs, _ = _gpu(agh, O.PATTERN_C2, k, text, nocase=True, flags=flags, delim=b"q")
+            assert (res.n_matched, recs) == want, (k, flags)
+        with agh.Query(O.PATTERN_C2, k, nocase=True, delim=b"q") as q:
+            assert q.scan_buffer(text, flags=agh.COUNT)[0].n_matched == want[0]
+            assert q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_FULLSCAN)[0].n_matched == want[0]
+    rng = random.Random(99)
+    for it in range(20):                                # small random cases, delimiter 'x' / 'X'
+        pat, k, text = _rand_case(rng, 6, max_m=20)
+        if b"x" in pat or b"X" in pat:
+            continue
+        text = bytes(c - 32 if (97 <= c <= 122 and rng.random() < 0.3) else c for c in text)
+        text = text.replace(b"\n", b"x" if rng.random() < 0.5 else b"X")
+        want = O.asearch(pat, k, text, delim=b"x", nocase=True, cap=100000)
+        res, recs, _ = _gpu(agh, pat, k, text, nocase=True, delim=b"x")
+        assert (res.n_matched, recs) == want, (pat, k, text)

@@ -115,6 +115,17 @@ def test_delimiters_through_the_shim(files, tmp_path, delim):
 
 
 @needs
+def test_nocase_letter_delimiter_through_the_shim(tmp_path):
+    """-i -d q: 'Q' ends a record as well (maskgen.c:259-266); count, records with the delimiter in
+    front, -n numbers."""
+    t, _ = O.corpus(16, seed=9, variants=O.VARIANTS_C2, plant_period=7, upper_permille=300)
+    f = tmp_path / "dq.txt"
+    f.write_bytes(t.tobytes().replace(b"\n", b"q"))
+    for args in (["-V0", "-i", "-d", "q", "-2", "-c"], ["-V0", "-i", "-d", "q", "-1"], ["-V0", "-i", "-d", "q", "-n", "-2"]):
+        _same(args + ["approximatematch"], [str(f)])
+
+
+@needs
 def test_pattern_file_through_the_shim(files, tmp_path):
     pf = tmp_path / "pats.txt"
     pf.write_bytes(b"approximatematch\naproximatematch\nzzzzqqqq\n")
