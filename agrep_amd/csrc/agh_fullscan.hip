@@ -45,6 +45,11 @@ __device__ __forceinline__ void fullscan_piece(uint4 v, const WT *lmask, WT fina
 // select, no branch.  Matches are not located here: the piece only ORs up the top level; a piece
 // whose OR reaches the final bit (one in thousands) is replayed by the exact path from the state
 // saved at its start.  17-18 VALU instructions per byte at k = 2 instead of 31.
+template <typename WT>
+struct MaskKill {
+    WT cm, kb;
+};
+
 template <typename WT, int K>
 __device__ __forceinline__ WT fullscan_piece_fast(uint4 v, const MaskKill<WT> *tab, Automaton<WT, K> &A)
 {
@@ -53,10 +58,29 @@ __device__ __forceinline__ WT fullscan_piece_fast(uint4 v, const MaskKill<WT> *t
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
         const uint32_t byte = (dws[b >> 2] >> (8 * (b & 3))) & 0xffu;
-        step_kill<WT, K>(A, tab[byte]);
+        const MaskKill<WT> e = tab[byte];
+        WT po = A.R[0];
+        WT pn = ((po << 1) | (WT)1) & e.cm;
+        A.R[0] = pn;
+#pragma unroll
+        for (int l = 1; l <= K; ++l) {
+            const WT cur = A.R[l];
+            const WT ne = ((((cur << 1) | (WT)1) & e.cm) | po | (((po | pn) << 1) | (WT)1)) &
+                          (e.kb | (((WT)1 << l) - (WT)1));
+            po = cur;
+            pn = ne;
+            A.R[l] = ne;
+        }
         any |= A.R[K];
     }
     return any;
+}
+
+// 0x80 in every byte of w that equals the delimiter (dd = delimiter in all four bytes)
+__device__ __forceinline__ uint32_t delim_bits(uint32_t w, uint32_t dd)
+{
+    const uint32_t x = w ^ dd;
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
 }
 
 // GEN: the general automaton (non-unit costs / <exact> segments) instead of the unit-cost one.

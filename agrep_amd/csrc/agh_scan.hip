@@ -22,13 +22,8 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
                                                 uint32_t tspan, uint32_t g_base)
 {
     __shared__ WT lmask[256];
-    __shared__ MaskKill<WT> ktab[(LEAN && !MB && !GEN) ? 256 : 1];
     __shared__ uint32_t pre[AGH_VGROUP + 1];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
-    if (LEAN && !MB && !GEN) {
-        ktab[threadIdx.x].cm = mask_g[threadIdx.x];
-        ktab[threadIdx.x].kb = threadIdx.x == q.delim ? (WT)0 : ~(WT)0;
-    }
     const uint32_t g0 = g_base + blockIdx.x * AGH_VGROUP;   // first slice of this workgroup
     if (threadIdx.x < AGH_VGROUP)               // the 8 counts arrive in one round trip
         pre[threadIdx.x + 1] = (g0 + threadIdx.x < nw) ? wave_cand[g0 + threadIdx.x] : 0u;
@@ -48,8 +43,6 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
     verify_ctx_init<WT, K, GEN>(c, text, n, q, lmask, mk, dbm);
     c.gtab = gtab;
     c.tspan = tspan;
-    // branch-free boundaries apply: unit costs, one-byte delimiter that no pattern position accepts
-    if (LEAN && !MB && !GEN && lmask[q.delim & 0xffu] == (WT)0) c.ktab = ktab;
 
     for (uint32_t ci = threadIdx.x; ci < total; ci += 256) {
         uint32_t sl = 0;

@@ -150,43 +150,6 @@ struct Automaton {
 };
 
 // ---------------------------------------------------------------------------------------
-// Branch-free record boundaries (k_fullscan's fast loop and the lean verifier's fast walk).
-// For unit costs and a one-byte delimiter that is not a member of any pattern position
-// (Mask[delim] == 0) the state right after a boundary is R_e = 2^e - 1 and the ordinary step on the
-// delimiter byte (CM = 0) yields a superset of it, so the boundary is one AND per level with
-// (kb | 2^e - 1): kb = 0 for the delimiter byte, ~0 otherwise, read from LDS together with the
-// byte's mask.
-// ---------------------------------------------------------------------------------------
-template <typename WT>
-struct MaskKill {
-    WT cm, kb;
-};
-
-template <typename WT, int K>
-__device__ __forceinline__ void step_kill(Automaton<WT, K> &A, const MaskKill<WT> e)
-{
-    WT po = A.R[0];
-    WT pn = ((po << 1) | (WT)1) & e.cm;
-    A.R[0] = pn;
-#pragma unroll
-    for (int l = 1; l <= K; ++l) {
-        const WT cur = A.R[l];
-        const WT ne = ((((cur << 1) | (WT)1) & e.cm) | po | (((po | pn) << 1) | (WT)1)) &
-                      (e.kb | (((WT)1 << l) - (WT)1));
-        po = cur;
-        pn = ne;
-        A.R[l] = ne;
-    }
-}
-
-// 0x80 in every byte of w that equals the delimiter (dd = delimiter in all four bytes)
-__device__ __forceinline__ uint32_t delim_bits(uint32_t w, uint32_t dd)
-{
-    const uint32_t x = w ^ dd;
-    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
-}
-
-// ---------------------------------------------------------------------------------------
 // verify: one workgroup per AGH_VGROUP sweep-wave slices, one lane per candidate sample
 // ---------------------------------------------------------------------------------------
 // Byte-wise reference walk of one window: used for windows at the head / tail of the text
@@ -319,7 +282,6 @@ struct VerifyCtx {
     const uint64_t *dbm;     // multi-byte delimiters: delimiter-end bitmap
     WT finalbit;
     uint32_t Lw, tailw, span;
-    const MaskKill<WT> *ktab; // LDS (mask, kill) table when the branch-free boundaries apply, else NULL
     const uint64_t *gtab;    // lean scans: per hash slot (gram, first/last offset) or NULL
     uint32_t tspan;          // window length when the gram's offset is known: m + 2k + spread
     Automaton<WT, K> RF;     // state right after a record boundary (reset + re-fed delimiter)
@@ -345,7 +307,6 @@ __device__ __forceinline__ void verify_ctx_init(VerifyCtx<WT, K> &c, const uint8
     c.tailw = (uint32_t)(q.fq + q.m + q.k);
     c.span = c.Lw + c.tailw;                    // <= 16 * NCH by construction
     c.gtab = nullptr;
-    c.ktab = nullptr;
     c.tspan = 0;
     c.RF.reset();
     c.rf_hit = c.RF.template step_q<GEN>(lmask[q.delim], c.finalbit, q);   // asearch.c:175-186
@@ -404,73 +365,6 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
     for (int ic = 0; ic < NCH; ++ic)
         ch[ic] = *reinterpret_cast<const u32x4_u *>(c.text + ws + 16 * ic);
 
-    if (LEAN && !MB && !GEN && c.ktab) {
-        // Lean fast walk: the automaton with branch-free boundaries; per step only "did the record
-        // with this many delimiters in front of it (inside the window) match" is kept (ev bit r).
-        // Where those records start is worked out afterwards, from the window bytes, for the lanes
-        // that saw a match.
-        Automaton<WT, K> A;
-        A.reset();
-        uint32_t ev = 0, r = 0;
-        const uint32_t fin = (uint32_t)c.q->m - 1u;
-#pragma unroll
-        for (int p = 0; p < NCH * 16; ++p) {
-            if ((uint32_t)p >= span) break;
-            const uint32_t dwv = ch[p >> 4][(p >> 2) & 3];
-            const MaskKill<WT> e = c.ktab[(dwv >> (8 * (p & 3))) & 0xffu];
-            step_kill<WT, K>(A, e);
-            ev |= ((uint32_t)(A.R[K] >> fin) & 1u) << r;
-            r += (uint32_t)(~e.kb) & 1u;                // the delimiter byte closes record r
-            r = r < 31u ? r : 31u;
-        }
-        if (r >= 31u) {                                 // a window full of delimiters: exact path
-            verify_window_slow<WT, K, LEAN, GEN>(c.text, c.n, *c.q, c.lmask, c.dbm, ws, ws + span, anchor,
-                                                 rc_anchor, *c.mk);
-            return;
-        }
-        if (ev) {
-            const uint32_t dd = c.q->delim * 0x01010101u;
-            uint64_t dmk[NMW];                          // delimiter positions inside [ws, ws + span)
-#pragma unroll
-            for (int i = 0; i < NMW; ++i) dmk[i] = 0;
-#pragma unroll
-            for (int d = 0; d < NCH * 4; ++d) {
-                const uint32_t z = delim_bits(ch[d >> 2][d & 3], dd) >> 7;      // bit 0/8/16/24 per byte
-                const uint32_t nib = (z | (z >> 7) | (z >> 14) | (z >> 21)) & 0xfu;
-                dmk[d >> 4] |= (uint64_t)nib << (4 * (d & 15));
-            }
-#pragma unroll
-            for (int i = 0; i < NMW; ++i) {
-                const int lo = i * 64;
-                if ((int)span <= lo) dmk[i] = 0;
-                else if ((int)span < lo + 64) dmk[i] &= (1ull << (span - lo)) - 1ull;
-            }
-            while (ev) {
-                const uint32_t rr = (uint32_t)__ffs((int)ev) - 1u;
-                ev &= ev - 1u;
-                uint64_t st;
-                if (rr == 0) {
-                    st = lean_record_start(c.text, ws, c.q->delim, *c.mk);
-                } else {                                // one past the rr-th delimiter of the window
-                    uint32_t left = rr;
-                    st = ~0ull;
-#pragma unroll
-                    for (int i = 0; i < NMW; ++i) {
-                        uint64_t m = dmk[i];
-                        const uint32_t cnt = (uint32_t)__popcll(m);
-                        if (st == ~0ull && left <= cnt) {
-                            for (uint32_t t = 1; t < left; ++t) m &= m - 1;
-                            st = ws + (uint64_t)(i * 64) + (uint64_t)(__ffsll((long long)m) - 1) + 1;
-                        } else if (st == ~0ull) {
-                            left -= cnt;
-                        }
-                    }
-                }
-                if (st != ~0ull) lean_insert(*c.mk, st);
-            }
-        }
-        return;
-    }
     Automaton<WT, K> A;
     A.reset();
     uint32_t seen = 0;
