@@ -1,6 +1,8 @@
 // agh_scan.hip -- the k-error automaton on candidate windows (k_verify) and the record output
 // kernels.  The automaton over every byte lives in agh_fullscan.hip (its own translation unit:
 // the two kernel families compile in parallel).  See agh_sweep.hip for the data flow of a scan.
+#include <stdlib.h>
+
 #include "agh_verify_inl.h"
 
 #define AGH_VGROUP 8u   // sweep-wave slices verified by one workgroup
@@ -24,33 +26,38 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
     __shared__ WT lmask[256];
     __shared__ uint32_t pre[AGH_VGROUP + 1];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
-    const uint32_t g0 = g_base + blockIdx.x * AGH_VGROUP;   // first slice of this workgroup
-    if (threadIdx.x < AGH_VGROUP)               // the 8 counts arrive in one round trip
-        pre[threadIdx.x + 1] = (g0 + threadIdx.x < nw) ? wave_cand[g0 + threadIdx.x] : 0u;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        pre[0] = 0;
-        for (uint32_t i = 1; i <= AGH_VGROUP; ++i) {
-            run += pre[i];
-            pre[i] = run;
-        }
-    }
-    __syncthreads();
-    const uint32_t total = pre[AGH_VGROUP];
-    if (total == 0) return;
     VerifyCtx<WT, K> c;
     verify_ctx_init<WT, K, GEN>(c, text, n, q, lmask, mk, dbm);
     c.gtab = gtab;
     c.tspan = tspan;
-
-    for (uint32_t ci = threadIdx.x; ci < total; ci += 256) {
-        uint32_t sl = 0;
+    // grid-stride over the groups of AGH_VGROUP slices: a 64 GiB scan has 32768 groups of ~540
+    // candidates; the mask table and the context are set up once per workgroup, not once per group
+    const uint32_t n_groups = (nw - g_base + AGH_VGROUP - 1u) / AGH_VGROUP;
+    for (uint32_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
+        const uint32_t g0 = g_base + gi * AGH_VGROUP;       // first slice of this group
+        __syncthreads();                        // everybody is done with pre[] of the last group
+        if (threadIdx.x < AGH_VGROUP)           // the 8 counts arrive in one round trip
+            pre[threadIdx.x + 1] = (g0 + threadIdx.x < nw) ? wave_cand[g0 + threadIdx.x] : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            pre[0] = 0;
+            for (uint32_t i = 1; i <= AGH_VGROUP; ++i) {
+                run += pre[i];
+                pre[i] = run;
+            }
+        }
+        __syncthreads();
+        const uint32_t total = pre[AGH_VGROUP];
+        for (uint32_t ci = threadIdx.x; ci < total; ci += 256) {
+            uint32_t sl = 0;
 #pragma unroll
-        for (uint32_t i = 1; i < AGH_VGROUP; ++i) sl += (pre[i] <= ci) ? 1u : 0u;
-        const uint32_t w = g0 + sl;
-        const uint64_t ent = cand[(uint64_t)w * AGH_SLICE_CAP + (ci - pre[sl])];
-        verify_candidate<WT, K, NCH, LEAN, MB, GEN>(c, ent, LEAN ? 0u : wave_prefix[w]);
+            for (uint32_t i = 1; i < AGH_VGROUP; ++i) sl += (pre[i] <= ci) ? 1u : 0u;
+            const uint32_t w = g0 + sl;
+            const uint64_t ent = cand[(uint64_t)w * AGH_SLICE_CAP + (ci - pre[sl])];
+            verify_candidate<WT, K, NCH, LEAN, MB, GEN>(c, ent, LEAN ? 0u : wave_prefix[w]);
+        }
     }
 }
 
@@ -147,6 +154,11 @@ static void launch_verify_n(const agh_scan_args &a, const uint64_t *gtab, uint32
     const uint32_t g_base = a.w_begin;
     if (w_hi <= g_base) return;
     uint32_t blocks = (w_hi - g_base + AGH_VGROUP - 1u) / AGH_VGROUP;
+    {   // grid cap (workgroups loop over the groups); AGH_VERIFY_BLOCKS=0: one workgroup per group
+        uint32_t cap = 16384u;                  // A/B on 64 GiB: 0 / 4096 / 8192 / 16384 all within 0.5 %
+        if (const char *e = getenv("AGH_VERIFY_BLOCKS")) cap = (uint32_t)strtoul(e, nullptr, 10);
+        if (cap && blocks > cap) blocks = cap;
+    }
     if (a.general)                          // single-byte delimiters only (the host checks)
         hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, true>), dim3(blocks), dim3(256), 0, st,
                            (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
