@@ -135,6 +135,7 @@ struct agh_query {
     // many errors): the multi-pattern tables hold its k+1 pieces (or the pattern itself, k = 0)
     bool piece_single = false;
     int pe_fq = 0, pe_minlen = 0;
+    int mp_stride = 1;                  // multi-pattern sweep: probe every 1 / 2 / 4 bytes (fill_multi_tables)
     uint32_t pe_qmask = 0, pe_fold = 0;
     bool multi_dense = false;           // hits are too dense for the candidate slices
     int npat = 0;
@@ -590,60 +591,70 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
         }
     const int npc = (int)pcs.size();
 
-    const int fq = minlen < 4 ? minlen : 4;     // prefix length probed at every text position
+    const int fq = minlen < 4 ? minlen : 4;     // length of the probed q-gram
     const uint32_t qmask = fq == 4 ? 0xffffffffu : ((1u << (8 * fq)) - 1u);
     const uint32_t fold = nocase ? (0x20202020u & qmask) : 0u;
+    // Probe stride: an entry of length L that occurs verbatim at text position j contains a 4-gram
+    // at a text position divisible by S at one of its offsets 0..S-1 as soon as L >= S + 3.  So a
+    // set whose shortest entry has >= 7 (>= 5) bytes is probed at every 4th (2nd) position only,
+    // with the grams of offsets 0..S-1 of every entry in the table -- 4 (8) probes per 16 bytes
+    // instead of 16, no unaligned extraction at S = 4.
+    const int stride = minlen >= 7 ? 4 : (minlen >= 5 ? 2 : 1);
+    q->mp_stride = stride;
     *fq_out = fq;
     *qmask_out = qmask;
     *fold_out = fold;
     *minlen_out = minlen;
 
+    const uint32_t NB = 1u << AGH_MP_BUCKET_BITS;
     std::vector<uint32_t> bits((1u << AGH_MP_BITS) / 32, 0), off(npc + 1, 0);
     std::vector<uint8_t> pool;
-    std::vector<uint32_t> bucket_of(npc);
-    const uint32_t NB = 1u << AGH_MP_BUCKET_BITS;
-    std::vector<uint32_t> bstart(NB + 1, 0), items(npc);
+    std::vector<uint32_t> bstart(NB + 1, 0);
     std::vector<char> usable(npc, 1);
     std::vector<uint32_t> piece_owner(npc);
     std::vector<uint8_t> piece_po(npc), owner_len(npat);
+    struct gram_item { uint32_t bucket, piece, o; };
+    std::vector<gram_item> gi;
     for (int i = 0; i < npc; ++i) {
         const unsigned char *src = pats[pcs[i].owner] + pcs[i].po;
         off[i] = (uint32_t)pool.size();
         piece_owner[i] = (uint32_t)pcs[i].owner;
         piece_po[i] = (uint8_t)pcs[i].po;
-        uint32_t g = 0;
         for (int t = 0; t < pcs[i].len; ++t) {
             unsigned char c = src[t];
             if (c == delim0) usable[i] = 0;   // can never lie inside one record
             if (nocase && is_upper(c)) c += 32;
             pool.push_back(c);
-            if (t < fq) g |= (uint32_t)src[t] << (8 * t);
         }
-        g = (g & qmask) | fold;
-        bucket_of[i] = agh_mp_bucket(g);
-        if (usable[i]) {
+        if (!usable[i]) continue;
+        for (int o = 0; o < stride; ++o) {
+            uint32_t g = 0;
+            for (int t = 0; t < fq; ++t) g |= (uint32_t)src[o + t] << (8 * t);     // o + fq <= len: len >= stride + 3
+            g = (g & qmask) | fold;
             const uint32_t h = fq == 4 ? agh_sample_hash18_q4(g) : agh_sample_hash18_q3(g);
             bits[h >> 5] |= 1u << (h & 31u);
             if (fq == 4) {                      // second Bloom probe (agh_multi.hip probe_chunk)
                 const uint32_t h2 = agh_sample_hash18b_q4(g);
                 bits[h2 >> 5] |= 1u << (h2 & 31u);
             }
-            bstart[bucket_of[i] + 1]++;
+            gi.push_back({agh_mp_bucket(g), (uint32_t)i, (uint32_t)o});
+            bstart[gi.back().bucket + 1]++;
         }
     }
     off[npc] = (uint32_t)pool.size();
     pool.resize(pool.size() + 16, 0);           // the exact verifier reads 16 bytes at any entry
     if (pool.size() >= (1u << 24)) return fail("pattern set too large (%zu bytes)", pool.size());
+    if ((size_t)npc >= (1u << 28)) return fail("too many pattern pieces");
     for (uint32_t b = 0; b < NB; ++b) bstart[b + 1] += bstart[b];
-    std::vector<uint32_t> info(npc ? npc : 1, 0u);
+    // bucket items: piece index | offset of the gram inside the piece << 28; info: pool offset, length
+    std::vector<uint32_t> items(gi.size() ? gi.size() : 1, 0u), info(gi.size() ? gi.size() : 1, 0u);
     {
         std::vector<uint32_t> fill(bstart.begin(), bstart.end() - 1);
-        for (int i = 0; i < npc; ++i)
-            if (usable[i]) {
-                const uint32_t at = fill[bucket_of[i]]++;
-                items[at] = (uint32_t)i;
-                info[at] = (off[i] << 8) | (uint32_t)pcs[i].len;
-            }
+        for (const gram_item &x : gi) {
+            const uint32_t at = fill[x.bucket]++;
+            items[at] = x.piece | (x.o << 28);
+            info[at] = (off[x.piece] << 8) | (uint32_t)pcs[x.piece].len;
+        }
     }
     // per-pattern position masks for the verifying automaton (as agh_query_literal builds them)
     std::vector<uint32_t> omask;
@@ -715,7 +726,6 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
     q->k = D;
     q->dlen = 1;
     q->delim[0] = delim[0];
-    q->fh = 1;
     memset(q->mask, 0, sizeof(q->mask));
     if (fill_multi_tables(q, pats, lens, npat, D, nocase, delim[0], &q->fq, &q->qmask, &q->fold,
                           &q->m) ||
@@ -723,6 +733,7 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
         agh_query_free(q);
         return nullptr;
     }
+    q->fh = q->mp_stride;
     return q;
 }
 
@@ -901,7 +912,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     dq.dfold = q->delim_fold ? 1u : 0u;
     dq.mb = q_mb(q) ? 1u : 0u;
     dq.fq = pe ? q->pe_fq : q->fq;
-    dq.fh = pe ? 1 : q->fh;
+    dq.fh = pe ? q->mp_stride : q->fh;                  // multi-pattern sweeps: the probe stride
     dq.qmask = pe ? q->pe_qmask : q->qmask;
     dq.fold = pe ? q->pe_fold : q->fold;
     dq.ci = (uint32_t)std::min(q->ci, q->k + 1);       // asearch1.c:42-44

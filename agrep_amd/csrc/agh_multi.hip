@@ -42,15 +42,15 @@ __device__ __forceinline__ uint32_t probe_bit(uint32_t g, const agh_dev_query &q
     return __builtin_amdgcn_ubfe((uint32_t)tab8[h >> 3], h & 7u, 1u);
 }
 
-// all 16 byte positions of one 16-byte chunk (nx = the 4 bytes that follow it)
-template <int MODE>
+// the probed positions of one 16-byte chunk: every STRIDE-th byte (nx = the 4 bytes that follow it)
+template <int MODE, int STRIDE>
 __device__ __forceinline__ uint32_t probe_chunk(uint4 v, uint32_t nx, const agh_dev_query &q,
                                                 const uint32_t *tab)
 {
     const uint32_t w[5] = {v.x, v.y, v.z, v.w, nx};
     uint32_t hits = 0;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
+    for (int p = 0; p < 16; p += STRIDE) {
         const int d = p >> 2, sh = p & 3;
         const uint32_t g = sh ? __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh) : w[d];
         hits = (probe_bit<MODE>(g, q, tab) << p) | hits;       // v_lshl_or_b32
@@ -111,6 +111,36 @@ __device__ __forceinline__ uint32_t swar_lower(uint32_t t)
     return t | (((ge & ~gt & ~t) & 0x80808080u) >> 2);
 }
 
+// Does the table entry (len bytes at pool) occur verbatim at text position s?  (Used when the
+// probed gram is not the entry's prefix; the prefix case compares against the window at j.)
+__device__ __forceinline__ bool multi_entry_at(const uint8_t *__restrict__ text, uint64_t n, bool fold,
+                                               const uint8_t *__restrict__ pool, uint32_t len, uint64_t s)
+{
+    if (s + len > n) return false;
+    const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    uint32_t t = 0;
+    if (s + 16 <= n16) {
+        const u32x4_u v = *reinterpret_cast<const u32x4_u *>(text + s);
+        const u32x4_u pv = *reinterpret_cast<const u32x4_u *>(pool);
+        const uint32_t head = len < 16u ? len : 16u;
+        uint32_t diff = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+            const uint32_t nb = head > 4u * d ? head - 4u * d : 0u;
+            const uint32_t m = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+            diff |= ((fold ? swar_lower(v[d]) : v[d]) ^ pv[d]) & m;
+        }
+        if (diff) return false;
+        t = 16;
+    }
+    for (; t < len; ++t) {
+        uint32_t c = text[s + t];
+        if (fold && c >= 'A' && c <= 'Z') c += 32u;
+        if (c != pool[t]) return false;
+    }
+    return true;
+}
+
 // Does any pattern occur at text position j?  Walks the bucket of patterns sharing the prefix;
 // the text window is fetched once (16 unaligned bytes), patterns of up to 16 bytes are compared
 // as four masked dwords (the pool is padded so that 16 bytes can always be read).
@@ -128,7 +158,7 @@ __device__ __forceinline__ bool multi_match_at(const uint8_t *__restrict__ text,
         tw[0] = tw[1] = tw[2] = tw[3] = 0;
         for (uint32_t t = 0; t < 16 && j + t < n; ++t) tw[t >> 2] |= (uint32_t)text[j + t] << (8 * (t & 3));
     }
-    const uint32_t g = (tw[0] & q.qmask) | q.fold;  // the q-byte prefix at j
+    const uint32_t g = (tw[0] & q.qmask) | q.fold;  // the probed q-gram at j
     if (fold) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) tw[d] = swar_lower(tw[d]);
@@ -137,6 +167,12 @@ __device__ __forceinline__ bool multi_match_at(const uint8_t *__restrict__ text,
     for (uint32_t it = mt.bucket_start[b]; it < mt.bucket_start[b + 1]; ++it) {
         const uint32_t info = mt.item_info[it];
         const uint32_t o = info >> 8, len = info & 0xffu;
+        const uint32_t go = mt.bucket_items[it] >> 28;     // the gram sits at this offset of the entry
+        if (go) {                                          // strided probing: the entry starts in front of j
+            if (j < go) continue;
+            if (multi_entry_at(text, n, fold, mt.pool + o, len, j - go)) return true;
+            continue;
+        }
         if (j + len > n) continue;
         const u32x4_u pv = *reinterpret_cast<const u32x4_u *>(mt.pool + o);
         const uint32_t head = len < 16u ? len : 16u;
@@ -251,22 +287,17 @@ __device__ __noinline__ void multi_approx_at(const uint8_t *__restrict__ text, u
     g = (g & q.qmask) | q.fold;
     const uint32_t b = agh_mp_bucket(g);
     for (uint32_t it = mt.bucket_start[b]; it < mt.bucket_start[b + 1]; ++it) {
-        const uint32_t pc = mt.bucket_items[it];
+        const uint32_t pc = mt.bucket_items[it] & 0x0fffffffu, go = mt.bucket_items[it] >> 28;
         const uint32_t o = mt.pat_off[pc], len = mt.pat_off[pc + 1] - o;
-        if (j + len > n) continue;
-        uint32_t t = 0;
-        for (; t < len; ++t) {
-            uint32_t c = text[j + t];
-            if (fold && c >= 'A' && c <= 'Z') c += 32u;
-            if (c != mt.pool[o + t]) break;
-        }
-        if (t != len) continue;
+        if (j < go) continue;
+        const uint64_t js = j - go;                         // where the piece starts
+        if (!multi_entry_at(text, n, fold != 0, mt.pool + o, len, js)) continue;
         const uint32_t owner = mt.piece_owner[pc], po = mt.piece_po[pc], m = mt.owner_len[owner];
         const uint64_t anchor = j & ~(uint64_t)15;          // rc_chunk = delimiters in front of it
         const uint64_t back = (uint64_t)po + q.k;
-        uint64_t ws = j > back ? j - back : 0;
+        uint64_t ws = js > back ? js - back : 0;
         if (ws > anchor) ws = anchor;
-        uint64_t we = j + (m - po) + q.k;
+        uint64_t we = js + (m - po) + q.k;
         if (we > n) we = n;
         approx_window<LEAN>(text, n, q, mt.owner_mask + (size_t)owner * 256u, m, ws, we, anchor,
                             rc_chunk, mk);
@@ -363,31 +394,37 @@ __device__ __forceinline__ void multi_approx_at_k(const uint8_t *__restrict__ te
     for (uint32_t it = mt.bucket_start[b]; it < mt.bucket_start[b + 1]; ++it) {
         const uint32_t info = mt.item_info[it];
         const uint32_t o = info >> 8, len = info & 0xffu;
-        if (j + len > n) continue;
-        const u32x4_u pv = *reinterpret_cast<const u32x4_u *>(mt.pool + o);
-        const uint32_t head = len < 16u ? len : 16u;
-        uint32_t diff = 0;
+        const uint32_t pc = mt.bucket_items[it] & 0x0fffffffu, go = mt.bucket_items[it] >> 28;
+        if (j < go) continue;
+        const uint64_t js = j - go;                         // where the piece starts
+        if (go) {
+            if (!multi_entry_at(text, n, fold, mt.pool + o, len, js)) continue;
+        } else {
+            if (j + len > n) continue;
+            const u32x4_u pv = *reinterpret_cast<const u32x4_u *>(mt.pool + o);
+            const uint32_t head = len < 16u ? len : 16u;
+            uint32_t diff = 0;
 #pragma unroll
-        for (uint32_t d = 0; d < 4; ++d) {
-            const uint32_t nb = head > 4u * d ? head - 4u * d : 0u;
-            const uint32_t mk4 = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
-            diff |= (tw[d] ^ pv[d]) & mk4;
+            for (uint32_t d = 0; d < 4; ++d) {
+                const uint32_t nb = head > 4u * d ? head - 4u * d : 0u;
+                const uint32_t mk4 = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+                diff |= (tw[d] ^ pv[d]) & mk4;
+            }
+            if (diff) continue;
+            uint32_t t = 16;
+            for (; t < len; ++t) {
+                uint32_t c = text[j + t];
+                if (fold && c >= 'A' && c <= 'Z') c += 32u;
+                if (c != mt.pool[o + t]) break;
+            }
+            if (t < len) continue;
         }
-        if (diff) continue;
-        uint32_t t = 16;
-        for (; t < len; ++t) {
-            uint32_t c = text[j + t];
-            if (fold && c >= 'A' && c <= 'Z') c += 32u;
-            if (c != mt.pool[o + t]) break;
-        }
-        if (t < len) continue;
-        const uint32_t pc = mt.bucket_items[it];
         const uint32_t owner = mt.piece_owner[pc], po = mt.piece_po[pc], m = mt.owner_len[owner];
         const uint64_t anchor = j & ~(uint64_t)15;          // rc_chunk = delimiters in front of it
         const uint64_t back = (uint64_t)po + K;
-        uint64_t ws = j > back ? j - back : 0;
+        uint64_t ws = js > back ? js - back : 0;
         if (ws > anchor) ws = anchor;
-        uint64_t we = j + (m - po) + K;
+        uint64_t we = js + (m - po) + K;
         if (we > n) we = n;
         approx_window_k<LEAN, K>(text, n, q, mt.owner_mask + (size_t)owner * 256u, m, ws, we, anchor,
                                  rc_chunk, mk);
@@ -414,7 +451,7 @@ __device__ __forceinline__ void multi_mark(const uint8_t *__restrict__ text, con
 // INLINE: dense hit sets (many 1..3-byte patterns) overflow the candidate slices; then every
 // hit is checked on the spot by its own lane (slow, but no buffer can overflow).  Only lean /
 // count-only bookkeeping is done inline.
-template <int MODE, bool INLINE>
+template <int MODE, bool INLINE, int STRIDE>
 __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ text, uint64_t n,
                                                      uint64_t n_full_strips, agh_dev_query q,
                                                      const uint32_t *__restrict__ bits_g,
@@ -460,7 +497,7 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
     auto strip_work = [&](uint4 v, uint32_t nx, uint64_t st) {
         uint32_t acc = 0;
         if (!(MODE & 4)) acc = nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
-        const uint32_t hits = probe_chunk<MODE>(v, nx, q, tab);
+        const uint32_t hits = probe_chunk<MODE, STRIDE>(v, nx, q, tab);
         uint32_t rc = 0, z = 0;
         if (!(MODE & 4)) {
             const uint32_t sc = wave_sum_to_lane63(acc);
@@ -513,7 +550,7 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
 }
 
 // The last, partial strip: one wave, bytes >= n masked to a non-delimiter filler.
-template <int MODE>
+template <int MODE, int STRIDE>
 __global__ __launch_bounds__(64) void k_sweep_multi_tail(const uint4 *__restrict__ text,
                                                          uint64_t n, agh_dev_query q,
                                                          const uint32_t *__restrict__ bits_g,
@@ -547,7 +584,7 @@ __global__ __launch_bounds__(64) void k_sweep_multi_tail(const uint4 *__restrict
     }
     uint32_t acc = 0;
     if (!(MODE & 4)) acc = nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
-    uint32_t hits = probe_chunk<MODE>(v, nx, q, bits_g);        // table straight from global/L2
+    uint32_t hits = probe_chunk<MODE, STRIDE>(v, nx, q, bits_g);    // table straight from global/L2
     if (off >= n) hits = 0;
     else if (off + 16 > n) hits &= (1u << (n - off)) - 1u;      // positions inside the text only
     const uint32_t sc = (MODE & 4) ? 0u : wave_sum_to_lane63(acc);
@@ -602,9 +639,9 @@ __global__ __launch_bounds__(256) void k_verify_multi(const uint8_t *__restrict_
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-template <int MODE>
-static void launch_sweep_multi_m(const agh_sweep_args &a, const agh_multi_dev &m,
-                                 const agh_marks &mk, bool inl, hipStream_t st)
+template <int MODE, int STRIDE>
+static void launch_sweep_multi_ms(const agh_sweep_args &a, const agh_multi_dev &m,
+                                  const agh_marks &mk, bool inl, hipStream_t st)
 {
     const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
     const uint64_t n_waves = (n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
@@ -621,22 +658,32 @@ static void launch_sweep_multi_m(const agh_sweep_args &a, const agh_multi_dev &m
     mt.owner_mask = m.owner_mask;
     mt.item_info = m.item_info;
     if (n_waves && inl)
-        hipLaunchKernelGGL((k_sweep_multi<MODE, true>), dim3((uint32_t)((n_waves + 3) / 4)),
+        hipLaunchKernelGGL((k_sweep_multi<MODE, true, STRIDE>), dim3((uint32_t)((n_waves + 3) / 4)),
                            dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,
                            (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand,
                            a.counters, mt, mk);
     else if (n_waves)
-        hipLaunchKernelGGL((k_sweep_multi<MODE, false>), dim3((uint32_t)((n_waves + 3) / 4)),
+        hipLaunchKernelGGL((k_sweep_multi<MODE, false, STRIDE>), dim3((uint32_t)((n_waves + 3) / 4)),
                            dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,
                            (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand,
                            a.counters, mt, mk);
     if (a.ev_end) (void)hipEventRecord(a.ev_end, st);
     if (a.n & (AGH_STRIP - 1))
-        hipLaunchKernelGGL((k_sweep_multi_tail<MODE>), dim3(1), dim3(64), 0, st,
+        hipLaunchKernelGGL((k_sweep_multi_tail<MODE, STRIDE>), dim3(1), dim3(64), 0, st,
                            (const uint4 *)a.text, a.n, a.q, (const uint32_t *)a.ftab,
                            a.wave_totals, a.cand, a.wave_cand, a.counters,
                            (inl && !a.lean) ? (const uint32_t *)a.strip_prefix
                                             : (const uint32_t *)nullptr);
+}
+
+// a.q.fh = the probe stride chosen by the host (fill_multi_tables): 1, 2 or 4; strides > 1 imply q == 4
+template <int MODE>
+static void launch_sweep_multi_m(const agh_sweep_args &a, const agh_multi_dev &m,
+                                 const agh_marks &mk, bool inl, hipStream_t st)
+{
+    if ((MODE & 2) && a.q.fh == 4) launch_sweep_multi_ms<MODE, 4>(a, m, mk, inl, st);
+    else if ((MODE & 2) && a.q.fh == 2) launch_sweep_multi_ms<MODE, 2>(a, m, mk, inl, st);
+    else launch_sweep_multi_ms<MODE, 1>(a, m, mk, inl, st);
 }
 
 // Multi-pattern sweep; a.ftab = the 2^18-bit prefix table.  The prefix scan of the census

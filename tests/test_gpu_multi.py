@@ -193,3 +193,44 @@ def test_multi_pattern_with_errors_edges(agh):
         agh.Query.multi([b"ab", b"needle"], k=2)        # length must exceed k
     with pytest.raises(agh.AghError):
         agh.Query.multi([b"nee\ndle"], k=1)
+
+
+@pytest.mark.parametrize("npat,lo,hi,stride,nocase", [(100, 5, 9, 2, False), (500, 7, 12, 4, False),
+                                                      (1024, 8, 12, 4, False), (64, 5, 6, 2, True),
+                                                      (200, 7, 30, 4, True), (3, 40, 60, 4, False)])
+def test_multi_pattern_strided_probing(agh, npat, lo, hi, stride, nocase):
+    """Sets whose shortest entry has >= 5 (>= 7) bytes are probed at every 2nd (4th) text position
+    only, with the 4-grams of entry offsets 0..S-1 in the table (fill_multi_tables): an entry that
+    occurs verbatim contains a 4-gram at a position divisible by S.  Same answers as the oracle,
+    occurrences planted at every alignment."""
+    rng = random.Random(npat * 13 + lo)
+    pats = _rand_patterns(rng, npat, lo, hi)
+    with agh.Query.multi(pats, nocase=nocase) as q:
+        assert q.info()["filter_h"] == stride
+    base, _ = O.corpus(96, seed=npat + 1, variants=(), plant_period=0)
+    text = _plant(base.tobytes(), pats, rng, every=5)
+    if nocase:
+        text = bytes(c - 32 if (97 <= c <= 122 and rng.random() < 0.4) else c for c in text)
+    res = _check(agh, pats, text, nocase=nocase)
+    assert res.n_matched > 50
+    # every alignment of one pattern, at the very start and the very end of the text too
+    p0 = pats[0]
+    small = b"".join(b"x" * i + p0 + b"\n" for i in range(9))
+    for t in (p0, p0 + b"\n", b"\n" + p0, small, small[:-1], b"y" * 3 + small):
+        _check(agh, pats, t, nocase=nocase)
+
+
+@pytest.mark.parametrize("npat,lo,hi,k,stride", [(30, 14, 24, 1, 4), (30, 10, 13, 1, 2), (20, 21, 29, 2, 4),
+                                                  (1, 16, 16, 1, 4)])
+def test_multi_pattern_with_errors_strided(agh, npat, lo, hi, k, stride):
+    """-f with errors over long patterns: the k+1 pieces have >= 5 / >= 7 bytes, so the piece sweep
+    probes every 2nd / 4th position; the pattern's automaton runs from the piece's start."""
+    rng = random.Random(npat * 17 + k)
+    pats = _rand_patterns(rng, npat, lo, hi)
+    with agh.Query.multi(pats, k=k) as q:
+        assert q.info()["filter_h"] == stride
+    base, _ = O.corpus(48, seed=npat + k + 3, variants=(), plant_period=0)
+    planted = [_mutate(rng.choice(pats), rng.randint(0, k + 1), rng) for _ in range(64)]
+    text = _plant(base.tobytes(), planted, rng, every=6)
+    res = _check_approx(agh, pats, k, text)
+    assert res.n_matched > 0
