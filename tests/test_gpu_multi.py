@@ -197,7 +197,7 @@ def test_multi_pattern_with_errors_edges(agh):
 
 @pytest.mark.parametrize("npat,lo,hi,stride,nocase", [(100, 5, 9, 2, False), (500, 7, 12, 4, False),
                                                       (1024, 8, 12, 4, False), (64, 5, 6, 2, True),
-                                                      (200, 7, 30, 4, True), (3, 40, 60, 4, False)])
+                                                      (200, 7, 30, 4, True), (3, 25, 38, 4, False)])
 def test_multi_pattern_strided_probing(agh, npat, lo, hi, stride, nocase):
     """Sets whose shortest entry has >= 5 (>= 7) bytes are probed at every 2nd (4th) text position
     only, with the 4-grams of entry offsets 0..S-1 in the table (fill_multi_tables): an entry that
