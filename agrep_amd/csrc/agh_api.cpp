@@ -871,7 +871,7 @@ struct seg_result {
 static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_t st,
                         unsigned flags, uint32_t head_byte, int tail_virtual,
                         uint64_t *d_match_pos, uint32_t *d_match_rec, uint32_t match_cap,
-                        seg_result *out)
+                        seg_result *out, const uint64_t *pre_dbm)
 {
     *out = seg_result();
     if (n == 0) return 0;
@@ -923,8 +923,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     dq.tail_virtual = tail_virtual;
 
     // ---- multi-byte delimiter: mark where (selected) delimiter occurrences end --------------
-    const uint64_t *d_dbm = nullptr;
-    if (q_mb(q)) {
+    const uint64_t *d_dbm = pre_dbm;           // the caller marked the delimiters of the whole text
+    if (q_mb(q) && !pre_dbm) {
         const uint64_t n_words = (n + 63) / 64 + 4;     // readers may touch a few words past n
         if (q->dbm.ensure(n_words * sizeof(uint64_t))) return -1;
         HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
@@ -1011,7 +1011,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             // dense hit set (many very short patterns): check hits inline from now on
             q->multi_dense = true;
             return scan_segment(q, d_text, n, st, flags, head_byte, tail_virtual, d_match_pos,
-                                d_match_rec, match_cap, out);
+                                d_match_rec, match_cap, out, pre_dbm);
         }
         const bool gave_up = q->h_counters[AGH_C_LEAN_FALLBACK] || q->h_counters[AGH_C_OVERFLOW];
         if (!gave_up) {
@@ -1267,7 +1267,7 @@ static uint64_t seg_nominal(const agh_query *q)
 }
 
 static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, hipStream_t st,
-                         std::vector<uint64_t> *cuts, bool lean)
+                         std::vector<uint64_t> *cuts, bool lean, const uint64_t *global_dbm)
 {
     cuts->clear();
     cuts->push_back(0);
@@ -1277,9 +1277,6 @@ static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, 
     uint64_t nominal = seg_nominal(q);
     if (lean && !getenv("AGH_SEG_MAX_MB")) nominal = AGH_LEAN_SEG_MAX;
     if (len > nominal) {
-        if (q_mb(q))
-            return fail("multi-byte delimiters: inputs above the %llu-byte segment limit are not "
-                        "supported yet", (unsigned long long)nominal);
         const uint64_t nb = (len - 1) / nominal;        // boundaries strictly inside the text
         if (nb + 1 > AGH_MAX_SEGS) return fail("input too large: more than %d segments", AGH_MAX_SEGS);
         if (q->cuts.ensure(3 * AGH_MAX_SEGS * sizeof(uint64_t))) return -1;
@@ -1291,14 +1288,17 @@ static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, 
         uint64_t *d = (uint64_t *)q->cuts.p;
         HIP_TRY(hipMemcpyAsync(d, h_bound, nb * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d + AGH_MAX_SEGS, h_lo, nb * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        agh_launch_find_cuts(base, d, d + AGH_MAX_SEGS, (uint32_t)nb, q->delim[0], d + 2 * AGH_MAX_SEGS, st);
+        if (global_dbm)                         // bitmap delimiters: cuts at 64-byte aligned delimiter ends
+            agh_launch_find_cuts_dbm(global_dbm, d, d + AGH_MAX_SEGS, (uint32_t)nb, d + 2 * AGH_MAX_SEGS, st);
+        else
+            agh_launch_find_cuts(base, d, d + AGH_MAX_SEGS, (uint32_t)nb, q->delim[0], d + 2 * AGH_MAX_SEGS, st);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_cut, d + 2 * AGH_MAX_SEGS, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (uint64_t i = 0; i < nb; ++i) {
             if (!h_cut[i])
-                return fail("no record ends at a 16-byte aligned offset between byte %llu and %llu "
-                            "(needed to cut an input above the %llu-byte segment limit)",
+                return fail("no record ends at a %d-byte aligned offset between byte %llu and %llu "
+                            "(needed to cut an input above the %llu-byte segment limit)", global_dbm ? 64 : 16,
                             (unsigned long long)h_lo[i], (unsigned long long)h_bound[i],
                             (unsigned long long)nominal);
             cuts->push_back(h_cut[i]);
@@ -1339,7 +1339,7 @@ static bool lean_pipeline_ok(const agh_query *q, unsigned flags, bool want_list)
 static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_t st,
                         unsigned flags, uint32_t head_byte, int tail_virtual,
                         uint64_t *d_match_pos, uint32_t *d_match_rec, uint32_t match_cap,
-                        seg_result *out);
+                        seg_result *out, const uint64_t *pre_dbm = nullptr);
 static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
                             unsigned flags, agh_result *res, uint64_t *d_match_pos,
                             uint32_t *d_match_rec, size_t match_cap, bool is_first, bool is_last);
@@ -1570,7 +1570,31 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
     const unsigned char *base = (const unsigned char *)dev_text;
     std::vector<uint64_t> cuts;
     const bool lean = lean_pipeline_ok(q, flags, d_match_pos != nullptr);
-    if (plan_segments(q, base, len, st, &cuts, lean)) return -1;
+    // Delimiters that come from the delimiter bitmap and a text above one segment: the bitmap is
+    // built once for the whole text (a selected occurrence depends on the ones in front of it, not on
+    // where a segment starts); every segment then works on its part of it.
+    const uint64_t *global_dbm = nullptr;
+    if (q_mb(q) && len > seg_nominal(q)) {
+        const uint64_t n_words = (len + 63) / 64 + 4;
+        if (q->dbm.ensure(n_words * sizeof(uint64_t))) return -1;
+        agh_dev_query dq;
+        memset(&dq, 0, sizeof(dq));
+        dq.delim = q->delim[q->dlen - 1];
+        dq.dlen = (uint32_t)q->dlen;
+        memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
+        dq.dfold = q->delim_fold ? 1u : 0u;
+        dq.mb = 1u;
+        dq.head_byte = is_first ? '\n' : q->delim[q->dlen - 1];
+        HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+        agh_launch_delim_bitmap(base, len, dq, (uint64_t *)q->dbm.p, n_words, q->d_counters, st);
+        HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (q->h_counters[AGH_C_DELIM_CHAIN])
+            return fail("a run of overlapping delimiter occurrences exceeds 4 KiB (unsupported)");
+        global_dbm = (const uint64_t *)q->dbm.p;
+    }
+    if (plan_segments(q, base, len, st, &cuts, lean, global_dbm)) return -1;
     if (lean) return lean_run(q, base, cuts, st, flags, res, is_first, is_last);
     for (size_t i = 0; i + 1 < cuts.size(); ++i) {
         const uint64_t off = cuts[i], end = cuts[i + 1];
@@ -1578,10 +1602,10 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
         uint64_t stored = res->n_stored;
         uint32_t cap_left = (uint32_t)std::min<uint64_t>(match_cap - stored, 0xffffffffu);
         if (scan_segment(q, base + off, end - off, st, flags,
-                         (i == 0 && is_first) ? '\n' : q->delim[0], end == len && is_last,
+                         (i == 0 && is_first) ? '\n' : q->delim[q->dlen - 1], end == len && is_last,
                          d_match_pos ? d_match_pos + stored : nullptr,
                          d_match_rec ? d_match_rec + stored : nullptr,
-                         d_match_pos ? cap_left : 0, &sr))
+                         d_match_pos ? cap_left : 0, &sr, global_dbm ? global_dbm + off / 64 : nullptr))
             return -1;
         if (d_match_pos && sr.stored && off > 0) {
             // the segment's kernels saw positions / record numbers relative to its own start

@@ -72,6 +72,8 @@ void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *w
 void agh_launch_verify_lean(const agh_scan_args &a, hipStream_t st);
 void agh_launch_find_cuts(const void *text, const uint64_t *bound, const uint64_t *lo,
                           uint32_t n_bounds, uint32_t delim, uint64_t *cut, hipStream_t st);
+void agh_launch_find_cuts_dbm(const uint64_t *dbm, const uint64_t *bound, const uint64_t *lo,
+                              uint32_t n_bounds, uint64_t *cut, hipStream_t st);
 void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
 void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_t seed,
                        const unsigned char *variants, const uint32_t *vlen,

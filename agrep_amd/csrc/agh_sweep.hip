@@ -580,6 +580,41 @@ __global__ __launch_bounds__(256) void k_find_cuts(const uint8_t *__restrict__ t
     if (threadIdx.x == 0) cut[blockIdx.x] = found;
 }
 
+// The same for delimiters that come from the delimiter bitmap (several bytes, or a folded letter):
+// a cut must also be a multiple of 64 so that a segment's part of the bitmap starts on a word.
+// cut[i] = the largest p <= bound[i], p > lo[i], p % 64 == 0, with a selected delimiter occurrence
+// ending at byte p - 1 (bit 63 of bitmap word p / 64 - 1), or 0.
+__global__ __launch_bounds__(256) void k_find_cuts_dbm(const uint64_t *__restrict__ dbm,
+                                                       const uint64_t *__restrict__ bound,
+                                                       const uint64_t *__restrict__ lo,
+                                                       uint64_t *__restrict__ cut)
+{
+    __shared__ uint32_t best;
+    const uint64_t b = bound[blockIdx.x] & ~(uint64_t)63, l = lo[blockIdx.x];
+    uint64_t found = 0;
+    for (uint64_t base = b; base > l;) {
+        if (threadIdx.x == 0) best = 0xffffffffu;
+        __syncthreads();
+        const uint64_t back = 64ull * threadIdx.x;
+        if (base >= back + 64 && base - back > l && (dbm[(base - back) / 64 - 1] >> 63))
+            atomicMin(&best, threadIdx.x);
+        __syncthreads();
+        const uint32_t t = best;
+        __syncthreads();
+        if (t != 0xffffffffu) { found = base - 64ull * t; break; }
+        if (base < 16384ull + l) break;
+        base -= 16384ull;
+    }
+    if (threadIdx.x == 0) cut[blockIdx.x] = found;
+}
+
+void agh_launch_find_cuts_dbm(const uint64_t *dbm, const uint64_t *bound, const uint64_t *lo,
+                              uint32_t n_bounds, uint64_t *cut, hipStream_t st)
+{
+    if (!n_bounds) return;
+    hipLaunchKernelGGL(k_find_cuts_dbm, dim3(n_bounds), dim3(256), 0, st, dbm, bound, lo, cut);
+}
+
 void agh_launch_find_cuts(const void *text, const uint64_t *bound, const uint64_t *lo,
                           uint32_t n_bounds, uint32_t delim, uint64_t *cut, hipStream_t st)
 {

@@ -704,3 +704,30 @@ def test_nocase_with_a_letter_as_delimiter(agh):
         want = O.asearch(pat, k, text, delim=b"x", nocase=True, cap=100000)
         res, recs, _ = _gpu(agh, pat, k, text, nocase=True, delim=b"x")
         assert (res.n_matched, recs) == want, (pat, k, text)
+
+
+@pytest.mark.parametrize("delim,nocase", [(b"\n\n", False), (b"From ", True), (b"q", True)])
+def test_bitmap_delimiters_above_one_segment(agh, monkeypatch, delim, nocase):
+    """Delimiters that come from the delimiter bitmap (several bytes, or a folded letter) on an
+    input above the segment limit: the bitmap is built once for the whole text, the cuts sit at
+    64-byte aligned delimiter ends, every segment works on its part of the bitmap.  Segmented ==
+    unsegmented == the oracle, with record lists (absolute positions and numbers)."""
+    text, _ = O.corpus(1536, seed=44, variants=O.VARIANTS_C2, plant_period=9,
+                       upper_permille=300 if nocase else 0)                    # 6 MiB
+    tb = text.tobytes().replace(b"\n", delim)
+    for k in (0, 2):
+        want = O.asearch(O.PATTERN_C2, k, tb, delim=delim, nocase=nocase, cap=400000)
+        with agh.Query(O.PATTERN_C2, k, nocase=nocase, delim=delim) as q:
+            one, ms1 = q.scan_buffer(tb, cap=400000)
+            monkeypatch.setenv("AGH_SEG_MAX_MB", "1")
+            try:
+                seg, ms = q.scan_buffer(tb, cap=400000)
+                seg_c, _ = q.scan_buffer(tb, flags=agh.COUNT)
+                seg_f, _ = q.scan_buffer(tb, flags=agh.FORCE_FULLSCAN | agh.COUNT)
+            finally:
+                monkeypatch.delenv("AGH_SEG_MAX_MB")
+        assert (one.n_matched, [(s, e) for s, e, _ in ms1]) == want
+        assert seg.n_segments >= 4
+        assert (seg.n_matched, [(s, e) for s, e, _ in ms]) == want, (delim, k)
+        assert [i for _, _, i in ms] == [i for _, _, i in ms1]
+        assert seg_c.n_matched == want[0] == seg_f.n_matched and seg.n_records == one.n_records
