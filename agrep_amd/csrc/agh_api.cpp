@@ -1827,8 +1827,9 @@ static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *
     memset(res, 0, sizeof(*res));
     const uint64_t seg_cap = std::max<uint64_t>(env_mb("AGH_STREAM_SEG_MB", 1024), 1) << 20;
     const bool early = (flags & AGH_FILENAMEONLY) != 0;
-    // -l: small first segments so that a hit near the top of a file is reported after ~64 MiB
-    uint64_t target = early ? std::min<uint64_t>(seg_cap, (uint64_t)64 << 20) : seg_cap;
+    // -l: small first segments (1 MiB, x4 each time) so that a hit near the top of a file is
+    // reported after the first megabyte has been read and scanned, whatever the engine costs
+    uint64_t target = early ? std::min<uint64_t>(seg_cap, (uint64_t)1 << 20) : seg_cap;
     const uint64_t hint = rd.size_hint();
     if (q->staging.ensure(std::min<uint64_t>(seg_cap, hint ? hint : seg_cap) + 2 * AGH_STAGE_CHUNK + 64))
         return -1;
@@ -1841,7 +1842,10 @@ static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *
     while (!eof) {
         if (busy[b]) HIP_TRY(hipEventSynchronize(q->pinned_ev[b]));
         busy[b] = false;
-        const ssize_t got = rd.fill(q->pinned[b], AGH_STAGE_CHUNK);
+        // (-l reads no further ahead than its current segment target)
+        const size_t ask = early ? (size_t)std::min<uint64_t>(AGH_STAGE_CHUNK, std::max<uint64_t>(target > used ? target - used : 0, 65536))
+                                 : AGH_STAGE_CHUNK;
+        const ssize_t got = rd.fill(q->pinned[b], ask);
         if (got < 0) return -1;
         if (got == 0) eof = true;
         if (got > 0) {
@@ -1858,7 +1862,6 @@ static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *
             HIP_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
             busy[b] = true;
             used += (uint64_t)got;
-            if ((size_t)got < AGH_STAGE_CHUNK && !rd.regular) { /* short read of a pipe: keep going */ }
         }
         if (!eof && used < target) { b ^= 1; continue; }
         // cut after the last delimiter of the chunk that has just arrived
@@ -1898,7 +1901,7 @@ static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *
             busy[b] = true;
         }
         used = tail_len;
-        if (early && target < seg_cap) target = std::min<uint64_t>(seg_cap, target * 2);
+        if (early && target < seg_cap) target = std::min<uint64_t>(seg_cap, target * 4);
         b ^= 1;
     }
     return 0;
