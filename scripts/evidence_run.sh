@@ -14,6 +14,7 @@ python scripts/pmc_summary.py pmc_${TAG}_multi k_sweep_multi 2147483648 gpurun_o
 python scripts/pmc_summary.py pmc_${TAG}_fullc k_fullscan 2147483648 gpurun_out/${TAG}_pmc_fullscan.json "prof_k2.py 2 GiB, k=2, count-only full scan (AGH_FORCE_FULLSCAN|AGH_COUNT)"
 python scripts/pmc_summary.py pmc_${TAG}_lean "k_sweep<4" 8589934592 gpurun_out/${TAG}_pmc_sweep.json "prof_k2.py 8 GiB, k=2, count-only (the headline kernel sequence on one segment)"
 python scripts/perf_multi.py 4 2>&1 | tail -7 > gpurun_out/${TAG}_perf_multi.log
+python scripts/perf_multi_strided.py 2>&1 | tail -4 > gpurun_out/${TAG}_perf_multi_strided.log
 python scripts/perf_short.py 2>&1 | tail -9 > gpurun_out/${TAG}_perf_piece_engine.log
 python scripts/perf_fullscan.py 4 2>&1 | tail -12 > gpurun_out/${TAG}_perf_fallback_engines.log
 python scripts/c5_files.py 8 512 2>&1 | tail -3 > gpurun_out/${TAG}_c5_files.log
