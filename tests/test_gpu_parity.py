@@ -731,3 +731,35 @@ def test_bitmap_delimiters_above_one_segment(agh, monkeypatch, delim, nocase):
         assert (seg.n_matched, [(s, e) for s, e, _ in ms]) == want, (delim, k)
         assert [i for _, _, i in ms] == [i for _, _, i in ms1]
         assert seg_c.n_matched == want[0] == seg_f.n_matched and seg.n_records == one.n_records
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_record_aligned_shards_add_up(agh, tmp_path, nranks):
+    """What `agrep-hip --gpus N` and a one-process-per-GPU job do with a file, on the one GPU there
+    is: agh_shard_cuts_fd cuts it into N record-aligned byte ranges, agh_scan_fd_range scans each
+    (count-only: streaming; with records: staged), counts add up and the record lists, shifted by
+    the shard offsets / the records in front, concatenate to the whole-file answer."""
+    body, _ = O.corpus(700, seed=90 + nranks, variants=O.VARIANTS_C2, plant_period=13)
+    data = b"no newline in front\n" + body.tobytes()[:-7]           # ragged: no trailing newline
+    f = tmp_path / "shard.txt"
+    f.write_bytes(data)
+    fd = os.open(str(f), os.O_RDONLY)
+    try:
+        cuts = agh.shard_cuts_fd(fd, nranks)
+        assert cuts[0] == 0 and cuts[-1] == len(data) and cuts == sorted(cuts)
+        for c in cuts[1:-1]:
+            assert c == len(data) or data[c - 1:c] == b"\n"
+        with agh.Query(O.PATTERN_C2, 2) as q:
+            whole, ms = q.scan_fd(fd, cap=100000)
+            total, recs, rec_off = 0, [], 0
+            for r in range(nranks):
+                cnt, _ = q.scan_fd_range(fd, cuts[r], cuts[r + 1], flags=agh.COUNT)
+                part, pm = q.scan_fd_range(fd, cuts[r], cuts[r + 1], cap=100000)
+                assert cnt.n_matched == part.n_matched == len(pm)
+                total += cnt.n_matched
+                recs += [(s + cuts[r], e + cuts[r], i + rec_off) for s, e, i in pm]
+                rec_off += part.n_records
+    finally:
+        os.close(fd)
+    assert total == whole.n_matched and recs == ms and rec_off == whole.n_records
+    assert (whole.n_matched, [(s, e) for s, e, _ in ms]) == O.asearch(O.PATTERN_C2, 2, data, cap=100000)
