@@ -95,3 +95,28 @@ def test_shard_pages_cover_everything():
             assert sum(c for _, c in got) == total
             for (f0, c0), (f1, _) in zip(got, got[1:]):
                 assert f0 + c0 == f1
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_c_abi_shard_cuts_equal_python_rule(world, tmp_path):
+    """agh_shard_cuts_fd (host-only code of the C-ABI, used by `agrep-hip --gpus N`) places the cuts
+    exactly where shard.record_cuts does: files from empty to 200 kB, with and without a trailing
+    newline, long records, delimiters right at the nominal offsets."""
+    import agrep_amd
+    rng = np.random.default_rng(100 + world)
+    cases = [b"", b"\n", b"abc", b"abc\n", b"\n" * 50, b"x" * 5000, b"x" * 4999 + b"\n" + b"y" * 5000]
+    for trial in range(25):
+        n = int(rng.integers(0, 200000))
+        a = rng.integers(97, 100, size=n).astype(np.uint8)
+        a[rng.random(n) < (0.0005 if trial % 3 == 0 else 0.02)] = 10
+        cases.append(a.tobytes())
+    for i, data in enumerate(cases):
+        f = tmp_path / ("c%d.bin" % i)
+        f.write_bytes(data)
+        fd = os.open(str(f), os.O_RDONLY)
+        try:
+            got = agrep_amd.shard_cuts_fd(fd, world)
+        finally:
+            os.close(fd)
+        want = shard.record_cuts(np.frombuffer(data, dtype=np.uint8), world)
+        assert got == want, (world, i, len(data), got, want)
