@@ -136,6 +136,7 @@ struct agh_query {
     bool piece_single = false;
     int pe_fq = 0, pe_minlen = 0;
     int mp_stride = 1;                  // multi-pattern sweep: probe every 1 / 2 / 4 bytes (fill_multi_tables)
+    bool mp_q5 = false;                 // ... with 5-byte grams (stride 4, entries of >= 8 bytes)
     uint32_t pe_qmask = 0, pe_fold = 0;
     bool multi_dense = false;           // hits are too dense for the candidate slices
     int npat = 0;
@@ -600,7 +601,11 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
     // with the grams of offsets 0..S-1 of every entry in the table -- 4 (8) probes per 16 bytes
     // instead of 16, no unaligned extraction at S = 4.
     const int stride = minlen >= 7 ? 4 : (minlen >= 5 ? 2 : 1);
+    // ... and with entries of >= 8 bytes the grams at offsets 0..3 can take a fifth byte: 26 x fewer
+    // chance hits for the verifier, same four probes
+    const bool q5 = minlen >= 8;
     q->mp_stride = stride;
+    q->mp_q5 = q5;
     *fq_out = fq;
     *qmask_out = qmask;
     *fold_out = fold;
@@ -631,10 +636,12 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
             uint32_t g = 0;
             for (int t = 0; t < fq; ++t) g |= (uint32_t)src[o + t] << (8 * t);     // o + fq <= len: len >= stride + 3
             g = (g & qmask) | fold;
-            const uint32_t h = fq == 4 ? agh_sample_hash18_q4(g) : agh_sample_hash18_q3(g);
+            uint32_t hs = g;                    // what the sweep hashes: the gram, or the 5-byte mix
+            if (q5) hs = agh_mix5(g, (uint32_t)src[o + 4] | (fold ? 0x20u : 0u));
+            const uint32_t h = fq == 4 ? agh_sample_hash18_q4(hs) : agh_sample_hash18_q3(hs);
             bits[h >> 5] |= 1u << (h & 31u);
             if (fq == 4) {                      // second Bloom probe (agh_multi.hip probe_chunk)
-                const uint32_t h2 = agh_sample_hash18b_q4(g);
+                const uint32_t h2 = agh_sample_hash18b_q4(hs);
                 bits[h2 >> 5] |= 1u << (h2 & 31u);
             }
             gi.push_back({agh_mp_bucket(g), (uint32_t)i, (uint32_t)o});
@@ -911,6 +918,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
     dq.dfold = q->delim_fold ? 1u : 0u;
     dq.mb = q_mb(q) ? 1u : 0u;
+    dq.mp_q5 = (multi && q->mp_q5) ? 1u : 0u;
     dq.fq = pe ? q->pe_fq : q->fq;
     dq.fh = pe ? q->mp_stride : q->fh;                  // multi-pattern sweeps: the probe stride
     dq.qmask = pe ? q->pe_qmask : q->qmask;
@@ -1408,6 +1416,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     dq.dbytes[0] = q->delim[0];
     dq.dfold = 0;
     dq.mb = 0;
+    dq.mp_q5 = 0;
     dq.fq = q->fq;
     dq.fh = q->fh;
     dq.qmask = q->qmask;

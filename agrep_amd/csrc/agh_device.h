@@ -60,6 +60,7 @@ struct agh_dev_query {
     uint8_t dbytes[8];  // the delimiter
     uint32_t dfold;     // 1: delimiter bytes match case-insensitively (-i with letters in the delimiter)
     uint32_t mb;        // 1: delimiter ends come from the delimiter bitmap (dlen > 1, or a folded letter)
+    uint32_t mp_q5;     // multi-pattern sweep at stride 4: the probed grams have 5 bytes (entries >= 8 bytes)
     int32_t fq;         // filter: sample length in bytes (1..4), 0 = no filter
     int32_t fh;         // filter: sample stride in bytes (4, 8 or 16)
     uint32_t qmask;     // low fq bytes
@@ -105,6 +106,12 @@ AGH_HD uint32_t agh_sample_prod18_q4(uint32_t s)
 AGH_HD uint32_t agh_sample_hash18_q4(uint32_t s)
 {
     return (agh_sample_prod18_q4(s) >> 14) & ((1u << AGH_MP_BITS) - 1u);
+}
+// 5-byte grams (strided multi-pattern sweep over entries of >= 8 bytes): the fifth byte is spread
+// over the dword (v_perm_b32) and XORed in; both Bloom hashes then take the mix.
+AGH_HD uint32_t agh_mix5(uint32_t g4, uint32_t next_dword)
+{
+    return g4 ^ ((next_dword & 0xffu) * 0x01010101u);
 }
 // second, independent 18-bit hash of a 4-byte prefix: the multi-pattern bit table is a Bloom
 // filter with two probes when q == 4 (the second probe runs only on first-level hits)

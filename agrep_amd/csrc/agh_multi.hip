@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t probe_bit(uint32_t g, const agh_dev_query &q
 }
 
 // the probed positions of one 16-byte chunk: every STRIDE-th byte (nx = the 4 bytes that follow it)
-template <int MODE, int STRIDE>
+template <int MODE, int STRIDE, bool Q5>
 __device__ __forceinline__ uint32_t probe_chunk(uint4 v, uint32_t nx, const agh_dev_query &q,
                                                 const uint32_t *tab)
 {
@@ -52,8 +52,12 @@ __device__ __forceinline__ uint32_t probe_chunk(uint4 v, uint32_t nx, const agh_
 #pragma unroll
     for (int p = 0; p < 16; p += STRIDE) {
         const int d = p >> 2, sh = p & 3;
-        const uint32_t g = sh ? __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh) : w[d];
-        hits = (probe_bit<MODE>(g, q, tab) << p) | hits;       // v_lshl_or_b32
+        uint32_t g = sh ? __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh) : w[d];
+        if (Q5) {                               // stride 4: the fifth byte is the next dword's first
+            if (MODE & 1) g |= q.fold;
+            g = agh_mix5(g, (MODE & 1) ? (w[d + 1] | 0x20u) : w[d + 1]);
+        }
+        hits = (probe_bit<Q5 ? (MODE & ~1) : MODE>(g, q, tab) << p) | hits;       // v_lshl_or_b32
     }
     if ((MODE & 2) && __ballot(hits != 0)) {
         // q == 4: the table is a two-probe Bloom filter.  First-level hits (0.4-0.8 % of all
@@ -68,6 +72,7 @@ __device__ __forceinline__ uint32_t probe_chunk(uint4 v, uint32_t nx, const agh_
             const uint32_t hi = d == 0 ? w[1] : (d == 1 ? w[2] : (d == 2 ? w[3] : w[4]));
             uint32_t g = __builtin_amdgcn_alignbyte(hi, lo, sh);
             if (MODE & 1) g |= q.fold;
+            if (Q5) g = agh_mix5(g, (MODE & 1) ? (hi | 0x20u) : hi);
             const uint32_t h2 = agh_sample_hash18b_q4(g);
             keep |= ((tab[h2 >> 5] >> (h2 & 31u)) & 1u) << p;
         }
@@ -451,7 +456,7 @@ __device__ __forceinline__ void multi_mark(const uint8_t *__restrict__ text, con
 // INLINE: dense hit sets (many 1..3-byte patterns) overflow the candidate slices; then every
 // hit is checked on the spot by its own lane (slow, but no buffer can overflow).  Only lean /
 // count-only bookkeeping is done inline.
-template <int MODE, bool INLINE, int STRIDE>
+template <int MODE, bool INLINE, int STRIDE, bool Q5>
 __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ text, uint64_t n,
                                                      uint64_t n_full_strips, agh_dev_query q,
                                                      const uint32_t *__restrict__ bits_g,
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
     auto strip_work = [&](uint4 v, uint32_t nx, uint64_t st) {
         uint32_t acc = 0;
         if (!(MODE & 4)) acc = nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
-        const uint32_t hits = probe_chunk<MODE, STRIDE>(v, nx, q, tab);
+        const uint32_t hits = probe_chunk<MODE, STRIDE, Q5>(v, nx, q, tab);
         uint32_t rc = 0, z = 0;
         if (!(MODE & 4)) {
             const uint32_t sc = wave_sum_to_lane63(acc);
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
 }
 
 // The last, partial strip: one wave, bytes >= n masked to a non-delimiter filler.
-template <int MODE, int STRIDE>
+template <int MODE, int STRIDE, bool Q5>
 __global__ __launch_bounds__(64) void k_sweep_multi_tail(const uint4 *__restrict__ text,
                                                          uint64_t n, agh_dev_query q,
                                                          const uint32_t *__restrict__ bits_g,
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(64) void k_sweep_multi_tail(const uint4 *__restrict
     }
     uint32_t acc = 0;
     if (!(MODE & 4)) acc = nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
-    uint32_t hits = probe_chunk<MODE, STRIDE>(v, nx, q, bits_g);    // table straight from global/L2
+    uint32_t hits = probe_chunk<MODE, STRIDE, Q5>(v, nx, q, bits_g);    // table straight from global/L2
     if (off >= n) hits = 0;
     else if (off + 16 > n) hits &= (1u << (n - off)) - 1u;      // positions inside the text only
     const uint32_t sc = (MODE & 4) ? 0u : wave_sum_to_lane63(acc);
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(256) void k_verify_multi(const uint8_t *__restrict_
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-template <int MODE, int STRIDE>
+template <int MODE, int STRIDE, bool Q5>
 static void launch_sweep_multi_ms(const agh_sweep_args &a, const agh_multi_dev &m,
                                   const agh_marks &mk, bool inl, hipStream_t st)
 {
@@ -658,18 +663,18 @@ static void launch_sweep_multi_ms(const agh_sweep_args &a, const agh_multi_dev &
     mt.owner_mask = m.owner_mask;
     mt.item_info = m.item_info;
     if (n_waves && inl)
-        hipLaunchKernelGGL((k_sweep_multi<MODE, true, STRIDE>), dim3((uint32_t)((n_waves + 3) / 4)),
+        hipLaunchKernelGGL((k_sweep_multi<MODE, true, STRIDE, Q5>), dim3((uint32_t)((n_waves + 3) / 4)),
                            dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,
                            (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand,
                            a.counters, mt, mk);
     else if (n_waves)
-        hipLaunchKernelGGL((k_sweep_multi<MODE, false, STRIDE>), dim3((uint32_t)((n_waves + 3) / 4)),
+        hipLaunchKernelGGL((k_sweep_multi<MODE, false, STRIDE, Q5>), dim3((uint32_t)((n_waves + 3) / 4)),
                            dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,
                            (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand,
                            a.counters, mt, mk);
     if (a.ev_end) (void)hipEventRecord(a.ev_end, st);
     if (a.n & (AGH_STRIP - 1))
-        hipLaunchKernelGGL((k_sweep_multi_tail<MODE, STRIDE>), dim3(1), dim3(64), 0, st,
+        hipLaunchKernelGGL((k_sweep_multi_tail<MODE, STRIDE, Q5>), dim3(1), dim3(64), 0, st,
                            (const uint4 *)a.text, a.n, a.q, (const uint32_t *)a.ftab,
                            a.wave_totals, a.cand, a.wave_cand, a.counters,
                            (inl && !a.lean) ? (const uint32_t *)a.strip_prefix
@@ -681,9 +686,10 @@ template <int MODE>
 static void launch_sweep_multi_m(const agh_sweep_args &a, const agh_multi_dev &m,
                                  const agh_marks &mk, bool inl, hipStream_t st)
 {
-    if ((MODE & 2) && a.q.fh == 4) launch_sweep_multi_ms<MODE, 4>(a, m, mk, inl, st);
-    else if ((MODE & 2) && a.q.fh == 2) launch_sweep_multi_ms<MODE, 2>(a, m, mk, inl, st);
-    else launch_sweep_multi_ms<MODE, 1>(a, m, mk, inl, st);
+    if ((MODE & 2) && a.q.fh == 4 && a.q.mp_q5) launch_sweep_multi_ms<MODE, 4, true>(a, m, mk, inl, st);
+    else if ((MODE & 2) && a.q.fh == 4) launch_sweep_multi_ms<MODE, 4, false>(a, m, mk, inl, st);
+    else if ((MODE & 2) && a.q.fh == 2) launch_sweep_multi_ms<MODE, 2, false>(a, m, mk, inl, st);
+    else launch_sweep_multi_ms<MODE, 1, false>(a, m, mk, inl, st);
 }
 
 // Multi-pattern sweep; a.ftab = the 2^18-bit prefix table.  The prefix scan of the census
