@@ -16,6 +16,8 @@ planted = A.corpus_fill_device(t.data_ptr(), n // 4096, seed=B.SEED, variants=B.
 torch.cuda.synchronize()
 print("corpus %.0f GiB, planted %s" % (gib, planted), flush=True)
 grid = [(0, 0), (0, 1), (4096, 0), (4096, 1), (2048, 1), (1024, 0), (1024, 1), (512, 1), (256, 1)]
+if os.environ.get("AGH_AB_GRID"):            # e.g. "0:0,32768:1,16384:1,8192:1"
+    grid = [tuple(int(x) for x in g.split(":")) for g in os.environ["AGH_AB_GRID"].split(",")]
 for k in (2, 0):
     q = A.Query(B.PATTERN, k)
     for part, ov in grid:
