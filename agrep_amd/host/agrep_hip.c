@@ -251,18 +251,25 @@ static int scan_one(agh_query *q, int fd, int want_records, struct filehit *out)
     return agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, out->bytes, total, &total);
 }
 
-/* agrep.c:3805-3956 output(): [file: ][N: ]record\n */
+/* agrep.c:3805-3956 output(): [file: ][N: ]record\n for newline-delimited records.  With a
+ * user delimiter (-d, OUTTAIL off, agrep.c:2265-2316) output() prints buffer[lasti .. i-D_length-1]:
+ * the delimiter IN FRONT of the record and the record, nothing behind it -- except for the first
+ * record of a file, which has no delimiter in front (asearch.c:162-170, lasti = Max_record).  The
+ * delimiter printed here is the one given with -d (under -i the text's own bytes may differ in
+ * case; the reference front end linked onto these engines prints those: INTEGRATION.md). */
 static void print_records(const struct filehit *h, const char *name, int with_name)
 {
     uint64_t i;
     size_t o = 0;
+    const int user_delim = !(opt.dlen == 1 && opt.delim[0] == '\n');
     for (i = 0; i < h->res.n_stored; i++) {
         const agh_match *m = &h->matches[i];
         const size_t len = (size_t)(m->end - m->start);
         if (with_name) printf("%s: ", name);
         if (opt.LINENUM) printf("%llu: ", (unsigned long long)(m->index + 1));
+        if (user_delim && m->index > 0) fwrite(opt.delim, 1, (size_t)opt.dlen, stdout);
         fwrite(h->bytes + o, 1, len, stdout);
-        fputc('\n', stdout);
+        if (!user_delim) fputc('\n', stdout);
         o += len;
     }
 }

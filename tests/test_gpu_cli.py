@@ -108,6 +108,14 @@ def test_cli_single_byte_delimiter_counts(tmp_path):
         rc_r, out_r, _ = _run(REF, a)
         rc_g, out_g, _ = _run(CLI, a)
         assert (rc_g, out_g) == (rc_r, out_r), (k, out_g, out_r)
+    # records under -d: the delimiter in front of every record but the first, nothing behind
+    # (output(), agrep.c:3805-3956, through the asearch path); -n numbers in front of the delimiter
+    for a in (["-V0", "-i", "-2", "-d", ";"], ["-V0", "-i", "-n", "-2", "-d", ";"], ["-V0", "-i", "-1", "-d", ";"]):
+        a = a + ["approximatematch", str(p)]
+        rc_r, out_r, _ = _run(REF, a)
+        rc_g, out_g, _ = _run(CLI, a)
+        assert (rc_g, out_g) == (rc_r, out_r), (a, out_g, out_r)
+        assert rc_g == 0 or b";three aproximatematch" in out_g
 
 
 @needs_ref
@@ -125,6 +133,10 @@ def test_cli_multi_byte_delimiter_counts(tmp_path):
             rc_r, out_r, _ = _run(REF, a)
             rc_g, out_g, _ = _run(CLI, a)
             assert (rc_g, out_g) == (rc_r, out_r), (dl, k, out_g, out_r)
+        a = ["-V0", "-i", "-1", "-d", dl, "approximatematch", str(p)]       # the records themselves
+        rc_r, out_r, _ = _run(REF, a)
+        rc_g, out_g, _ = _run(CLI, a)
+        assert (rc_g, out_g) == (rc_r, out_r), (dl, out_g, out_r)
 
 
 def test_cli_rejects_what_is_outside_the_hot_path(files):
