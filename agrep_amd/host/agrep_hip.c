@@ -257,6 +257,8 @@ static int scan_one(agh_query *q, int fd, int want_records, struct filehit *out)
  * record of a file, which has no delimiter in front (asearch.c:162-170, lasti = Max_record).  The
  * delimiter printed here is the one given with -d (under -i the text's own bytes may differ in
  * case; the reference front end linked onto these engines prints those: INTEGRATION.md). */
+static int first_output = 1, eat_first = 0;     /* output()'s FIRSTOUTPUT / EATFIRST (agrep.c:3820-3826, 3731-3741) */
+
 static void print_records(const struct filehit *h, const char *name, int with_name)
 {
     uint64_t i;
@@ -265,10 +267,21 @@ static void print_records(const struct filehit *h, const char *name, int with_na
     for (i = 0; i < h->res.n_stored; i++) {
         const agh_match *m = &h->matches[i];
         const size_t len = (size_t)(m->end - m->start);
+        const unsigned char *body = h->bytes + o;
+        /* what output() walks over: [delimiter] record, or record + newline */
+        const size_t dl = (user_delim && m->index > 0) ? (size_t)opt.dlen : 0;
+        size_t p = 0;                           /* position in (delimiter, record) */
+#define SEQ(x) ((x) < dl ? opt.delim[(x)] : body[(x) - dl])
+        if (first_output) {                     /* the very first output eats one leading newline ... */
+            if (dl + len > 0 && SEQ(0) == '\n') { p = 1; eat_first = 1; }
+            first_output = 0;
+        }
+        while (p < dl + len && SEQ(p) == '\n') { fputc('\n', stdout); p++; }   /* agrep.c:3832-3843 */
         if (with_name) printf("%s: ", name);
         if (opt.LINENUM) printf("%llu: ", (unsigned long long)(m->index + 1));
-        if (user_delim && m->index > 0) fwrite(opt.delim, 1, (size_t)opt.dlen, stdout);
-        fwrite(h->bytes + o, 1, len, stdout);
+        for (; p < dl; p++) fputc(opt.delim[p], stdout);
+        if (p - dl < len) fwrite(body + (p - dl), 1, len - (p - dl), stdout);
+#undef SEQ
         if (!user_delim) fputc('\n', stdout);
         o += len;
     }
@@ -572,6 +585,7 @@ int main(int argc, char **argv)
             total = run_pass(q, files, nfiles, 1, 0, &files_matched);
             agh_query_free(q);
         }
+        if (eat_first) fputc('\n', stdout);
         if (opt.VERBOSE > 0 && !opt.SILENT) printf("Grand Total: %ld match(es) found.\n", total);
         return (int)total;
     }
@@ -676,6 +690,7 @@ int main(int argc, char **argv)
         if (q) agh_query_free(q);
     }
 
+    if (eat_first) fputc('\n', stdout);         /* ... and gives it back at the end (agrep.c:3731-3741) */
     if (opt.VERBOSE > 0 && !opt.SILENT)          /* agrep.c:3229-3231 */
         printf("Grand Total: %ld match(es) found.\n", total);
     return (int)total;                          /* main.c:79,96: exit status = matches (mod 256) */
