@@ -14,6 +14,12 @@
  *       -> "<num_of_matched>\n"   (memory mode: free of quirk Q1)
  *   ref_harness lines  FILE [agrep options] PATTERN
  *       -> the matched records exactly as the reference prints them
+ *   ref_harness membuf:N FILE [agrep options] PATTERN
+ *       -> memory mode on BOTH sides: output into a caller buffer of N bytes (agrep_outbuffer,
+ *          agrep.h:130 OUTPUT_OVERFLOW); prints "ret=<r> matched=<n> outlen=<bytes>\n" and the bytes
+ *
+ * The same source linked with agrep_amd/host/ref_shim.c instead of the reference's engine objects
+ * (oracle/Makefile, _ref/ref_harness_gpu) exercises the shim's memory mode.
  *
  * Memory-mode contract (docs/README:104-115): the buffer begins with '\n' and has
  * writable slack behind it; a dummy existing file name must be the last argv
@@ -71,8 +77,7 @@ int main(int argc, char **argv)
         first_opt = 3;
         buf = slurp(argv[2], &len);
     }
-    if (strcmp(mode, "lines") != 0) av[ac++] = "-V0";
-    else av[ac++] = "-V0";
+    av[ac++] = "-V0";
     for (i = first_opt; i < argc && ac < 62; i++) av[ac++] = argv[i];
     av[ac++] = "/dev/null";           /* dummy existing target file */
     av[ac] = NULL;
@@ -81,6 +86,16 @@ int main(int argc, char **argv)
         ret = memagrep(ac, av, (int)len, buf, 0, stdout);
         fflush(stdout);
         return ret < 0 ? 1 : 0;
+    }
+    if (strncmp(mode, "membuf:", 7) == 0) {
+        int cap = atoi(mode + 7), i2;
+        char *out = (char *)calloc((size_t)cap + 16, 1);
+        extern int agrep_outpointer;
+        ret = memagrep(ac, av, (int)len, buf, cap, out);
+        printf("ret=%d matched=%d outlen=%d\n", ret < 0 ? -1 : 0, num_of_matched, agrep_outpointer);
+        for (i2 = 0; i2 < agrep_outpointer && i2 < cap; i2++) putchar(out[i2]);
+        fflush(stdout);
+        return 0;
     }
     {
         /* silence record output for tables/count: route it to /dev/null */

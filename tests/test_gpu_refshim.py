@@ -141,3 +141,32 @@ def test_stdin_and_missing_file(files):
         rc_g, out_g, err_g = _run(GPU, args, stdin=data)
         assert (rc_g, out_g) == (rc_r, out_r), (args, err_g[:300])
     _same(["-V0", "-2", "-c", "approximatematch", "/nonexistent/file"], files[:1])
+
+
+HARNESS = os.path.join(O.REF_DIR, "ref_harness")
+HARNESS_GPU = os.path.join(O.REF_DIR, "ref_harness_gpu")
+
+
+@pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(HARNESS_GPU)),
+                    reason="oracle/_ref/ref_harness(_gpu) not built (make -C oracle ref ref_gpu)")
+@pytest.mark.parametrize("opts", [["-i", "-2"], ["-2"], ["-i", "-n", "-1"], ["-2", "-c"], ["-i", "-1", "-l"],
+                                  ["-i", "-d", ";", "-2"], ["-I2", "-2"], ["-w", "-1"]])
+def test_memory_mode_through_the_shim(files, tmp_path, opts):
+    """memagrep() (the library entry point glimpse links: fd == -1, AGREP_POINTER; agrep.c:3282):
+    the text is the caller's buffer, the output goes into the caller's buffer (agrep_outbuffer) and
+    overflows loudly (OUTPUT_OVERFLOW, agrep.h:130).  oracle/ref_harness.c linked with the
+    reference engines and with ref_shim.c: same return value, match count and output bytes --
+    with room for everything, and with a buffer that overflows after a few records."""
+    src = files[1]
+    if "-d" in opts:
+        f = tmp_path / "semi.txt"
+        f.write_bytes(open(src, "rb").read().replace(b"\\n", b";"))
+        src = str(f)
+    for cap in (1 << 20, 300):
+        a = ["membuf:%d" % cap, src] + opts + ["approximatematch"]
+        rc_r, out_r, _ = _run(HARNESS, a)
+        rc_g, out_g, err_g = _run(HARNESS_GPU, a)
+        assert (rc_g, out_g) == (rc_r, out_r), (a, out_g[:300], out_r[:300], err_g[:300])
+    for mode in ("lines", "count"):
+        a = [mode, src] + opts + ["approximatematch"]
+        assert _run(HARNESS_GPU, a)[:2] == _run(HARNESS, a)[:2], a
