@@ -160,7 +160,7 @@ def test_memory_mode_through_the_shim(files, tmp_path, opts):
     src = files[1]
     if "-d" in opts:
         f = tmp_path / "semi.txt"
-        f.write_bytes(open(src, "rb").read().replace(b"\\n", b";"))
+        f.write_bytes(open(src, "rb").read().replace(b"\n", b";"))
         src = str(f)
     for cap in (1 << 20, 300):
         a = ["membuf:%d" % cap, src] + opts + ["approximatematch"]
