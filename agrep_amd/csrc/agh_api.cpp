@@ -116,6 +116,7 @@ struct agh_query {
     // buffers, dependency / timing events, the device scratch of the segment cutter
     hipStream_t aux_stream = nullptr;
     dev_buf cand_b, wave_cand_b, cuts;
+    dev_buf tickets;                    // fused lean kernel: one work counter (own 256-byte line) per segment
     std::vector<hipEvent_t> dep_events, time_events;
     uint64_t *h_cuts = nullptr;         // pinned: bounds, lower limits, cuts
     uint64_t bitmap_bits_hint = 0;      // records seen by the previous scan (+25 %)
@@ -800,6 +801,7 @@ extern "C" void agh_query_free(agh_query *q)
     q->cand_b.release();
     q->wave_cand_b.release();
     q->cuts.release();
+    q->tickets.release();
     if (q->ev0) (void)hipEventDestroy(q->ev0);
     if (q->ev1) (void)hipEventDestroy(q->ev1);
     if (q->ev2) (void)hipEventDestroy(q->ev2);
@@ -868,6 +870,7 @@ static const uint64_t AGH_LEAN_SEG_MAX = (uint64_t)64 << 30;     // lean scans: 
 // verifier runs on a second stream; AGH_PART_MB / AGH_OVERLAP override (A/B runs)
 #define AGH_PART_MB_DEFAULT 0
 #define AGH_OVERLAP_DEFAULT 0
+#define AGH_FUSED_DEFAULT 1
 
 struct seg_result {
     uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
@@ -1336,6 +1339,29 @@ static uint64_t env_mb(const char *name, uint64_t dflt_mb)
     return dflt_mb;
 }
 
+// CUs of the current device (the fused lean kernel launches persistent workgroups)
+static uint32_t device_cus()
+{
+    static int cached_dev = -1;
+    static uint32_t cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256u;
+    if (dev != cached_dev) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached = (uint32_t)v;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
+// AGH_FUSED=0: count-only scans as two kernels (k_sweep, then k_verify) instead of the fused one
+static bool fused_enabled()
+{
+    const char *e = getenv("AGH_FUSED");
+    return e ? e[0] != '0' : AGH_FUSED_DEFAULT != 0;
+}
+
 static bool lean_pipeline_ok(const agh_query *q, unsigned flags, bool want_list)
 {
     const bool invert = (flags & AGH_INVERT) != 0;
@@ -1399,6 +1425,10 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
             HIP_TRY(hipMemsetAsync(q->hashset.p, 0, q->hashset.cap, st));
         q->hashset_dirty = true;
     }
+    // work counters of the fused kernel: a line of their own each -- on the counters' line the
+    // sweepers' ticket atomics would queue behind the verifier's ANYHIT stores
+    if (q->tickets.ensure((size_t)nseg * 256u)) return -1;
+    HIP_TRY(hipMemsetAsync(q->tickets.p, 0, (size_t)nseg * 256u, st));
     hipStream_t aux = st;
     if (overlap) {
         if (!q->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&q->aux_stream, hipStreamNonBlocking));
@@ -1477,8 +1507,51 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         va.gtab = tight_verify_enabled() ? q->d_gtab : nullptr;
         va.gram_spread = q->gram_spread;
 
+        // one kernel for sweep + verify where the query's shape has a fused instance; the partial
+        // last strip (n % 1024 bytes) still goes through k_sweep_tail + k_verify
+        bool fused = false;
+        if (!early && !overlap && !part_bytes && va.gtab && fused_enabled()) {
+            agh_fused_args fa;
+            fa.text = text;
+            fa.n = n;
+            fa.q = dq;
+            fa.ftab = q->d_ftab;
+            fa.mask = q->d_mask;
+            fa.wide = q->wide;
+            fa.gtab = va.gtab;
+            fa.gram_spread = q->gram_spread;
+            fa.mk = va.mk;
+            fa.n_cu = device_cus();
+            fa.ticket = (uint32_t *)((char *)q->tickets.p + (size_t)i * 256u);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (timing) {
+                if (get_events(q->time_events, n_time + 2, hipEventDefault)) return -1;
+                e0 = q->time_events[n_time];
+                e1 = q->time_events[n_time + 1];
+                HIP_TRY(hipEventRecord(e0, st));
+            }
+            fused = agh_launch_sweep_fused(fa, q->fh, st);
+            if (fused) {
+                if (timing) {
+                    HIP_TRY(hipEventRecord(e1, st));
+                    n_time += 2;
+                    ++jobs[i].n_parts;
+                }
+                HIP_TRY(hipMemsetAsync(wcand[slot]->p, 0, ((size_t)nw + 8) * sizeof(uint32_t), st));
+                if (n & (AGH_STRIP - 1)) {
+                    sa.tail_only = 1;
+                    sa.w_begin = sa.w_end = 0;
+                    sa.ev_begin = sa.ev_end = nullptr;
+                    agh_launch_sweep(sa, q->fh, st);
+                    va.w_begin = (uint32_t)((n >> AGH_STRIP_SHIFT) / AGH_WAVE_STRIPS) & ~7u;
+                    va.w_end = 0;
+                    agh_launch_verify_lean(va, st);
+                }
+                HIP_TRY(hipGetLastError());
+            }
+        }
         uint64_t pb = early ? ((uint64_t)64 << 20) : part_bytes;
-        for (uint64_t off = 0; off < n;) {
+        for (uint64_t off = fused ? n : 0; off < n;) {
             const uint64_t part_end = (pb && off + pb < n) ? off + pb : n;
             const bool last = part_end == n;
             sa.w_begin = va.w_begin = (uint32_t)(off / ((uint64_t)AGH_WAVE_STRIPS * AGH_STRIP));

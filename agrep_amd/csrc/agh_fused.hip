@@ -1,0 +1,297 @@
+// agh_fused.hip -- count-only (lean) scans in ONE kernel: four sweeping waves and two verifying
+// waves per workgroup.
+//
+// The two-kernel lean pipeline (k_sweep, then k_verify) spends ~7 % of a 64 GiB scan in k_verify,
+// and running the verifier on a second stream only displaces sweep workgroups.  Here the verifiers
+// are two EXTRA waves of each sweep workgroup: they take no LDS or wave slot away from the
+// sweepers (4 workgroups x 6 waves = 24 of a CU's 32 wave slots), their line fetches ride along
+// the stream, and candidates never go through HBM -- they are handed over 64 at a time through a
+// small LDS ring.  Measured (scripts/ab_fused.py, same process, same corpus): 64 GiB, k = 2:
+// 11.0-11.3 ms for the two kernels, 10.6-10.8 ms fused; with the verifier switched off the kernel
+// takes 10.1-10.4 ms, so about two thirds of the verifier's cost stay visible -- its ~4 % of extra,
+// random HBM traffic is not free next to a stream that already runs at the HBM ceiling.
+// Two things mattered on the way (kept in mind for any kernel built like this one):
+//   * the work counter needs a cache line of its own: on the scan counters' line the sweepers'
+//     ticket atomics queued behind the verifiers' stores and the kernel took 14 ms;
+//   * the verifier takes the address of the query struct, which moves the kernel-argument copy
+//     to scratch: the sweepers read their two fields from a register copy.
+//
+//   sweeping wave:  persistent; takes the next 256 KiB wave range from a global ticket counter
+//                   (requested one range ahead), streams it exactly like k_sweep<H, lean>, queues
+//                   hits in its private LDS queue; when 64 are queued it takes a ring chunk
+//                   (LDS ticket), copies them and publishes the chunk.
+//   verifying wave: consumes the chunks in ticket order, one lane per candidate, with the same
+//                   verify_candidate() the stand-alone k_verify runs; matched records go into the
+//                   hash set of record starts.  Leaves when the four sweepers are done and every
+//                   chunk has been consumed.
+//
+// Reference semantics are those of the verifier (asearch.c:66-324 on the candidate windows); this
+// file only changes where the work runs.
+//
+// Compiled once per k (-DAGH_FU_K=0..3, four objects in parallel): every instance carries the
+// fully unrolled automaton of its k, as in agh_scan.hip.
+#include <stdlib.h>
+
+#include "agh_sweep_inl.h"
+#include "agh_verify_inl.h"
+
+#ifndef AGH_FU_K
+#error "compile with -DAGH_FU_K=0..3"
+#endif
+// Verifying waves per workgroup.  Four workgroups of 4 + NV waves must fit a CU: with NV = 2 that is
+// 6 waves per SIMD (<= 80 VGPRs, <= 128 SGPRs; the kernels use 53-67 / ~106).  Measured on the
+// 64 GiB bench corpus, NV = 1, 2, 3, 4 and three or four workgroups per CU are all within 0.1 %
+// (scripts/ab_fused.py, profiles/r02_ab_fused.log): the kernel sits at the HBM ceiling either way;
+// two keeps headroom for candidate-dense text without giving up sweeping waves.
+#define AGH_FU_NV 2
+#define AGH_FU_CHUNKS 4u                 // LDS ring: 4 chunks of 64 candidates (2 KiB)
+// Waits poll LDS every ~0.5 us (s_sleep 16).  The longest legitimate wait is the kernel's own run
+// time (a verifier whose sweepers find nothing): tens of ms.  After ~4 s a wait gives up and
+// raises AGH_C_LEAN_FALLBACK, which makes the host redo the segment with the numbered pipeline.
+#define AGH_FU_SPIN_LIMIT (1u << 23)
+
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t *p)
+{
+    return __atomic_load_n(p, __ATOMIC_RELAXED);
+}
+
+template <typename WT, int H, int MODE, int K, int NCH, int NV>
+__global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
+    const uint4 *__restrict__ text, uint64_t n, uint64_t n_full_strips, agh_dev_query q,
+    const uint8_t *__restrict__ ftab_g, const WT *__restrict__ mask_g, agh_marks mk,
+    const uint64_t *__restrict__ gtab, uint32_t tspan, uint32_t n_ranges,
+    uint32_t *__restrict__ work)
+{
+    static_assert((MODE & 4) && !(MODE & 8), "lean sweeps with one-byte delimiters only");
+    static_assert(AGH_FU_CHUNKS % NV == 0, "a verifying wave owns fixed ring chunks");
+    __shared__ __attribute__((aligned(16))) uint8_t ftab[AGH_FT_SIZE];
+    __shared__ uint64_t cq_all[4 * AGH_CQ_LEN];
+    __shared__ uint64_t ring[AGH_FU_CHUNKS * 64];
+    __shared__ WT lmask[256];
+    __shared__ uint32_t ring_ready[AGH_FU_CHUNKS];   // ticket + 1 of the chunk that is published
+    __shared__ uint32_t ring_freed[AGH_FU_CHUNKS];   // ticket + 1 of the chunk that was consumed last
+    __shared__ uint32_t ring_count[AGH_FU_CHUNKS];
+    __shared__ uint32_t tickets, done;
+
+    if (threadIdx.x < 256) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(ftab_g);
+        uint4 *dst = reinterpret_cast<uint4 *>(ftab);
+        constexpr int PER = AGH_FT_SIZE / 16 / 256;
+        uint4 tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) tmp[i] = src[threadIdx.x + i * 256];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) dst[threadIdx.x + i * 256] = tmp[i];
+    } else {
+        const uint32_t t = threadIdx.x - 256u;
+        for (uint32_t i = t; i < 256u; i += 64u * NV) lmask[i] = mask_g[i];
+        if (t < AGH_FU_CHUNKS) ring_ready[t] = ring_freed[t] = 0u;
+        if (t == 0) tickets = done = 0u;
+    }
+    __syncthreads();
+    const int lane = lane_id();
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+
+    if (wib >= 4) {
+        // ---------------------------------------------------------------- a verifying wave:
+        // chunk tickets wib-4, wib-4+NV, ... (always the same ring slots)
+        VerifyCtx<WT, K> c;
+        verify_ctx_init<WT, K, false>(c, reinterpret_cast<const uint8_t *>(text), n, q, lmask,
+                                            mk, nullptr);
+        c.gtab = gtab;
+        c.tspan = tspan;
+        uint32_t total = 0;
+        for (uint32_t v = wib - 4u;; v += (uint32_t)NV) {
+            const uint32_t slot = v % AGH_FU_CHUNKS;
+            bool more = true;
+            for (uint32_t spins = 0;; ++spins) {
+                if (lds_peek(&ring_ready[slot]) == v + 1u) break;
+                if (lds_peek(&done) == 4u && lds_peek(&tickets) <= v) { more = false; break; }
+                if (spins > AGH_FU_SPIN_LIMIT) {    // never seen; a stuck protocol must not hang the GPU
+                    mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
+                    more = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (!more) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t cnt = lds_peek(&ring_count[slot]);
+            total += cnt;
+            const bool valid = (uint32_t)lane < cnt;
+            const uint64_t ent = valid ? ring[slot * 64u + (uint32_t)lane] : 0;
+            VerifyWin win;
+            win.j = win.ws = 0;
+            win.span = win.mode = 0;
+            if (valid) win = verify_locate<WT, K, NCH, true>(c, ent);
+            if (verify_same_window_as_prev_lane(win)) win.mode = 0u;
+            if (win.mode) verify_walk<WT, K, NCH, true, false, false>(c, ent, 0u, win);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __atomic_store_n(&ring_freed[slot], v + 1u, __ATOMIC_RELAXED);
+        }
+        if (lane == 0 && total) atomicAdd(&mk.counters[AGH_C_CAND], total);
+        return;
+    }
+
+    // -------------------------------------------------------------------- a sweeping wave
+    // (the verifier takes the address of q, which sends the kernel-argument copy to scratch: the
+    // sweepers probe with a register copy of the two fields they read)
+    agh_dev_query qs;
+    qs.qmask = q.qmask;
+    qs.fold = q.fold;
+    uint64_t *cq = cq_all + wib * AGH_CQ_LEN;
+    uint32_t qn = 0;
+    // hand the first `take` queued candidates to the verifier, keep the rest
+    auto hand_over = [&](uint32_t take) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&tickets, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        const uint32_t slot = t % AGH_FU_CHUNKS;
+        if (t >= AGH_FU_CHUNKS) {               // the chunk's previous contents (ticket t - CHUNKS)
+            uint32_t spins = 0;
+            while (lds_peek(&ring_freed[slot]) != t - AGH_FU_CHUNKS + 1u) {
+                if (++spins > AGH_FU_SPIN_LIMIT) {  // (see the verifier's wait)
+                    mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if ((uint32_t)lane < take) ring[slot * 64u + (uint32_t)lane] = cq[lane];
+        if (lane == 0) ring_count[slot] = take;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __atomic_store_n(&ring_ready[slot], t + 1u, __ATOMIC_RELAXED);
+        const uint32_t rest = qn - take;        // < 32: move it to the front
+        uint64_t keep = 0;
+        if ((uint32_t)lane < rest) keep = cq[take + (uint32_t)lane];
+        if ((uint32_t)lane < rest) cq[lane] = keep;
+        qn = rest;
+    };
+    const uint32_t rc0[4] = {0u, 0u, 0u, 0u};
+    auto supertile = [&](uint4 v0, uint4 v1, uint4 v2, uint4 v3, uint64_t s) {
+        uint32_t a = 0, hits = 0;
+        sweep_chunk<H, MODE>(v0, 0u, qs, ftab, a, hits, 0);
+        sweep_chunk<H, MODE>(v1, 0u, qs, ftab, a, hits, 4);
+        sweep_chunk<H, MODE>(v2, 0u, qs, ftab, a, hits, 8);
+        sweep_chunk<H, MODE>(v3, 0u, qs, ftab, a, hits, 12);
+        if (__ballot(hits != 0))
+            emit_candidates_to(hits, s, rc0, cq, qn, [&]() { hand_over(64u); });
+    };
+
+    uint32_t r = 0;
+    if (lane == 0) r = atomicAdd(work, 1u);
+    r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    while (r < n_ranges) {
+        uint32_t r_next = 0;
+        bool have_next = false;                 // (lane 0's view)
+        const uint64_t s0 = (uint64_t)r * AGH_WAVE_STRIPS;
+        uint64_t s1 = s0 + AGH_WAVE_STRIPS;
+        if (s1 > n_full_strips) s1 = n_full_strips;
+        uint64_t s = s0;
+        if (s + 4 <= s1) {
+            const uint4 *p = text + s * 64 + lane;
+            uint4 c0 = ld_stream(p), c1 = ld_stream(p + 64), c2 = ld_stream(p + 128), c3 = ld_stream(p + 192);
+            for (; s + 8 <= s1; s += 4) {
+                const uint4 *pn = text + (s + 4) * 64 + lane;
+                uint4 n0 = ld_stream(pn), n1 = ld_stream(pn + 64), n2 = ld_stream(pn + 128), n3 = ld_stream(pn + 192);
+                // the next range's ticket is requested mid-range: in flight behind the stream
+                if (s == s0 + AGH_WAVE_STRIPS / 2 && lane == 0) { r_next = atomicAdd(work, 1u); have_next = true; }
+                supertile(c0, c1, c2, c3, s);
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            }
+            supertile(c0, c1, c2, c3, s);
+            s += 4;
+        }
+        for (; s < s1; ++s) {                   // < 4 strips left in the range
+            const uint4 v0 = ld_stream(text + s * 64 + lane);
+            uint32_t a = 0, hits = 0;
+            sweep_chunk<H, MODE>(v0, 0u, qs, ftab, a, hits, 0);
+            if (__ballot(hits != 0))
+                emit_candidates_to(hits, s, rc0, cq, qn, [&]() { hand_over(64u); });
+        }
+        if (!have_next && lane == 0) r_next = atomicAdd(work, 1u);   // (short last range)
+        r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_next);
+    }
+    while (qn) hand_over(qn < 64u ? qn : 64u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(&done, 1u);
+}
+
+template <typename WT, int H, int MODE, int NCH>
+static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st)
+{
+    constexpr int K = AGH_FU_K;
+    constexpr int NV = AGH_FU_NV;
+    const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
+    const uint32_t n_ranges = (uint32_t)((n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS);
+    if (!n_ranges) return;
+    // persistent workgroups: four per CU (LDS), fewer when the text has fewer ranges
+    uint32_t blocks = a.n_cu * 4u;
+    const uint32_t need = (n_ranges + 3u) / 4u;
+    if (blocks > need) blocks = need;
+    if (const char *e = getenv("AGH_FUSED_BLOCKS")) blocks = (uint32_t)strtoul(e, nullptr, 10);   // (A/B runs)
+    hipLaunchKernelGGL((k_sweep_fused<WT, H, MODE, K, NCH, NV>), dim3(blocks), dim3(256 + 64 * NV), 0,
+                       st, (const uint4 *)a.text, a.n, n_full, a.q, a.ftab, (const WT *)a.mask,
+                       a.mk, a.gtab, tspan, n_ranges, a.ticket);
+}
+
+template <typename WT, int H, int NCH>
+static void launch_fused_m(const agh_fused_args &a, uint32_t tspan, hipStream_t st)
+{
+    switch ((a.q.fold ? 1 : 0) | (a.q.fq == 4 ? 2 : 0)) {
+    case 0: launch_fused<WT, H, 4, NCH>(a, tspan, st); break;
+    case 1: launch_fused<WT, H, 5, NCH>(a, tspan, st); break;
+    case 2: launch_fused<WT, H, 6, NCH>(a, tspan, st); break;
+    default: launch_fused<WT, H, 7, NCH>(a, tspan, st); break;
+    }
+}
+
+template <typename WT, int NCH>
+static void launch_fused_h(const agh_fused_args &a, int H, uint32_t tspan, hipStream_t st)
+{
+    switch (H) {
+    case 4: launch_fused_m<WT, 4, NCH>(a, tspan, st); break;
+    case 8: launch_fused_m<WT, 8, NCH>(a, tspan, st); break;
+    default: launch_fused_m<WT, 16, NCH>(a, tspan, st); break;
+    }
+}
+
+// The instances of this object's k.  Returns false when the window does not fit one (the caller
+// runs k_sweep + k_verify): windows of 2 or 3 16-byte pieces for 32-bit automata (m <= 32), 4 or 7
+// for 64-bit ones -- the same geometry launch_verify_t picks for lean scans with a gram table.
+#define AGH_FU_CAT2(a, b) a##b
+#define AGH_FU_CAT(a, b) AGH_FU_CAT2(a, b)
+bool AGH_FU_CAT(agh_launch_sweep_fused_k, AGH_FU_K)(const agh_fused_args &a, int H, hipStream_t st)
+{
+    const uint32_t tspan = (uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread;
+    const int tn = (int)((tspan + 15u) / 16u);
+    if (!a.wide) {
+        if (tn <= 2) launch_fused_h<uint32_t, 2>(a, H, tspan, st);
+        else if (tn <= 3) launch_fused_h<uint32_t, 3>(a, H, tspan, st);
+        else return false;
+    } else {
+        if (tn <= 4) launch_fused_h<uint64_t, 4>(a, H, tspan, st);
+        else if (tn <= 7) launch_fused_h<uint64_t, 7>(a, H, tspan, st);
+        else return false;
+    }
+    return true;
+}
+
+#if AGH_FU_K == 0
+bool agh_launch_sweep_fused_k1(const agh_fused_args &a, int H, hipStream_t st);
+bool agh_launch_sweep_fused_k2(const agh_fused_args &a, int H, hipStream_t st);
+bool agh_launch_sweep_fused_k3(const agh_fused_args &a, int H, hipStream_t st);
+
+bool agh_launch_sweep_fused(const agh_fused_args &a, int H, hipStream_t st)
+{
+    if (a.q.mb || !a.gtab || (H != 4 && H != 8 && H != 16)) return false;
+    switch (a.q.k) {
+    case 0: return agh_launch_sweep_fused_k0(a, H, st);
+    case 1: return agh_launch_sweep_fused_k1(a, H, st);
+    case 2: return agh_launch_sweep_fused_k2(a, H, st);
+    case 3: return agh_launch_sweep_fused_k3(a, H, st);
+    default: return false;
+    }
+}
+#endif

@@ -36,6 +36,7 @@ struct agh_sweep_args {
     // AGH_WAVE_STRIPS KiB); w_end == 0: the whole text.  Lean sweeps only: parts let the
     // verifier of one part run while the next part is swept, and let -l stop early.
     uint32_t w_begin = 0, w_end = 0;
+    int tail_only = 0;       // 1: only the partial last strip (the fused kernel swept the rest)
 };
 
 struct agh_scan_args {
@@ -61,6 +62,22 @@ struct agh_scan_args {
 };
 
 void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st);
+
+// count-only scans in one kernel (agh_fused.hip): sweep + verify of all full strips
+struct agh_fused_args {
+    const void *text;
+    uint64_t n;
+    agh_dev_query q;
+    const uint8_t *ftab;
+    const void *mask;        // 256 x uint32_t or uint64_t (device)
+    int wide;                // 1: 64-bit state words
+    const uint64_t *gtab;
+    uint32_t gram_spread;
+    agh_marks mk;            // hash set + counters
+    uint32_t *ticket;        // zeroed work counter in a cache line of its own
+    uint32_t n_cu;
+};
+bool agh_launch_sweep_fused(const agh_fused_args &a, int H, hipStream_t st);
 void agh_launch_verify(const agh_scan_args &a, hipStream_t st);
 void agh_launch_fullscan(const agh_scan_args &a, hipStream_t st);
 void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st);

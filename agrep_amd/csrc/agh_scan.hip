@@ -50,13 +50,21 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
         }
         __syncthreads();
         const uint32_t total = pre[AGH_VGROUP];
-        for (uint32_t ci = threadIdx.x; ci < total; ci += 256) {
+        // (uniform trip count: the lane-to-lane window comparison needs all 64 lanes)
+        for (uint32_t c0 = 0; c0 < total; c0 += 256) {
+            const uint32_t ci = c0 + threadIdx.x;
+            const bool valid = ci < total;
             uint32_t sl = 0;
 #pragma unroll
             for (uint32_t i = 1; i < AGH_VGROUP; ++i) sl += (pre[i] <= ci) ? 1u : 0u;
             const uint32_t w = g0 + sl;
-            const uint64_t ent = cand[(uint64_t)w * AGH_SLICE_CAP + (ci - pre[sl])];
-            verify_candidate<WT, K, NCH, LEAN, MB, GEN>(c, ent, LEAN ? 0u : wave_prefix[w]);
+            const uint64_t ent = valid ? cand[(uint64_t)w * AGH_SLICE_CAP + (ci - pre[sl])] : 0;
+            VerifyWin win;
+            win.j = win.ws = 0;
+            win.span = win.mode = 0;
+            if (valid) win = verify_locate<WT, K, NCH, LEAN>(c, ent);
+            if (LEAN && verify_same_window_as_prev_lane(win)) win.mode = 0u;
+            if (win.mode) verify_walk<WT, K, NCH, LEAN, MB, GEN>(c, ent, LEAN ? 0u : wave_prefix[w], win);
         }
     }
 }

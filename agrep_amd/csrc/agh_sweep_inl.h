@@ -1,0 +1,102 @@
+// agh_sweep_inl.h -- the per-chunk pieces of the sweep (sample probes, candidate queue) shared by
+// k_sweep (agh_sweep.hip) and the fused sweep + verify kernel (agh_fused.hip).
+#pragma once
+#include "agh_device_inl.h"
+
+// ---------------------------------------------------------------------------------------
+// sweep: delimiter census + q-gram sample filter
+// ---------------------------------------------------------------------------------------
+// MODE bit 0: the query folds ASCII case (OR 0x20 into every sampled byte);
+// MODE bit 1: 4-byte samples (no mask needed, 32-bit hash) instead of <= 3-byte samples;
+// MODE bit 2: lean sweep -- no delimiter census (count-only scans identify a record by the
+//             offset of its first byte, found by the verifier, instead of by its number);
+// MODE bit 3: multi-byte delimiter -- the census reads the delimiter-end bitmap.
+template <int MODE>
+__device__ __forceinline__ uint32_t probe(uint32_t w, const agh_dev_query &q,
+                                          const uint8_t *ftab)
+{
+    if (MODE & 2) {
+        const uint32_t s = (MODE & 1) ? (w | q.fold) : w;
+        return ftab[agh_sample_hash_q4(s)];
+    } else {
+        const uint32_t s = (MODE & 1) ? ((w & q.qmask) | q.fold) : (w & q.qmask);
+        return ftab[agh_sample_hash_q3(s)];
+    }
+}
+
+// One 16-byte chunk: accumulate the non-delimiter popcount and the sample hit bits.
+template <int H, int MODE>
+__device__ __forceinline__ void sweep_chunk(uint4 v, uint32_t dd, const agh_dev_query &q,
+                                            const uint8_t *ftab, uint32_t &acc,
+                                            uint32_t &hits, int bitbase, uint32_t dbits16 = 0)
+{
+    if (MODE & 8) {
+        // multi-byte delimiter: the chunk's 16 delimiter-end bits come from the bitmap; keep
+        // the "128 minus delimiters" convention of the SWAR census
+        if (!(MODE & 4)) acc += 128u - (uint32_t)__popc(dbits16 & 0xffffu);
+    } else if (!(MODE & 4)) {
+        acc += nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
+    }
+    if (H > 0) {
+        hits |= probe<MODE>(v.x, q, ftab) << bitbase;
+        if (H <= 8) hits |= probe<MODE>(v.z, q, ftab) << (bitbase + 2);
+        if (H <= 4) {
+            hits |= probe<MODE>(v.y, q, ftab) << (bitbase + 1);
+            hits |= probe<MODE>(v.w, q, ftab) << (bitbase + 3);
+        }
+    }
+}
+
+// Candidates of one wave.  They are queued in LDS (cq, private to the wave) and written to the
+// wave's private slice of the candidate buffer 64 at a time with one coalesced store:
+//   * no atomics -- one hot global counter saturates at ~90 updates/us on this chip and would
+//     cap the whole sweep;
+//   * no global store per hit -- vmcnt also counts stores, so a store issued between the
+//     prefetch and its use stalls the wave until that store has completed (measured: ~7 % of
+//     the sweep).
+// hits: bit (4*u + d) of lane l = sample at dword d of the lane's chunk in strip s+u.
+// rc[u] = delimiters (inside this wave's range) in front of the lane's chunk of strip s+u --
+// stored with the candidate so that the verifier can number records without re-reading text.
+// qn (queued) and cnt (already in the slice) are wave-uniform.
+template <typename OnFull>
+__device__ __forceinline__ void emit_candidates_to(uint32_t hits, uint64_t s,
+                                                   const uint32_t rc[4], uint64_t *cq,
+                                                   uint32_t &qn, OnFull on_full)
+{
+    uint64_t hm = __ballot(hits != 0);
+    const int lane = lane_id();
+    while (hm) {
+        int l = __ffsll((long long)hm) - 1;
+        hm &= hm - 1;
+        uint32_t hbits = (uint32_t)__builtin_amdgcn_readlane((int)hits, l);
+        uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)rc[0], l);
+        uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)rc[1], l);
+        uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)rc[2], l);
+        uint32_t r3 = (uint32_t)__builtin_amdgcn_readlane((int)rc[3], l);
+        int c = __popc(hbits);
+        if (lane < c) {
+            uint32_t t = hbits;
+            for (int j = 0; j < lane; ++j) t &= t - 1;
+            int b = __ffs((int)t) - 1;
+            int u = b >> 2;
+            // dword index of the sample: < 2^32 inside a numbered segment (<= 16 GiB), where the
+            // upper half carries the record count; lean sweeps (r == 0) use all 64 bits, so one
+            // launch can cover any text length
+            const uint64_t dw = ((s + (uint64_t)u) * 64u + (uint64_t)l) * 4u + (uint64_t)(b & 3);
+            uint32_t r = u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3));
+            cq[qn + (uint32_t)lane] = ((uint64_t)r << 32) | dw;
+        }
+        qn += (uint32_t)c;
+        if (qn >= 64u) on_full();
+    }
+}
+
+__device__ __forceinline__ void emit_candidates(uint32_t hits, uint64_t s, const uint32_t rc[4],
+                                                uint64_t *cq, uint32_t &qn,
+                                                uint64_t *__restrict__ slice, uint32_t &cnt,
+                                                uint32_t *counters)
+{
+    emit_candidates_to(hits, s, rc, cq, qn,
+                       [&]() { flush_candidates(cq, qn, 64u, slice, cnt, counters); });
+}
+

@@ -31,12 +31,20 @@ __device__ __forceinline__ void mark_record(const agh_marks &mk, uint32_t r, uin
 __device__ __forceinline__ void lean_insert(const agh_marks &mk, uint64_t rec_start)
 {
     const uint64_t key = rec_start + 1;         // 0 = empty slot
-    mk.counters[AGH_C_ANYHIT] = 1u;             // -l scans stop at the first part with a hit
     uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & mk.hashset_mask;
     for (int probe = 0; probe < 64; ++probe) {
-        const uint64_t old = atomicCAS((unsigned long long *)&mk.hashset[slot], 0ull,
-                                       (unsigned long long)key);
-        if (old == 0 || old == key) return;
+        // most inserts repeat a record already in the set (several candidate windows per
+        // occurrence): a plain load settles those without an L2 atomic
+        uint64_t old = __atomic_load_n(&mk.hashset[slot], __ATOMIC_RELAXED);
+        if (old == key) return;
+        if (old == 0) {
+            old = atomicCAS((unsigned long long *)&mk.hashset[slot], 0ull, (unsigned long long)key);
+            if (old == 0) {
+                mk.counters[AGH_C_ANYHIT] = 1u; // -l scans stop at the first part with a hit
+                return;
+            }
+            if (old == key) return;
+        }
         slot = (slot + 1) & mk.hashset_mask;
     }
     mk.counters[AGH_C_LEAN_FALLBACK] = 1u;      // table too full: the host re-runs numbered
@@ -312,19 +320,23 @@ __device__ __forceinline__ void verify_ctx_init(VerifyCtx<WT, K> &c, const uint8
     c.rf_hit = c.RF.template step_q<GEN>(lmask[q.delim], c.finalbit, q);   // asearch.c:175-186
 }
 
-// Fast path geometry, identical for every lane: the window starts Lw = max(m+k+1, 16) bytes in
-// front of the sample and spans Lw + q + m + k bytes; it is fetched with NCH unaligned 16-byte
-// loads issued together and walked branch-free out of registers.  Match positions and
-// delimiter positions are collected as bit masks; record numbers are derived from them after
-// the walk.  Windows that touch the head or the tail of the text take the byte-wise path.
-template <typename WT, int K, int NCH, bool LEAN, bool MB, bool GEN = false>
-__device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint64_t ent,
-                                                 uint32_t wave_base)
+// Where the window of a candidate lies.  mode 0: nothing to do (beyond the text, or the sample's
+// gram is not one of the pattern's); 1: fast path, window [ws, ws + span); 2: byte-wise path.
+struct VerifyWin {
+    uint64_t j, ws;
+    uint32_t span, mode;
+};
+
+template <typename WT, int K, int NCH, bool LEAN>
+__device__ __forceinline__ VerifyWin verify_locate(const VerifyCtx<WT, K> &c, uint64_t ent)
 {
-    constexpr int NMW = (NCH * 16 + 63) / 64;           // 64-bit words per position mask
+    VerifyWin w;
+    w.ws = 0;
+    w.span = 0;
+    w.mode = 0;
     const uint64_t j = LEAN ? ent * 4u : (ent & 0xffffffffull) * 4u;   // lean entries: 64-bit dword index
-    if (j >= c.n) return;
-    const uint32_t rc_anchor = LEAN ? 0u : wave_base + (uint32_t)(ent >> 32);  // record no. at anchor
+    w.j = j;
+    if (j >= c.n) return w;
     const uint64_t anchor = j & ~(uint64_t)15;                           // sample's chunk start
 
     // Lean scans with a gram table: the sample's q-gram says where in the pattern it sits.
@@ -342,7 +354,7 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
         if (e & AGH_GT_AMBIGUOUS) {
             fast = false;                       // full window, byte-wise
         } else {
-            if ((uint32_t)e != g) return;
+            if ((uint32_t)e != g) return w;
             lw = (uint32_t)((e >> 40) & 0xffu) + (uint32_t)c.q->k + 1u;   // + one warm-up byte
             span = c.tspan;
             // numbered scans count delimiters from the window start to the sample's chunk
@@ -351,7 +363,39 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
         }
     }
     fast = fast && j >= lw && (j - lw) + span < c.n && (j - lw) + 16u * NCH <= c.n16;
-    if (!fast) {
+    w.mode = fast ? 1u : 2u;
+    w.ws = fast ? j - lw : 0;
+    w.span = span;
+    return w;
+}
+
+// Candidates in neighbouring lanes are neighbours in the text, and the sampled grams of ONE
+// occurrence (3-4 of them for m = 16, H = 4) all point at the same window when no indel sits
+// between them: the lane whose fast-path window equals its predecessor's has nothing to add.
+// Must be called by all 64 lanes (lanes without a candidate pass mode 0).
+__device__ __forceinline__ bool verify_same_window_as_prev_lane(const VerifyWin &w)
+{
+    const uint32_t lo = (uint32_t)w.ws, hi = (uint32_t)(w.ws >> 32) | (w.mode << 8);
+    const uint32_t plo = (uint32_t)__shfl_up((int)lo, 1), phi = (uint32_t)__shfl_up((int)hi, 1);
+    return lane_id() > 0 && w.mode == 1u && plo == lo && phi == hi;
+}
+
+// Fast path geometry, identical for every lane: the window starts Lw = max(m+k+1, 16) bytes in
+// front of the sample and spans Lw + q + m + k bytes; it is fetched with NCH unaligned 16-byte
+// loads issued together and walked branch-free out of registers.  Match positions and
+// delimiter positions are collected as bit masks; record numbers are derived from them after
+// the walk.  Windows that touch the head or the tail of the text take the byte-wise path.
+template <typename WT, int K, int NCH, bool LEAN, bool MB, bool GEN = false>
+__device__ __forceinline__ void verify_walk(const VerifyCtx<WT, K> &c, uint64_t ent,
+                                            uint32_t wave_base, const VerifyWin &win)
+{
+    constexpr int NMW = (NCH * 16 + 63) / 64;           // 64-bit words per position mask
+    if (win.mode == 0u) return;
+    const uint64_t j = win.j;
+    const uint32_t rc_anchor = LEAN ? 0u : wave_base + (uint32_t)(ent >> 32);  // record no. at anchor
+    const uint64_t anchor = j & ~(uint64_t)15;                           // sample's chunk start
+    const uint32_t span = win.span;
+    if (win.mode == 2u) {
         const uint64_t ws = j > c.Lw ? j - c.Lw : 0;
         uint64_t we = j + c.tailw;
         if (we > c.n) we = c.n;
@@ -359,7 +403,7 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
                                         *c.mk);
         return;
     }
-    const uint64_t ws = j - lw;
+    const uint64_t ws = win.ws;
     u32x4_u ch[NCH];
 #pragma unroll
     for (int ic = 0; ic < NCH; ++ic)
@@ -474,4 +518,12 @@ __device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint
             }
         }
     }
+}
+
+template <typename WT, int K, int NCH, bool LEAN, bool MB, bool GEN = false>
+__device__ __forceinline__ void verify_candidate(const VerifyCtx<WT, K> &c, uint64_t ent,
+                                                 uint32_t wave_base)
+{
+    const VerifyWin w = verify_locate<WT, K, NCH, LEAN>(c, ent);
+    verify_walk<WT, K, NCH, LEAN, MB, GEN>(c, ent, wave_base, w);
 }
