@@ -1532,6 +1532,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
             }
             fused = agh_launch_sweep_fused(fa, q->fh, st);
             if (fused) {
+                res->fused_segments += 1;
                 if (timing) {
                     HIP_TRY(hipEventRecord(e1, st));
                     n_time += 2;

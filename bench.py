@@ -15,7 +15,8 @@ the RCCL all-reduce of the counts through the C-ABI (agh_reduce_counts, N > 1).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   k0           -- the same K steps timed the same way with k = 0 (the metric's other point)
-  roofline     -- dominant kernel k_sweep<H>: algorithmic bytes (1 B per corpus byte) / its
+  roofline     -- dominant kernel (k_sweep_fused<H>: sweep + verify of a count-only scan in one
+                  kernel; k_sweep<H> with AGH_FUSED=0): algorithmic bytes (1 B per corpus byte) / its
                   average launch duration, HIP events recorded around every launch on the
                   stream it is launched on, against the 8 TB/s HBM peak; `traffic` = HBM read
                   bytes per launch from rocprofv3's FETCH_SIZE counter, measured in THIS run by
@@ -131,7 +132,7 @@ def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes):
 
 
 def measure_traffic(seg_gib, k, timeout_s):
-    """HBM read bytes of ONE k_sweep launch, measured now: a child process runs a few scans of
+    """HBM read bytes of ONE launch of the dominant kernel, measured now: a child process runs a few scans of
     one segment of the same corpus under `rocprofv3 --pmc FETCH_SIZE` (its own pass, with
     --kernel-trace only, as MI355X_MICROARCH.md prescribes); FETCH_SIZE is in KiB and counts the
     128-byte requests of gfx950 as 64 bytes (the guide's correction: x 2).  None on any failure."""
@@ -153,10 +154,10 @@ def measure_traffic(seg_gib, k, timeout_s):
             return None, "rocprofv3 pass failed (rc %d)" % r.returncode
         vals = []
         for row in csv.DictReader(open(files[0])):
-            if row.get("Counter_Name") == "FETCH_SIZE" and row.get("Kernel_Name", "").startswith("void k_sweep<"):
+            if row.get("Counter_Name") == "FETCH_SIZE" and row.get("Kernel_Name", "").startswith(("void k_sweep<", "void k_sweep_fused<")):
                 vals.append(float(row["Counter_Value"]))
         if not vals:
-            return None, "no k_sweep rows in the counter file"
+            return None, "no k_sweep / k_sweep_fused rows in the counter file"
         # one row per launch (the counter is summed over the XCDs by rocprofv3); drop nothing
         per_launch = sum(vals) / len(vals)
         return int(per_launch * 1024 * 2), "rocprofv3 --pmc FETCH_SIZE, %d launches of %g GiB, KiB x 1024 x 2" % (len(vals), seg_gib)
@@ -325,7 +326,9 @@ def main():
                    "mmatches_per_s": round(matched0 / 1e6 / (elapsed0 / args.steps), 3),
                    "filter_sample": "q=%d bytes every h=%d bytes" % (info0["filter_q"], info0["filter_h"]),
                    "sweep_avg_launch_ms": round(sweep_ms0 / max(launches0, 1), 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep<%d>" % info["filter_h"],
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_sweep_fused<H=%d> (sweep + verify of a count-only scan in one kernel)"
+                                    if res.fused_segments else "k_sweep<%d>") % info["filter_h"],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(per_launch_bytes),

@@ -78,14 +78,15 @@ typedef struct {
     uint32_t engine;        /* AGH_ENGINE_* */
     uint32_t truncated;     /* 1: more matches than the agh_match array could hold */
     double   device_ms;     /* AGH_TIME_SCAN: GPU time of the whole scan (hipEvent), excluding staging; else 0 */
-    double   sweep_ms;      /* AGH_TIME_SWEEP (else 0): of which the k_sweep kernel launches (the kernel that reads every
-                               byte), hipEvents recorded right around them on the scan stream */
+    double   sweep_ms;      /* AGH_TIME_SWEEP (else 0): of which the k_sweep / k_sweep_fused kernel launches (the kernel that
+                               reads every byte), hipEvents recorded right around them on the scan stream */
     uint32_t sweep_launches;/* AGH_TIME_SWEEP: number of k_sweep launches sweep_ms is the sum of */
     uint32_t lean_reruns;   /* segments whose count-only (lean) scan gave up (a record start more than 64 KiB
                                in front of a match, hash set full, candidate slices full) and were scanned
                                again on the numbered pipeline: the result is exact, the time doubled */
     uint32_t n_segments;    /* kernel sequences the text was cut into (<= 8 GiB each, at record boundaries) */
-    uint32_t reserved;
+    uint32_t fused_segments;/* of which count-only segments ran as ONE kernel (k_sweep_fused: sweep + verify;
+                               sweep_ms then covers that kernel) */
 } agh_result;
 
 /* ---- query construction ------------------------------------------------------------- */

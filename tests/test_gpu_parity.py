@@ -48,6 +48,15 @@ def _check(agh, pat, k, text, nocase=False):
         res_n, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
     assert res_c.n_matched == want[0], ("lean", pat, k, nocase)
     assert res_n.n_matched == want[0] and res_n.n_records == res.n_records
+    # the lean path is one fused kernel where the query's shape has an instance; the two-kernel
+    # form (k_sweep, then k_verify) serves the other shapes and -l: keep both honest
+    os.environ["AGH_FUSED"] = "0"
+    try:
+        with agh.Query(pat, k, nocase=nocase) as q:
+            res_2, _ = q.scan_buffer(text, flags=agh.COUNT)
+    finally:
+        del os.environ["AGH_FUSED"]
+    assert res_2.n_matched == want[0], ("lean, two kernels", pat, k, nocase)
     # ... and so does the count-only full scan (no census pass in front of k_fullscan)
     with agh.Query(pat, k, nocase=nocase) as q:
         res_lf, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_FULLSCAN)
@@ -763,3 +772,42 @@ def test_record_aligned_shards_add_up(agh, tmp_path, nranks):
         os.close(fd)
     assert total == whole.n_matched and recs == ms and rec_off == whole.n_records
     assert (whole.n_matched, [(s, e) for s, e, _ in ms]) == O.asearch(O.PATTERN_C2, 2, data, cap=100000)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_fused_count_on_candidate_dense_text(agh, k):
+    """Every sample is a candidate (the text is made of the pattern's own grams): the verifying
+    waves of the fused kernel are the bottleneck, the ring runs full, the hash set overflows into
+    the numbered re-run -- and the count still equals the numbered pipeline's and the oracle's."""
+    import torch
+    rng = np.random.default_rng(77 + k)
+    pat = O.PATTERN_C2
+    parts = []
+    for _ in range(40000):
+        a = int(rng.integers(0, len(pat) - 4))
+        b = int(rng.integers(a + 3, len(pat) + 1))
+        parts.append(pat[a:b])
+        if rng.random() < 0.2:
+            parts.append(b"\n")
+        if rng.random() < 0.05:
+            parts.append(pat)
+    text = b"".join(parts) + b"\n"
+    want = O.asearch(pat, k, text)[0]
+    with agh.Query(pat, k) as q:
+        r_f, _ = q.scan_buffer(text, flags=agh.COUNT)
+        r_n, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
+    assert r_f.n_matched == r_n.n_matched == want
+    # the same text many times over on the device (64 MiB): fused against two kernels
+    reps = (64 << 20) // len(text)
+    t = torch.frombuffer(bytearray(text * reps), dtype=torch.uint8).cuda()
+    with agh.Query(pat, k) as q:
+        r1 = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+        os.environ["AGH_FUSED"] = "0"
+        try:
+            r2 = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+        finally:
+            del os.environ["AGH_FUSED"]
+    assert r1.n_matched == r2.n_matched == want * reps
+    if k <= 2:                                  # (k = 3 at m = 16 is the piece engine)
+        assert r1.n_candidates == r2.n_candidates
+        assert r1.fused_segments == 1 and r2.fused_segments == 0
