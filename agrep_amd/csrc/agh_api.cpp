@@ -871,6 +871,12 @@ static const uint64_t AGH_LEAN_SEG_MAX = (uint64_t)64 << 30;     // lean scans: 
 #define AGH_PART_MB_DEFAULT 0
 #define AGH_OVERLAP_DEFAULT 0
 #define AGH_FUSED_DEFAULT 1
+// ... from this segment size on (MiB; AGH_FUSED_MIN_MB overrides, the tests run with 0).  The
+// persistent kernel pays ~70 us once (the candidates queued last are verified after the stream has
+// ended, and 4096 waves drawing 256 KiB tickets finish less evenly than hardware-dispatched
+// workgroups): measured against the two-kernel form (scripts/ab_fused.py, k = 2 / k = 0) it is
+// -3 % / -3 % at 4 GiB, even at 8 GiB, +1.8 % / +1.6 % at 16 GiB, +5 % / 0 % at 64 GiB.
+#define AGH_FUSED_MIN_MB_DEFAULT 12288
 
 struct seg_result {
     uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
@@ -1510,7 +1516,8 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         // one kernel for sweep + verify where the query's shape has a fused instance; the partial
         // last strip (n % 1024 bytes) still goes through k_sweep_tail + k_verify
         bool fused = false;
-        if (!early && !overlap && !part_bytes && va.gtab && fused_enabled()) {
+        if (!early && !overlap && !part_bytes && va.gtab && fused_enabled() &&
+            n >= (env_mb("AGH_FUSED_MIN_MB", AGH_FUSED_MIN_MB_DEFAULT) << 20)) {
             agh_fused_args fa;
             fa.text = text;
             fa.n = n;

@@ -20,10 +20,11 @@
 //                   (requested one range ahead), streams it exactly like k_sweep<H, lean>, queues
 //                   hits in its private LDS queue; when 64 are queued it takes a ring chunk
 //                   (LDS ticket), copies them and publishes the chunk.
-//   verifying wave: consumes the chunks in ticket order, one lane per candidate, with the same
-//                   verify_candidate() the stand-alone k_verify runs; matched records go into the
-//                   hash set of record starts.  Leaves when the four sweepers are done and every
-//                   chunk has been consumed.
+//   verifying wave: takes the next chunk number, waits for that chunk, verifies it one lane per
+//                   candidate with the same verify_locate() / verify_walk() the stand-alone
+//                   k_verify runs; matched records go into the hash set of record starts.  Leaves
+//                   when the four sweepers are done and its chunk number was never handed out.
+//                   Sweeping waves that have run out of ranges turn into verifying waves.
 //
 // Reference semantics are those of the verifier (asearch.c:66-324 on the candidate windows); this
 // file only changes where the work runs.
@@ -63,15 +64,14 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
     uint32_t *__restrict__ work)
 {
     static_assert((MODE & 4) && !(MODE & 8), "lean sweeps with one-byte delimiters only");
-    static_assert(AGH_FU_CHUNKS % NV == 0, "a verifying wave owns fixed ring chunks");
-    __shared__ __attribute__((aligned(16))) uint8_t ftab[AGH_FT_SIZE];
+        __shared__ __attribute__((aligned(16))) uint8_t ftab[AGH_FT_SIZE];
     __shared__ uint64_t cq_all[4 * AGH_CQ_LEN];
     __shared__ uint64_t ring[AGH_FU_CHUNKS * 64];
     __shared__ WT lmask[256];
     __shared__ uint32_t ring_ready[AGH_FU_CHUNKS];   // ticket + 1 of the chunk that is published
     __shared__ uint32_t ring_freed[AGH_FU_CHUNKS];   // ticket + 1 of the chunk that was consumed last
     __shared__ uint32_t ring_count[AGH_FU_CHUNKS];
-    __shared__ uint32_t tickets, done;
+    __shared__ uint32_t tickets, done, next_chunk;
 
     if (threadIdx.x < 256) {
         const uint4 *src = reinterpret_cast<const uint4 *>(ftab_g);
@@ -86,136 +86,142 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
         const uint32_t t = threadIdx.x - 256u;
         for (uint32_t i = t; i < 256u; i += 64u * NV) lmask[i] = mask_g[i];
         if (t < AGH_FU_CHUNKS) ring_ready[t] = ring_freed[t] = 0u;
-        if (t == 0) tickets = done = 0u;
+        if (t == 0) tickets = done = next_chunk = 0u;
     }
     __syncthreads();
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
 
-    if (wib >= 4) {
-        // ---------------------------------------------------------------- a verifying wave:
-        // chunk tickets wib-4, wib-4+NV, ... (always the same ring slots)
-        VerifyCtx<WT, K> c;
-        verify_ctx_init<WT, K, false>(c, reinterpret_cast<const uint8_t *>(text), n, q, lmask,
-                                            mk, nullptr);
-        c.gtab = gtab;
-        c.tspan = tspan;
-        uint32_t total = 0;
-        for (uint32_t v = wib - 4u;; v += (uint32_t)NV) {
-            const uint32_t slot = v % AGH_FU_CHUNKS;
-            bool more = true;
-            for (uint32_t spins = 0;; ++spins) {
-                if (lds_peek(&ring_ready[slot]) == v + 1u) break;
-                if (lds_peek(&done) == 4u && lds_peek(&tickets) <= v) { more = false; break; }
-                if (spins > AGH_FU_SPIN_LIMIT) {    // never seen; a stuck protocol must not hang the GPU
-                    mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
-                    more = false;
-                    break;
+    if (wib < 4) {
+        // ---------------------------------------------------------------- a sweeping wave
+        // (the verifier takes the address of q, which sends the kernel-argument copy to scratch: the
+        // sweepers probe with a register copy of the two fields they read)
+        agh_dev_query qs;
+        qs.qmask = q.qmask;
+        qs.fold = q.fold;
+        uint64_t *cq = cq_all + wib * AGH_CQ_LEN;
+        uint32_t qn = 0;
+        // hand the first `take` queued candidates to the verifier, keep the rest
+        auto hand_over = [&](uint32_t take) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&tickets, 1u);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            const uint32_t slot = t % AGH_FU_CHUNKS;
+            if (t >= AGH_FU_CHUNKS) {               // the chunk's previous contents (ticket t - CHUNKS)
+                uint32_t spins = 0;
+                while (lds_peek(&ring_freed[slot]) != t - AGH_FU_CHUNKS + 1u) {
+                    if (++spins > AGH_FU_SPIN_LIMIT) {  // (see the verifier's wait)
+                        mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
                 }
-                __builtin_amdgcn_s_sleep(16);
             }
-            if (!more) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint32_t cnt = lds_peek(&ring_count[slot]);
-            total += cnt;
-            const bool valid = (uint32_t)lane < cnt;
-            const uint64_t ent = valid ? ring[slot * 64u + (uint32_t)lane] : 0;
-            VerifyWin win;
-            win.j = win.ws = 0;
-            win.span = win.mode = 0;
-            if (valid) win = verify_locate<WT, K, NCH, true>(c, ent);
-            if (verify_same_window_as_prev_lane(win)) win.mode = 0u;
-            if (win.mode) verify_walk<WT, K, NCH, true, false, false>(c, ent, 0u, win);
+            if ((uint32_t)lane < take) ring[slot * 64u + (uint32_t)lane] = cq[lane];
+            if (lane == 0) ring_count[slot] = take;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __atomic_store_n(&ring_freed[slot], v + 1u, __ATOMIC_RELAXED);
-        }
-        if (lane == 0 && total) atomicAdd(&mk.counters[AGH_C_CAND], total);
-        return;
-    }
-
-    // -------------------------------------------------------------------- a sweeping wave
-    // (the verifier takes the address of q, which sends the kernel-argument copy to scratch: the
-    // sweepers probe with a register copy of the two fields they read)
-    agh_dev_query qs;
-    qs.qmask = q.qmask;
-    qs.fold = q.fold;
-    uint64_t *cq = cq_all + wib * AGH_CQ_LEN;
-    uint32_t qn = 0;
-    // hand the first `take` queued candidates to the verifier, keep the rest
-    auto hand_over = [&](uint32_t take) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&tickets, 1u);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        const uint32_t slot = t % AGH_FU_CHUNKS;
-        if (t >= AGH_FU_CHUNKS) {               // the chunk's previous contents (ticket t - CHUNKS)
-            uint32_t spins = 0;
-            while (lds_peek(&ring_freed[slot]) != t - AGH_FU_CHUNKS + 1u) {
-                if (++spins > AGH_FU_SPIN_LIMIT) {  // (see the verifier's wait)
-                    mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if ((uint32_t)lane < take) ring[slot * 64u + (uint32_t)lane] = cq[lane];
-        if (lane == 0) ring_count[slot] = take;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __atomic_store_n(&ring_ready[slot], t + 1u, __ATOMIC_RELAXED);
-        const uint32_t rest = qn - take;        // < 32: move it to the front
-        uint64_t keep = 0;
-        if ((uint32_t)lane < rest) keep = cq[take + (uint32_t)lane];
-        if ((uint32_t)lane < rest) cq[lane] = keep;
-        qn = rest;
-    };
-    const uint32_t rc0[4] = {0u, 0u, 0u, 0u};
-    auto supertile = [&](uint4 v0, uint4 v1, uint4 v2, uint4 v3, uint64_t s) {
-        uint32_t a = 0, hits = 0;
-        sweep_chunk<H, MODE>(v0, 0u, qs, ftab, a, hits, 0);
-        sweep_chunk<H, MODE>(v1, 0u, qs, ftab, a, hits, 4);
-        sweep_chunk<H, MODE>(v2, 0u, qs, ftab, a, hits, 8);
-        sweep_chunk<H, MODE>(v3, 0u, qs, ftab, a, hits, 12);
-        if (__ballot(hits != 0))
-            emit_candidates_to(hits, s, rc0, cq, qn, [&]() { hand_over(64u); });
-    };
-
-    uint32_t r = 0;
-    if (lane == 0) r = atomicAdd(work, 1u);
-    r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-    while (r < n_ranges) {
-        uint32_t r_next = 0;
-        bool have_next = false;                 // (lane 0's view)
-        const uint64_t s0 = (uint64_t)r * AGH_WAVE_STRIPS;
-        uint64_t s1 = s0 + AGH_WAVE_STRIPS;
-        if (s1 > n_full_strips) s1 = n_full_strips;
-        uint64_t s = s0;
-        if (s + 4 <= s1) {
-            const uint4 *p = text + s * 64 + lane;
-            uint4 c0 = ld_stream(p), c1 = ld_stream(p + 64), c2 = ld_stream(p + 128), c3 = ld_stream(p + 192);
-            for (; s + 8 <= s1; s += 4) {
-                const uint4 *pn = text + (s + 4) * 64 + lane;
-                uint4 n0 = ld_stream(pn), n1 = ld_stream(pn + 64), n2 = ld_stream(pn + 128), n3 = ld_stream(pn + 192);
-                // the next range's ticket is requested mid-range: in flight behind the stream
-                if (s == s0 + AGH_WAVE_STRIPS / 2 && lane == 0) { r_next = atomicAdd(work, 1u); have_next = true; }
-                supertile(c0, c1, c2, c3, s);
-                c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-            }
-            supertile(c0, c1, c2, c3, s);
-            s += 4;
-        }
-        for (; s < s1; ++s) {                   // < 4 strips left in the range
-            const uint4 v0 = ld_stream(text + s * 64 + lane);
+            if (lane == 0) __atomic_store_n(&ring_ready[slot], t + 1u, __ATOMIC_RELAXED);
+            const uint32_t rest = qn - take;        // < 32: move it to the front
+            uint64_t keep = 0;
+            if ((uint32_t)lane < rest) keep = cq[take + (uint32_t)lane];
+            if ((uint32_t)lane < rest) cq[lane] = keep;
+            qn = rest;
+        };
+        const uint32_t rc0[4] = {0u, 0u, 0u, 0u};
+        auto supertile = [&](uint4 v0, uint4 v1, uint4 v2, uint4 v3, uint64_t s) {
             uint32_t a = 0, hits = 0;
             sweep_chunk<H, MODE>(v0, 0u, qs, ftab, a, hits, 0);
+            sweep_chunk<H, MODE>(v1, 0u, qs, ftab, a, hits, 4);
+            sweep_chunk<H, MODE>(v2, 0u, qs, ftab, a, hits, 8);
+            sweep_chunk<H, MODE>(v3, 0u, qs, ftab, a, hits, 12);
             if (__ballot(hits != 0))
                 emit_candidates_to(hits, s, rc0, cq, qn, [&]() { hand_over(64u); });
+        };
+
+        // the first range is the wave's own number (4096 waves asking one counter at the same
+        // moment would wait ~45 us for the last answer); the counter hands out the rest
+        const uint32_t first_dynamic = gridDim.x * 4u;
+        uint32_t r = blockIdx.x * 4u + wib;
+        while (r < n_ranges) {
+            uint32_t r_next = 0;
+            bool have_next = false;                 // (lane 0's view)
+            const uint64_t s0 = (uint64_t)r * AGH_WAVE_STRIPS;
+            uint64_t s1 = s0 + AGH_WAVE_STRIPS;
+            if (s1 > n_full_strips) s1 = n_full_strips;
+            uint64_t s = s0;
+            if (s + 4 <= s1) {
+                const uint4 *p = text + s * 64 + lane;
+                uint4 c0 = ld_stream(p), c1 = ld_stream(p + 64), c2 = ld_stream(p + 128), c3 = ld_stream(p + 192);
+                for (; s + 8 <= s1; s += 4) {
+                    const uint4 *pn = text + (s + 4) * 64 + lane;
+                    uint4 n0 = ld_stream(pn), n1 = ld_stream(pn + 64), n2 = ld_stream(pn + 128), n3 = ld_stream(pn + 192);
+                    // the next range's ticket is requested mid-range: in flight behind the stream
+                    if (s == s0 + AGH_WAVE_STRIPS / 2 && lane == 0) { r_next = first_dynamic + atomicAdd(work, 1u); have_next = true; }
+                    supertile(c0, c1, c2, c3, s);
+                    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+                }
+                supertile(c0, c1, c2, c3, s);
+                s += 4;
+            }
+            for (; s < s1; ++s) {                   // < 4 strips left in the range
+                const uint4 v0 = ld_stream(text + s * 64 + lane);
+                uint32_t a = 0, hits = 0;
+                sweep_chunk<H, MODE>(v0, 0u, qs, ftab, a, hits, 0);
+                if (__ballot(hits != 0))
+                    emit_candidates_to(hits, s, rc0, cq, qn, [&]() { hand_over(64u); });
+            }
+            if (!have_next && lane == 0) r_next = first_dynamic + atomicAdd(work, 1u);   // (short last range)
+            r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_next);
         }
-        if (!have_next && lane == 0) r_next = atomicAdd(work, 1u);   // (short last range)
-        r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_next);
+        while (qn) hand_over(qn < 64u ? qn : 64u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) atomicAdd(&done, 1u);
     }
-    while (qn) hand_over(qn < 64u ? qn : 64u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) atomicAdd(&done, 1u);
+
+    // ---------------------------------------------------------------------- verifying:
+    // the two verifying waves from the start, and every sweeping wave once it has run out of
+    // ranges (so the chunks handed over last do not wait in line for two waves while four idle).
+    // A consumer takes the next chunk number, waits until that chunk is published, verifies it
+    // one lane per candidate and frees the ring slot.
+    VerifyCtx<WT, K> c;
+    verify_ctx_init<WT, K, false>(c, reinterpret_cast<const uint8_t *>(text), n, q, lmask, mk,
+                                  nullptr);
+    c.gtab = gtab;
+    c.tspan = tspan;
+    uint32_t total = 0;
+    for (;;) {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&next_chunk, 1u);
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        const uint32_t slot = v % AGH_FU_CHUNKS;
+        bool more = true;
+        for (uint32_t spins = 0;; ++spins) {
+            if (lds_peek(&ring_ready[slot]) == v + 1u) break;
+            if (lds_peek(&done) == 4u && lds_peek(&tickets) <= v) { more = false; break; }
+            if (spins > AGH_FU_SPIN_LIMIT) {        // never seen; a stuck protocol must not hang the GPU
+                mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
+                more = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (!more) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t cnt = lds_peek(&ring_count[slot]);
+        total += cnt;
+        const bool valid = (uint32_t)lane < cnt;
+        const uint64_t ent = valid ? ring[slot * 64u + (uint32_t)lane] : 0;
+        VerifyWin win;
+        win.j = win.ws = 0;
+        win.span = win.mode = 0;
+        if (valid) win = verify_locate<WT, K, NCH, true>(c, ent);
+        if (verify_same_window_as_prev_lane(win)) win.mode = 0u;
+        if (win.mode) verify_walk<WT, K, NCH, true, false, false>(c, ent, 0u, win);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __atomic_store_n(&ring_freed[slot], v + 1u, __ATOMIC_RELAXED);
+    }
+    if (lane == 0 && total) atomicAdd(&mk.counters[AGH_C_CAND], total);
 }
 
 template <typename WT, int H, int MODE, int NCH>

@@ -4,6 +4,7 @@ corpus, plus ragged sizes for the tail path.  usage: scripts/ab_fused.py [total 
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
+os.environ["AGH_FUSED_MIN_MB"] = "0"      # compare the two forms at every size (the default picks by size)
 import torch
 import agrep_amd as A
 import bench as B
@@ -31,7 +32,7 @@ for k in (2, 0):
         os.environ["AGH_FUSED"] = f[0]
         os.environ.pop("AGH_FUSED_BLOCKS", None)
         if len(f) > 1: os.environ["AGH_FUSED_BLOCKS"] = str(256 * int(f[1]))   # workgroups per CU
-        for timed in (False,):
+        for timed in (False, True):
             fl = A.COUNT | (A.TIME_SWEEP if timed else 0)
             for _ in range(2):
                 r = q.scan_device(t.data_ptr(), n, flags=fl, time_sweep=False, time_scan=False)

@@ -811,3 +811,11 @@ def test_fused_count_on_candidate_dense_text(agh, k):
     if k <= 2:                                  # (k = 3 at m = 16 is the piece engine)
         assert r1.n_candidates == r2.n_candidates
         assert r1.fused_segments == 1 and r2.fused_segments == 0
+        # the default policy keeps texts of this size on the two-kernel form
+        saved = os.environ.pop("AGH_FUSED_MIN_MB")
+        try:
+            with agh.Query(pat, k) as q:
+                r3 = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+        finally:
+            os.environ["AGH_FUSED_MIN_MB"] = saved
+        assert r3.fused_segments == 0 and r3.n_matched == r1.n_matched
