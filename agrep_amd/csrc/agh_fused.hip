@@ -10,6 +10,11 @@
 // 11.0-11.3 ms for the two kernels, 10.6-10.8 ms fused; with the verifier switched off the kernel
 // takes 10.1-10.4 ms, so about two thirds of the verifier's cost stay visible -- its ~4 % of extra,
 // random HBM traffic is not free next to a stream that already runs at the HBM ceiling.
+// Tried on top and dropped (slower or equal, scripts/ab_fused.py): static range assignment (-6 ... -10 %:
+// the waves' speeds differ, the ticket counter is what balances them); tickets below 128 KiB (the
+// counter saturates near 70 requests/us: 64 KiB tickets 14.7 ms, 32 KiB 25 ms); streaming across
+// range boundaries with the ticket read deferred behind the stream (+1 %: the boundary bubble is
+// not what costs); 1, 3 or 4 verifying waves and three workgroups per CU (all within 0.1 %).
 // Two things mattered on the way (kept in mind for any kernel built like this one):
 //   * the work counter needs a cache line of its own: on the scan counters' line the sweepers'
 //     ticket atomics queued behind the verifiers' stores and the kernel took 14 ms;
