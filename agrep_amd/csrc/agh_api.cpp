@@ -1348,8 +1348,8 @@ static uint64_t env_mb(const char *name, uint64_t dflt_mb)
 // CUs of the current device (the fused lean kernel launches persistent workgroups)
 static uint32_t device_cus()
 {
-    static int cached_dev = -1;
-    static uint32_t cached = 0;
+    static thread_local int cached_dev = -1;     // (agrep-hip --gpus N: one host thread per device)
+    static thread_local uint32_t cached = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256u;
     if (dev != cached_dev) {
