@@ -1433,8 +1433,13 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     }
     // work counters of the fused kernel: a line of their own each -- on the counters' line the
     // sweepers' ticket atomics would queue behind the verifier's ANYHIT stores
-    if (q->tickets.ensure((size_t)nseg * 256u)) return -1;
-    HIP_TRY(hipMemsetAsync(q->tickets.p, 0, (size_t)nseg * 256u, st));
+    const uint64_t fused_min = env_mb("AGH_FUSED_MIN_MB", AGH_FUSED_MIN_MB_DEFAULT) << 20;
+    const bool may_fuse = !early && !overlap && !part_bytes && fused_enabled() && max_n >= fused_min &&
+                          tight_verify_enabled() && q->d_gtab;
+    if (may_fuse) {
+        if (q->tickets.ensure((size_t)nseg * 256u)) return -1;
+        HIP_TRY(hipMemsetAsync(q->tickets.p, 0, (size_t)nseg * 256u, st));
+    }
     hipStream_t aux = st;
     if (overlap) {
         if (!q->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&q->aux_stream, hipStreamNonBlocking));
@@ -1516,8 +1521,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         // one kernel for sweep + verify where the query's shape has a fused instance; the partial
         // last strip (n % 1024 bytes) still goes through k_sweep_tail + k_verify
         bool fused = false;
-        if (!early && !overlap && !part_bytes && va.gtab && fused_enabled() &&
-            n >= (env_mb("AGH_FUSED_MIN_MB", AGH_FUSED_MIN_MB_DEFAULT) << 20)) {
+        if (may_fuse && n >= fused_min) {
             agh_fused_args fa;
             fa.text = text;
             fa.n = n;
