@@ -3,6 +3,7 @@ against the oracle.  usage: stress_parity.py [seconds] [seed]"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
+os.environ["AGH_FUSED_MIN_MB"] = "0"          # count-only scans: the fused kernel at every size ...
 import numpy as np
 import agrep_amd as A
 import _oracle as O
@@ -114,7 +115,9 @@ while time.time() < t_end:
                 q.set_costs(*costs)
             got = {}
             for lab, fl, cap in (("default", 0, 300000), ("fullscan", A.FORCE_FULLSCAN, 300000),
-                                 ("lean", A.COUNT, 0), ("numbered", A.COUNT | A.FORCE_NUMBERED, 0)):
+                                 ("lean", A.COUNT, 0), ("lean, two kernels", A.COUNT, 0),
+                                 ("numbered", A.COUNT | A.FORCE_NUMBERED, 0)):
+                os.environ["AGH_FUSED"] = "0" if lab == "lean, two kernels" else "1"   # ... and its two-kernel form
                 res, ms = q.scan_buffer(text, flags=fl, cap=cap)
                 full_list = cap and want[0] <= cap          # else the device list is a truncated subset
                 got[lab] = (res.n_matched, [(s, e) for s, e, _ in ms]) if full_list else (res.n_matched, want[1])
