@@ -47,8 +47,8 @@
 // Verifying waves per workgroup.  Four workgroups of 4 + NV waves must fit a CU: with NV = 2 that is
 // 6 waves per SIMD (<= 80 VGPRs, <= 128 SGPRs; the kernels use 53-67 / ~106).  Measured on the
 // 64 GiB bench corpus, NV = 1, 2, 3, 4 and three or four workgroups per CU are all within 0.1 %
-// (scripts/ab_fused.py, profiles/r02_ab_fused.log): the kernel sits at the HBM ceiling either way;
-// two keeps headroom for candidate-dense text without giving up sweeping waves.
+// (a build-time A/B hook, since removed): the kernel sits at the HBM ceiling either way; two keeps
+// headroom for candidate-dense text without giving up sweeping waves.
 #define AGH_FU_NV 2
 #define AGH_FU_CHUNKS 4u                 // LDS ring: 4 chunks of 64 candidates (2 KiB)
 // Waits poll LDS every ~0.5 us (s_sleep 16).  The longest legitimate wait is the kernel's own run
