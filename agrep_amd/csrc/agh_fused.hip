@@ -11,10 +11,17 @@
 // takes 10.1-10.4 ms, so about two thirds of the verifier's cost stay visible -- its ~4 % of extra,
 // random HBM traffic is not free next to a stream that already runs at the HBM ceiling.
 // Tried on top and dropped (slower or equal, scripts/ab_fused.py): static range assignment (-6 ... -10 %:
-// the waves' speeds differ, the ticket counter is what balances them); tickets below 128 KiB (the
-// counter saturates near 70 requests/us: 64 KiB tickets 14.7 ms, 32 KiB 25 ms); streaming across
-// range boundaries with the ticket read deferred behind the stream (+1 %: the boundary bubble is
-// not what costs); 1, 3 or 4 verifying waves and three workgroups per CU (all within 0.1 %).
+// under saturation the workgroups of XCDs 0, 1, 6, 7 stream a range in ~88 us and those of XCDs
+// 2-5 in 130-170 us (scripts/fused_trace.py; inside a workgroup the four waves differ by 2 us) --
+// the ticket counter is what balances them); other ticket sizes (AGH_FUSED_RANGE_KB: 96 KiB -8 %,
+// 128 KiB 0 ... -2 %, 512 KiB -1 ... -3 %, 1024 KiB +0.5 % at 64 GiB and -5 % at 16 GiB; 64 KiB and
+// below saturate the counter near 70 requests/us: 14.7 ms); streaming across range boundaries with
+// the ticket read deferred behind the stream (+1 %: the boundary bubble is not what costs); 1, 3 or
+// 4 verifying waves (within 0.1 %).  Only three of the four workgroups launched per CU are resident
+// (the trace shows a quarter of them starting when the first ones leave): 4 x 38 KiB of LDS do not
+// fit next to whatever the CU keeps for itself, k_sweep's 4 x 35 KiB do; the late workgroups find
+// no tickets left and exit.  A 36 KiB layout (or a bit table instead of the byte table: 4 KiB)
+// would put 16 instead of 12 sweeping waves on a CU -- not tried yet.
 // Two things mattered on the way (kept in mind for any kernel built like this one):
 //   * the work counter needs a cache line of its own: on the scan counters' line the sweepers'
 //     ticket atomics queued behind the verifiers' stores and the kernel took 14 ms;
@@ -51,10 +58,20 @@
 // headroom for candidate-dense text without giving up sweeping waves.
 #define AGH_FU_NV 2
 #define AGH_FU_CHUNKS 4u                 // LDS ring: 4 chunks of 64 candidates (2 KiB)
+// a wave's private queue: handed over at 64, one emit round adds at most 16 (one lane's hit bits)
+#define AGH_FU_CQ_LEN 80u
 // Waits poll LDS every ~0.5 us (s_sleep 16).  The longest legitimate wait is the kernel's own run
 // time (a verifier whose sweepers find nothing): tens of ms.  After ~4 s a wait gives up and
 // raises AGH_C_LEAN_FALLBACK, which makes the host redo the segment with the numbered pipeline.
 #define AGH_FU_SPIN_LIMIT (1u << 23)
+
+#ifdef AGH_FU_TRACE
+// diagnostics build (make EXP=1): when each wave stopped sweeping / left the kernel, in 100 MHz ticks
+__device__ uint64_t g_fu_trace[4 * 8192];
+#define AGH_FU_STAMP(slot) do { if (lane == 0) g_fu_trace[(slot) * 8192 + (blockIdx.x * 8u + wib) % 8192u] = wall_clock64(); } while (0)
+#else
+#define AGH_FU_STAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint32_t lds_peek(const uint32_t *p)
 {
@@ -66,11 +83,11 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
     const uint4 *__restrict__ text, uint64_t n, uint64_t n_full_strips, agh_dev_query q,
     const uint8_t *__restrict__ ftab_g, const WT *__restrict__ mask_g, agh_marks mk,
     const uint64_t *__restrict__ gtab, uint32_t tspan, uint32_t n_ranges,
-    uint32_t *__restrict__ work)
+    uint32_t *__restrict__ work, uint32_t range_strips)
 {
     static_assert((MODE & 4) && !(MODE & 8), "lean sweeps with one-byte delimiters only");
         __shared__ __attribute__((aligned(16))) uint8_t ftab[AGH_FT_SIZE];
-    __shared__ uint64_t cq_all[4 * AGH_CQ_LEN];
+    __shared__ uint64_t cq_all[4 * AGH_FU_CQ_LEN];
     __shared__ uint64_t ring[AGH_FU_CHUNKS * 64];
     __shared__ WT lmask[256];
     __shared__ uint32_t ring_ready[AGH_FU_CHUNKS];   // ticket + 1 of the chunk that is published
@@ -96,6 +113,7 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
     __syncthreads();
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    AGH_FU_STAMP(0);
 
     if (wib < 4) {
         // ---------------------------------------------------------------- a sweeping wave
@@ -104,7 +122,7 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
         agh_dev_query qs;
         qs.qmask = q.qmask;
         qs.fold = q.fold;
-        uint64_t *cq = cq_all + wib * AGH_CQ_LEN;
+        uint64_t *cq = cq_all + wib * AGH_FU_CQ_LEN;
         uint32_t qn = 0;
         // hand the first `take` queued candidates to the verifier, keep the rest
         auto hand_over = [&](uint32_t take) {
@@ -148,11 +166,13 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
         // moment would wait ~45 us for the last answer); the counter hands out the rest
         const uint32_t first_dynamic = gridDim.x * 4u;
         uint32_t r = blockIdx.x * 4u + wib;
+        uint32_t n_done = 0;
         while (r < n_ranges) {
+            ++n_done;
             uint32_t r_next = 0;
             bool have_next = false;                 // (lane 0's view)
-            const uint64_t s0 = (uint64_t)r * AGH_WAVE_STRIPS;
-            uint64_t s1 = s0 + AGH_WAVE_STRIPS;
+            const uint64_t s0 = (uint64_t)r * range_strips;
+            uint64_t s1 = s0 + range_strips;
             if (s1 > n_full_strips) s1 = n_full_strips;
             uint64_t s = s0;
             if (s + 4 <= s1) {
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
                     const uint4 *pn = text + (s + 4) * 64 + lane;
                     uint4 n0 = ld_stream(pn), n1 = ld_stream(pn + 64), n2 = ld_stream(pn + 128), n3 = ld_stream(pn + 192);
                     // the next range's ticket is requested mid-range: in flight behind the stream
-                    if (s == s0 + AGH_WAVE_STRIPS / 2 && lane == 0) { r_next = first_dynamic + atomicAdd(work, 1u); have_next = true; }
+                    if (s == s0 + range_strips / 2 && lane == 0) { r_next = first_dynamic + atomicAdd(work, 1u); have_next = true; }
                     supertile(c0, c1, c2, c3, s);
                     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
                 }
@@ -179,6 +199,10 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
             if (!have_next && lane == 0) r_next = first_dynamic + atomicAdd(work, 1u);   // (short last range)
             r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_next);
         }
+        AGH_FU_STAMP(1);
+#ifdef AGH_FU_TRACE
+        if (lane == 0) g_fu_trace[3 * 8192 + (blockIdx.x * 8u + wib) % 8192u] = n_done;
+#endif
         while (qn) hand_over(qn < 64u ? qn : 64u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) atomicAdd(&done, 1u);
@@ -227,6 +251,7 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
         if (lane == 0) __atomic_store_n(&ring_freed[slot], v + 1u, __ATOMIC_RELAXED);
     }
     if (lane == 0 && total) atomicAdd(&mk.counters[AGH_C_CAND], total);
+    AGH_FU_STAMP(2);
 }
 
 template <typename WT, int H, int MODE, int NCH>
@@ -235,7 +260,11 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     constexpr int K = AGH_FU_K;
     constexpr int NV = AGH_FU_NV;
     const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
-    const uint32_t n_ranges = (uint32_t)((n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS);
+    // KiB per ticket (a multiple of 8: the ticket for the next range is requested half-way)
+    uint32_t range_strips = AGH_WAVE_STRIPS;
+    if (const char *e = getenv("AGH_FUSED_RANGE_KB")) range_strips = ((uint32_t)strtoul(e, nullptr, 10) + 7u) & ~7u;
+    if (range_strips < 16u) range_strips = 16u;
+    const uint32_t n_ranges = (uint32_t)((n_full + range_strips - 1) / range_strips);
     if (!n_ranges) return;
     // persistent workgroups: four per CU (LDS), fewer when the text has fewer ranges
     uint32_t blocks = a.n_cu * 4u;
@@ -244,7 +273,7 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     if (const char *e = getenv("AGH_FUSED_BLOCKS")) blocks = (uint32_t)strtoul(e, nullptr, 10);   // (A/B runs)
     hipLaunchKernelGGL((k_sweep_fused<WT, H, MODE, K, NCH, NV>), dim3(blocks), dim3(256 + 64 * NV), 0,
                        st, (const uint4 *)a.text, a.n, n_full, a.q, a.ftab, (const WT *)a.mask,
-                       a.mk, a.gtab, tspan, n_ranges, a.ticket);
+                       a.mk, a.gtab, tspan, n_ranges, a.ticket, range_strips);
 }
 
 template <typename WT, int H, int NCH>
@@ -288,6 +317,13 @@ bool AGH_FU_CAT(agh_launch_sweep_fused_k, AGH_FU_K)(const agh_fused_args &a, int
     }
     return true;
 }
+
+#if defined(AGH_FU_TRACE) && AGH_FU_K == 2
+extern "C" int agh_debug_fused_trace(uint64_t *out)      // 4 x 8192 stamps of the last k = 2 launch
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fu_trace), sizeof(uint64_t) * 4 * 8192) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #if AGH_FU_K == 0
 bool agh_launch_sweep_fused_k1(const agh_fused_args &a, int H, hipStream_t st);

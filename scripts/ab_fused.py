@@ -16,7 +16,7 @@ t = torch.empty(n, dtype=torch.uint8, device='cuda')
 planted = A.corpus_fill_device(t.data_ptr(), n // 4096, seed=B.SEED, variants=B.VARIANTS, plant_period=500)
 torch.cuda.synchronize()
 print("corpus %.0f GiB, planted %s" % (gib, planted), flush=True)
-modes = os.environ.get("AGH_AB_MODES", "0,1,0,1").split(",")   # fused flag [+ workgroups per CU]
+modes = os.environ.get("AGH_AB_MODES", "0,1,0,1").split(",")   # fused flag [+ KiB per ticket]
 for k in (2, 0):
     q = A.Query(B.PATTERN, k)
     # ragged sizes first: both pipelines must agree byte for byte on the count
@@ -30,8 +30,8 @@ for k in (2, 0):
         print("k=%d n=%d  two-kernel %s  fused %s  %s" % (k, nn, got[0], got[1], "OK" if got[0][0] == got[1][0] else "MISMATCH"), flush=True)
     for f in modes:
         os.environ["AGH_FUSED"] = f[0]
-        os.environ.pop("AGH_FUSED_BLOCKS", None)
-        if len(f) > 1: os.environ["AGH_FUSED_BLOCKS"] = str(256 * int(f[1]))   # workgroups per CU
+        os.environ.pop("AGH_FUSED_RANGE_KB", None)
+        if len(f) > 1: os.environ["AGH_FUSED_RANGE_KB"] = f[1:]          # KiB per ticket
         for timed in (False, True):
             fl = A.COUNT | (A.TIME_SWEEP if timed else 0)
             for _ in range(2):
