@@ -303,8 +303,9 @@ static int upload_tables(agh_query *q)
         std::vector<char> used(AGH_FT_SIZE, 0);
         for (int i = q->run_a; i + q->fq <= run_end; ++i)
             for_each_gram(q, i, fold, [&](uint32_t s) {
-                const uint32_t h = q->fq == 4 ? agh_sample_hash_q4(s) : agh_sample_hash_q3(s);
-                tab[h] = 1;
+                const uint32_t pr = q->fq == 4 ? agh_sample_prod_q4(s) : agh_sample_prod_q3(s);
+                const uint32_t h = q->fq == 4 ? AGH_Q4_SLOT(pr) : AGH_Q3_SLOT(pr);
+                tab[h] |= (uint8_t)(1u << (q->fq == 4 ? AGH_Q4_BIT(pr) : AGH_Q3_BIT(pr)));   // 8 bits per slot
                 if (!used[h]) {
                     used[h] = 1;
                     gt[h] = (uint64_t)s | ((uint64_t)i << 32) | ((uint64_t)i << 40);

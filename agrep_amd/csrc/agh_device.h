@@ -85,12 +85,21 @@ struct agh_dev_query {
 #else
 #define AGH_HD static inline
 #endif
+// The filter table holds 2^18 BITS in 2^15 bytes: the byte a sample selects (its 15-bit slot, which
+// is also its slot in the gram table) and the bit inside it come from one 32-bit product.  Eight
+// times fewer chance hits than one flag per byte at the same LDS size, for two more VALU operations
+// per probe (v_bfe for the bit number, v_bfe to take the bit).
 // q == 4: the sample has 32 significant bits, fold the top byte down first.
-AGH_HD uint32_t agh_sample_hash_q4(uint32_t s)
+AGH_HD uint32_t agh_sample_prod_q4(uint32_t s)
 {
     uint32_t t = (s ^ (s >> 11)) & 0xffffffu;
-    uint32_t p = t * 0x9E3779u;              // 24 x 24 -> low 32 bits (v_mul_u32_u24)
-    return (p >> 14) & (AGH_FT_SIZE - 1u);
+    return t * 0x9E3779u;                    // 24 x 24 -> low 32 bits (v_mul_u32_u24)
+}
+#define AGH_Q4_SLOT(p) (((p) >> 14) & (AGH_FT_SIZE - 1u))
+#define AGH_Q4_BIT(p) (((p) >> 11) & 7u)
+AGH_HD uint32_t agh_sample_hash_q4(uint32_t s)
+{
+    return AGH_Q4_SLOT(agh_sample_prod_q4(s));
 }
 // 18-bit variant for the multi-pattern bit table, probed at EVERY text position (16 probes per
 // 16 bytes), so every instruction counts: one shift + one v_mad_u32_u24 (the 24-bit multiply
@@ -132,8 +141,13 @@ AGH_HD uint32_t agh_mp_bucket(uint32_t s)
     return (x ^ (x >> 15)) >> (32 - AGH_MP_BUCKET_BITS);
 }
 // q <= 3: the sample already fits 24 bits.
+AGH_HD uint32_t agh_sample_prod_q3(uint32_t s)
+{
+    return (s & 0xffffffu) * 0x85EBCAu;
+}
+#define AGH_Q3_SLOT(p) (((p) >> 13) & (AGH_FT_SIZE - 1u))
+#define AGH_Q3_BIT(p) (((p) >> 10) & 7u)
 AGH_HD uint32_t agh_sample_hash_q3(uint32_t s)
 {
-    uint32_t p = (s & 0xffffffu) * 0x85EBCAu;
-    return (p >> 13) & (AGH_FT_SIZE - 1u);
+    return AGH_Q3_SLOT(agh_sample_prod_q3(s));
 }

@@ -20,8 +20,8 @@
 // 4 verifying waves (within 0.1 %).  Only three of the four workgroups launched per CU are resident
 // (the trace shows a quarter of them starting when the first ones leave): 4 x 38 KiB of LDS do not
 // fit next to whatever the CU keeps for itself, k_sweep's 4 x 35 KiB do; the late workgroups find
-// no tickets left and exit.  A 36 KiB layout (or a bit table instead of the byte table: 4 KiB)
-// would put 16 instead of 12 sweeping waves on a CU -- not tried yet.
+// no tickets left and exit.  A 36 KiB layout (e.g. 2^17 filter bits) would put 16 instead of 12
+// sweeping waves on a CU -- not tried yet.
 // Two things mattered on the way (kept in mind for any kernel built like this one):
 //   * the work counter needs a cache line of its own: on the scan counters' line the sweepers'
 //     ticket atomics queued behind the verifiers' stores and the kernel took 14 ms;

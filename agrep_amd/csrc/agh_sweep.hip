@@ -6,7 +6,7 @@
 //   k_sweep<H>      streams every text byte once (non-temporal 16 B/lane coalesced loads).  Per
 //                   1 KiB strip it counts the record delimiters (SWAR zero-byte test + v_bcnt;
 //                   skipped by lean = count-only scans) and probes one q-byte sample every H
-//                   bytes against a 32 KiB byte table in LDS; samples that hit go through a
+//                   bytes against a 2^18-bit table (32 KiB) in LDS; samples that hit go through a
 //                   per-wave LDS queue into the wave's private slice of the candidate buffer
 //                   (no atomics).  This is the kernel the roofline is quoted on.
 //   k_scan_local /  exclusive scan of the per-wave delimiter totals (numbered scans).

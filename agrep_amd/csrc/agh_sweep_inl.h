@@ -17,10 +17,12 @@ __device__ __forceinline__ uint32_t probe(uint32_t w, const agh_dev_query &q,
 {
     if (MODE & 2) {
         const uint32_t s = (MODE & 1) ? (w | q.fold) : w;
-        return ftab[agh_sample_hash_q4(s)];
+        const uint32_t p = agh_sample_prod_q4(s);
+        return ((uint32_t)ftab[AGH_Q4_SLOT(p)] >> AGH_Q4_BIT(p)) & 1u;
     } else {
         const uint32_t s = (MODE & 1) ? ((w & q.qmask) | q.fold) : (w & q.qmask);
-        return ftab[agh_sample_hash_q3(s)];
+        const uint32_t p = agh_sample_prod_q3(s);
+        return ((uint32_t)ftab[AGH_Q3_SLOT(p)] >> AGH_Q3_BIT(p)) & 1u;
     }
 }
 
