@@ -42,7 +42,8 @@ static int fail(const char *fmt, ...)
     } while (0)
 
 extern "C" const char *agh_last_error(void) { return g_err; }
-extern "C" void agh_set_error(const char *msg)      // agh_comm.cpp reports through the same text
+// (internal: agh_comm.cpp reports through the same text; not part of the ABI, hence hidden)
+extern "C" __attribute__((visibility("hidden"))) void agh_set_error(const char *msg)
 {
     snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
 }

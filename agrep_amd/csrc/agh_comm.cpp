@@ -19,7 +19,7 @@
 
 #include "../../include/agrep_hip.h"
 
-extern "C" void agh_set_error(const char *msg);     // agh_api.cpp: agh_last_error() text
+extern "C" __attribute__((visibility("hidden"))) void agh_set_error(const char *msg);   // agh_api.cpp: agh_last_error() text
 
 static int cfail(const char *fmt, ...)
 {

@@ -23,6 +23,21 @@ def test_header_symbols_are_exported():
         assert hasattr(lib, n), "libagrep_hip.so does not export %s" % n
 
 
+def test_product_library_is_not_the_diagnostics_build():
+    """`make EXP=1` (A/B variants of the sweep, trace stamps in the fused kernel) builds into its own
+    object directory; the library that ships must not carry its entry points, and nothing the header
+    does not declare may start with agh_ ."""
+    import subprocess
+    import agrep_amd
+    path = agrep_amd._ffi.LIB_PATH
+    out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("agh_")})
+    assert "agh_probe_variant_ms" not in exported and "agh_debug_fused_trace" not in exported, \
+        "libagrep_hip.so was built with EXP=1: run `make -C agrep_amd/csrc` again"
+    extra = [n for n in exported if n not in _declared()]
+    assert extra == [], "exported but not declared in include/agrep_hip.h: %s" % extra
+
+
 def test_no_silent_fallback_without_gpu():
     """Product path must fail loudly when no HIP device is usable."""
     import agrep_amd
