@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libagrep_hip.so")
+# AGH_LIB_PATH: a variant build for A/B runs (e.g. make -C agrep_amd/csrc FT_BITS=14)
+LIB_PATH = os.environ.get("AGH_LIB_PATH") or os.path.join(_HERE, "libagrep_hip.so")
 
 COUNT = 0x01
 FILENAMEONLY = 0x02

@@ -19,7 +19,9 @@
 // scan falls back to the numbered (census) mode.
 #define AGH_LEAN_BACK_CAP (64u * 1024u)
 // q-gram filter table: one byte per hash bucket, resident in LDS (32 KiB / workgroup).
-#define AGH_FT_BITS 15
+#ifndef AGH_FT_BITS
+#define AGH_FT_BITS 15         // filter table: 2^15 bytes = 2^18 bits (make FT_BITS=14 builds a 16 KiB variant for A/B)
+#endif
 #define AGH_FT_SIZE (1u << AGH_FT_BITS)
 // Full-scan kernel: bytes per lane chunk (= one census strip), bytes per lane per refill of the
 // per-wave LDS ring, the ring's row stride (+16 B keeps the b128 reads conflict-free), lanes per
