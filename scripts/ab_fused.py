@@ -1,6 +1,7 @@
 """A/B of the count-only pipeline inside one process (same box, same corpus): AGH_FUSED=0 (k_sweep, then
 k_verify) against AGH_FUSED=1 (sweep + verify in one kernel, agh_fused.hip), k = 2 and 0 on the bench
-corpus, plus ragged sizes for the tail path.  usage: scripts/ab_fused.py [total GiB, default 64] [steps]"""
+corpus, plus ragged sizes for the tail path.  usage: scripts/ab_fused.py [total GiB, default 64] [steps]
+AGH_LIB_PATH=<variant .so> runs the same against another build (e.g. make -C agrep_amd/csrc FT_BITS=14)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
