@@ -107,6 +107,7 @@ struct agh_query {
     dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, hashset, dbm, staging, match_pos,
         match_rec, match_start, match_end, match_off, gather;
     uint64_t staged_len = 0;            // bytes of the text currently held in `staging`
+    bool staged_first = true, staged_last = true;   // ... is the head / the tail of its file (agh_scan_fd_range)
     hipStream_t stage_stream = nullptr; // H2D copies of agh_scan_fd
     unsigned char *pinned[2] = {nullptr, nullptr};
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
@@ -181,6 +182,9 @@ static std::vector<uint8_t> folded_members(const std::vector<uint8_t> &v, bool f
     return out;
 }
 
+#ifndef AGH_SHAPE_H2_DEFAULT
+#define AGH_SHAPE_H2_DEFAULT 0  // (A/B pending: scripts/ab_fused.py)
+#endif
 #define AGH_CLASS_MAX 40        // largest class a sampled position may have ([a-z], [0-9a-z] ...)
 #define AGH_GRAMS_MAX 2048      // expanded q-grams of one query (32 Ki table slots: <= 6 % full)
 
@@ -256,6 +260,36 @@ static void choose_filter(agh_query *q)
                 if (better) { best_h = h; best_q = qmax; best_a = a; best_len = len; best_grams = grams; }
                 break;                          // smaller strides of the same run are never better
             }
+        }
+    }
+    // H = 2: 4-byte samples at every even offset.  They overlap, so one error can spoil two of
+    // them: lossless iff floor((len - k - 4 + 1) / 2) >= 2k + 1.  (m, k) = (16, 2) gets q = 4 this way
+    // instead of q = 3 every 4 bytes: twice the probes, but the chance occurrences of the pattern's
+    // grams in the text -- two thirds of all candidates on the bench corpus -- become 27 x rarer.
+    // AGH_SHAPE_H2: 0 never, 1 (default) where the best other shape samples 3 bytes or none applies.
+    {
+        const char *e = getenv("AGH_SHAPE_H2");
+        const int h2_mode = e && *e ? atoi(e) : AGH_SHAPE_H2_DEFAULT;
+        if (h2_mode > 0 && best_q < 4) {
+            int h2_a = -1, h2_len = 0;
+            double h2_grams = 0;
+            for (int a = 0; a < q->m; ++a)
+                for (int len = 4; a + len <= q->m; ++len) {
+                    bool ok = true;
+                    for (int p = a; p < a + len && ok; ++p) ok = width[(size_t)p] >= 1 && width[(size_t)p] <= AGH_CLASS_MAX;
+                    if (!ok) break;
+                    if ((len - q->k - 3) / 2 < 2 * q->k + 1) continue;
+                    double grams = 0;
+                    for (int g = a; g + 4 <= a + len; ++g) {
+                        double prod = 1;
+                        for (int t = 0; t < 4; ++t) prod *= (double)width[(size_t)(g + t)];
+                        grams += prod;
+                    }
+                    if (grams > AGH_GRAMS_MAX) continue;
+                    if (h2_a < 0 || grams < h2_grams) { h2_a = a; h2_len = len; h2_grams = grams; }
+                    break;                      // longer runs from the same start only add grams
+                }
+            if (h2_a >= 0) { best_h = 2; best_q = 4; best_a = h2_a; best_len = h2_len; }
         }
     }
     if (!best_h) return;
@@ -907,6 +941,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const uint64_t nw = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
     if (multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
     if (n > ((uint64_t)16 << 30) - 4096) return fail("segments are limited to 16 GiB");
+    if (q->fh == 2 && !multi && n > ((uint64_t)8 << 30) - 4096) return fail("segments of this query are limited to 8 GiB");
     if (multi && (flags & AGH_FORCE_FULLSCAN))
         return fail("multi-pattern queries have no full-scan engine");
     const bool want_filter = (q->fq > 0 || pe) && !(flags & AGH_FORCE_FULLSCAN) && !q->table && !invert_list &&
@@ -1282,7 +1317,9 @@ static uint64_t seg_nominal(const agh_query *q)
         uint64_t mb = strtoull(e, nullptr, 10);
         if (mb >= 1 && mb <= 8192) return mb << 20;
     }
-    return (q->multi || q->piece_single) ? ((uint64_t)2 << 30) : AGH_SEG_MAX_DEFAULT;
+    if (q->multi || q->piece_single) return (uint64_t)2 << 30;
+    // H == 2 candidates are 32-bit HALFWORD indices in numbered scans: 8 GiB reach, 4 GiB nominal
+    return q->fh == 2 ? ((uint64_t)4 << 30) : AGH_SEG_MAX_DEFAULT;
 }
 
 static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, hipStream_t st,
@@ -1774,7 +1811,7 @@ static int collect_matches(agh_query *q, uint64_t len, const agh_result *res, ag
 }
 
 static int scan_staged(agh_query *q, uint64_t len, unsigned flags, agh_result *res,
-                       agh_match *matches, size_t cap)
+                       agh_match *matches, size_t cap, bool is_first = true, bool is_last = true)
 {
     uint64_t *d_pos = nullptr;
     uint32_t *d_rec = nullptr;
@@ -1785,7 +1822,9 @@ static int scan_staged(agh_query *q, uint64_t len, unsigned flags, agh_result *r
         d_rec = (uint32_t *)q->match_rec.p;
     }
     q->staged_len = len;
-    if (scan_device_impl(q, q->staging.p, len, nullptr, flags, res, d_pos, d_rec, cap, true, true)) return -1;
+    q->staged_first = is_first;                 // (agh_rescan_staged scans the same shard again)
+    q->staged_last = is_last;
+    if (scan_device_impl(q, q->staging.p, len, nullptr, flags, res, d_pos, d_rec, cap, is_first, is_last)) return -1;
     return d_pos ? collect_matches(q, len, res, matches) : 0;
 }
 
@@ -1918,7 +1957,8 @@ static int scan_device_range(agh_query *q, const void *dev_text, uint64_t len, h
 // is bounded whatever the input size, a pipe never needs a second copy, and -l stops READING at
 // the first segment with a match (asearch.c:130-161: print the name, return).  The scan of a
 // segment (~0.2 ms per GiB) is not overlapped with the staging (~20 ms per GiB over PCIe).
-static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *res)
+static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *res, bool is_first,
+                       bool is_last)
 {
     memset(res, 0, sizeof(*res));
     const uint64_t seg_cap = std::max<uint64_t>(env_mb("AGH_STREAM_SEG_MB", 1024), 1) << 20;
@@ -1931,7 +1971,9 @@ static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *
         return -1;
     q->staged_len = 0;                          // what stays in HBM is not the whole input
     uint64_t used = 0;                          // bytes of the current segment staged so far
-    bool first = true, eof = false;
+    // a shard with begin > 0 follows a delimiter (not the virtual '\n' in front of a file) and one
+    // that ends before EOF gets no delimiter appended: both only at the real ends of the file
+    bool first = is_first, eof = false;
     int b = 0;
     bool busy[2] = {false, false};
     const unsigned char dl = q->delim[0];
@@ -1975,7 +2017,7 @@ static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *
         HIP_TRY(hipStreamSynchronize(q->stage_stream));
         if (cut) {
             agh_result r;
-            if (scan_device_range(q, q->staging.p, cut, nullptr, flags, &r, first, eof)) return -1;
+            if (scan_device_range(q, q->staging.p, cut, nullptr, flags, &r, first, eof && is_last)) return -1;
             res->n_matched += r.n_matched;
             res->n_records += r.n_records;
             res->n_candidates += r.n_candidates;
@@ -2013,8 +2055,16 @@ static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, u
     fd_reader rd;
     if (rd.open_fd(fd, with_range, begin, end)) return -1;
     const bool count_only = (flags & (AGH_COUNT | AGH_FILENAMEONLY)) && !(matches && cap);
+    // one rank's shard of a file: the virtual head byte / the appended delimiter (asearch.c:69-91)
+    // belong to the shards that hold the file's first / last byte
+    bool is_first = true, is_last = true;
+    if (with_range) {
+        struct stat sb;
+        is_first = begin == 0;
+        is_last = !(fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && end < (uint64_t)sb.st_size);
+    }
     if (count_only && !q_mb(q) && env_mb("AGH_STREAM", 1) != 0)
-        return stream_scan(q, rd, flags, res);
+        return stream_scan(q, rd, flags, res, is_first, is_last);
 
     // records wanted: the whole input is staged, then scanned (agh_fetch_records gathers from it)
     size_t want = rd.regular ? (size_t)rd.left + 64 : AGH_STAGE_CHUNK * 2;
@@ -2045,7 +2095,7 @@ static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, u
         b ^= 1;
     }
     HIP_TRY(hipStreamSynchronize(q->stage_stream));
-    return scan_staged(q, used, flags, res, matches, cap);
+    return scan_staged(q, used, flags, res, matches, cap, is_first, is_last);
 }
 
 extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res,
@@ -2103,7 +2153,7 @@ extern "C" int agh_rescan_staged(agh_query *q, unsigned flags, agh_result *res,
                                  agh_match *matches, size_t cap)
 {
     if (!q || !res) return fail("null argument");
-    return scan_staged(q, q->staged_len, flags, res, matches, cap);
+    return scan_staged(q, q->staged_len, flags, res, matches, cap, q->staged_first, q->staged_last);
 }
 
 // Bytes of matched records of the most recent agh_scan_fd / agh_scan_buffer, concatenated in

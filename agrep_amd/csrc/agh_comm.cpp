@@ -244,11 +244,24 @@ static int all_reduce_many(agh_comm *const *cs, int n, void *const *host, size_t
         HIPC_TRY(hipMemcpyAsync(cs[i]->d_buf, host[i], count * elem, hipMemcpyHostToDevice, cs[i]->stream));
     }
     if (n > 1) NCCL_TRY(R.GroupStart());
-    for (int i = 0; i < n; ++i) {
-        HIPC_TRY(hipSetDevice(cs[i]->device));
-        NCCL_TRY(R.AllReduce(cs[i]->d_buf, cs[i]->d_buf, count, dt, op, cs[i]->comm, cs[i]->stream));
+    // inside the group nothing returns early: an open group would leave every later collective of
+    // this thread undefined (and agh_comm_free could hang), so the first error is kept and the group
+    // is closed before it is reported
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) {
+        const hipError_t he = hipSetDevice(cs[i]->device);
+        if (he != hipSuccess) {
+            rc = cfail("hipSetDevice(%d) failed: %s", cs[i]->device, hipGetErrorString(he));
+            break;
+        }
+        const ncclResult_t nr = R.AllReduce(cs[i]->d_buf, cs[i]->d_buf, count, dt, op, cs[i]->comm, cs[i]->stream);
+        if (nr != ncclSuccess) rc = cfail("ncclAllReduce failed on rank %d: %s", cs[i]->rank, R.GetErrorString(nr));
     }
-    if (n > 1) NCCL_TRY(R.GroupEnd());
+    if (n > 1) {
+        const ncclResult_t ge = R.GroupEnd();
+        if (ge != ncclSuccess && rc == 0) rc = cfail("ncclGroupEnd failed: %s", R.GetErrorString(ge));
+    }
+    if (rc) return rc;
     for (int i = 0; i < n; ++i) {
         HIPC_TRY(hipSetDevice(cs[i]->device));
         HIPC_TRY(hipMemcpyAsync(host[i], cs[i]->d_buf, count * elem, hipMemcpyDeviceToHost, cs[i]->stream));

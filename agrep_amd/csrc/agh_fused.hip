@@ -58,12 +58,18 @@
 // headroom for candidate-dense text without giving up sweeping waves.
 #define AGH_FU_NV 2
 #define AGH_FU_CHUNKS 4u                 // LDS ring: 4 chunks of 64 candidates (2 KiB)
-// a wave's private queue: handed over at 64, one emit round adds at most 16 (one lane's hit bits)
-#define AGH_FU_CQ_LEN 80u
+// a wave's private queue: handed over at 64, one emit round adds at most 16 (one lane's hit bits;
+// 32 with H == 2)
+#define AGH_FU_CQ_LEN 96u
 // Waits poll LDS every ~0.5 us (s_sleep 16).  The longest legitimate wait is the kernel's own run
 // time (a verifier whose sweepers find nothing): tens of ms.  After ~4 s a wait gives up and
 // raises AGH_C_LEAN_FALLBACK, which makes the host redo the segment with the numbered pipeline.
 #define AGH_FU_SPIN_LIMIT (1u << 23)
+// small tickets at the end of the text (see launch_fused): MiB of text handed out in tickets of ... KiB
+#ifndef AGH_FU_TAIL_MB_DEFAULT
+#define AGH_FU_TAIL_MB_DEFAULT 0u
+#endif
+#define AGH_FU_TAIL_KB_DEFAULT 64u
 
 #ifdef AGH_FU_TRACE
 // diagnostics build (make EXP=1): when each wave stopped sweeping / left the kernel, in 100 MHz ticks
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
     const uint4 *__restrict__ text, uint64_t n, uint64_t n_full_strips, agh_dev_query q,
     const uint8_t *__restrict__ ftab_g, const WT *__restrict__ mask_g, agh_marks mk,
     const uint64_t *__restrict__ gtab, uint32_t tspan, uint32_t n_ranges,
-    uint32_t *__restrict__ work, uint32_t range_strips)
+    uint32_t *__restrict__ work, uint32_t range_strips, uint32_t n_big, uint32_t tail_strips)
 {
     static_assert((MODE & 4) && !(MODE & 8), "lean sweeps with one-byte delimiters only");
         __shared__ __attribute__((aligned(16))) uint8_t ftab[AGH_FT_SIZE];
@@ -152,14 +158,28 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
             qn = rest;
         };
         const uint32_t rc0[4] = {0u, 0u, 0u, 0u};
-        auto supertile = [&](uint4 v0, uint4 v1, uint4 v2, uint4 v3, uint64_t s) {
+        // nx3 (H == 2): first dword of strip s+4 (the last sample of lane 63 reaches into it)
+        auto supertile = [&](uint4 v0, uint4 v1, uint4 v2, uint4 v3, uint64_t s, uint32_t nx3) {
             uint32_t a = 0, hits = 0;
-            sweep_chunk<H, MODE>(v0, 0u, qs, ftab, a, hits, 0);
-            sweep_chunk<H, MODE>(v1, 0u, qs, ftab, a, hits, 4);
-            sweep_chunk<H, MODE>(v2, 0u, qs, ftab, a, hits, 8);
-            sweep_chunk<H, MODE>(v3, 0u, qs, ftab, a, hits, 12);
+            uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+            if (H == 2) {
+                x0 = next_lane_dword(v0.x, (uint32_t)__builtin_amdgcn_readlane((int)v1.x, 0));
+                x1 = next_lane_dword(v1.x, (uint32_t)__builtin_amdgcn_readlane((int)v2.x, 0));
+                x2 = next_lane_dword(v2.x, (uint32_t)__builtin_amdgcn_readlane((int)v3.x, 0));
+                x3 = next_lane_dword(v3.x, nx3);
+            }
+            sweep_chunk<H, MODE>(v0, 0u, qs, ftab, a, hits, 0, 0u, x0);
+            sweep_chunk<H, MODE>(v1, 0u, qs, ftab, a, hits, 4, 0u, x1);
+            sweep_chunk<H, MODE>(v2, 0u, qs, ftab, a, hits, 8, 0u, x2);
+            sweep_chunk<H, MODE>(v3, 0u, qs, ftab, a, hits, 12, 0u, x3);
             if (__ballot(hits != 0))
-                emit_candidates_to(hits, s, rc0, cq, qn, [&]() { hand_over(64u); });
+                emit_candidates_to<H>(hits, s, rc0, cq, qn, [&]() { hand_over(64u); });
+        };
+        const uint64_t n_dw = ((n + 15) & ~(uint64_t)15) / 4;      // readable dwords of the text
+        auto first_dword_of = [&](uint64_t st) -> uint32_t {       // (uniform; 0 past the text)
+            if (H != 2) return 0u;
+            const uint64_t i = st * 256u;
+            return i < n_dw ? reinterpret_cast<const uint32_t *>(text)[i] : 0u;
         };
 
         // the first range is the wave's own number (4096 waves asking one counter at the same
@@ -171,9 +191,13 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
             ++n_done;
             uint32_t r_next = 0;
             bool have_next = false;                 // (lane 0's view)
-            const uint64_t s0 = (uint64_t)r * range_strips;
-            uint64_t s1 = s0 + range_strips;
+            // tickets 0 .. n_big-1 are ranges of range_strips KiB; the text behind them is handed out
+            // in smaller tickets of tail_strips KiB, so that the waves finish closer together
+            const uint64_t s0 = r < n_big ? (uint64_t)r * range_strips
+                                          : (uint64_t)n_big * range_strips + (uint64_t)(r - n_big) * tail_strips;
+            uint64_t s1 = s0 + (r < n_big ? range_strips : tail_strips);
             if (s1 > n_full_strips) s1 = n_full_strips;
+            const uint64_t s_half = s0 + (((s1 - s0) >> 1) & ~(uint64_t)3);
             uint64_t s = s0;
             if (s + 4 <= s1) {
                 const uint4 *p = text + s * 64 + lane;
@@ -182,19 +206,21 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
                     const uint4 *pn = text + (s + 4) * 64 + lane;
                     uint4 n0 = ld_stream(pn), n1 = ld_stream(pn + 64), n2 = ld_stream(pn + 128), n3 = ld_stream(pn + 192);
                     // the next range's ticket is requested mid-range: in flight behind the stream
-                    if (s == s0 + range_strips / 2 && lane == 0) { r_next = first_dynamic + atomicAdd(work, 1u); have_next = true; }
-                    supertile(c0, c1, c2, c3, s);
+                    if (s == s_half && lane == 0) { r_next = first_dynamic + atomicAdd(work, 1u); have_next = true; }
+                    supertile(c0, c1, c2, c3, s, H == 2 ? (uint32_t)__builtin_amdgcn_readlane((int)n0.x, 0) : 0u);
                     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
                 }
-                supertile(c0, c1, c2, c3, s);
+                supertile(c0, c1, c2, c3, s, first_dword_of(s + 4));
                 s += 4;
             }
             for (; s < s1; ++s) {                   // < 4 strips left in the range
                 const uint4 v0 = ld_stream(text + s * 64 + lane);
                 uint32_t a = 0, hits = 0;
-                sweep_chunk<H, MODE>(v0, 0u, qs, ftab, a, hits, 0);
+                sweep_chunk<H, MODE>(v0, 0u, qs, ftab, a, hits, 0, 0u,
+                                     H == 2 ? next_lane_dword(v0.x, first_dword_of(s + 1)) : 0u);
+                if (H == 2) hits >>= 24;
                 if (__ballot(hits != 0))
-                    emit_candidates_to(hits, s, rc0, cq, qn, [&]() { hand_over(64u); });
+                    emit_candidates_to<H>(hits, s, rc0, cq, qn, [&]() { hand_over(64u); });
             }
             if (!have_next && lane == 0) r_next = first_dynamic + atomicAdd(work, 1u);   // (short last range)
             r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_next);
@@ -260,20 +286,48 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     constexpr int K = AGH_FU_K;
     constexpr int NV = AGH_FU_NV;
     const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
-    // KiB per ticket (a multiple of 8: the ticket for the next range is requested half-way)
+    // KiB per ticket (a multiple of 8: the ticket for the next range is requested half-way); the
+    // diagnostics overrides are clamped -- a zero grid or a wrapped range size must not reach the launch
     uint32_t range_strips = AGH_WAVE_STRIPS;
-    if (const char *e = getenv("AGH_FUSED_RANGE_KB")) range_strips = ((uint32_t)strtoul(e, nullptr, 10) + 7u) & ~7u;
+    if (const char *e = getenv("AGH_FUSED_RANGE_KB")) {
+        const unsigned long v = strtoul(e, nullptr, 10);
+        range_strips = (uint32_t)((v > 65536ul ? 65536ul : v) + 7ul) & ~7u;
+    }
     if (range_strips < 16u) range_strips = 16u;
-    const uint32_t n_ranges = (uint32_t)((n_full + range_strips - 1) / range_strips);
+    // the last AGH_FUSED_TAIL_MB of the text go out in tickets of AGH_FUSED_TAIL_KB: the waves stop
+    // within a small ticket's time of each other instead of a large one's (scripts/ab_fused.py)
+    uint32_t tail_strips = AGH_FU_TAIL_KB_DEFAULT;
+    uint64_t tail_total = (uint64_t)AGH_FU_TAIL_MB_DEFAULT << 10;            // in strips (KiB)
+    if (const char *e = getenv("AGH_FUSED_TAIL_KB")) {
+        const unsigned long v = strtoul(e, nullptr, 10);
+        tail_strips = (uint32_t)((v > 65536ul ? 65536ul : v) + 7ul) & ~7u;
+    }
+    if (const char *e = getenv("AGH_FUSED_TAIL_MB")) {
+        const unsigned long v = strtoul(e, nullptr, 10);
+        tail_total = (uint64_t)(v > (1ul << 20) ? (1ul << 20) : v) << 10;
+    }
+    if (tail_strips < 8u) tail_strips = 8u;
+    if (tail_strips >= range_strips) tail_total = 0;                        // nothing smaller to hand out
+    if (tail_total > n_full / 2) tail_total = n_full / 2;                   // short texts: half of it at most
+    const uint64_t n_big64 = (n_full - tail_total) / range_strips;          // whole large tickets
+    const uint64_t rest = n_full - n_big64 * range_strips;
+    const uint64_t n_small = tail_total ? (rest + tail_strips - 1) / tail_strips
+                                        : (rest + range_strips - 1) / range_strips;
+    const uint32_t n_big = tail_total ? (uint32_t)n_big64 : (uint32_t)(n_big64 + n_small);
+    if (!tail_total) tail_strips = range_strips;
+    const uint32_t n_ranges = (uint32_t)(n_big64 + n_small);
     if (!n_ranges) return;
     // persistent workgroups: four per CU (LDS), fewer when the text has fewer ranges
     uint32_t blocks = a.n_cu * 4u;
     const uint32_t need = (n_ranges + 3u) / 4u;
     if (blocks > need) blocks = need;
-    if (const char *e = getenv("AGH_FUSED_BLOCKS")) blocks = (uint32_t)strtoul(e, nullptr, 10);   // (A/B runs)
+    if (const char *e = getenv("AGH_FUSED_BLOCKS")) {                        // (A/B runs)
+        const unsigned long v = strtoul(e, nullptr, 10);
+        blocks = (uint32_t)(v < 1ul ? 1ul : (v > (unsigned long)a.n_cu * 8ul ? (unsigned long)a.n_cu * 8ul : v));
+    }
     hipLaunchKernelGGL((k_sweep_fused<WT, H, MODE, K, NCH, NV>), dim3(blocks), dim3(256 + 64 * NV), 0,
                        st, (const uint4 *)a.text, a.n, n_full, a.q, a.ftab, (const WT *)a.mask,
-                       a.mk, a.gtab, tspan, n_ranges, a.ticket, range_strips);
+                       a.mk, a.gtab, tspan, n_ranges, a.ticket, range_strips, n_big, tail_strips);
 }
 
 template <typename WT, int H, int NCH>
@@ -291,6 +345,10 @@ template <typename WT, int NCH>
 static void launch_fused_h(const agh_fused_args &a, int H, uint32_t tspan, hipStream_t st)
 {
     switch (H) {
+    case 2:                                     // H == 2 samples have four bytes (MODE bit 1)
+        if (a.q.fold) launch_fused<WT, 2, 7, NCH>(a, tspan, st);
+        else launch_fused<WT, 2, 6, NCH>(a, tspan, st);
+        break;
     case 4: launch_fused_m<WT, 4, NCH>(a, tspan, st); break;
     case 8: launch_fused_m<WT, 8, NCH>(a, tspan, st); break;
     default: launch_fused_m<WT, 16, NCH>(a, tspan, st); break;
@@ -332,7 +390,7 @@ bool agh_launch_sweep_fused_k3(const agh_fused_args &a, int H, hipStream_t st);
 
 bool agh_launch_sweep_fused(const agh_fused_args &a, int H, hipStream_t st)
 {
-    if (a.q.mb || !a.gtab || (H != 4 && H != 8 && H != 16)) return false;
+    if (a.q.mb || !a.gtab || (H != 2 && H != 4 && H != 8 && H != 16)) return false;
     switch (a.q.k) {
     case 0: return agh_launch_sweep_fused_k0(a, H, st);
     case 1: return agh_launch_sweep_fused_k1(a, H, st);

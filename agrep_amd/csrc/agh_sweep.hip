@@ -35,17 +35,26 @@ __device__ __forceinline__ void sweep_supertile(uint4 v0, uint4 v1, uint4 v2, ui
                                                 uint32_t *__restrict__ strip_prefix,
                                                 uint64_t *cq, uint32_t &qn,
                                                 uint64_t *__restrict__ slice, uint32_t &run,
-                                                uint32_t &ncand, uint32_t *counters)
+                                                uint32_t &ncand, uint32_t *counters,
+                                                uint32_t nx3 = 0)
 {
+    // nx3 (H == 2 only): first dword of strip s+4, which the last sample of lane 63 reaches into
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, hits = 0;
-    sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0, db.x);
-    sweep_chunk<H, MODE>(v1, dd, q, ftab, a1, hits, 4, db.x >> 16);
-    sweep_chunk<H, MODE>(v2, dd, q, ftab, a2, hits, 8, db.y);
-    sweep_chunk<H, MODE>(v3, dd, q, ftab, a3, hits, 12, db.y >> 16);
+    uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+    if (H == 2) {
+        x0 = next_lane_dword(v0.x, (uint32_t)__builtin_amdgcn_readlane((int)v1.x, 0));
+        x1 = next_lane_dword(v1.x, (uint32_t)__builtin_amdgcn_readlane((int)v2.x, 0));
+        x2 = next_lane_dword(v2.x, (uint32_t)__builtin_amdgcn_readlane((int)v3.x, 0));
+        x3 = next_lane_dword(v3.x, nx3);
+    }
+    sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0, db.x, x0);
+    sweep_chunk<H, MODE>(v1, dd, q, ftab, a1, hits, 4, db.x >> 16, x1);
+    sweep_chunk<H, MODE>(v2, dd, q, ftab, a2, hits, 8, db.y, x2);
+    sweep_chunk<H, MODE>(v3, dd, q, ftab, a3, hits, 12, db.y >> 16, x3);
     if (MODE & 4) {
         if (__ballot(hits != 0)) {
             const uint32_t rc[4] = {0u, 0u, 0u, 0u};
-            emit_candidates(hits, s, rc, cq, qn, slice, ncand, counters);
+            emit_candidates<H>(hits, s, rc, cq, qn, slice, ncand, counters);
         }
         return;
     }
@@ -71,7 +80,7 @@ __device__ __forceinline__ void sweep_supertile(uint4 v0, uint4 v1, uint4 v2, ui
         rc[1] = run + z0 + lb - (ex01 >> 16);
         rc[2] = run + z0 + z1 + lb - (ex23 & 0xffffu);
         rc[3] = run + z0 + z1 + z2 + lb - (ex23 >> 16);
-        emit_candidates(hits, s, rc, cq, qn, slice, ncand, counters);
+        emit_candidates<H>(hits, s, rc, cq, qn, slice, ncand, counters);
     }
     run += z0 + z1 + z2 + z3;
 }
@@ -90,8 +99,10 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
                                                  uint64_t *__restrict__ cand,
                                                  uint32_t *__restrict__ wave_cand,
                                                  uint32_t *__restrict__ counters,
-                                                 const uint16_t *__restrict__ dbm16)
+                                                 const uint16_t *__restrict__ dbm16,
+                                                 uint64_t n_dw)
 {
+    // n_dw: readable dwords of the text (H == 2 looks one dword past a strip)
     __shared__ __attribute__((aligned(16))) uint8_t ftab[H > 0 ? AGH_FT_SIZE : 16];
     __shared__ uint64_t cq_all[H > 0 ? (BLOCK / WAVE) * AGH_CQ_LEN : 1];
     if (H > 0) {
@@ -128,6 +139,12 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
         return make_uint2((uint32_t)d[0] | ((uint32_t)d[64] << 16),
                           (uint32_t)d[128] | ((uint32_t)d[192] << 16));
     };
+    // H == 2: the dword right behind strip st-1 (uniform; 0 past the readable text)
+    auto first_dword_of = [&](uint64_t st) -> uint32_t {
+        if (H != 2) return 0u;
+        const uint64_t i = st * 256u;
+        return i < n_dw ? reinterpret_cast<const uint32_t *>(text)[i] : 0u;
+    };
     if (PREFETCH) {
         if (s + 4 <= s1) {
             const uint4 *p = text + s * 64 + lane;
@@ -138,12 +155,13 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
                 uint4 n0 = ld_stream(pn), n1 = ld_stream(pn + 64), n2 = ld_stream(pn + 128), n3 = ld_stream(pn + 192);
                 uint2 nd = dbits(s + 4);
                 sweep_supertile<H, MODE>(c0, c1, c2, c3, cd, s, lane, dd, q, ftab, strip_prefix,
-                                         cq, qn, slice, run, ncand, counters);
+                                         cq, qn, slice, run, ncand, counters,
+                                         H == 2 ? (uint32_t)__builtin_amdgcn_readlane((int)n0.x, 0) : 0u);
                 c0 = n0; c1 = n1; c2 = n2; c3 = n3;
                 cd = nd;
             }
             sweep_supertile<H, MODE>(c0, c1, c2, c3, cd, s, lane, dd, q, ftab, strip_prefix, cq,
-                                     qn, slice, run, ncand, counters);
+                                     qn, slice, run, ncand, counters, first_dword_of(s + 4));
             s += 4;
         }
     } else {
@@ -151,18 +169,20 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
             const uint4 *p = text + s * 64 + lane;
             uint4 v0 = ld_stream(p), v1 = ld_stream(p + 64), v2 = ld_stream(p + 128), v3 = ld_stream(p + 192);   // 4 x 1 KiB in flight
             sweep_supertile<H, MODE>(v0, v1, v2, v3, dbits(s), s, lane, dd, q, ftab,
-                                     strip_prefix, cq, qn, slice, run, ncand, counters);
+                                     strip_prefix, cq, qn, slice, run, ncand, counters, first_dword_of(s + 4));
         }
     }
     for (; s < s1; ++s) {                       // < 4 strips left in the range
         uint4 v0 = ld_stream(text + s * 64 + lane);
         uint32_t a0 = 0, hits = 0;
         sweep_chunk<H, MODE>(v0, dd, q, ftab, a0, hits, 0,
-                             ((MODE & 8) && !(MODE & 4)) ? (uint32_t)dbm16[s * 64 + lane] : 0u);
+                             ((MODE & 8) && !(MODE & 4)) ? (uint32_t)dbm16[s * 64 + lane] : 0u,
+                             H == 2 ? next_lane_dword(v0.x, first_dword_of(s + 1)) : 0u);
+        if (H == 2) hits >>= 24;                // eight pushes from the top: probe i at bit i
         if (MODE & 4) {
             if (__ballot(hits != 0)) {
                 const uint32_t rc[4] = {0u, 0u, 0u, 0u};
-                emit_candidates(hits, s, rc, cq, qn, slice, ncand, counters);
+                emit_candidates<H>(hits, s, rc, cq, qn, slice, ncand, counters);
             }
             continue;
         }
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const uint4 *__restrict__ text,
             uint32_t rc[4];
             rc[0] = run + 128u * (uint32_t)lane - (sc0 - a0);
             rc[1] = rc[2] = rc[3] = 0;
-            emit_candidates(hits, s, rc, cq, qn, slice, ncand, counters);
+            emit_candidates<H>(hits, s, rc, cq, qn, slice, ncand, counters);
         }
         run += 8192u - p0;
     }
@@ -211,7 +231,14 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
     }
     uint32_t a0 = 0, hits = 0;
     sweep_chunk<H, MODE>(v, dd, q, ftab_g, a0, hits, 0,       // table straight from global/L2
-                         ((MODE & 8) && !(MODE & 4) && off < n) ? (uint32_t)dbm16[off >> 4] : 0u);
+                         ((MODE & 8) && !(MODE & 4) && off < n) ? (uint32_t)dbm16[off >> 4] : 0u,
+                         H == 2 ? next_lane_dword(v.x, fill4) : 0u);
+    if (H == 2) {
+        hits >>= 24;
+        // samples that start at or behind the end of the text are no candidates
+        if (off >= n) hits = 0;
+        else if (off + 16 > n) hits &= (1u << ((n - off + 1) >> 1)) - 1u;
+    }
     const uint32_t sc0 = (MODE & 4) ? 0u : wave_sum_to_lane63(a0);
     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)sc0, 63);
     const uint32_t z = (MODE & 4) ? 0u : 8192u - p0;
@@ -227,7 +254,7 @@ __global__ __launch_bounds__(64) void k_sweep_tail(const uint4 *__restrict__ tex
             // lean entries are 64-bit dword indices: the record-count half must stay zero
             rc[0] = (MODE & 4) ? 0u : before + 128u * (uint32_t)lane - (sc0 - a0);
             rc[1] = rc[2] = rc[3] = 0;
-            emit_candidates(hits, s, rc, cq, qn, cand + w * AGH_SLICE_CAP, ncand, counters);
+            emit_candidates<H>(hits, s, rc, cq, qn, cand + w * AGH_SLICE_CAP, ncand, counters);
             if (qn) flush_candidates(cq, qn, qn, cand + w * AGH_SLICE_CAP, ncand, counters);
         }
         if (lane == 0) wave_cand[w] = ncand < AGH_SLICE_CAP ? ncand : AGH_SLICE_CAP;
@@ -655,7 +682,8 @@ static void launch_sweep_hm(const agh_sweep_args &a, hipStream_t st)
         hipLaunchKernelGGL((k_sweep<H, MODE, AGH_SWEEP_BLOCK, true>), dim3(blocks),
                            dim3(AGH_SWEEP_BLOCK), 0, st, (const uint4 *)a.text, n_full,
                            a.w_begin, a.q, a.ftab, a.strip_prefix, a.wave_totals, a.cand,
-                           a.wave_cand, a.counters, (const uint16_t *)a.dbm);
+                           a.wave_cand, a.counters, (const uint16_t *)a.dbm,
+                           (uint64_t)(((a.n + 15) & ~(uint64_t)15) / 4));
     }
     if (a.ev_end) (void)hipEventRecord(a.ev_end, st);
     if (!to_end) return;                        // parts are lean: the tail belongs to the last one
@@ -697,6 +725,7 @@ void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st)
         if (a.q.mb) launch_sweep_hm<0, 8>(a, st);
         else launch_sweep_hm<0, 0>(a, st);
         break;
+    case 2: launch_sweep_t<2>(a, st); break;
     case 4: launch_sweep_t<4>(a, st); break;
     case 8: launch_sweep_t<8>(a, st); break;
     default: launch_sweep_t<16>(a, st); break;

@@ -290,6 +290,7 @@ struct VerifyCtx {
     const uint64_t *dbm;     // multi-byte delimiters: delimiter-end bitmap
     WT finalbit;
     uint32_t Lw, tailw, span;
+    uint32_t jshift;         // candidate entry -> byte offset: 2 (dword index), 1 for H == 2 samples
     const uint64_t *gtab;    // lean scans: per hash slot (gram, first/last offset) or NULL
     uint32_t tspan;          // window length when the gram's offset is known: m + 2k + spread
     Automaton<WT, K> RF;     // state right after a record boundary (reset + re-fed delimiter)
@@ -314,6 +315,7 @@ __device__ __forceinline__ void verify_ctx_init(VerifyCtx<WT, K> &c, const uint8
     c.Lw = (uint32_t)(q.m + q.k + 1) > 16u ? (uint32_t)(q.m + q.k + 1) : 16u;
     c.tailw = (uint32_t)(q.fq + q.m + q.k);
     c.span = c.Lw + c.tailw;                    // <= 16 * NCH by construction
+    c.jshift = q.fh == 2 ? 1u : 2u;
     c.gtab = nullptr;
     c.tspan = 0;
     c.RF.reset();
@@ -334,7 +336,8 @@ __device__ __forceinline__ VerifyWin verify_locate(const VerifyCtx<WT, K> &c, ui
     w.ws = 0;
     w.span = 0;
     w.mode = 0;
-    const uint64_t j = LEAN ? ent * 4u : (ent & 0xffffffffull) * 4u;   // lean entries: 64-bit dword index
+    // lean entries: 64-bit dword index (halfword index for H == 2 samples: jshift 1)
+    const uint64_t j = (LEAN ? ent : (ent & 0xffffffffull)) << c.jshift;
     w.j = j;
     if (j >= c.n) return w;
     const uint64_t anchor = j & ~(uint64_t)15;                           // sample's chunk start
@@ -348,7 +351,8 @@ __device__ __forceinline__ VerifyWin verify_locate(const VerifyCtx<WT, K> &c, ui
     uint32_t lw = c.Lw, span = c.span;
     bool fast = true;
     if (c.gtab) {
-        const uint32_t dw = *reinterpret_cast<const uint32_t *>(c.text + j);   // j is 4-aligned
+        typedef uint32_t u32_a2 __attribute__((aligned(2)));
+        const uint32_t dw = *reinterpret_cast<const u32_a2 *>(c.text + j);     // j is 4-aligned (2 with H == 2)
         const uint32_t g = (dw & c.q->qmask) | c.q->fold;
         const uint64_t e = c.gtab[c.q->fq == 4 ? agh_sample_hash_q4(g) : agh_sample_hash_q3(g)];
         if (e & AGH_GT_AMBIGUOUS) {

@@ -395,7 +395,9 @@ static void *gpu_worker(void *arg)
         if (fd < 0) continue;                    /* reported once by the main thread */
         if (opt.FILENAMEONLY) {
             agh_result r;
-            if (agh_scan_fd(q, fd, AGH_FILENAMEONLY, &r, NULL, 0)) t->failed = 1;
+            /* the same flags as the one-GPU path (scan_one): -l -v lists the files with a record
+             * that does NOT match */
+            if (agh_scan_fd(q, fd, AGH_FILENAMEONLY | (opt.INVERSE ? AGH_INVERT : 0u), &r, NULL, 0)) t->failed = 1;
             else t->file_hit[f] = r.n_matched ? 1 : 0;
         } else {
             uint64_t cuts[65];

@@ -47,38 +47,41 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 12345
 
 
-def cpu_baseline_extras(ref, host, sample_bytes, k, tmpdir):
-    """the reference is single-threaded, so 'all host cores' = P independent
-    processes on P record-aligned shards started together (aggregate = bytes / max wall time);
-    plus the scalar C restatement (oracle) as a second, quirk-free CPU datapoint."""
-    import _oracle as O
-    out = {}
-    procs = min(os.cpu_count() or 1, 32)
-    pages = sample_bytes // 4096
+def ref_all_cores(ref, host, k, tmpdir, procs):
+    """The reference is single-threaded: 'all host cores' = `procs` independent agrep processes on
+    `procs` record-aligned pieces of `host` (pages end with a newline), started together.
+    -> (sum of the counts, seconds from the first start to the last exit)"""
+    from concurrent.futures import ThreadPoolExecutor
+    n = host.size
+    pages = n // 4096
     per = (pages + procs - 1) // procs
-    paths = []
+    spans = [(i * per * 4096, min(n, (i + 1) * per * 4096)) for i in range(procs) if i * per * 4096 < n]
+    paths = [os.path.join(tmpdir, "agh_bench_shard_%d_%d.txt" % (os.getpid(), i)) for i in range(len(spans))]
     try:
-        for i in range(procs):
-            lo, hi = i * per * 4096, min(sample_bytes, (i + 1) * per * 4096)
-            if lo >= hi:
-                break
-            pth = os.path.join(tmpdir, "agh_bench_shard_%d_%d.txt" % (os.getpid(), i))
-            host[lo:hi].tofile(pth)                       # pages end with a newline: record aligned
-            paths.append(pth)
+        with ThreadPoolExecutor(max_workers=8) as ex:             # (tofile releases the GIL)
+            list(ex.map(lambda a: host[a[0][0]:a[0][1]].tofile(a[1]), zip(spans, paths)))
         cmd = [ref, "-V0", "-%d" % k, "-c", PATTERN.decode()]
         t0 = time.time()
         ps = [subprocess.Popen(cmd + [pth], stdout=subprocess.PIPE) for pth in paths]
         outs = [p_.communicate()[0] for p_ in ps]
         dt = time.time() - t0
-        total = sum(int(o.split()[0]) for o in outs if o.strip())
-        out["all_cores"] = {"value": round(sample_bytes / 1e9 / dt, 3), "unit": "GB/s", "cores": len(paths),
-                            "kind": "reference", "seconds": round(dt, 3), "count": total,
-                            "sample": "the same bytes as %d record-aligned shard files, one agrep process each, "
-                                      "started together" % len(paths)}
     finally:
         for pth in paths:
             if os.path.exists(pth):
                 os.unlink(pth)
+    return sum(int(o.split()[0]) for o in outs if o.strip()), dt, len(paths)
+
+
+def cpu_baseline_extras(ref, host, sample_bytes, k, tmpdir):
+    """the all-cores leg on the sample, plus the scalar C restatement (oracle) as a
+    second, quirk-free CPU datapoint."""
+    import _oracle as O
+    out = {}
+    total, dt, np_ = ref_all_cores(ref, host[:sample_bytes], k, tmpdir, min(os.cpu_count() or 1, 32))
+    out["all_cores"] = {"value": round(sample_bytes / 1e9 / dt, 3), "unit": "GB/s", "cores": np_,
+                        "kind": "reference", "seconds": round(dt, 3), "count": total,
+                        "sample": "the same bytes as %d record-aligned shard files, one agrep process each, "
+                                  "started together" % np_}
     nb = min(sample_bytes, 256 << 20)
     t0 = time.time()
     cnt = O.asearch(PATTERN, k, host[:nb])[0]
@@ -89,46 +92,36 @@ def cpu_baseline_extras(ref, host, sample_bytes, k, tmpdir):
     return out
 
 
-def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes):
-    """Time the reference CPU agrep (1 core) on the first sample_bytes of the corpus."""
+def reference_all_shards(text_dev, n_bytes, k, q, shard_bytes, first_shard_host):
+    """Parity of the WHOLE corpus against the reference CPU agrep: shard by shard (4 GiB each: the
+    SURVEY 8d shards) through /dev/shm, every shard cut into one file per core, one reference
+    process per file; the GPU count of the same shard beside it.  Not a timing leg."""
+    import agrep_amd as A
     ref = os.path.join(ROOT, "oracle", "_ref", "agrep")
-    sample_bytes = min(sample_bytes, n_bytes)
-    host = text_dev[:sample_bytes].cpu().numpy()
-    if os.path.exists(ref):
-        d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-        path = os.path.join(d, "agh_bench_sample_%d.txt" % os.getpid())
-        try:
-            host.tofile(path)
-            cmd = [ref, "-V0", "-%d" % k, "-c", PATTERN.decode(), path]
-            subprocess.run(cmd, stdout=subprocess.PIPE)            # warm-up pass (page cache)
-            t0 = time.time()
-            out = subprocess.run(cmd, stdout=subprocess.PIPE).stdout
-            dt = time.time() - t0
-        finally:
-            if os.path.exists(path):
-                os.unlink(path)
-        cnt = int(out.split()[0]) if out.strip() else -1
-        extra = {}
-        try:
-            extra = cpu_baseline_extras(ref, host, sample_bytes, k, d)
-        except Exception as e:                                  # never lose the headline over this
-            extra = {"extras_error": str(e)[:200]}
-        return {"value": round(sample_bytes / 1e9 / dt, 4), "unit": "GB/s", "cores": 1,
-                **extra,
-                "kind": "reference",
-                "sample": "shard 0 of 16 = the first %.2f GiB of the 64 GiB corpus, `agrep -V0 -%d -c %s` "
-                          "(sgrep.c:agrep() path), page cache warm, 1 process"
-                          % (sample_bytes / 2**30, k, PATTERN.decode()),
-                "seconds": round(dt, 3), "count": cnt,
-                "count_equals_gpu": bool(cnt == gpu_count_on_sample)}
-    import _oracle as O                                        # the restatement as a port
-    sample_bytes = min(sample_bytes, 256 << 20)
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    procs = min(os.cpu_count() or 1, 32)
+    n_shards = n_bytes // shard_bytes
     t0 = time.time()
-    cnt = O.asearch(PATTERN, k, host[:sample_bytes])[0]
-    dt = time.time() - t0
-    return {"value": round(sample_bytes / 1e9 / dt, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "first %.2f GiB, oracle/agrep_oracle.c orc_asearch (scalar)" % (sample_bytes / 2**30),
-            "seconds": round(dt, 3), "count": int(cnt)}
+    ref_counts, gpu_counts = [], []
+    ref_seconds = 0.0
+    for sh in range(n_shards):
+        lo = sh * shard_bytes
+        host = first_shard_host if (sh == 0 and first_shard_host is not None and first_shard_host.size == shard_bytes) \
+            else text_dev[lo:lo + shard_bytes].cpu().numpy()
+        cnt, dt, _ = ref_all_cores(ref, host, k, d, procs)
+        del host
+        ref_counts.append(int(cnt))
+        ref_seconds += dt
+        gpu_counts.append(int(q.scan_device(text_dev.data_ptr() + lo, shard_bytes, flags=A.COUNT,
+                                            time_sweep=False, time_scan=False).n_matched))
+    return {"shards": n_shards, "shard_bytes": shard_bytes, "processes_per_shard": procs,
+            "reference_count": sum(ref_counts), "gpu_count": sum(gpu_counts),
+            "shards_equal": sum(1 for a, b in zip(ref_counts, gpu_counts) if a == b),
+            "equal": ref_counts == gpu_counts, "reference_seconds": round(ref_seconds, 2),
+            "reference_GBps_all_cores": round(n_shards * shard_bytes / 1e9 / max(ref_seconds, 1e-9), 2),
+            "wall_seconds": round(time.time() - t0, 1),
+            "what": "`agrep -V0 -%d -c %s` (unmodified reference, sgrep.c path) over every byte of the corpus, "
+                    "per-shard counts compared with the GPU's" % (k, PATTERN.decode())}
 
 
 def measure_traffic(seg_gib, k, timeout_s):
@@ -170,16 +163,30 @@ def measure_traffic(seg_gib, k, timeout_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)     # ~1.1 s timed per k at 64 GiB on one GPU
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--total-gib", type=float, default=64.0,
                     help="corpus GiB of the whole job (BASELINE: 64), split evenly over the ranks")
     ap.add_argument("-k", type=int, default=2)
     ap.add_argument("--cpu-sample-gib", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-all-shards", action="store_true",
+                    help="skip the reference run over every shard of the corpus (N = 1 only, ~1 min)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 FETCH_SIZE pass")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per
+        # GPU over RCCL, the contract's own command line) and become that launcher
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
 
     import torch
     import torch.distributed as dist
@@ -342,7 +349,8 @@ def main():
             sb = int(args.cpu_sample_gib * (1 << 30)) // 4096 * 4096
             sb = min(sb, n)
             gpu_cnt = q.scan_device(text.data_ptr(), sb, flags=A.COUNT).n_matched
-            out["cpu_baseline"] = cpu_baseline(text, n, args.k, int(gpu_cnt), sb)
+            out["cpu_baseline"] = cpu_baseline(text, n, args.k, int(gpu_cnt), sb, q=q,
+                                               all_shards=not args.no_all_shards)
         else:
             out["cpu_baseline"] = None
     q.close()

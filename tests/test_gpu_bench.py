@@ -41,6 +41,9 @@ def test_bench_single_and_two_ranks():
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] in ("reference", "port")
     if cb["kind"] == "reference":
         assert cb["count_equals_gpu"] is True
+        # the reference over EVERY shard of the corpus (here 4 x 128 MiB), count by count
+        assert cb["all_shards_count_equals_gpu"] is True, cb.get("all_shards")
+        assert cb["all_shards"]["shards"] == 4 and cb["all_shards"]["gpu_count"] == a["matched_records"]
 
     env.update(AGH_BENCH_BACKEND="gloo", AGH_BENCH_ONE_GPU="1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
@@ -54,6 +57,21 @@ def test_bench_single_and_two_ranks():
     assert b["matched_records"] == a["matched_records"] and b["matched_equals_planted"] is True
     assert b["config"]["bytes_per_gpu"] * 2 == a["config"]["bytes_per_gpu"]
     assert b["config"]["total_bytes"] == a["config"]["total_bytes"] and b["scaling"] == "strong"
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no RANK in the environment starts the two ranks itself
+    (torch.distributed.run, one process per GPU) -- here both on GPU 0 with the counts over gloo."""
+    env = dict(os.environ, AGH_BENCH_BACKEND="gloo", AGH_BENCH_ONE_GPU="1")
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-gib", "0.5",
+                        "--steps", "3", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = _last_json(r.stdout)
+    assert b["n_gpus"] == 2 and b["matched_equals_planted"] is True and b["scaling"] == "strong"
+    assert b["config"]["bytes_per_gpu"] * 2 == b["config"]["total_bytes"]
 
 
 def test_bench_rccl_code_path_with_one_rank():

@@ -819,3 +819,60 @@ def test_fused_count_on_candidate_dense_text(agh, k):
         finally:
             os.environ["AGH_FUSED_MIN_MB"] = saved
         assert r3.fused_segments == 0 and r3.n_matched == r1.n_matched
+
+
+def test_h2_sample_shape_parity(agh, monkeypatch):
+    """The H = 2 / q = 4 sample shape (4-byte samples at every even offset, overlapping; lossless iff
+    floor((m-k-3)/2) >= 2k+1: agh_api.cpp choose_filter): every pipeline against the oracle, the
+    planted occurrences at every alignment, across strip / range / text-end boundaries."""
+    monkeypatch.setenv("AGH_SHAPE_H2", "1")
+    monkeypatch.setenv("AGH_FUSED_MIN_MB", "0")
+    with agh.Query(O.PATTERN_C2, 2) as q:
+        assert (q.info()["filter_q"], q.info()["filter_h"]) == (4, 2)
+    with agh.Query(b"abcdefghij", 1) as q:              # no h >= 4 shape exists for (10, 1)
+        assert (q.info()["filter_q"], q.info()["filter_h"]) == (4, 2)
+    with agh.Query(O.PATTERN_C2, 0) as q:               # q = 4 already: the larger stride stays
+        assert (q.info()["filter_q"], q.info()["filter_h"]) == (4, 8)
+    for nocase in (False, True):
+        text, planted = O.corpus(512, seed=4321, variants=O.VARIANTS_C2, plant_period=40,
+                                 upper_permille=500 if nocase else 0)
+        res = _check(agh, O.PATTERN_C2, 2, text, nocase)
+        assert res.engine == agh.ENGINE_FILTER
+    rng = random.Random(22)
+    for _ in range(40):
+        pat, k, text = _rand_case(rng, 6, max_m=29)
+        _check(agh, pat, k, text)
+    # occurrences (0..2 edits) at every byte alignment around strip (1 KiB), supertile (4 KiB) and wave
+    # range (256 KiB) boundaries and at the very end of the text
+    pat = O.PATTERN_C2
+    variants = [pat, pat[:5] + pat[6:], pat[:7] + b"X" + pat[7:], pat[:3] + b"Q" + pat[4:9] + pat[10:]]
+    for boundary in (1024, 4096, 262144):
+        for v in variants:
+            t = bytearray(b"z" * (boundary + 3000))
+            for i in range(50, len(t), 97):
+                t[i] = 10
+            for shift in range(0, 24):
+                tt = bytearray(t)
+                at = boundary - shift
+                tt[at:at + len(v)] = v
+                for p in range(at - 1, at + len(v) + 1):
+                    if tt[p] == 10:
+                        tt[p] = ord("z")
+                tb = bytes(tt)
+                want = O.asearch(pat, 2, tb, cap=1000)
+                assert want[0] == 1
+                with agh.Query(pat, 2) as q:
+                    r1, ms = q.scan_buffer(tb, cap=1000)
+                    r2, _ = q.scan_buffer(tb, flags=agh.COUNT)
+                assert (r1.n_matched, [(s, e) for s, e, _ in ms]) == want, (boundary, shift, v)
+                assert r2.n_matched == 1, (boundary, shift, v)
+    for tail in range(0, 40):
+        tb = b"y" * 3000 + b"\n" + b"w" * tail + pat
+        for cut in range(0, 3):
+            tt = tb[:len(tb) - cut] if cut else tb
+            want = O.asearch(pat, 2, tt, cap=100)
+            with agh.Query(pat, 2) as q:
+                r1, ms = q.scan_buffer(tt, cap=100)
+                r2, _ = q.scan_buffer(tt, flags=agh.COUNT)
+            assert (r1.n_matched, [(s, e) for s, e, _ in ms]) == want, (tail, cut)
+            assert r2.n_matched == want[0], (tail, cut)
