@@ -142,10 +142,10 @@ struct agh_query {
     bool mp_q5 = false;                 // ... with 5-byte grams (stride 4, entries of >= 8 bytes)
     uint32_t pe_qmask = 0, pe_fold = 0;
     bool multi_dense = false;           // hits are too dense for the candidate slices
+    bool fs_fast_off = false;           // full scan: the replay lists overflowed once (match-dense text): exact kernel from now on
     int npat = 0;
-    void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_off = nullptr,
-         *d_mp_pool = nullptr, *d_mp_owner = nullptr, *d_mp_po = nullptr, *d_mp_olen = nullptr,
-         *d_mp_omask = nullptr, *d_mp_info = nullptr;
+    void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_pool = nullptr,
+         *d_mp_omask = nullptr;
 };
 
 // delimiter ends come from the delimiter bitmap: several bytes, or one letter under -i
@@ -183,7 +183,9 @@ static std::vector<uint8_t> folded_members(const std::vector<uint8_t> &v, bool f
 }
 
 #ifndef AGH_SHAPE_H2_DEFAULT
-#define AGH_SHAPE_H2_DEFAULT 0  // (A/B pending: scripts/ab_fused.py)
+// 64 GiB, k = 2, fused: 10.61 -> 10.30 ms, candidates 17.5 M -> 9.9 M; 8 GiB 1.413 -> 1.392 ms
+// (profiles/r03_ab_headline.log)
+#define AGH_SHAPE_H2_DEFAULT 1
 #endif
 #define AGH_CLASS_MAX 40        // largest class a sampled position may have ([a-z], [0-9a-z] ...)
 #define AGH_GRAMS_MAX 2048      // expanded q-grams of one query (32 Ki table slots: <= 6 % full)
@@ -229,8 +231,19 @@ static void choose_filter(agh_query *q)
         if (is_case_pair(v)) any_pair = true;
     }
     for (int p = 0; p < q->m; ++p) {
-        const std::vector<uint8_t> v = folded_members(position_members(q, p), any_pair);
+        const std::vector<uint8_t> raw = position_members(q, p);
+        const std::vector<uint8_t> v = folded_members(raw, any_pair);
         width[(size_t)p] = v.size();
+        // A position that accepts '\n' or a delimiter byte (-x / -w guards, patterns that hold the
+        // record separator) can be matched by a byte that is NOT in the scanned text: the virtual
+        // '\n' in front of a file, the delimiter appended at its end (asearch.c:69-91), the last byte
+        // of the previous segment.  Samples are taken from real text only, so such positions end a
+        // run: the sampled core of an occurrence then lies inside its record.
+        for (uint8_t c : raw) {
+            bool virt = c == '\n';
+            for (int j = 0; j < q->dlen; ++j) virt = virt || c == q->delim[j] || (q->delim_fold && (c | 0x20) == q->delim[j]);
+            if (virt) { width[(size_t)p] = 0; break; }
+        }
     }
     static const int hs[3] = {16, 8, 4};
     int best_h = 0, best_q = 0, best_a = 0, best_len = 0;
@@ -653,15 +666,11 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
     std::vector<uint8_t> pool;
     std::vector<uint32_t> bstart(NB + 1, 0);
     std::vector<char> usable(npc, 1);
-    std::vector<uint32_t> piece_owner(npc);
-    std::vector<uint8_t> piece_po(npc), owner_len(npat);
     struct gram_item { uint32_t bucket, piece, o; };
     std::vector<gram_item> gi;
     for (int i = 0; i < npc; ++i) {
         const unsigned char *src = pats[pcs[i].owner] + pcs[i].po;
         off[i] = (uint32_t)pool.size();
-        piece_owner[i] = (uint32_t)pcs[i].owner;
-        piece_po[i] = (uint8_t)pcs[i].po;
         for (int t = 0; t < pcs[i].len; ++t) {
             unsigned char c = src[t];
             if (c == delim0) usable[i] = 0;   // can never lie inside one record
@@ -675,7 +684,7 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
             g = (g & qmask) | fold;
             uint32_t hs = g;                    // what the sweep hashes: the gram, or the 5-byte mix
             if (q5) hs = agh_mix5(g, (uint32_t)src[o + 4] | (fold ? 0x20u : 0u));
-            const uint32_t h = fq == 4 ? agh_sample_hash18_q4(hs) : agh_sample_hash18_q3(hs);
+            const uint32_t h = fq == 4 ? (agh_sample_prod_q4(hs) & ((1u << AGH_MP_BITS) - 1u)) : agh_sample_hash18_q3(hs);
             bits[h >> 5] |= 1u << (h & 31u);
             if (fq == 4) {                      // second Bloom probe (agh_multi.hip probe_chunk)
                 const uint32_t h2 = agh_sample_hash18b_q4(hs);
@@ -690,14 +699,17 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
     if (pool.size() >= (1u << 24)) return fail("pattern set too large (%zu bytes)", pool.size());
     if ((size_t)npc >= (1u << 28)) return fail("too many pattern pieces");
     for (uint32_t b = 0; b < NB; ++b) bstart[b + 1] += bstart[b];
-    // bucket items: piece index | offset of the gram inside the piece << 28; info: pool offset, length
-    std::vector<uint32_t> items(gi.size() ? gi.size() : 1, 0u), info(gi.size() ? gi.size() : 1, 0u);
+    // bucket items (agh_launch.h): everything the verifier needs about an entry in one 16-byte load
+    std::vector<agh_mp_item> items(gi.size() ? gi.size() : 1);
+    memset(items.data(), 0, items.size() * sizeof(agh_mp_item));
     {
         std::vector<uint32_t> fill(bstart.begin(), bstart.end() - 1);
         for (const gram_item &x : gi) {
             const uint32_t at = fill[x.bucket]++;
-            items[at] = x.piece | (x.o << 28);
-            info[at] = (off[x.piece] << 8) | (uint32_t)pcs[x.piece].len;
+            items[at].piece = x.piece | (x.o << 28);
+            items[at].info = (off[x.piece] << 8) | (uint32_t)pcs[x.piece].len;
+            items[at].owner = (uint32_t)pcs[x.piece].owner;
+            items[at].pom = ((uint32_t)pcs[x.piece].po << 8) | (uint32_t)(lens[pcs[x.piece].owner] & 0xff);
         }
     }
     // per-pattern position masks for the verifying automaton (as agh_query_literal builds them)
@@ -705,7 +717,6 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
     if (D > 0) {
         omask.assign((size_t)npat * 256, 0u);
         for (int p = 0; p < npat; ++p) {
-            owner_len[p] = (uint8_t)lens[p];
             for (int t = 0; t < lens[p]; ++t) {
                 int c = pats[p][t];
                 if (nocase && is_upper(c)) c += 32;
@@ -719,14 +730,11 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
         if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         return 0;
     };
+    bstart.push_back(bstart.back());            // (the verifier reads [b] and [b + 1] as one pair)
     if (up(&q->d_mp_bits, bits.data(), bits.size() * 4) || up(&q->d_mp_bstart, bstart.data(), bstart.size() * 4) ||
-        up(&q->d_mp_items, items.data(), items.size() * 4) || up(&q->d_mp_off, off.data(), off.size() * 4) ||
+        up(&q->d_mp_items, items.data(), items.size() * sizeof(agh_mp_item)) ||
         up(&q->d_mp_pool, pool.data(), pool.size()) ||
-        up(&q->d_mp_owner, piece_owner.data(), piece_owner.size() * 4) ||
-        up(&q->d_mp_po, piece_po.data(), piece_po.size()) ||
-        up(&q->d_mp_olen, owner_len.data(), owner_len.size()) ||
-        up(&q->d_mp_omask, omask.data(), omask.size() * 4) ||
-        up(&q->d_mp_info, info.data(), info.size() * 4))
+        up(&q->d_mp_omask, omask.data(), omask.size() * 4))
         return -1;
     return 0;
 }
@@ -820,13 +828,8 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_mp_bits) (void)hipFree(q->d_mp_bits);
     if (q->d_mp_bstart) (void)hipFree(q->d_mp_bstart);
     if (q->d_mp_items) (void)hipFree(q->d_mp_items);
-    if (q->d_mp_off) (void)hipFree(q->d_mp_off);
     if (q->d_mp_pool) (void)hipFree(q->d_mp_pool);
-    if (q->d_mp_owner) (void)hipFree(q->d_mp_owner);
-    if (q->d_mp_po) (void)hipFree(q->d_mp_po);
-    if (q->d_mp_olen) (void)hipFree(q->d_mp_olen);
     if (q->d_mp_omask) (void)hipFree(q->d_mp_omask);
-    if (q->d_mp_info) (void)hipFree(q->d_mp_info);
     if (q->d_counters) (void)hipFree(q->d_counters);
     if (q->d_chunk_totals) (void)hipFree(q->d_chunk_totals);
     if (q->h_counters) (void)hipHostFree(q->h_counters);
@@ -881,19 +884,39 @@ static bool tight_verify_enabled()
     return !(e && e[0] == '0');
 }
 
+// Full scan, fast form (k_fullscan_fast + k_fullscan_replay): unit costs, a one-byte delimiter that
+// no pattern position accepts.  The replay lists live in the candidate buffers a full scan does not
+// use otherwise.  AGH_FS_FAST=0: the exact kernel (A/B runs).
+#define AGH_FF_SLICE_HOST 256u      // = AGH_FF_SLICE (agh_fullscan.hip)
+static bool fs_fast_ok(const agh_query *q)
+{
+    const char *e = getenv("AGH_FS_FAST");
+    if (e && e[0] == '0') return false;
+    return !q->fs_fast_off && !q->multi && !q->table && !q->general && !(q->dlen > 1 || q->delim_fold) &&
+           q->mask[q->delim[0]] == 0;
+}
+
+static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
+{
+    va->fs_fast = 0;
+    if (!fs_fast_ok(q)) return 0;
+    const uint64_t n_tiles = (n + 65535) / 65536;
+    if (q->cand.ensure(n_tiles * AGH_FF_SLICE_HOST * sizeof(uint64_t))) return -1;
+    if (q->wave_cand.ensure((n_tiles + 8) * sizeof(uint32_t))) return -1;
+    va->fs_fast = 1;
+    va->fs_replay = (uint64_t *)q->cand.p;
+    va->fs_tile_cnt = (uint32_t *)q->wave_cand.p;
+    return 0;
+}
+
 static agh_multi_dev multi_dev(const agh_query *q)
 {
     agh_multi_dev m;
     m.bits = (const uint32_t *)q->d_mp_bits;
     m.bucket_start = (const uint32_t *)q->d_mp_bstart;
-    m.bucket_items = (const uint32_t *)q->d_mp_items;
-    m.pat_off = (const uint32_t *)q->d_mp_off;
+    m.items = (const agh_mp_item *)q->d_mp_items;
     m.pool = (const uint8_t *)q->d_mp_pool;
-    m.piece_owner = (const uint32_t *)q->d_mp_owner;
-    m.piece_po = (const uint8_t *)q->d_mp_po;
-    m.owner_len = (const uint8_t *)q->d_mp_olen;
     m.owner_mask = (const uint32_t *)q->d_mp_omask;
-    m.item_info = (const uint32_t *)q->d_mp_info;
     return m;
 }
 
@@ -911,8 +934,10 @@ static const uint64_t AGH_LEAN_SEG_MAX = (uint64_t)64 << 30;     // lean scans: 
 // persistent kernel pays ~70 us once (the candidates queued last are verified after the stream has
 // ended, and 4096 waves drawing 256 KiB tickets finish less evenly than hardware-dispatched
 // workgroups): measured against the two-kernel form (scripts/ab_fused.py, k = 2 / k = 0) it is
-// -3 % / -3 % at 4 GiB, even at 8 GiB, +1.8 % / +1.6 % at 16 GiB, +5 % / 0 % at 64 GiB.
-#define AGH_FUSED_MIN_MB_DEFAULT 12288
+// -3 % / -3 % at 4 GiB, even at 8 GiB, +1.8 % / +1.6 % at 16 GiB, +5 % / 0 % at 64 GiB in round 2;
+// round 3 (H = 2 samples at k = 2, small tickets at the end; profiles/r03_ab_headline.log): -3 % / -4 %
+// at 4 GiB, +1.9 % / +0.2 % at 8 GiB, +3.5 % / +3.5 % at 16 GiB, +6.7 % / +3.7 % at 64 GiB.
+#define AGH_FUSED_MIN_MB_DEFAULT 6144
 
 struct seg_result {
     uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
@@ -1036,8 +1061,17 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.counters = q->d_counters;
         va.mk.hashset = (uint64_t *)q->hashset.p;
         va.mk.hashset_mask = (uint32_t)(slots - 1);
-        if (multi) agh_launch_sweep_multi(sa, multi_dev(q), va.mk, q->multi_dense, st);
-        else agh_launch_sweep(sa, q->fh, st);
+        if (multi && q->multi_dense) {
+            // dense hit set: probes and verification of the full strips in one kernel, nothing goes
+            // through the slices but the partial last strip
+            agh_launch_dense_multi(sa, multi_dev(q), va.mk, st);
+            sa.tail_only = 1;
+            agh_launch_sweep_multi(sa, st);
+        } else if (multi) {
+            agh_launch_sweep_multi(sa, st);
+        } else {
+            agh_launch_sweep(sa, q->fh, st);
+        }
         va.text = d_text;
         va.n = n;
         va.q = dq;
@@ -1116,6 +1150,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.hashset_mask = (uint32_t)(slots - 1);
         va.table = q->table;
         va.tab = q->tab;
+        if (fs_fast_setup(q, n, &va)) return -1;
+        const bool fs_fast = va.fs_fast != 0;
         if (q->table) agh_launch_tablescan(va, st);
         else agh_launch_fullscan(va, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8), nullptr, 0u,
@@ -1126,6 +1162,13 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         q->hashset_dirty = false;
+        if (fs_fast && q->h_counters[AGH_C_OVERFLOW]) {
+            // more pieces to replay than the lists hold (a match in every few records): this text
+            // belongs to the kernel that does its bookkeeping on the way
+            q->fs_fast_off = true;
+            return scan_segment(q, d_text, n, st, flags, head_byte, tail_virtual, d_match_pos, d_match_rec,
+                                match_cap, out, pre_dbm);
+        }
         if (!q->h_counters[AGH_C_LEAN_FALLBACK]) {
             if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
             out->matched = q->h_counters[AGH_C_MATCHED];
@@ -1199,11 +1242,11 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                 mk0.match_rec = d_match_rec;
                 mk0.match_cap = match_cap;
                 sa.ev_begin = sa.ev_end = nullptr;
-                agh_launch_sweep_multi(sa, multi_dev(q), mk0, true, st);
+                agh_launch_dense_multi(sa, multi_dev(q), mk0, st);
+                sa.tail_only = 1;
+                agh_launch_sweep_multi(sa, st);
             } else if (multi) {
-                agh_marks none;
-                memset(&none, 0, sizeof(none));
-                agh_launch_sweep_multi(sa, multi_dev(q), none, false, st);
+                agh_launch_sweep_multi(sa, st);
                 agh_launch_census_scan(sa, true, st);
             } else {
                 agh_launch_sweep(sa, use_filter ? q->fh : 0, st);
@@ -1237,6 +1280,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.hashset_mask = 0;
         va.gtab = (tight_verify_enabled() && !multi) ? q->d_gtab : nullptr;
         va.gram_spread = q->gram_spread;
+        if (!multi && !use_filter && !q->table && fs_fast_setup(q, n, &va)) return -1;
+        const bool fs_fast = va.fs_fast != 0;
         if (multi) agh_launch_verify_multi(va, multi_dev(q), false, st);
         else if (use_filter) agh_launch_verify(va, st);
         else if (q->table) agh_launch_tablescan(va, st);
@@ -1268,6 +1313,11 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                     q->h_counters[AGH_C_OVERFLOW], q->h_counters[AGH_C_BM_OVERFLOW],
                     q->h_counters[AGH_C_MATCHED], (unsigned long long)bm_words * 32);
         q->bitmap_bits_hint = (uint64_t)n_delims + n_delims / 4 + 1024;
+        if (fs_fast && q->h_counters[AGH_C_OVERFLOW]) {     // replay lists full: the exact kernel (see above)
+            q->fs_fast_off = true;
+            bits_hint = std::max<uint64_t>(bits_hint, (uint64_t)n_delims + 1024);
+            continue;
+        }
         const bool slice_overflow = use_filter && q->h_counters[AGH_C_OVERFLOW];
         const bool bm_overflow = q->h_counters[AGH_C_BM_OVERFLOW] != 0 ||
                                  (uint64_t)n_delims + 2 > (uint64_t)bm_words * 32;

@@ -292,6 +292,279 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
 }
 
 // ---------------------------------------------------------------------------------------
+// fast full scan: the hot loop without any record bookkeeping, two text streams per lane
+// ---------------------------------------------------------------------------------------
+// For the queries fullscan_piece_fast serves (unit costs, one-byte delimiter outside every pattern
+// class) the kernel above still carries the exact path -- seen / record number / record start /
+// h16 / d16, 146 VGPRs -- although one piece in thousands needs it.  Here the hot kernel ONLY runs
+// the branch-free step and ORs up the top level; a piece whose OR reaches the final bit (or that
+// holds the last byte of the text) is written to a per-tile list, and k_fullscan_replay walks those
+// pieces exactly afterwards: state rebuilt from the m+k+1 bytes in front of the piece (SURVEY B.5,
+// the same warm-up a chunk start uses), records identified after the fact.
+// PACK: patterns of m <= 16 positions -- every literal query that ends up here with k <= 4 has
+// m < 3(k+1) -- run TWO text streams per lane in the halves of one 32-bit word: stream B's state is
+// R << 16.  The left shift carries bit 15 of stream A into bit 16, which is stream B's position 1
+// and is forced to 1 by the "| 1" of every shift anyway, so the halves never disturb each other.
+// A wave then owns a PAIR of 64 KiB tiles; per byte pair: two table reads, cm = cmA | cmB,
+// kb = kbA & kbB, one automaton step -- 9-10 VALU instructions per byte at k = 2 instead of 21.
+#define AGH_FF_SLICE 256u       // replay entries per 64 KiB tile (6 % of its pieces; more: the exact kernel)
+
+template <typename WT, int K>
+__device__ __forceinline__ WT ff_step(Automaton<WT, K> &A, WT cm, WT kb, WT ones)
+{
+    WT po = A.R[0];
+    WT aprev = (po << 1) | ones;
+    WT pn = aprev & cm;
+    A.R[0] = pn;
+#pragma unroll
+    for (int l = 1; l <= K; ++l) {
+        const WT cur = A.R[l];
+        const WT al = (cur << 1) | ones;
+        const WT b = (pn << 1) | aprev;                     // ((R(l-1) | R(l-1)') << 1) | 1
+        const WT lvl = (WT)((((WT)1 << l) - (WT)1) * ones); // 2^l - 1 in every stream
+        const WT ne = ((al & cm) | po | b) & (kb | lvl);
+        po = cur;
+        pn = ne;
+        aprev = al;
+        A.R[l] = ne;
+    }
+    return A.R[K];
+}
+
+// 16 bytes of stream A (and, PACK, 16 bytes of stream B) through the automaton; -> OR of the top level
+template <typename WT, int K, bool PACK>
+__device__ __forceinline__ WT ff_piece(uint4 va, uint4 vb, const MaskKill<WT> *tabA,
+                                       const MaskKill<WT> *tabB, Automaton<WT, K> &A, WT ones)
+{
+    const uint32_t da[4] = {va.x, va.y, va.z, va.w}, db[4] = {vb.x, vb.y, vb.z, vb.w};
+    WT any = 0;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const MaskKill<WT> ea = tabA[(da[b >> 2] >> (8 * (b & 3))) & 0xffu];
+        WT cm = ea.cm, kb = ea.kb;
+        if (PACK) {
+            const MaskKill<WT> eb = tabB[(db[b >> 2] >> (8 * (b & 3))) & 0xffu];
+            cm |= eb.cm;
+            kb &= eb.kb;
+        }
+        any |= ff_step<WT, K>(A, cm, kb, ones);
+    }
+    return any;
+}
+
+template <typename WT, int K, bool PACK>
+__global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan_fast(
+    const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, const WT *__restrict__ mask_g,
+    uint64_t *__restrict__ replay, uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters)
+{
+    constexpr int NS = PACK ? 2 : 1;                    // text streams per lane
+    __shared__ MaskKill<WT> tabA[256];
+    __shared__ MaskKill<WT> tabB[PACK ? 256 : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * NS * WAVE * AGH_FS_ROW];
+    {
+        const WT cm = mask_g[threadIdx.x];
+        const bool isd = threadIdx.x == q.delim;
+        if (PACK) {
+            tabA[threadIdx.x].cm = cm & (WT)0xffffu;
+            tabA[threadIdx.x].kb = isd ? (WT)0xffff0000u : ~(WT)0;
+            tabB[threadIdx.x].cm = (WT)(cm << 16);
+            tabB[threadIdx.x].kb = isd ? (WT)0x0000ffffu : ~(WT)0;
+        } else {
+            tabA[threadIdx.x].cm = cm;
+            tabA[threadIdx.x].kb = isd ? (WT)0 : ~(WT)0;
+        }
+    }
+    __syncthreads();
+    const WT ones = PACK ? (WT)0x00010001u : (WT)1;
+    const WT finalA = (WT)1 << (q.m - 1);
+    const WT finalB = PACK ? (WT)(finalA << 16) : (WT)0;
+    const int lane = lane_id();
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    uint8_t *ring = ring_all + wib * (NS * WAVE * AGH_FS_ROW);
+    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_FS_CHUNK;
+    const uint64_t n_tiles = (n + tile_bytes - 1) / tile_bytes;
+    const uint64_t n_units = (n_tiles + NS - 1) / NS;   // tiles, or pairs of tiles
+    const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
+    const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    const uint32_t warm = ((uint32_t)(q.m + q.k + 1) + 15u) & ~15u;   // <= 80 bytes
+    const uint32_t seg_lo = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
+    uint8_t *ring_w = ring + seg_lo * AGH_FS_ROW + part * 16u;
+    const uint8_t *ring_r = ring + (uint32_t)lane * AGH_FS_ROW;
+
+    for (uint64_t unit = (uint64_t)blockIdx.x * (AGH_FS_THREADS / WAVE) + wib; unit < n_units;
+         unit += (uint64_t)gridDim.x * (AGH_FS_THREADS / WAVE)) {
+        uint64_t t0[NS], cs[NS];
+        uint32_t len[NS], cnt[NS];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            t0[st] = (unit * NS + (uint64_t)st) * tile_bytes;
+            cs[st] = t0[st] + (uint64_t)lane * AGH_FS_CHUNK;
+            len[st] = cs[st] < n ? (uint32_t)(n - cs[st] < AGH_FS_CHUNK ? n - cs[st] : AGH_FS_CHUNK) : 0u;
+            cnt[st] = 0;
+        }
+        auto gather = [&](uint32_t r, uint4 (&g)[NS][4]) {
+#pragma unroll
+            for (int st = 0; st < NS; ++st)
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    const uint64_t a = t0[st] + (uint64_t)(seg_lo + 16u * i) * AGH_FS_CHUNK + r * AGH_FS_ROUND + part * 16u;
+                    g[st][i] = a < n16 ? ld_stream(reinterpret_cast<const uint4 *>(text + a))
+                                       : make_uint4(fill4, fill4, fill4, fill4);
+                }
+        };
+        uint4 g[NS][4];
+        gather(0, g);
+
+        // state at the chunk starts: the m+k+1 (rounded to 16) bytes in front of them, or the
+        // virtual head byte at the start of the text (asearch.c:69-78)
+        Automaton<WT, K> A;
+        A.reset();
+        {
+            const uint4 fillv = make_uint4(fill4, fill4, fill4, fill4);
+            for (uint32_t t = 0; t < warm / 16; ++t) {
+                uint4 wa = fillv, wb = fillv;
+                if (len[0] && cs[0] >= warm) wa = *reinterpret_cast<const uint4 *>(text + cs[0] - warm + 16u * t);
+                if (PACK && len[NS - 1] && cs[NS - 1] >= warm) wb = *reinterpret_cast<const uint4 *>(text + cs[NS - 1] - warm + 16u * t);
+                (void)ff_piece<WT, K, PACK>(wa, wb, tabA, tabB, A, ones);
+            }
+            if (cs[0] == 0) {                   // (only stream A of the first unit starts the text)
+                Automaton<WT, K> H;
+                H.reset();
+                const MaskKill<WT> eh = tabA[q.head_byte & 0xffu];
+                (void)ff_step<WT, K>(H, (WT)(eh.cm & (PACK ? (WT)0xffffu : ~(WT)0)), (WT)(eh.kb | (PACK ? (WT)0xffff0000u : (WT)0)),
+                                     (WT)1);
+#pragma unroll
+                for (int l = 0; l <= K; ++l)
+                    A.R[l] = PACK ? (WT)((A.R[l] & (WT)0xffff0000u) | (H.R[l] & (WT)0xffffu)) : H.R[l];
+            }
+        }
+        for (uint32_t r = 0; r < AGH_FS_CHUNK / AGH_FS_ROUND; ++r) {
+#pragma unroll
+            for (int st = 0; st < NS; ++st)
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i)
+                    *reinterpret_cast<uint4 *>(ring_w + st * (WAVE * AGH_FS_ROW) + 16u * i * AGH_FS_ROW) = g[st][i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the whole wave's rows are in
+            __builtin_amdgcn_wave_barrier();
+            uint4 v[NS][4];
+#pragma unroll
+            for (int st = 0; st < NS; ++st)
+#pragma unroll
+                for (uint32_t p = 0; p < 4; ++p)
+                    v[st][p] = *reinterpret_cast<const uint4 *>(ring_r + st * (WAVE * AGH_FS_ROW) + 16u * p);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next round overwrites
+            __builtin_amdgcn_wave_barrier();
+            if (r + 1 < AGH_FS_CHUNK / AGH_FS_ROUND) gather(r + 1, g);   // in flight during the walk
+            uint32_t flags = 0;                 // bit 4*st + p: piece p of stream st goes to the replay list
+#pragma unroll
+            for (uint32_t p = 0; p < 4; ++p) {
+                const uint32_t off = r * AGH_FS_ROUND + 16u * p;
+                const WT any = ff_piece<WT, K, PACK>(v[0][p], v[NS - 1][p], tabA, tabB, A, ones);
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    const WT fb = st == 0 ? finalA : finalB;
+                    // a match may end in the piece, or the piece holds the last byte of the text
+                    // (partial pieces and the appended delimiter, asearch.c:87-91, are the replay's)
+                    const bool in_text = off < len[st];
+                    const bool last = in_text && cs[st] + off + 16u >= n;
+                    if (in_text && (((any & fb) != 0) || last)) flags |= 1u << (4 * st + p);
+                }
+            }
+            if (__ballot(flags != 0u)) {
+#pragma unroll
+                for (int st = 0; st < NS; ++st)
+#pragma unroll
+                    for (uint32_t p = 0; p < 4; ++p) {
+                        const bool f = (flags >> (4 * st + p)) & 1u;
+                        const uint64_t fm = __ballot(f);
+                        if (!fm) continue;
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                        const uint64_t tile = unit * NS + (uint64_t)st;
+                        if (f) {
+                            const uint32_t at = cnt[st] + rank;
+                            if (at < AGH_FF_SLICE) replay[tile * AGH_FF_SLICE + at] = cs[st] + r * AGH_FS_ROUND + 16u * p;
+                            else counters[AGH_C_OVERFLOW] = 1u;
+                        }
+                        cnt[st] += (uint32_t)__popcll(fm);
+                    }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const uint64_t tile = unit * NS + (uint64_t)st;
+                if (tile < n_tiles) tile_cnt[tile] = cnt[st] < AGH_FF_SLICE ? cnt[st] : AGH_FF_SLICE;
+            }
+        }
+    }
+}
+
+// The listed pieces, exactly: one lane per piece, one wave per tile.
+template <typename WT, int K, bool LEAN>
+__global__ __launch_bounds__(256) void k_fullscan_replay(
+    const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, const WT *__restrict__ mask_g,
+    const uint64_t *__restrict__ replay, const uint32_t *__restrict__ tile_cnt, uint32_t n_tiles,
+    const uint32_t *__restrict__ strip_prefix, const uint32_t *__restrict__ wave_prefix,
+    uint32_t n_strips, agh_marks mk)
+{
+    __shared__ WT lmask[256];
+    lmask[threadIdx.x] = mask_g[threadIdx.x];
+    __syncthreads();
+    const WT finalbit = (WT)1 << (q.m - 1);
+    const uint32_t warm = ((uint32_t)(q.m + q.k + 1) + 15u) & ~15u;
+    const uint32_t total_delims = LEAN ? 0u : mk.counters[AGH_C_NDELIM];
+    for (uint32_t tile = blockIdx.x * 4u + threadIdx.x / WAVE; tile < n_tiles; tile += gridDim.x * 4u) {
+        const uint32_t cnt = tile_cnt[tile];
+        for (uint32_t e = (uint32_t)lane_id(); e < cnt; e += WAVE) {
+            const uint64_t P = replay[(uint64_t)tile * AGH_FF_SLICE + e];
+            const uint64_t start = P >= warm ? P - warm : 0;
+            uint64_t end = P + 16;
+            if (end > n) end = n;
+            Automaton<WT, K> A;
+            A.reset();
+            if (start == 0) A.step(lmask[q.head_byte], finalbit);
+            uint64_t last_delim = ~0ull;        // last delimiter at an offset in [start, i)
+            bool seen = false;
+            uint32_t rec = 0;
+            if (!LEAN) {
+                // record number of byte P: census of its strip + the delimiters from the strip start
+                const uint64_t strip = P >> AGH_STRIP_SHIFT;
+                rec = strip < n_strips ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] : total_delims;
+                const uint32_t dd = q.delim * 0x01010101u;
+                for (uint64_t i = strip << AGH_STRIP_SHIFT; i < P; i += 16)
+                    rec += delims_in(*reinterpret_cast<const uint4 *>(text + i), dd);
+            }
+            for (uint64_t i = start; i < end; ++i) {
+                const uint32_t c = text[i];
+                const bool hit = A.step(lmask[c], finalbit);
+                if (hit && !seen && i >= P) {
+                    seen = true;
+                    if (LEAN) {
+                        const uint64_t st = last_delim != ~0ull ? last_delim + 1 : lean_record_start(text, start, q.delim, mk);
+                        if (st != ~0ull) lean_insert(mk, st);
+                    } else {
+                        mark_record(mk, rec, i);
+                    }
+                }
+                if (c == q.delim) {             // (outside every pattern class: the re-fed step cannot hit)
+                    A.reset();
+                    A.step(lmask[c], finalbit);
+                    seen = false;
+                    last_delim = i;
+                    if (!LEAN && i >= P) ++rec;
+                }
+            }
+            if (end == n && q.tail_virtual) {   // asearch.c:87-91
+                uint64_t st = 0;
+                if (LEAN) st = last_delim != ~0ull ? last_delim + 1 : lean_record_start(text, start, q.delim, mk);
+                if (!LEAN || st != ~0ull)
+                    feed_virtual_tail<WT, K, LEAN, false>(text, n, q, lmask, nullptr, A, seen, rec, st, mk);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // host-callable launcher
 // ---------------------------------------------------------------------------------------
 template <typename WT, int K>
@@ -302,6 +575,36 @@ static void launch_fullscan_t(const agh_scan_args &a, hipStream_t st)
     if (!n_tiles) return;
     const uint64_t want = (n_tiles + (AGH_FS_THREADS / WAVE) - 1) / (AGH_FS_THREADS / WAVE);
     const uint32_t blocks = want > 16384 ? 16384u : (uint32_t)want;    // grid-stride beyond that
+    if (a.fs_fast) {
+        // unit costs, one-byte delimiter outside every pattern class (the host checked): the lean hot
+        // kernel + the exact replay of the pieces it listed
+        const bool leanv = a.mk.hashset != nullptr;
+        const bool pack = sizeof(WT) == 4 && a.q.m <= 16;
+        const uint64_t units = pack ? (n_tiles + 1) / 2 : n_tiles;
+        const uint64_t wantf = (units + (AGH_FS_THREADS / WAVE) - 1) / (AGH_FS_THREADS / WAVE);
+        const uint32_t blocksf = wantf > 16384 ? 16384u : (uint32_t)wantf;
+        if constexpr (sizeof(WT) == 4) {
+            if (pack)
+                hipLaunchKernelGGL((k_fullscan_fast<uint32_t, K, true>), dim3(blocksf), dim3(AGH_FS_THREADS), 0, st,
+                                   (const uint8_t *)a.text, a.n, a.q, (const uint32_t *)a.mask, a.fs_replay,
+                                   a.fs_tile_cnt, a.mk.counters);
+        }
+        if (!pack)
+            hipLaunchKernelGGL((k_fullscan_fast<WT, K, false>), dim3(blocksf), dim3(AGH_FS_THREADS), 0, st,
+                               (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.fs_replay,
+                               a.fs_tile_cnt, a.mk.counters);
+        const uint32_t nt = (uint32_t)n_tiles;
+        const uint32_t rblocks = (nt + 3u) / 4u > 16384u ? 16384u : (nt + 3u) / 4u;
+        if (leanv)
+            hipLaunchKernelGGL((k_fullscan_replay<WT, K, true>), dim3(rblocks), dim3(256), 0, st,
+                               (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, (const uint64_t *)a.fs_replay,
+                               (const uint32_t *)a.fs_tile_cnt, nt, a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);
+        else
+            hipLaunchKernelGGL((k_fullscan_replay<WT, K, false>), dim3(rblocks), dim3(256), 0, st,
+                               (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, (const uint64_t *)a.fs_replay,
+                               (const uint32_t *)a.fs_tile_cnt, nt, a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);
+        return;
+    }
 #define AGH_FS_LAUNCH(MBV, GENV, LEANV)                                                       \
     hipLaunchKernelGGL((k_fullscan<WT, K, MBV, GENV, LEANV>), dim3(blocks), dim3(AGH_FS_THREADS), \
                        0, st, (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask,             \

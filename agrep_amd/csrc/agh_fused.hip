@@ -67,9 +67,9 @@
 #define AGH_FU_SPIN_LIMIT (1u << 23)
 // small tickets at the end of the text (see launch_fused): MiB of text handed out in tickets of ... KiB
 #ifndef AGH_FU_TAIL_MB_DEFAULT
-#define AGH_FU_TAIL_MB_DEFAULT 0u
+#define AGH_FU_TAIL_MB_DEFAULT 512u
 #endif
-#define AGH_FU_TAIL_KB_DEFAULT 64u
+#define AGH_FU_TAIL_KB_DEFAULT 128u
 
 #ifdef AGH_FU_TRACE
 // diagnostics build (make EXP=1): when each wave stopped sweeping / left the kernel, in 100 MHz ticks
@@ -295,7 +295,10 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     }
     if (range_strips < 16u) range_strips = 16u;
     // the last AGH_FUSED_TAIL_MB of the text go out in tickets of AGH_FUSED_TAIL_KB: the waves stop
-    // within a small ticket's time of each other instead of a large one's (scripts/ab_fused.py)
+    // within a small ticket's time of each other instead of a large one's.  scripts/ab_round3.py,
+    // 64 GiB k = 2 / k = 0: no tail 10.61 / 10.15 ms, 512 MiB in 128 KiB tickets 10.48 / 10.05,
+    // 256 MiB in 64 KiB 10.49 / 10.03, 512 MiB in 32 KiB 10.71 / 10.16; at 8 GiB 128 KiB tickets are
+    // neutral (1.413 -> 1.419 ms) and 64 KiB ones cost 1-5 %
     uint32_t tail_strips = AGH_FU_TAIL_KB_DEFAULT;
     uint64_t tail_total = (uint64_t)AGH_FU_TAIL_MB_DEFAULT << 10;            // in strips (KiB)
     if (const char *e = getenv("AGH_FUSED_TAIL_KB")) {

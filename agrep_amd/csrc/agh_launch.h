@@ -59,6 +59,11 @@ struct agh_scan_args {
     uint32_t gram_spread;
     agh_marks mk;
     uint32_t w_begin, w_end; // lean verify: slices [w_begin, w_end) only (w_end == 0: all nw)
+    // full scan, fast form (agh_fullscan.hip k_fullscan_fast + k_fullscan_replay): list of pieces to
+    // walk exactly (AGH_FF_SLICE entries per 64 KiB tile) and its per-tile counts
+    int fs_fast;
+    uint64_t *fs_replay;
+    uint32_t *fs_tile_cnt;
 };
 
 void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st);
@@ -107,21 +112,25 @@ void agh_launch_gather_records(const void *text, const uint64_t *start, const ui
 void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &q, uint64_t *dbm,
                              uint64_t n_words, uint32_t *counters, hipStream_t st);
 
-// multi-pattern (-f) device tables
-struct agh_multi_dev {
-    const uint32_t *bits;          // 2^18-bit prefix table
-    const uint32_t *bucket_start;
-    const uint32_t *bucket_items;
-    const uint32_t *pat_off;
-    const uint8_t *pool;
-    const uint32_t *piece_owner;   // k-error queries: see agh_multi.hip
-    const uint8_t *piece_po;
-    const uint8_t *owner_len;
-    const uint32_t *owner_mask;
-    const uint32_t *item_info;     // (pool offset << 8) | length per bucket item
+// multi-pattern (-f) device tables: 2^18-bit gram table, bucket directory, bucket items
+struct agh_mp_item {
+    uint32_t info;      // (pool offset << 8) | length of the entry (a pattern, or a piece of one)
+    uint32_t piece;     // entry number | (offset of the probed gram inside the entry << 28)
+    uint32_t owner;     // k-error queries: the pattern the piece was cut from
+    uint32_t pom;       // ... (offset of the piece inside that pattern << 8) | pattern length
 };
-void agh_launch_sweep_multi(const agh_sweep_args &a, const agh_multi_dev &m, const agh_marks &mk,
-                            bool inl, hipStream_t st);
+struct agh_multi_dev {
+    const uint32_t *bits;          // 2^18-bit table of entry grams (two Bloom probes when q == 4)
+    const uint32_t *bucket_start;  // (1 << AGH_MP_BUCKET_BITS) + 1 offsets into items
+    const agh_mp_item *items;      // grouped by gram bucket
+    const uint8_t *pool;           // entry bytes (lower-cased when the query folds case), padded by 16
+    const uint32_t *owner_mask;    // k-error queries: [pattern][256] position masks (bit p-1 = position p)
+};
+// a.ftab = the bit table; a.tail_only: only the partial last strip (the dense kernel took the rest)
+void agh_launch_sweep_multi(const agh_sweep_args &a, hipStream_t st);
+// dense hit sets: probes + verification of all full strips in one kernel
+void agh_launch_dense_multi(const agh_sweep_args &a, const agh_multi_dev &m, const agh_marks &mk,
+                            hipStream_t st);
 void agh_launch_verify_multi(const agh_scan_args &a, const agh_multi_dev &m, bool lean,
                              hipStream_t st);
 void agh_launch_census_scan(const agh_sweep_args &a, bool with_cand, hipStream_t st);

@@ -124,6 +124,55 @@ def reference_all_shards(text_dev, n_bytes, k, q, shard_bytes, first_shard_host)
                     "per-shard counts compared with the GPU's" % (k, PATTERN.decode())}
 
 
+def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes, q=None, all_shards=False):
+    """Time the reference CPU agrep (1 core) on the first sample_bytes of the corpus; with
+    all_shards also run it (all cores) over the whole corpus and compare the counts."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "agrep")
+    sample_bytes = min(sample_bytes, n_bytes)
+    host = text_dev[:sample_bytes].cpu().numpy()
+    if os.path.exists(ref):
+        d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        path = os.path.join(d, "agh_bench_sample_%d.txt" % os.getpid())
+        try:
+            host.tofile(path)
+            cmd = [ref, "-V0", "-%d" % k, "-c", PATTERN.decode(), path]
+            subprocess.run(cmd, stdout=subprocess.PIPE)            # warm-up pass (page cache)
+            t0 = time.time()
+            out = subprocess.run(cmd, stdout=subprocess.PIPE).stdout
+            dt = time.time() - t0
+        finally:
+            if os.path.exists(path):
+                os.unlink(path)
+        cnt = int(out.split()[0]) if out.strip() else -1
+        extra = {}
+        try:
+            extra = cpu_baseline_extras(ref, host, sample_bytes, k, d)
+        except Exception as e:                                  # never lose the headline over this
+            extra = {"extras_error": str(e)[:200]}
+        if all_shards and q is not None and n_bytes >= 2 * sample_bytes and n_bytes % sample_bytes == 0:
+            try:
+                extra["all_shards"] = reference_all_shards(text_dev, n_bytes, k, q, sample_bytes, host)
+                extra["all_shards_count_equals_gpu"] = bool(extra["all_shards"]["equal"])
+            except Exception as e:
+                extra["all_shards_error"] = str(e)[:200]
+        return {"value": round(sample_bytes / 1e9 / dt, 4), "unit": "GB/s", "cores": 1,
+                **extra,
+                "kind": "reference",
+                "sample": "shard 0 of 16 = the first %.2f GiB of the 64 GiB corpus, `agrep -V0 -%d -c %s` "
+                          "(sgrep.c:agrep() path), page cache warm, 1 process"
+                          % (sample_bytes / 2**30, k, PATTERN.decode()),
+                "seconds": round(dt, 3), "count": cnt,
+                "count_equals_gpu": bool(cnt == gpu_count_on_sample)}
+    import _oracle as O                                        # the restatement as a port
+    sample_bytes = min(sample_bytes, 256 << 20)
+    t0 = time.time()
+    cnt = O.asearch(PATTERN, k, host[:sample_bytes])[0]
+    dt = time.time() - t0
+    return {"value": round(sample_bytes / 1e9 / dt, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "first %.2f GiB, oracle/agrep_oracle.c orc_asearch (scalar)" % (sample_bytes / 2**30),
+            "seconds": round(dt, 3), "count": int(cnt)}
+
+
 def measure_traffic(seg_gib, k, timeout_s):
     """HBM read bytes of ONE launch of the dominant kernel, measured now: a child process runs a few scans of
     one segment of the same corpus under `rocprofv3 --pmc FETCH_SIZE` (its own pass, with

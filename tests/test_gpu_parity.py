@@ -99,15 +99,18 @@ def test_headline_pattern_on_generated_corpus(agh, k, nocase):
 
 
 def test_filter_shape_selection(agh):
-    """floor((m-k-q+1)/h) >= k+1 (DESIGN.md 'sample lemma')."""
-    want = {(16, 0): (4, 8), (16, 1): (4, 4), (16, 2): (3, 4), (48, 3): (4, 8), (8, 1): (0, 0),
+    """floor((m-k-q+1)/h) >= k+1 (DESIGN.md 'sample lemma'); (16, 2) takes the H = 2 shape."""
+    os.environ.pop("AGH_SHAPE_H2", None)
+    want = {(16, 0): (4, 8), (16, 1): (4, 4), (16, 2): (4, 2), (48, 3): (4, 8), (8, 1): (0, 0),
             (8, 0): (4, 4), (29, 4): (4, 4), (29, 5): (0, 0), (64, 3): (4, 8), (4, 0): (0, 0)}
     for (m, k), (fq, fh) in want.items():
         with agh.Query(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789-+"[:m], k) as q:
             info = q.info()
         assert (info["filter_q"], info["filter_h"]) == (fq, fh), (m, k, info)
-        if fq:
+        if fq and fh > 2:
             assert (m - k - fq + 1) // fh >= k + 1
+        elif fq:                    # H = 2: the 4-byte samples overlap, one error spoils two
+            assert (m - k - fq + 1) // fh >= 2 * k + 1
 
 
 def _load_scan():
@@ -876,3 +879,31 @@ def test_h2_sample_shape_parity(agh, monkeypatch):
                 r2, _ = q.scan_buffer(tt, flags=agh.COUNT)
             assert (r1.n_matched, [(s, e) for s, e, _ in ms]) == want, (tail, cut)
             assert r2.n_matched == want[0], (tail, cut)
+
+
+def test_fullscan_fast_form_equals_exact_kernel(agh, monkeypatch):
+    """Full scans of unit-cost queries run as k_fullscan_fast (two text streams per lane for m <= 16)
+    + k_fullscan_replay; AGH_FS_FAST=0 is the one-kernel exact form.  Same records from both, also
+    where the replay lists overflow (a match in every record) and the scan falls back."""
+    text, _ = O.corpus(700, seed=99, variants=O.VARIANTS_C2, plant_period=30)
+    tb = text.tobytes()
+    rng = random.Random(5)
+    long_pat = bytes(rng.choice(b"abcdefghij") for _ in range(40))
+    cases = [(O.PATTERN_C2, 2), (O.PATTERN_C2, 0), (b"approxim", 2), (b"match", 1), (b"approximate", 3),
+             (b"approximatematchapproxim", 3), (long_pat, 2), (b"ab", 1), (b"e", 0)]
+    dense = b"xxapproximatematchxx\n" * 30000 + b"approximatematch"          # every record matches
+    for pat, k in cases:
+        for t in (tb, tb[:70000] + b"approximatemat", dense):
+            if len(pat) <= 29:
+                want = O.asearch(pat, k, t, cap=400000)
+            else:
+                want = O.wm_count(pat, k, t, word_bits=64, cap=400000)
+            for fast in ("1", "0"):
+                monkeypatch.setenv("AGH_FS_FAST", fast)
+                with agh.Query(pat, k) as q:
+                    r1, ms = q.scan_buffer(t, flags=agh.FORCE_FULLSCAN, cap=400000)
+                    r2, _ = q.scan_buffer(t, flags=agh.FORCE_FULLSCAN | agh.COUNT)
+                    r3, _ = q.scan_buffer(t, flags=agh.FORCE_FULLSCAN | agh.COUNT | agh.FORCE_NUMBERED)
+                assert r1.engine == agh.ENGINE_FULLSCAN
+                assert (r1.n_matched, [(s, e) for s, e, _ in ms]) == want, (pat, k, fast, len(t))
+                assert r2.n_matched == r3.n_matched == want[0], (pat, k, fast, len(t))
