@@ -14,6 +14,7 @@ TIME_SCAN = 0x100
 FORCE_FULLSCAN = 0x10
 FORCE_FILTER = 0x20
 FORCE_NUMBERED = 0x40
+Q_NOCASE, Q_WORD, Q_WHOLELINE = 1, 2, 4
 ENGINE_FULLSCAN = 1
 ENGINE_FILTER = 2
 
@@ -66,6 +67,10 @@ def lib():
     L.agh_query_multi.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, u8p,
                                   C.c_int]
     L.agh_query_multi.restype = vp
+    L.agh_query_literal_ex.argtypes = [u8p, C.c_int, C.c_int, C.c_uint, u8p, C.c_int]
+    L.agh_query_literal_ex.restype = vp
+    L.agh_query_multi_ex.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_uint, u8p, C.c_int]
+    L.agh_query_multi_ex.restype = vp
     L.agh_query_multi_approx.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                          C.c_int, u8p, C.c_int]
     L.agh_query_multi_approx.restype = vp
@@ -142,7 +147,7 @@ def set_device(i):
 class Query:
     """A compiled pattern (agh_query_literal / agh_query_from_maskgen)."""
 
-    def __init__(self, pattern, k=0, nocase=False, delim=b"\n", _handle=None):
+    def __init__(self, pattern, k=0, nocase=False, delim=b"\n", _handle=None, word=False, wholeline=False):
         self._h = None
         L = lib()
         if _handle is not None:
@@ -150,7 +155,11 @@ class Query:
         else:
             pattern = bytes(pattern)
             delim = bytes(delim)
-            self._h = L.agh_query_literal(pattern, len(pattern), k, int(nocase), delim, len(delim))
+            if word or wholeline:               # -w / -x guards of the simple-pattern engines
+                qf = (Q_NOCASE if nocase else 0) | (Q_WORD if word else 0) | (Q_WHOLELINE if wholeline else 0)
+                self._h = L.agh_query_literal_ex(pattern, len(pattern), k, qf, delim, len(delim))
+            else:
+                self._h = L.agh_query_literal(pattern, len(pattern), k, int(nocase), delim, len(delim))
         if not self._h:
             raise AghError(L.agh_last_error().decode("latin1"))
 
@@ -166,7 +175,7 @@ class Query:
         return cls(None, _handle=h)
 
     @classmethod
-    def multi(cls, patterns, nocase=False, delim=b"\n", k=0):
+    def multi(cls, patterns, nocase=False, delim=b"\n", k=0, word=False, wholeline=False):
         """-f: multi-pattern query; exact (agh_query_multi) or with k errors
         (agh_query_multi_approx)."""
         pats = [bytes(p) for p in patterns]
@@ -175,6 +184,9 @@ class Query:
         if k:
             h = lib().agh_query_multi_approx(arr, lens, len(pats), int(k), int(nocase), bytes(delim),
                                              len(delim))
+        elif word or wholeline:
+            qf = (Q_NOCASE if nocase else 0) | (Q_WORD if word else 0) | (Q_WHOLELINE if wholeline else 0)
+            h = lib().agh_query_multi_ex(arr, lens, len(pats), qf, bytes(delim), len(delim))
         else:
             h = lib().agh_query_multi(arr, lens, len(pats), int(nocase), bytes(delim), len(delim))
         if not h:

@@ -138,6 +138,7 @@ struct agh_query {
     // many errors): the multi-pattern tables hold its k+1 pieces (or the pattern itself, k = 0)
     bool piece_single = false;
     int pe_fq = 0, pe_minlen = 0;
+    int guard = 0;                      // -f with -w (1) / -x (2): checked by the exact verifier
     int mp_stride = 1;                  // multi-pattern sweep: probe every 1 / 2 / 4 bytes (fill_multi_tables)
     bool mp_q5 = false;                 // ... with 5-byte grams (stride 4, entries of >= 8 bytes)
     uint32_t pe_qmask = 0, pe_fold = 0;
@@ -436,11 +437,21 @@ static agh_query *finish_query(agh_query *q)
     return q;
 }
 
-extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, int nocase,
-                                        const unsigned char *delim, int dlen)
+static bool c_isalnum(int c)       // isalnum() of the C locale, the one bm() and monkey1() see
 {
-    if (!pat || m < 1 || m > AGH_MAX_PATTERN) {
-        fail("pattern length %d outside 1..%d", m, AGH_MAX_PATTERN);
+    return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
+}
+
+extern "C" agh_query *agh_query_literal_ex(const unsigned char *pat, int m, int D, unsigned qflags,
+                                           const unsigned char *delim, int dlen)
+{
+    const int nocase = (qflags & AGH_Q_NOCASE) ? 1 : 0;
+    // guard positions around the pattern: -x wraps it into '\n' (sgrep.c:252-259), -w into the class
+    // of non-alphanumeric bytes (the test bm() makes on the bytes next to an occurrence, sgrep.c:750-756)
+    const int guard = (qflags & AGH_Q_WHOLELINE) ? 2 : ((qflags & AGH_Q_WORD) ? 1 : 0);
+    const int M = m + (guard ? 2 : 0);
+    if (!pat || m < 1 || M > AGH_MAX_PATTERN) {
+        fail("pattern length %d outside 1..%d", m, AGH_MAX_PATTERN - (guard ? 2 : 0));
         return nullptr;
     }
     if (D < 0 || D > AGH_MAX_ERRORS || D >= m) {   // checksg.c:34-41
@@ -458,7 +469,7 @@ extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, 
     // the delimiter positions too ("X" ends a record of -d x); such delimiters go through the
     // delimiter bitmap (delim_class folds), whatever their length
     agh_query *q = new agh_query();
-    q->m = m;
+    q->m = M;
     q->k = D;
     q->dlen = dlen;
     memcpy(q->delim, delim, (size_t)dlen);
@@ -468,13 +479,29 @@ extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, 
             if (is_upper(q->delim[i])) q->delim[i] = (unsigned char)(q->delim[i] + 32);
     }
     memset(q->mask, 0, sizeof(q->mask));
+    const int off = guard ? 1 : 0;
     for (int p = 0; p < m; ++p) {
         int c = pat[p];
         if (nocase && is_upper(c)) c += 32;             // maskgen.c:52-59
-        q->mask[c] |= (uint64_t)1 << p;
-        if (nocase && is_lower(c)) q->mask[c - 32] |= (uint64_t)1 << p;   // maskgen.c:259-266
+        q->mask[c] |= (uint64_t)1 << (p + off);
+        if (nocase && is_lower(c)) q->mask[c - 32] |= (uint64_t)1 << (p + off);   // maskgen.c:259-266
+    }
+    if (guard) {
+        const uint64_t ends = (uint64_t)1 | ((uint64_t)1 << (M - 1));
+        for (int c = 0; c < 256; ++c)
+            if (guard == 2 ? c == '\n' : !c_isalnum(c)) q->mask[c] |= ends;
+        if (D > 0) {                                    // no error may touch a guard (maskgen.c:171-187)
+            q->general = true;
+            q->no_err = (M == 64 ? ~0ull : (((uint64_t)1 << M) - 1)) & ~ends;
+        }
     }
     return finish_query(q);
+}
+
+extern "C" agh_query *agh_query_literal(const unsigned char *pat, int m, int D, int nocase,
+                                        const unsigned char *delim, int dlen)
+{
+    return agh_query_literal_ex(pat, m, D, nocase ? AGH_Q_NOCASE : 0u, delim, dlen);
 }
 
 // One byte through asearch.c's recurrence on reference-layout tables (host copy of what
@@ -745,9 +772,10 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
 // single-pattern k-error predicate over all patterns (BASELINE config 5), filtered through
 // D+1 verbatim pieces per pattern (agh_multi.hip).
 static agh_query *build_multi(const unsigned char *const *pats, const int *lens, int npat, int D,
-                              int nocase, const unsigned char *delim, int dlen)
+                              int nocase, const unsigned char *delim, int dlen, int guard = 0)
 {
     if (!pats || !lens || npat < 1) { fail("no patterns"); return nullptr; }
+    if (guard && D > 0) { fail("-w / -x with a pattern file need exact matching"); return nullptr; }
     if (!delim || dlen != 1) {
         fail("multi-pattern scans support single-byte delimiters only");
         return nullptr;
@@ -775,6 +803,7 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
     agh_query *q = new agh_query();
     q->multi = true;
     q->npat = npat;
+    q->guard = guard;
     q->k = D;
     q->dlen = 1;
     q->delim[0] = delim[0];
@@ -793,6 +822,13 @@ extern "C" agh_query *agh_query_multi(const unsigned char *const *pats, const in
                                       int nocase, const unsigned char *delim, int dlen)
 {
     return build_multi(pats, lens, npat, 0, nocase, delim, dlen);
+}
+
+extern "C" agh_query *agh_query_multi_ex(const unsigned char *const *pats, const int *lens, int npat,
+                                         unsigned qflags, const unsigned char *delim, int dlen)
+{
+    return build_multi(pats, lens, npat, 0, (qflags & AGH_Q_NOCASE) ? 1 : 0, delim, dlen,
+                       (qflags & AGH_Q_WHOLELINE) ? 2 : ((qflags & AGH_Q_WORD) ? 1 : 0));
 }
 
 extern "C" agh_query *agh_query_multi_approx(const unsigned char *const *pats, const int *lens,
@@ -990,6 +1026,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     dq.dfold = q->delim_fold ? 1u : 0u;
     dq.mb = q_mb(q) ? 1u : 0u;
     dq.mp_q5 = (multi && q->mp_q5) ? 1u : 0u;
+    dq.guard = q->multi ? (uint32_t)q->guard : 0u;
     dq.fq = pe ? q->pe_fq : q->fq;
     dq.fh = pe ? q->mp_stride : q->fh;                  // multi-pattern sweeps: the probe stride
     dq.qmask = pe ? q->pe_qmask : q->qmask;
@@ -1547,6 +1584,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     dq.dfold = 0;
     dq.mb = 0;
     dq.mp_q5 = 0;
+    dq.guard = 0;
     dq.fq = q->fq;
     dq.fh = q->fh;
     dq.qmask = q->qmask;

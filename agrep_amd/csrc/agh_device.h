@@ -63,6 +63,7 @@ struct agh_dev_query {
     uint32_t dfold;     // 1: delimiter bytes match case-insensitively (-i with letters in the delimiter)
     uint32_t mb;        // 1: delimiter ends come from the delimiter bitmap (dlen > 1, or a folded letter)
     uint32_t mp_q5;     // multi-pattern sweep at stride 4: the probed grams have 5 bytes (entries >= 8 bytes)
+    uint32_t guard;     // -f: 1 = -w (non-alphanumeric bytes around an occurrence), 2 = -x (whole line)
     int32_t fq;         // filter: sample length in bytes (1..4), 0 = no filter
     int32_t fh;         // filter: sample stride in bytes (4, 8 or 16)
     uint32_t qmask;     // low fq bytes

@@ -331,51 +331,62 @@ __device__ __forceinline__ WT ff_step(Automaton<WT, K> &A, WT cm, WT kb, WT ones
     return A.R[K];
 }
 
-// 16 bytes of stream A (and, PACK, 16 bytes of stream B) through the automaton; -> OR of the top level
-template <typename WT, int K, bool PACK>
-__device__ __forceinline__ WT ff_piece(uint4 va, uint4 vb, const MaskKill<WT> *tabA,
-                                       const MaskKill<WT> *tabB, Automaton<WT, K> &A, WT ones)
+// 16 bytes of one stream through the automaton (m <= 32 / 64: one stream per lane); -> OR of the top level
+template <typename WT, int K>
+__device__ __forceinline__ WT ff_piece(uint4 va, const MaskKill<WT> *tab, Automaton<WT, K> &A)
 {
-    const uint32_t da[4] = {va.x, va.y, va.z, va.w}, db[4] = {vb.x, vb.y, vb.z, vb.w};
+    const uint32_t da[4] = {va.x, va.y, va.z, va.w};
     WT any = 0;
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
-        const MaskKill<WT> ea = tabA[(da[b >> 2] >> (8 * (b & 3))) & 0xffu];
-        WT cm = ea.cm, kb = ea.kb;
-        if (PACK) {
-            const MaskKill<WT> eb = tabB[(db[b >> 2] >> (8 * (b & 3))) & 0xffu];
-            cm |= eb.cm;
-            kb &= eb.kb;
-        }
-        any |= ff_step<WT, K>(A, cm, kb, ones);
+        const MaskKill<WT> e = tab[(da[b >> 2] >> (8 * (b & 3))) & 0xffu];
+        any |= ff_step<WT, K>(A, e.cm, e.kb, (WT)1);
     }
     return any;
 }
 
+// ... and of two streams in the halves of a 32-bit word.  One table of 32-bit entries serves both:
+// low half = the byte's position mask (m <= 16), high half = 0xffff unless the byte is the delimiter;
+// two v_perm_b32 put the halves of the two entries where the packed step wants them
+// (cm = maskA | maskB << 16, kb = killA | killB << 16).
+template <int K>
+__device__ __forceinline__ uint32_t ff_piece2(uint4 va, uint4 vb, const uint32_t *tab, Automaton<uint32_t, K> &A)
+{
+    const uint32_t da[4] = {va.x, va.y, va.z, va.w}, db[4] = {vb.x, vb.y, vb.z, vb.w};
+    uint32_t any = 0;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const uint32_t ta = tab[(da[b >> 2] >> (8 * (b & 3))) & 0xffu];
+        const uint32_t tb = tab[(db[b >> 2] >> (8 * (b & 3))) & 0xffu];
+        const uint32_t cm = __builtin_amdgcn_perm(tb, ta, 0x05040100u);
+        const uint32_t kb = __builtin_amdgcn_perm(tb, ta, 0x07060302u);
+        any |= ff_step<uint32_t, K>(A, cm, kb, 0x00010001u);
+    }
+    return any;
+}
+
+#define AGH_FF_THREADS 128u     // two waves per workgroup: 2 x 10 KiB of ring for the two-stream form
+
 template <typename WT, int K, bool PACK>
-__global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan_fast(
+__global__ __launch_bounds__(AGH_FF_THREADS) void k_fullscan_fast(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, const WT *__restrict__ mask_g,
     uint64_t *__restrict__ replay, uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters)
 {
     constexpr int NS = PACK ? 2 : 1;                    // text streams per lane
-    __shared__ MaskKill<WT> tabA[256];
-    __shared__ MaskKill<WT> tabB[PACK ? 256 : 1];
-    __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * NS * WAVE * AGH_FS_ROW];
-    {
-        const WT cm = mask_g[threadIdx.x];
-        const bool isd = threadIdx.x == q.delim;
+    __shared__ MaskKill<WT> tabA[PACK ? 1 : 256];
+    __shared__ uint32_t tab2[PACK ? 256 : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FF_THREADS / WAVE) * NS * WAVE * AGH_FS_ROW];
+    for (uint32_t c = threadIdx.x; c < 256u; c += AGH_FF_THREADS) {
+        const WT cm = mask_g[c];
+        const bool isd = c == q.delim;
         if (PACK) {
-            tabA[threadIdx.x].cm = cm & (WT)0xffffu;
-            tabA[threadIdx.x].kb = isd ? (WT)0xffff0000u : ~(WT)0;
-            tabB[threadIdx.x].cm = (WT)(cm << 16);
-            tabB[threadIdx.x].kb = isd ? (WT)0x0000ffffu : ~(WT)0;
+            tab2[c] = ((uint32_t)cm & 0xffffu) | (isd ? 0u : 0xffff0000u);
         } else {
-            tabA[threadIdx.x].cm = cm;
-            tabA[threadIdx.x].kb = isd ? (WT)0 : ~(WT)0;
+            tabA[c].cm = cm;
+            tabA[c].kb = isd ? (WT)0 : ~(WT)0;
         }
     }
     __syncthreads();
-    const WT ones = PACK ? (WT)0x00010001u : (WT)1;
     const WT finalA = (WT)1 << (q.m - 1);
     const WT finalB = PACK ? (WT)(finalA << 16) : (WT)0;
     const int lane = lane_id();
@@ -390,9 +401,13 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan_fast(
     const uint32_t seg_lo = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
     uint8_t *ring_w = ring + seg_lo * AGH_FS_ROW + part * 16u;
     const uint8_t *ring_r = ring + (uint32_t)lane * AGH_FS_ROW;
+    auto piece = [&](uint4 va, uint4 vb, Automaton<WT, K> &A) -> WT {
+        if constexpr (PACK) return ff_piece2<K>(va, vb, tab2, A);
+        else return ff_piece<WT, K>(va, tabA, A);
+    };
 
-    for (uint64_t unit = (uint64_t)blockIdx.x * (AGH_FS_THREADS / WAVE) + wib; unit < n_units;
-         unit += (uint64_t)gridDim.x * (AGH_FS_THREADS / WAVE)) {
+    for (uint64_t unit = (uint64_t)blockIdx.x * (AGH_FF_THREADS / WAVE) + wib; unit < n_units;
+         unit += (uint64_t)gridDim.x * (AGH_FF_THREADS / WAVE)) {
         uint64_t t0[NS], cs[NS];
         uint32_t len[NS], cnt[NS];
 #pragma unroll
@@ -425,14 +440,14 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan_fast(
                 uint4 wa = fillv, wb = fillv;
                 if (len[0] && cs[0] >= warm) wa = *reinterpret_cast<const uint4 *>(text + cs[0] - warm + 16u * t);
                 if (PACK && len[NS - 1] && cs[NS - 1] >= warm) wb = *reinterpret_cast<const uint4 *>(text + cs[NS - 1] - warm + 16u * t);
-                (void)ff_piece<WT, K, PACK>(wa, wb, tabA, tabB, A, ones);
+                (void)piece(wa, wb, A);
             }
             if (cs[0] == 0) {                   // (only stream A of the first unit starts the text)
                 Automaton<WT, K> H;
                 H.reset();
-                const MaskKill<WT> eh = tabA[q.head_byte & 0xffu];
-                (void)ff_step<WT, K>(H, (WT)(eh.cm & (PACK ? (WT)0xffffu : ~(WT)0)), (WT)(eh.kb | (PACK ? (WT)0xffff0000u : (WT)0)),
-                                     (WT)1);
+                const uint32_t hb = q.head_byte & 0xffu;
+                const WT hcm = mask_g[hb];
+                (void)ff_step<WT, K>(H, PACK ? (WT)(hcm & (WT)0xffffu) : hcm, hb == q.delim ? (WT)0 : ~(WT)0, (WT)1);
 #pragma unroll
                 for (int l = 0; l <= K; ++l)
                     A.R[l] = PACK ? (WT)((A.R[l] & (WT)0xffff0000u) | (H.R[l] & (WT)0xffffu)) : H.R[l];
@@ -446,20 +461,20 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan_fast(
                     *reinterpret_cast<uint4 *>(ring_w + st * (WAVE * AGH_FS_ROW) + 16u * i * AGH_FS_ROW) = g[st][i];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the whole wave's rows are in
             __builtin_amdgcn_wave_barrier();
-            uint4 v[NS][4];
-#pragma unroll
-            for (int st = 0; st < NS; ++st)
-#pragma unroll
-                for (uint32_t p = 0; p < 4; ++p)
-                    v[st][p] = *reinterpret_cast<const uint4 *>(ring_r + st * (WAVE * AGH_FS_ROW) + 16u * p);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next round overwrites
-            __builtin_amdgcn_wave_barrier();
             if (r + 1 < AGH_FS_CHUNK / AGH_FS_ROUND) gather(r + 1, g);   // in flight during the walk
             uint32_t flags = 0;                 // bit 4*st + p: piece p of stream st goes to the replay list
-#pragma unroll
+            // (not unrolled: across four pieces the scheduler hoists table reads until the two-stream
+            // instances need 134-138 VGPRs -- one wave per SIMD less -- and a register cap spills)
+#pragma unroll 1
             for (uint32_t p = 0; p < 4; ++p) {
                 const uint32_t off = r * AGH_FS_ROUND + 16u * p;
-                const WT any = ff_piece<WT, K, PACK>(v[0][p], v[NS - 1][p], tabA, tabB, A, ones);
+                // the lane's own 16 bytes of every stream, read when they are needed (the ring is not
+                // written again before the next round: eight VGPRs of text instead of thirty-two)
+                uint4 v[NS];
+#pragma unroll
+                for (int st = 0; st < NS; ++st)
+                    v[st] = *reinterpret_cast<const uint4 *>(ring_r + st * (WAVE * AGH_FS_ROW) + 16u * p);
+                const WT any = piece(v[0], v[NS - 1], A);
 #pragma unroll
                 for (int st = 0; st < NS; ++st) {
                     const WT fb = st == 0 ? finalA : finalB;
@@ -581,16 +596,16 @@ static void launch_fullscan_t(const agh_scan_args &a, hipStream_t st)
         const bool leanv = a.mk.hashset != nullptr;
         const bool pack = sizeof(WT) == 4 && a.q.m <= 16;
         const uint64_t units = pack ? (n_tiles + 1) / 2 : n_tiles;
-        const uint64_t wantf = (units + (AGH_FS_THREADS / WAVE) - 1) / (AGH_FS_THREADS / WAVE);
-        const uint32_t blocksf = wantf > 16384 ? 16384u : (uint32_t)wantf;
+        const uint64_t wantf = (units + (AGH_FF_THREADS / WAVE) - 1) / (AGH_FF_THREADS / WAVE);
+        const uint32_t blocksf = wantf > 32768 ? 32768u : (uint32_t)wantf;
         if constexpr (sizeof(WT) == 4) {
             if (pack)
-                hipLaunchKernelGGL((k_fullscan_fast<uint32_t, K, true>), dim3(blocksf), dim3(AGH_FS_THREADS), 0, st,
+                hipLaunchKernelGGL((k_fullscan_fast<uint32_t, K, true>), dim3(blocksf), dim3(AGH_FF_THREADS), 0, st,
                                    (const uint8_t *)a.text, a.n, a.q, (const uint32_t *)a.mask, a.fs_replay,
                                    a.fs_tile_cnt, a.mk.counters);
         }
         if (!pack)
-            hipLaunchKernelGGL((k_fullscan_fast<WT, K, false>), dim3(blocksf), dim3(AGH_FS_THREADS), 0, st,
+            hipLaunchKernelGGL((k_fullscan_fast<WT, K, false>), dim3(blocksf), dim3(AGH_FF_THREADS), 0, st,
                                (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.fs_replay,
                                a.fs_tile_cnt, a.mk.counters);
         const uint32_t nt = (uint32_t)n_tiles;

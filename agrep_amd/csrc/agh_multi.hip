@@ -95,6 +95,11 @@ __device__ __forceinline__ uint32_t probe_chunk_l2(uint32_t h, uint32_t w0, uint
     return keep;
 }
 
+__device__ __forceinline__ bool dev_isalnum(uint32_t c)      // isalnum() of the C locale
+{
+    return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u);
+}
+
 // ASCII upper -> lower in four bytes at once (newmgrep.c: tr[] folds case under -i).
 __device__ __forceinline__ uint32_t swar_lower(uint32_t t)
 {
@@ -345,6 +350,16 @@ __device__ __forceinline__ void mp_verify_at(const uint8_t *__restrict__ text, u
         item.info = raw.x; item.piece = raw.y; item.owner = raw.z; item.pom = raw.w;
         const uint64_t js = mp_item_occurs(text, n, q, mt, item, w, j);
         if (js == ~0ull) continue;
+        if (K == 0 && q.guard) {
+            // -w / -x with -f (newmgrep.c:869-872, :835-840): the bytes next to the occurrence; the
+            // virtual byte in front of the text and the delimiter appended behind it count
+            const uint32_t len = item.info & 0xffu;
+            const uint32_t before = js ? text[js - 1] : q.head_byte;
+            const uint32_t after = js + len < n ? text[js + len] : q.delim;
+            const bool ok = q.guard == 2u ? (before == '\n' && after == '\n')
+                                          : !(dev_isalnum(before) || dev_isalnum(after));
+            if (!ok) continue;
+        }
         if (K == 0) {
             multi_mark<LEAN>(text, q, mk, j, rc_chunk);
             return;                             // one verbatim entry is enough for the record

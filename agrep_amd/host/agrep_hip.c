@@ -1,6 +1,6 @@
 /*
  * agrep_hip.c -- C host side of the MI355X agrep scanner: the command-line surface of the
- * reference for the k-error hot path ( -# -c -l -i -d -B -y -n -h -s -e -k -f -I -S -D -V0 ), driving the
+ * reference for the k-error hot path ( -# -c -l -i -w -x -d -B -y -n -h -s -e -k -f -I -S -D -V0 ), driving the
  * HIP C-ABI of include/agrep_hip.h.  It mirrors, for literal patterns,
  *
  *   option parsing      agrep.c:2121-2739  (grouped flags, a digit run ends its group)
@@ -38,6 +38,8 @@ static struct {
     int SILENT;            /* -s  */
     int INVERSE;           /* -v  */
     int BESTMATCH;         /* -B  */
+    int WORDBOUND;         /* -w  */
+    int WHOLELINE;         /* -x  */
     int NOPROMPT;          /* -y  */
     int VERBOSE;           /* -V# (default 1: print the Grand Total line) */
     int APPROX;            /* a -# was given */
@@ -47,13 +49,14 @@ static struct {
     const char *pattern;
     const char *pattern_file;  /* -f  PAT_FILE */
     int gpus;              /* --gpus N: shard every file over N GPUs (0: the plain one-GPU path) */
+    int approx_f;          /* --approx-f: -# applies to -f patterns too (BASELINE config 5; the reference ignores it) */
 } opt;
 
 static void die_usage(const char *msg)
 {
     fprintf(stderr, "%s: %s\n", Progname, msg);
     fprintf(stderr,
-            "usage: %s [--gpus N] [-#cilnhsvyB] [-V0] [-d delim] [-e pattern | -f patternfile | pattern] [file ...]\n",
+            "usage: %s [--gpus N] [--approx-f] [-#cilwxnhsvyB] [-V0] [-d delim] [-e pattern | -f patternfile | pattern] [file ...]\n",
             Progname);
     exit(2);
 }
@@ -99,6 +102,10 @@ static int parse_options(int argc, char **argv, char **files)
                 die_usage("--gpus needs a device count in 1..64");
             continue;
         }
+        if (opt.pattern == NULL && strcmp(a, "--approx-f") == 0) {   /* not a reference option either */
+            opt.approx_f = 1;
+            continue;
+        }
         if (a[0] == '-' && a[1] != '\0') {
             char *p = a + 1;
             if (opt.pattern != NULL) {           /* after the pattern everything is a file */
@@ -128,6 +135,8 @@ static int parse_options(int argc, char **argv, char **files)
                 case 'v': opt.INVERSE = 1; break;
                 case 'y': opt.NOPROMPT = 1; break;
                 case 'B': opt.BESTMATCH = 1; break;
+                case 'w': opt.WORDBOUND = 1; break;
+                case 'x': opt.WHOLELINE = 1; break;
                 case 'k': literal_only = 1; break;
                 case 'V':
                     opt.VERBOSE = (*p >= '0' && *p <= '9') ? atoi(p) : 1;
@@ -171,9 +180,9 @@ static int parse_options(int argc, char **argv, char **files)
     if (opt.pattern_file) {
         /* compat.c:26-37: -B is ignored with -f; -# is not supported with -f (warning only) */
         if (opt.BESTMATCH) opt.BESTMATCH = 0;
-        if (opt.APPROX && opt.D > 0)
+        if (opt.APPROX && opt.D > 0 && !opt.approx_f)
             fprintf(stderr, "%s: approximate matching is not supported with -f option\n", Progname);
-        opt.D = 0;
+        if (!opt.approx_f) opt.D = 0;
         if (opt.COUNT && opt.FILENAMEONLY) opt.FILENAMEONLY = 0;
         return nfiles;
     }
@@ -521,10 +530,14 @@ static int g_multi_n;
 static agh_query *build_cli_query(void)
 {
     agh_query *q;
+    const unsigned qf = (opt.NOUPPER ? AGH_Q_NOCASE : 0u) | (opt.WORDBOUND ? AGH_Q_WORD : 0u) |
+                        (opt.WHOLELINE ? AGH_Q_WHOLELINE : 0u);
+    if (opt.pattern_file && opt.approx_f && opt.D > 0)      /* union of the k-error predicate over the patterns */
+        return agh_query_multi_approx(g_multi_pats, g_multi_lens, g_multi_n, opt.D, opt.NOUPPER, opt.delim, opt.dlen);
     if (opt.pattern_file)
-        return agh_query_multi(g_multi_pats, g_multi_lens, g_multi_n, opt.NOUPPER, opt.delim, opt.dlen);
-    q = agh_query_literal((const unsigned char *)opt.pattern, (int)strlen(opt.pattern), opt.D,
-                          opt.NOUPPER, opt.delim, opt.dlen);
+        return agh_query_multi_ex(g_multi_pats, g_multi_lens, g_multi_n, qf, opt.delim, opt.dlen);
+    q = agh_query_literal_ex((const unsigned char *)opt.pattern, (int)strlen(opt.pattern), opt.D, qf,
+                             opt.delim, opt.dlen);
     if (q && (opt.I || opt.S || opt.DD) &&
         agh_query_set_costs(q, opt.I ? opt.I : 1, opt.S ? opt.S : 1, opt.DD ? opt.DD : 1)) {
         agh_query_free(q);
@@ -619,8 +632,10 @@ int main(int argc, char **argv)
         q = NULL;
         for (D = 0; D <= maxD && D < m; D++) {
             long fm = 0;
-            q = agh_query_literal((const unsigned char *)opt.pattern, m, D, opt.NOUPPER,
-                                  opt.delim, opt.dlen);
+            q = agh_query_literal_ex((const unsigned char *)opt.pattern, m, D,
+                                     (opt.NOUPPER ? AGH_Q_NOCASE : 0u) | (opt.WORDBOUND ? AGH_Q_WORD : 0u) |
+                                         (opt.WHOLELINE ? AGH_Q_WHOLELINE : 0u),
+                                     opt.delim, opt.dlen);
             if (!q) { fprintf(stderr, "%s: %s\n", Progname, agh_last_error()); exit(2); }
             found = run_pass(q, files, nfiles, 0, 1, &fm);
             if (found > 0) break;

@@ -326,10 +326,29 @@ int bitap(char old_D_pat[], char *Pattern, int fd, int M, int D)
     return run_scan(g_bq, &src, (const unsigned char *)old_D_pat, D_length);
 }
 
+/* AGH_REF_QUIRKS=q6: reproduce quirk Q6 of the reference on request -- its simple-pattern engines
+ * fold case whether or not -i was given (char_tr() fills TR[] unconditionally, sgrep.c:226-236;
+ * bm() compares through TR[]), so `agrep word file` also prints "Word".  Off by default: the GPU
+ * engines are case-sensitive without -i, like the reference's own bitap path. */
+static int quirk_q6(void)
+{
+    const char *e = getenv("AGH_REF_QUIRKS");
+    return e && (strstr(e, "q6") || strstr(e, "Q6"));
+}
+
+/* the guards the simple-pattern engines read from globals: -i, -w (bm()'s isalnum test,
+ * sgrep.c:750-756; monkey1()'s, newmgrep.c:869-872), -x (char_tr()'s "\n pat \n", sgrep.c:252-259) */
+static unsigned simple_qflags(int D)
+{
+    return ((NOUPPER || (D == 0 && quirk_q6())) ? AGH_Q_NOCASE : 0u) | (WORDBOUND ? AGH_Q_WORD : 0u) |
+           (WHOLELINE ? AGH_Q_WHOLELINE : 0u);
+}
+
 /* ---- sgrep(): the simple-pattern engines ------------------------------------------------ */
 static agh_query *g_sq;
 static unsigned char g_sq_pat[300];
-static int g_sq_m = -1, g_sq_D, g_sq_i, g_sq_dlen;
+static int g_sq_m = -1, g_sq_D, g_sq_dlen;
+static unsigned g_sq_i;
 static unsigned char g_sq_delim[AGH_MAX_DELIM + 1];
 
 int sgrep(unsigned char *in_pat, int in_m, int fd, int D, int samepattern)
@@ -337,6 +356,7 @@ int sgrep(unsigned char *in_pat, int in_m, int fd, int D, int samepattern)
     unsigned char pat[300];
     const unsigned char *delim = (const unsigned char *)"\n";
     int m = in_m, k, j, dlen = 1;
+    unsigned qf;
     struct text_src src;
     (void)samepattern;
     if (m <= 0 || m >= 256) return shim_fail("pattern too long");
@@ -351,21 +371,20 @@ int sgrep(unsigned char *in_pat, int in_m, int fd, int D, int samepattern)
             for (j = k; j < m; j++) pat[j] = pat[j + 1];
             m--;
         }
-    if (WHOLELINE || WORDBOUND)
-        return shim_fail("-x / -w on the simple-pattern path are not served by the GPU engines (use -# or -n: the maskgen path is)");
     if (DELIMITER) {                                    /* agrep.c:3182-3185: the exact bytes */
         delim = D_pattern;
         dlen = D_length;
     }
     if (dlen < 1 || dlen > AGH_MAX_DELIM) return shim_fail("delimiter pattern too long");
-    if (!g_sq || m != g_sq_m || D != g_sq_D || NOUPPER != g_sq_i || dlen != g_sq_dlen ||
+    qf = simple_qflags(D);
+    if (!g_sq || m != g_sq_m || D != g_sq_D || qf != g_sq_i || dlen != g_sq_dlen ||
         memcmp(pat, g_sq_pat, (size_t)m) || memcmp(delim, g_sq_delim, (size_t)dlen)) {
         if (g_sq) agh_query_free(g_sq);
-        g_sq = agh_query_literal(pat, m, D, NOUPPER, delim, dlen);
+        g_sq = agh_query_literal_ex(pat, m, D, qf, delim, dlen);
         if (!g_sq) { g_sq_m = -1; return shim_fail(agh_last_error()); }
         memcpy(g_sq_pat, pat, (size_t)m);
         memcpy(g_sq_delim, delim, (size_t)dlen);
-        g_sq_m = m; g_sq_D = D; g_sq_i = NOUPPER; g_sq_dlen = dlen;
+        g_sq_m = m; g_sq_D = D; g_sq_i = qf; g_sq_dlen = dlen;
     }
     text_of(fd, &src);
     return run_simple(g_sq, &src, delim, dlen);
@@ -374,7 +393,8 @@ int sgrep(unsigned char *in_pat, int in_m, int fd, int D, int samepattern)
 /* ---- prepf() / mgrep(): -f pattern files ------------------------------------------------ */
 static agh_query *g_mq;
 static const unsigned char **g_mp;
-static int *g_ml, g_mn, g_mq_i = -1, g_mq_dlen;
+static int *g_ml, g_mn, g_mq_dlen;
+static unsigned g_mq_i = ~0u;
 static unsigned char g_mq_delim[AGH_MAX_DELIM + 1];
 
 int prepf(int mfp, unsigned char *mbuf, int mlen)
@@ -477,7 +497,7 @@ static int mgrep_all_terminals(int fd, const unsigned char *delim, int dlen)
         len = src.mem_len;
     }
     for (t = 0; t < g_mn && rc == 0; t++) {
-        agh_query *q = agh_query_literal(g_mp[t], g_ml[t], 0, NOUPPER, delim, dlen);
+        agh_query *q = agh_query_literal_ex(g_mp[t], g_ml[t], 0, simple_qflags(0), delim, dlen);
         agh_result res;
         size_t mcap = 65536, a, b, w;
         if (!q) { rc = shim_fail(agh_last_error()); break; }
@@ -533,8 +553,6 @@ int mgrep(int fd, void *AParse)
     int dlen = 1;
     struct text_src src;
     if (g_mn <= 0) return 0;
-    if (WHOLELINE || WORDBOUND)
-        return shim_fail("-x / -w with -f are not served by the GPU engines");
     if (DELIMITER) {
         delim = D_pattern;
         dlen = D_length;
@@ -553,11 +571,11 @@ int mgrep(int fd, void *AParse)
             return rc;
         }
     }
-    if (!g_mq || g_mq_i != NOUPPER || g_mq_dlen != dlen || memcmp(delim, g_mq_delim, (size_t)dlen)) {
+    if (!g_mq || g_mq_i != simple_qflags(0) || g_mq_dlen != dlen || memcmp(delim, g_mq_delim, (size_t)dlen)) {
         if (g_mq) agh_query_free(g_mq);
-        g_mq = agh_query_multi(g_mp, g_ml, g_mn, NOUPPER, delim, dlen);
+        g_mq = agh_query_multi_ex(g_mp, g_ml, g_mn, simple_qflags(0), delim, dlen);
         if (!g_mq) return shim_fail(agh_last_error());
-        g_mq_i = NOUPPER;
+        g_mq_i = simple_qflags(0);
         g_mq_dlen = dlen;
         memcpy(g_mq_delim, delim, (size_t)dlen);
     }

@@ -99,6 +99,21 @@ typedef struct {
 agh_query *agh_query_literal(const unsigned char *pat, int m, int D, int nocase,
                              const unsigned char *delim, int dlen);
 
+/* The same with the guards of the simple-pattern engines (the globals sgrep() and mgrep() consult):
+ *   AGH_Q_NOCASE     -i   NOUPPER
+ *   AGH_Q_WORD       -w   WORDBOUND: the occurrence must have a non-alphanumeric byte (isalnum() of the
+ *                         C locale; the ends of the text count) on both sides -- bm()'s test,
+ *                         sgrep.c:750-756, monkey1()'s for -f, newmgrep.c:869-872
+ *   AGH_Q_WHOLELINE  -x   WHOLELINE: char_tr() wraps the pattern into "\n pat \n" (sgrep.c:252-259):
+ *                         the occurrence is a whole line
+ * With D > 0 no error may touch the guard positions (maskgen.c:171-187 sets their NO_ERR_MASK bits).
+ * m <= AGH_MAX_PATTERN - 2 with a guard. */
+#define AGH_Q_NOCASE    0x1u
+#define AGH_Q_WORD      0x2u
+#define AGH_Q_WHOLELINE 0x4u
+agh_query *agh_query_literal_ex(const unsigned char *pat, int m, int D, unsigned qflags,
+                                const unsigned char *delim, int dlen);
+
 /* Replaces the consumption of maskgen()'s globals by bitap()/asearch()/asearch0()
  * (externs at bitap.c:43-64, asearch.c:4-24): pass the reference's tables unchanged.
  * Mask[256], Init0 = Init[0], Init1, NO_ERR_MASK, endposition, D_endpos as maskgen() left
@@ -119,6 +134,9 @@ agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint
  * exact matching only, like mgrep() (compat.c:34-37 ignores -# with -f).  nocase = -i. */
 agh_query *agh_query_multi(const unsigned char *const *pats, const int *lens, int npat,
                            int nocase, const unsigned char *delim, int dlen);
+/* ... with -w / -x (AGH_Q_* above; newmgrep.c:835-872): exact patterns only. */
+agh_query *agh_query_multi_ex(const unsigned char *const *pats, const int *lens, int npat,
+                              unsigned qflags, const unsigned char *delim, int dlen);
 
 /* -f with errors (BASELINE config 5; beyond the reference, which ignores -# together with -f,
  * compat.c:34-37): a record matches iff it holds a substring within edit distance D of ANY
@@ -202,9 +220,11 @@ int agh_reduce_file_hits_all(agh_comm *const *comms, int n, unsigned char *const
                              size_t n_files);
 
 /* Record-aligned shards of a file (SURVEY 8e ownership rule: a record belongs to the range that
- * holds its first byte): cuts[0] = 0 <= cuts[1] <= ... <= cuts[nranks] = file size, every inner
- * cut placed just after the first delimiter at or after r * size / nranks.  fd must be seekable
- * (pread).  delim/dlen as in agh_query_literal. */
+ * holds its first byte): cuts[0] = 0 <= cuts[1] <= ... <= cuts[nranks] = file size, inner cut r
+ * is the nominal offset r * size / nranks itself if a record starts there (the byte in front of it is
+ * the delimiter), else the offset just after the next delimiter at or after it -- the rule of
+ * agrep_amd/shard.py:record_cuts, so callers that derive the cuts themselves get the same shards as
+ * `agrep-hip --gpus`.  fd must be seekable (pread).  delim/dlen as in agh_query_literal. */
 int agh_shard_cuts_fd(int fd, const unsigned char *delim, int dlen, int nranks, uint64_t *cuts);
 
 /* agh_scan_fd restricted to the byte range [begin, end) of a seekable file -- one rank's shard. */

@@ -140,7 +140,7 @@ def test_cli_multi_byte_delimiter_counts(tmp_path):
 
 
 def test_cli_rejects_what_is_outside_the_hot_path(files):
-    for a in (["-2", "a|b", files[0]], ["-2", "[ab]cdefgh", files[0]], ["-w", "x", files[0]],
+    for a in (["-2", "a|b", files[0]], ["-2", "[ab]cdefgh", files[0]], ["-G", "x", files[0]],
               ["-9", "approximatematch", files[0]], ["-2", "ab", files[0]]):
         rc, out, err = _run(CLI, a)
         assert rc == 2 and err
@@ -152,7 +152,8 @@ def _n_devices():
 
 
 @pytest.mark.parametrize("args", [["-V0", "-2", "-c"], ["-2", "-c"], ["-V0", "-2"], ["-V0", "-n", "-i", "-2"],
-                                  ["-V0", "-1", "-l"], ["-2", "-l"], ["-V0", "-c"], ["-V0", "-h", "-2"]])
+                                  ["-V0", "-1", "-l"], ["-2", "-l"], ["-V0", "-c"], ["-V0", "-h", "-2"],
+                                  ["-V0", "-i", "-v", "-l", "-2"], ["-V0", "-v", "-l"], ["-V0", "-i", "-v", "-c", "-1"]])
 def test_cli_multi_gpu_equals_single(files, args):
     """--gpus N: every file cut into N record-aligned shards, one host thread + one
     query per device, the -c sum / the -l hit vector reduced with RCCL inside the C-ABI
@@ -211,3 +212,57 @@ def test_cli_nocase_letter_delimiter(tmp_path):
         rc_r, out_r, _ = _run(REF, a)
         rc_g, out_g, err_g = _run(CLI, a)
         assert (rc_g, out_g) == (rc_r, out_r), (a, out_g[:200], out_r[:200], err_g[:200])
+
+
+@needs_ref
+def test_cli_config_c1_exact_m8_1mib_count(tmp_path):
+    """BASELINE configs[0] as worded: exact m = 8 pattern, 1 MiB ASCII file, k = 0, -c -- the bm() path
+    of the reference (sgrep.c:694-1016) against the device's k = 0 filter path, CLI to CLI."""
+    text, planted = O.corpus(256, seed=8, variants=(b"approxim", b"approxim", b"aproxim"), plant_period=20)
+    f = tmp_path / "c1.txt"
+    f.write_bytes(text.tobytes())
+    assert f.stat().st_size == 1 << 20
+    for args in (["-c"], ["-V0", "-c"], ["-V0", "-l"], ["-V0"]):
+        a = args + ["approxim", str(f)]
+        rc_r, out_r, _ = _run(REF, a)
+        rc_g, out_g, err_g = _run(CLI, a)
+        assert (rc_g, out_g) == (rc_r, out_r) and err_g == b"", (a, out_g[:200], out_r[:200])
+    assert int(_run(CLI, ["-V0", "-c", "approxim", str(f)])[1]) >= planted[0] + planted[1] > 0
+
+
+@needs_ref
+def test_cli_word_and_line_guards(files, tmp_path):
+    """-w / -x in the C CLI (agh_query_literal_ex): k = 0 against the reference's simple path, k > 0
+    against its maskgen path."""
+    for w in ("the", "at", "match"):
+        for mode in (["-V0", "-w", "-c"], ["-V0", "-w"], ["-V0", "-w", "-l"], ["-V0", "-w", "-1", "-c"],
+                     ["-V0", "-w", "-i", "-1"]):
+            a = mode + [w] + files[:2]
+            rc_r, out_r, _ = _run(REF, a)
+            rc_g, out_g, err_g = _run(CLI, a)
+            assert (rc_g, out_g) == (rc_r, out_r), (a, out_g[:200], out_r[:200], err_g[:200])
+    lines = open(files[1], "rb").read().split(b"\n")[:300]
+    for i in range(7, len(lines), 41):
+        lines[i] = b"approximatematch"
+    f = tmp_path / "x.txt"
+    f.write_bytes(b"\n".join(lines) + b"\n")
+    for mode in (["-V0", "-x", "-c"], ["-V0", "-x", "-l"], ["-V0", "-x", "-n"], ["-V0", "-x", "-1", "-c"]):
+        a = mode + ["approximatematch", str(f)]
+        assert _run(CLI, a)[:2] == _run(REF, a)[:2], a
+
+
+def test_cli_pattern_file_with_errors(files, tmp_path):
+    """--approx-f: -# applies to the patterns of -f (BASELINE config 5; the reference warns and ignores it,
+    compat.c:34-37).  Same count as the union of the single-pattern scans through the same CLI."""
+    pf = tmp_path / "pats.txt"
+    pats = [b"approximatematch", b"zzzzqqqqxx", b"etaoinshrdlu"]
+    pf.write_bytes(b"\n".join(pats) + b"\n")
+    rc, out, err = _run(CLI, ["--approx-f", "-V0", "-2", "-c", "-f", str(pf), files[0]])
+    assert err == b"", err
+    single = int(_run(CLI, ["-V0", "-2", "-c", "approximatematch", files[0]])[1])
+    assert int(out) >= single > 0
+    rc2, out2, err2 = _run(CLI, ["-V0", "-2", "-c", "-f", str(pf), files[0]])      # reference behaviour: warning, exact
+    assert b"not supported with -f" in err2 and int(out2) <= int(out)
+    for g in ("1",):
+        assert _run(CLI, ["--gpus", g, "--approx-f", "-V0", "-2", "-l", "-f", str(pf)] + files)[1] == \
+            _run(CLI, ["--approx-f", "-V0", "-2", "-l", "-f", str(pf)] + files)[1]

@@ -173,3 +173,118 @@ def test_c5_1024_exact_patterns_8gib():
           "oracle_slice_matched": int(want), "gpu_slice_matched": int(got), "segments": int(r.n_segments)})
     assert got == want
     assert r.n_matched >= sum(planted) > 0
+
+
+def _c5_patterns(lo, hi, npat=1024, seed=1024):
+    rng = random.Random(seed)
+    pats = set()
+    while len(pats) < npat:
+        pats.add(bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(lo, hi))))
+    return sorted(pats)
+
+
+def _edit(p, edits, rng):
+    a = bytearray(p)
+    for _ in range(edits):
+        op, at = rng.randint(0, 2), rng.randrange(1, len(a) - 1)
+        if op == 0:
+            a[at] = ord("Q")
+        elif op == 1:
+            del a[at]
+        else:
+            a.insert(at, ord("Z"))
+    return bytes(a)
+
+
+def test_c5_1024_patterns_k1_8gib():
+    """BASELINE config 5 as worded, one GPU's share: -f with 1024 patterns (8..12 bytes), k = 1, 8 GiB
+    resident, count-only (-l / -c).  The reference ignores -# with -f (compat.c:34-37), so this is the
+    union of the single-pattern predicate (unpinned), anchored three ways: the planted
+    0..1-edit records are all found and the 3-edit ones are not needed, lean == numbered, and on a
+    slice the record set equals (a) the oracle's union over all 1024 patterns and (b) the union of
+    1024 single-pattern scans of the device's own k-error engine."""
+    import torch
+    import agrep_amd as A
+    pats = _c5_patterns(8, 12)
+    rng = random.Random(7)
+    base = [pats[3], pats[500], pats[900]]
+    variants = (base[0], base[1], _edit(base[0], 1, rng), _edit(base[1], 1, rng), _edit(base[2], 1, rng),
+                _edit(base[0], 3, rng), _edit(base[2], 3, rng))
+    n = 8 << 30
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    planted = A.corpus_fill_device(t.data_ptr(), n // 4096, seed=55, variants=variants, plant_period=500)
+    q = A.Query.multi(pats, k=1)
+    try:
+        r = q.scan_device(t.data_ptr(), n, flags=A.COUNT)
+        xs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            q.scan_device(t.data_ptr(), n, flags=A.COUNT, time_sweep=False, time_scan=False)
+            xs.append(time.perf_counter() - t0)
+        rn = q.scan_device(t.data_ptr(), 2 << 30)                        # numbered, one segment
+        rl = q.scan_device(t.data_ptr(), 2 << 30, flags=A.COUNT)
+        # (b) the device's single-pattern engine, pattern by pattern, on 64 MiB
+        sl = 64 << 20
+        cap = 200000
+        pos = torch.empty(cap, dtype=torch.int64, device="cuda")
+        rm = q.scan_device(t.data_ptr(), sl, match_pos_ptr=pos.data_ptr(), match_cap=cap)
+        host = t[:sl].cpu().numpy()
+        nl = np.flatnonzero(host == 10)
+        got = set(np.searchsorted(nl, pos[:int(rm.n_stored)].cpu().numpy()).tolist())
+        want = set()
+        for p in pats:
+            with A.Query(p, 1) as q1:
+                r1 = q1.scan_device(t.data_ptr(), sl, match_pos_ptr=pos.data_ptr(), match_cap=cap)
+                assert not r1.truncated
+                want.update(np.searchsorted(nl, pos[:int(r1.n_stored)].cpu().numpy()).tolist())
+        # (a) the oracle on the first 2 MiB
+        osl = 2 << 20
+        orc = set()
+        for p in pats:
+            orc.update(s for s, _ in O.asearch(p, 1, host[:osl], cap=100000)[1])
+        ro = q.scan_buffer(host[:osl].tobytes(), cap=100000)
+    finally:
+        q.close()
+    planted_le1 = int(sum(planted[:5]))
+    _log({"test": "c5_1024x8..12_k1_8gib", "bytes": n, "matched": int(r.n_matched), "planted_0_1_edits": planted_le1,
+          "planted_3_edits": int(sum(planted[5:])), "candidates": int(r.n_candidates), "segments": int(r.n_segments),
+          "count_only_GBps": round(n / 1e9 / sorted(xs)[1], 1), "count_only_ms": round(sorted(xs)[1] * 1e3, 3),
+          "numbered_2gib": int(rn.n_matched), "lean_2gib": int(rl.n_matched), "slice_records_multi": len(got),
+          "slice_records_single_union": len(want), "oracle_2mib_records": len(orc)})
+    assert r.n_matched >= planted_le1 > 0 and r.lean_reruns == 0
+    assert rn.n_matched == rl.n_matched
+    assert not rm.truncated and got == want
+    assert sorted(s for s, _, _ in ro[1]) == sorted(orc) and ro[0].n_matched == len(orc)
+
+
+def test_c5_as_worded_4_to_12_bytes_k1_dense():
+    """The same set as BASELINE words it (lengths 4..12, k = 1): 80 % of all records match and every
+    text position is a candidate -- no slice can hold that, the dense kernel verifies its queue on
+    the spot.  256 MiB must finish in under 50 ms (round 2: 370 ms); == the oracle on a slice."""
+    import torch
+    import agrep_amd as A
+    pats = _c5_patterns(4, 12)
+    n = 256 << 20
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    A.corpus_fill_device(t.data_ptr(), n // 4096, seed=5, variants=tuple(pats[:7]), plant_period=500)
+    with A.Query.multi(pats, k=1) as q:
+        q.scan_device(t.data_ptr(), n, flags=A.COUNT)                   # (finds out that the set is dense)
+        xs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = q.scan_device(t.data_ptr(), n, flags=A.COUNT, time_sweep=False, time_scan=False)
+            xs.append(time.perf_counter() - t0)
+        rn = q.scan_device(t.data_ptr(), 64 << 20)
+        rl = q.scan_device(t.data_ptr(), 64 << 20, flags=A.COUNT)
+        osl = 256 << 10
+        host = t[:osl].cpu().numpy()
+        orc = set()
+        for p in pats:
+            orc.update(s for s, _ in O.asearch(p, 1, host, cap=100000)[1])
+        ro = q.scan_buffer(host.tobytes(), cap=100000)
+    ms = sorted(xs)[1] * 1e3
+    _log({"test": "c5_1024x4..12_k1_dense_256mib", "bytes": n, "matched": int(r.n_matched), "count_only_ms": round(ms, 2),
+          "count_only_GBps": round(n / 1e6 / ms, 2), "oracle_256kib_records": len(orc)})
+    assert rn.n_matched == rl.n_matched > 0
+    assert sorted(s for s, _, _ in ro[1]) == sorted(orc)
+    assert ms < 50.0, ms

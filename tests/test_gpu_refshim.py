@@ -170,3 +170,61 @@ def test_memory_mode_through_the_shim(files, tmp_path, opts):
     for mode in ("lines", "count"):
         a = [mode, src] + opts + ["approximatematch"]
         assert _run(HARNESS_GPU, a)[:2] == _run(HARNESS, a)[:2], a
+
+
+def _same_env(args, files_, env):
+    e = dict(os.environ, **env)
+    r = subprocess.run([REF] + args + files_, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    g = subprocess.run([GPU] + args + files_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    assert g.stdout == r.stdout, (args, env, g.stdout[:300], r.stdout[:300], g.stderr[:300])
+    assert g.returncode == r.returncode, (args, env)
+
+
+@needs
+def test_word_and_line_guards_on_the_simple_seam(files, tmp_path):
+    """-w / -x at k = 0 go to sgrep() (checksg.c:133-134): bm()'s isalnum() test on the bytes next to an
+    occurrence (sgrep.c:750-756) and char_tr()'s "\\n pat \\n" wrap (sgrep.c:252-259); with -f,
+    monkey1()'s test (newmgrep.c:869-872).  Served through agh_query_literal_ex / agh_query_multi_ex."""
+    words = [b"the", b"at", b"match", b"approximatematch"]
+    for w in words:
+        for mode in (["-c"], [], ["-l"], ["-h"]):
+            _same(["-V0", "-w"] + mode + [w.decode()], files[:2])
+    # -x: whole lines.  The reference's simple path prints the line that FOLLOWS a hit as well and then
+    # misses a hit on that line (sgrep.c:779-781 starts looking for the end of the record behind the
+    # '\n' the pattern ended with) -- a quirk, not reproduced: counts are compared on a text whose hits
+    # are not adjacent, records against the reference's own maskgen path (-n)
+    lines = open(files[1], "rb").read().split(b"\n")[:400]
+    for i in range(5, len(lines), 37):
+        lines[i] = b"approximatematch"
+    lines[11] = b"approximatematch "
+    lines[12] = b"xapproximatematch"
+    f = tmp_path / "x.txt"
+    f.write_bytes(b"\n".join(lines) + b"\n")
+    for mode in (["-c"], ["-l"]):
+        _same(["-V0", "-x"] + mode + ["approximatematch"], [str(f)])
+    _same(["-V0", "-x", "-n", "approximatematch"], [str(f)])
+    numbered = _run(REF, ["-V0", "-x", "-n", "approximatematch", str(f)])[1]
+    plain = _run(GPU, ["-V0", "-x", "approximatematch", str(f)])
+    assert plain[1] == b"".join(l.split(b": ", 1)[1] + b"\n" for l in numbered.splitlines()), plain[2][:300]
+    assert plain[1].count(b"\n") == len(range(5, len(lines), 37))
+    # -f with -w / -x
+    pf = tmp_path / "pats.txt"
+    pf.write_bytes(b"the\nmatch\nat\nzzzzqq\napproximatematch\n")
+    for mode in (["-c"], [], ["-l"]):
+        _same(["-V0", "-w"] + mode + ["-f", str(pf)], files[:2])
+    _same(["-V0", "-x", "-c", "-f", str(pf)], [str(f)])
+
+
+@needs
+def test_q6_mode_reproduces_the_reference_case_folding(tmp_path):
+    """Quirk Q6: the reference's simple-pattern engines compare through TR[], which char_tr() fills
+    with the case folding whether or not -i was given (sgrep.c:226-236), so `agrep word file` prints
+    "Word" too.  The GPU engines do not; AGH_REF_QUIRKS=q6 makes the drop-in do it on request."""
+    t, _ = O.corpus(24, seed=66, variants=O.VARIANTS_C2, plant_period=9, upper_permille=250)
+    f = tmp_path / "mixed.txt"
+    f.write_bytes(t.tobytes())
+    for args in (["-V0", "-c"], ["-V0"], ["-V0", "-w", "-c"], ["-V0", "-l"]):
+        _same_env(args + ["approximatematch"], [str(f)], {"AGH_REF_QUIRKS": "q6"})
+    r = subprocess.run([REF, "-V0", "-c", "approximatematch", str(f)], stdout=subprocess.PIPE).stdout
+    g = subprocess.run([GPU, "-V0", "-c", "approximatematch", str(f)], stdout=subprocess.PIPE).stdout
+    assert int(g.split()[0]) < int(r.split()[0])         # without the switch: case-sensitive, fewer records
