@@ -32,7 +32,8 @@ class Result(C.Structure):
                 ("n_candidates", C.c_uint64), ("n_stored", C.c_uint64), ("engine", C.c_uint32),
                 ("truncated", C.c_uint32), ("device_ms", C.c_double), ("sweep_ms", C.c_double),
                 ("sweep_launches", C.c_uint32), ("lean_reruns", C.c_uint32),
-                ("n_segments", C.c_uint32), ("fused_segments", C.c_uint32)]
+                ("n_segments", C.c_uint32), ("fused_segments", C.c_uint32),
+                ("copied_segments", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _LIB = None

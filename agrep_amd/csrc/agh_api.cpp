@@ -118,6 +118,7 @@ struct agh_query {
     // buffers, dependency / timing events, the device scratch of the segment cutter
     hipStream_t aux_stream = nullptr;
     dev_buf cand_b, wave_cand_b, cuts;
+    dev_buf seg_copy;                   // aligned copy of a segment whose cut is not 16-byte aligned
     dev_buf tickets;                    // fused lean kernel: one work counter (own 256-byte line) per segment
     std::vector<hipEvent_t> dep_events, time_events;
     uint64_t *h_cuts = nullptr;         // pinned: bounds, lower limits, cuts
@@ -844,14 +845,13 @@ extern "C" int agh_query_set_costs(agh_query *q, int I, int S, int DD)
 {
     if (!q) return fail("null query");
     if (q->multi) return fail("multi-pattern queries use unit costs");
-    if (q->table && (I != 1 || S != 1 || DD != 1))
-        return fail("edit costs are not supported together with wildcards / AND / OR");
     if (I < 1 || S < 1 || DD < 1)
         return fail("costs must be >= 1 (cost 0 turns every position into a self loop, asearch1.c:41)");
     q->ci = I;
     q->cs = S;
     q->cd = DD;
-    if (I != 1 || S != 1 || DD != 1) q->general = true;
+    // (the table engine runs asearch1.c's recurrence on its own tables: agh_table.hip feed_costs)
+    if ((I != 1 || S != 1 || DD != 1) && !q->table) q->general = true;
     return 0;
 }
 
@@ -876,6 +876,7 @@ extern "C" void agh_query_free(agh_query *q)
     q->cand_b.release();
     q->wave_cand_b.release();
     q->cuts.release();
+    q->seg_copy.release();
     q->tickets.release();
     if (q->ev0) (void)hipEventDestroy(q->ev0);
     if (q->ev1) (void)hipEventDestroy(q->ev1);
@@ -928,8 +929,9 @@ static bool fs_fast_ok(const agh_query *q)
 {
     const char *e = getenv("AGH_FS_FAST");
     if (e && e[0] == '0') return false;
-    return !q->fs_fast_off && !q->multi && !q->table && !q->general && !(q->dlen > 1 || q->delim_fold) &&
-           q->mask[q->delim[0]] == 0;
+    // k = 0: one level, nothing to pack -- the one-kernel form is faster there (3.8 vs 3.2 TB/s)
+    return !q->fs_fast_off && q->k >= 1 && !q->multi && !q->table && !q->general &&
+           !(q->dlen > 1 || q->delim_fold) && q->mask[q->delim[0]] == 0;
 }
 
 static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
@@ -1105,7 +1107,16 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.tail_only = 1;
             agh_launch_sweep_multi(sa, st);
         } else if (multi) {
+            // AGH_MP_FUSED=0: candidates through the slices, k_verify_multi afterwards (A/B runs)
+            const agh_multi_dev md = multi_dev(q);
+            const char *e = getenv("AGH_MP_FUSED");
+            if (!(e && e[0] == '0')) {
+                sa.fuse_mt = &md;
+                sa.fuse_mk = &va.mk;
+            }
             agh_launch_sweep_multi(sa, st);
+            sa.fuse_mt = nullptr;
+            sa.fuse_mk = nullptr;
         } else {
             agh_launch_sweep(sa, q->fh, st);
         }
@@ -1431,19 +1442,33 @@ static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, 
         uint64_t *d = (uint64_t *)q->cuts.p;
         HIP_TRY(hipMemcpyAsync(d, h_bound, nb * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d + AGH_MAX_SEGS, h_lo, nb * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        if (global_dbm)                         // bitmap delimiters: cuts at 64-byte aligned delimiter ends
-            agh_launch_find_cuts_dbm(global_dbm, d, d + AGH_MAX_SEGS, (uint32_t)nb, d + 2 * AGH_MAX_SEGS, st);
-        else
-            agh_launch_find_cuts(base, d, d + AGH_MAX_SEGS, (uint32_t)nb, q->delim[0], d + 2 * AGH_MAX_SEGS, st);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h_cut, d + 2 * AGH_MAX_SEGS, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        // aligned cuts first (a segment that starts on a 16-byte -- bitmap delimiters: 64-byte --
+        // boundary is scanned where it lies); where no record ends on such a boundary (fixed-width
+        // records behind an odd header), any record end: that segment is copied to an aligned buffer
+        auto find = [&](uint32_t step, uint64_t *host_out) -> int {
+            if (global_dbm)
+                agh_launch_find_cuts_dbm(global_dbm, d, d + AGH_MAX_SEGS, (uint32_t)nb, step, d + 2 * AGH_MAX_SEGS, st);
+            else
+                agh_launch_find_cuts(base, d, d + AGH_MAX_SEGS, (uint32_t)nb, q->delim[0], step, d + 2 * AGH_MAX_SEGS, st);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(host_out, d + 2 * AGH_MAX_SEGS, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            return 0;
+        };
+        if (find(global_dbm ? 64u : 16u, h_cut)) return -1;
+        bool missing = false;
+        for (uint64_t i = 0; i < nb; ++i) missing = missing || !h_cut[i];
+        if (missing && !getenv("AGH_ALIGNED_CUTS_ONLY")) {
+            std::vector<uint64_t> any(nb, 0);
+            if (find(1u, any.data())) return -1;
+            for (uint64_t i = 0; i < nb; ++i)
+                if (!h_cut[i]) h_cut[i] = any[i];
+        }
         for (uint64_t i = 0; i < nb; ++i) {
             if (!h_cut[i])
-                return fail("no record ends at a %d-byte aligned offset between byte %llu and %llu "
-                            "(needed to cut an input above the %llu-byte segment limit)", global_dbm ? 64 : 16,
-                            (unsigned long long)h_lo[i], (unsigned long long)h_bound[i],
-                            (unsigned long long)nominal);
+                return fail("no record ends between byte %llu and %llu (needed to cut an input above the "
+                            "%llu-byte segment limit)", (unsigned long long)h_lo[i],
+                            (unsigned long long)h_bound[i], (unsigned long long)nominal);
             cuts->push_back(h_cut[i]);
         }
     }
@@ -1816,17 +1841,35 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
         global_dbm = (const uint64_t *)q->dbm.p;
     }
     if (plan_segments(q, base, len, st, &cuts, lean, global_dbm)) return -1;
-    if (lean) return lean_run(q, base, cuts, st, flags, res, is_first, is_last);
+    if (lean) {
+        bool aligned = true;                    // (the segment STARTS: the last entry is the end of the text)
+        for (size_t i = 0; i + 1 < cuts.size(); ++i) aligned = aligned && (cuts[i] & 15u) == 0;
+        if (aligned) return lean_run(q, base, cuts, st, flags, res, is_first, is_last);
+        // a cut that is not 16-byte aligned: segment by segment through aligned copies (below), in
+        // the segment sizes of that path
+        if (plan_segments(q, base, len, st, &cuts, false, global_dbm)) return -1;
+    }
     for (size_t i = 0; i + 1 < cuts.size(); ++i) {
         const uint64_t off = cuts[i], end = cuts[i + 1];
         seg_result sr;
         uint64_t stored = res->n_stored;
         uint32_t cap_left = (uint32_t)std::min<uint64_t>(match_cap - stored, 0xffffffffu);
-        if (scan_segment(q, base + off, end - off, st, flags,
+        // a segment that does not start on an aligned offset (no record ended on one near the
+        // boundary: plan_segments) is scanned from an aligned copy, with a delimiter bitmap of its own
+        const unsigned char *seg_text = base + off;
+        const uint64_t *seg_dbm = global_dbm ? global_dbm + off / 64 : nullptr;
+        if (off & (global_dbm ? 63u : 15u)) {
+            if (q->seg_copy.ensure(end - off + 64)) return -1;
+            HIP_TRY(hipMemcpyAsync(q->seg_copy.p, base + off, end - off, hipMemcpyDeviceToDevice, st));
+            seg_text = (const unsigned char *)q->seg_copy.p;
+            seg_dbm = nullptr;
+            res->copied_segments += 1;
+        }
+        if (scan_segment(q, seg_text, end - off, st, flags,
                          (i == 0 && is_first) ? '\n' : q->delim[q->dlen - 1], end == len && is_last,
                          d_match_pos ? d_match_pos + stored : nullptr,
                          d_match_rec ? d_match_rec + stored : nullptr,
-                         d_match_pos ? cap_left : 0, &sr, global_dbm ? global_dbm + off / 64 : nullptr))
+                         d_match_pos ? cap_left : 0, &sr, seg_dbm))
             return -1;
         if (d_match_pos && sr.stored && off > 0) {
             // the segment's kernels saw positions / record numbers relative to its own start

@@ -17,7 +17,7 @@
 #define AGH_MP_SLICE_CAP (AGH_WAVE_STRIPS * 64u)
 // Lean scans: how far back the verifier looks for the start of a matched record before the
 // scan falls back to the numbered (census) mode.
-#define AGH_LEAN_BACK_CAP (64u * 1024u)
+#define AGH_LEAN_BACK_CAP (1024u * 1024u)
 // q-gram filter table: one byte per hash bucket, resident in LDS (32 KiB / workgroup).
 #ifndef AGH_FT_BITS
 #define AGH_FT_BITS 15         // filter table: 2^15 bytes = 2^18 bits (make FT_BITS=14 builds a 16 KiB variant for A/B)

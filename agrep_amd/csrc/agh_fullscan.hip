@@ -3,6 +3,22 @@
 // 1-byte pieces, multi-byte delimiters together with costs, -v with record output).
 #include "agh_verify_inl.h"
 
+// The ring feeder reads the two 64-byte halves of a 128-byte line in consecutive rounds: plain
+// loads, so that the second half still finds the line (non-temporal loads, which buy the sweeps
+// their last 10 %, cost here: 4 GiB count-only, k = 0 / 1: 3.55 / 2.94 -> 3.82 / 3.17 TB/s;
+// make VARIANT=fsnt VARFLAGS=-DAGH_FS_NT=1 builds the other form for A/B, profiles/r03_perf_fullscan*.log)
+#ifndef AGH_FS_NT
+#define AGH_FS_NT 0
+#endif
+__device__ __forceinline__ uint4 fs_load(const uint4 *p)
+{
+#if AGH_FS_NT
+    return ld_stream(p);
+#else
+    return *p;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------
 // fullscan: the automaton over every byte
 // ---------------------------------------------------------------------------------------
@@ -151,7 +167,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_fullscan(
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
                 const uint64_t a = t0 + (uint64_t)(seg_lo + 16u * i) * AGH_FS_CHUNK + r * AGH_FS_ROUND + part * 16u;
-                g[i] = a < n16 ? ld_stream(reinterpret_cast<const uint4 *>(text + a))
+                g[i] = a < n16 ? fs_load(reinterpret_cast<const uint4 *>(text + a))
                                : make_uint4(fill4, fill4, fill4, fill4);
             }
         };
@@ -423,7 +439,7 @@ __global__ __launch_bounds__(AGH_FF_THREADS) void k_fullscan_fast(
 #pragma unroll
                 for (uint32_t i = 0; i < 4; ++i) {
                     const uint64_t a = t0[st] + (uint64_t)(seg_lo + 16u * i) * AGH_FS_CHUNK + r * AGH_FS_ROUND + part * 16u;
-                    g[st][i] = a < n16 ? ld_stream(reinterpret_cast<const uint4 *>(text + a))
+                    g[st][i] = a < n16 ? fs_load(reinterpret_cast<const uint4 *>(text + a))
                                        : make_uint4(fill4, fill4, fill4, fill4);
                 }
         };

@@ -37,6 +37,10 @@ struct agh_sweep_args {
     // verifier of one part run while the next part is swept, and let -l stop early.
     uint32_t w_begin = 0, w_end = 0;
     int tail_only = 0;       // 1: only the partial last strip (the fused kernel swept the rest)
+    // multi-pattern count-only sweeps: verify full queues inside the sweep (tables and marks of the
+    // verifier; NULL: candidates go to the slices)
+    const struct agh_multi_dev *fuse_mt = nullptr;
+    const struct agh_marks *fuse_mk = nullptr;
 };
 
 struct agh_scan_args {
@@ -93,9 +97,9 @@ void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *w
                               uint32_t nw, uint32_t *counters, hipStream_t st);
 void agh_launch_verify_lean(const agh_scan_args &a, hipStream_t st);
 void agh_launch_find_cuts(const void *text, const uint64_t *bound, const uint64_t *lo,
-                          uint32_t n_bounds, uint32_t delim, uint64_t *cut, hipStream_t st);
+                          uint32_t n_bounds, uint32_t delim, uint32_t step, uint64_t *cut, hipStream_t st);
 void agh_launch_find_cuts_dbm(const uint64_t *dbm, const uint64_t *bound, const uint64_t *lo,
-                              uint32_t n_bounds, uint64_t *cut, hipStream_t st);
+                              uint32_t n_bounds, uint32_t step, uint64_t *cut, hipStream_t st);
 void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
 void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_t seed,
                        const unsigned char *variants, const uint32_t *vlen,

@@ -23,6 +23,8 @@
 //   k_dense_multi     sets whose hits do not fit the slices (hundreds of 1..3-byte entries; -f with
 //                     errors over 4-byte patterns): the same probes, but the queue is verified on
 //                     the spot, 64 candidates at a time, one per lane -- nothing can overflow.
+#include <string.h>
+
 #include "agh_verify_inl.h"
 #include "agh_sweep_inl.h"
 
@@ -381,14 +383,20 @@ __device__ __forceinline__ void mp_verify_at(const uint8_t *__restrict__ text, u
 // ---------------------------------------------------------------------------------------
 // One wave per 256 KiB range, 4 KiB supertiles, next supertile prefetched -- as k_sweep.
 // MODE: bit 0 fold case, bit 1 q == 4, bit 2 lean (no census).
-template <int MODE, int STRIDE, bool Q5>
+// FK >= 0 (count-only scans, FK = the number of errors): a full queue is not written to the wave's
+// slice but verified on the spot, one candidate per lane.  The sweep is bound by VALU issue and the
+// verifier by the latency of its dependent loads; in one kernel the other waves of the SIMD fill
+// the verifier's waits, where two kernels pay for both one after the other (-f with k = 1, 4 GiB:
+// sweep 1.25 ms + verify 0.62 ms as two kernels).
+template <int MODE, int STRIDE, bool Q5, int FK>
 __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ text, uint64_t n,
                                                      uint64_t n_full_strips, agh_dev_query q,
                                                      const uint32_t *__restrict__ bits_g,
                                                      uint32_t *__restrict__ wave_totals,
                                                      uint64_t *__restrict__ cand,
                                                      uint32_t *__restrict__ wave_cand,
-                                                     uint32_t *__restrict__ counters)
+                                                     uint32_t *__restrict__ counters,
+                                                     agh_multi_tables mt, agh_marks mk)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[AGH_MP_WORDS];
     __shared__ uint64_t cq_all[4 * AGH_MP_CQ_LEN];
@@ -417,7 +425,26 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
     uint32_t run = 0, ncand = 0, qn = 0;
     uint64_t *cq = cq_all + wib * AGH_MP_CQ_LEN;
     uint64_t *slice = cand + w * AGH_MP_SLICE_CAP;
-    auto flush64 = [&]() { flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, 64u, slice, ncand, counters); };
+    // fused form: the first `take` queued candidates are verified, one per lane; the rest stay queued
+    auto verify_queue = [&](uint32_t take) {
+        if constexpr (FK >= 0) {
+            if ((uint32_t)lane < take) {
+                const uint64_t ent = cq[lane];
+                mp_verify_at<true, (FK >= 0 ? FK : 0)>(reinterpret_cast<const uint8_t *>(text), n, q, mt,
+                                                        ent & 0xffffffffull, 0u, mk);
+            }
+            ncand += take;
+            const uint32_t rest = qn - take;
+            uint64_t keep = 0;
+            if ((uint32_t)lane < rest) keep = cq[take + (uint32_t)lane];
+            if ((uint32_t)lane < rest) cq[lane] = keep;
+            qn = rest;
+        }
+    };
+    auto flush64 = [&]() {
+        if constexpr (FK >= 0) verify_queue(64u);
+        else flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, 64u, slice, ncand, counters);
+    };
     // the dword right behind strip st-1 (uniform; 0 past the readable text)
     auto first_dword_of = [&](uint64_t st) -> uint32_t {
         const uint64_t i = st * 256u;
@@ -512,10 +539,18 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
         s += 4;
     }
     for (; s < s1; ++s) single(ld_stream(text + s * 64 + lane), s, first_dword_of(s + 1));
-    if (qn) flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, qn, slice, ncand, counters);
-    if (lane == 0) {
-        wave_totals[w] = run;
-        wave_cand[w] = ncand < AGH_MP_SLICE_CAP ? ncand : AGH_MP_SLICE_CAP;
+    if constexpr (FK >= 0) {
+        if (qn) verify_queue(qn);
+        if (lane == 0) {
+            wave_cand[w] = 0u;                  // nothing went through the slice
+            if (ncand) atomicAdd(&counters[AGH_C_CAND], ncand);
+        }
+    } else {
+        if (qn) flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, qn, slice, ncand, counters);
+        if (lane == 0) {
+            wave_totals[w] = run;
+            wave_cand[w] = ncand < AGH_MP_SLICE_CAP ? ncand : AGH_MP_SLICE_CAP;
+        }
     }
 }
 
@@ -695,10 +730,27 @@ static void launch_sweep_multi_ms(const agh_sweep_args &a, hipStream_t st)
     const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
     const uint64_t n_waves = (n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
     if (a.ev_begin) (void)hipEventRecord(a.ev_begin, st);
-    if (n_waves && !a.tail_only)
-        hipLaunchKernelGGL((k_sweep_multi<MODE, STRIDE, Q5>), dim3((uint32_t)((n_waves + 3) / 4)),
-                           dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,
-                           (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand, a.counters);
+    agh_multi_dev none_mt;
+    agh_marks none_mk;
+    memset(&none_mt, 0, sizeof(none_mt));
+    memset(&none_mk, 0, sizeof(none_mk));
+#define AGH_SM_LAUNCH(FKV, MT, MK)                                                            \
+    hipLaunchKernelGGL((k_sweep_multi<MODE, STRIDE, Q5, FKV>), dim3((uint32_t)((n_waves + 3) / 4)), \
+                       dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,             \
+                       (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand, a.counters, MT, MK)
+    if (n_waves && !a.tail_only) {
+        // count-only scans with q == 4 and k <= 2: verification inside the sweep
+        const bool fuse = (MODE & 4) && (MODE & 2) && a.fuse_mt && a.fuse_mk && a.q.k >= 0 && a.q.k <= 2;
+        if constexpr ((MODE & 6) == 6) {
+            if (fuse && a.q.k == 0) AGH_SM_LAUNCH(0, *a.fuse_mt, *a.fuse_mk);
+            else if (fuse && a.q.k == 1) AGH_SM_LAUNCH(1, *a.fuse_mt, *a.fuse_mk);
+            else if (fuse) AGH_SM_LAUNCH(2, *a.fuse_mt, *a.fuse_mk);
+            else AGH_SM_LAUNCH(-1, none_mt, none_mk);
+        } else {
+            AGH_SM_LAUNCH(-1, none_mt, none_mk);
+        }
+    }
+#undef AGH_SM_LAUNCH
     if (a.ev_end) (void)hipEventRecord(a.ev_end, st);
     if (a.n & (AGH_STRIP - 1))
         hipLaunchKernelGGL((k_sweep_multi_tail<MODE, STRIDE, Q5>), dim3(1), dim3(64), 0, st,

@@ -491,68 +491,72 @@ __global__ __launch_bounds__(256) void k_hashset_count(uint64_t *__restrict__ ta
 __global__ __launch_bounds__(256) void k_find_cuts(const uint8_t *__restrict__ text,
                                                    const uint64_t *__restrict__ bound,
                                                    const uint64_t *__restrict__ lo,
-                                                   uint32_t delim, uint64_t *__restrict__ cut)
+                                                   uint32_t delim, uint32_t step,
+                                                   uint64_t *__restrict__ cut)
 {
+    // step = 16: cuts at 16-byte aligned offsets (the kernels take an aligned base as it is);
+    // step = 1: any record end (the host copies such a segment to an aligned buffer)
     __shared__ uint32_t best;
     const uint64_t b = bound[blockIdx.x], l = lo[blockIdx.x];
     uint64_t found = 0;
     for (uint64_t base = b; base > l;) {
         if (threadIdx.x == 0) best = 0xffffffffu;
         __syncthreads();
-        const uint64_t back = 16ull * threadIdx.x;
+        const uint64_t back = (uint64_t)step * threadIdx.x;
         if (base >= back && base - back > l && text[base - back - 1] == delim)
             atomicMin(&best, threadIdx.x);
         __syncthreads();
         const uint32_t t = best;
         __syncthreads();
-        if (t != 0xffffffffu) { found = base - 16ull * t; break; }
-        if (base < 4096ull + l) break;
-        base -= 4096ull;
+        if (t != 0xffffffffu) { found = base - (uint64_t)step * t; break; }
+        if (base < 256ull * step + l) break;
+        base -= 256ull * step;
     }
     if (threadIdx.x == 0) cut[blockIdx.x] = found;
 }
 
 // The same for delimiters that come from the delimiter bitmap (several bytes, or a folded letter):
-// a cut must also be a multiple of 64 so that a segment's part of the bitmap starts on a word.
-// cut[i] = the largest p <= bound[i], p > lo[i], p % 64 == 0, with a selected delimiter occurrence
-// ending at byte p - 1 (bit 63 of bitmap word p / 64 - 1), or 0.
+// step = 64: a cut that is a multiple of 64, so that a segment's part of the bitmap starts on a
+// word; step = 1: any selected delimiter end (the segment is copied and gets a bitmap of its own).
+// cut[i] = the largest p <= bound[i], p > lo[i], p % step == 0, with a selected delimiter occurrence
+// ending at byte p - 1, or 0.
 __global__ __launch_bounds__(256) void k_find_cuts_dbm(const uint64_t *__restrict__ dbm,
                                                        const uint64_t *__restrict__ bound,
                                                        const uint64_t *__restrict__ lo,
-                                                       uint64_t *__restrict__ cut)
+                                                       uint32_t step, uint64_t *__restrict__ cut)
 {
     __shared__ uint32_t best;
-    const uint64_t b = bound[blockIdx.x] & ~(uint64_t)63, l = lo[blockIdx.x];
+    const uint64_t b = bound[blockIdx.x] & ~(uint64_t)(step - 1), l = lo[blockIdx.x];
     uint64_t found = 0;
     for (uint64_t base = b; base > l;) {
         if (threadIdx.x == 0) best = 0xffffffffu;
         __syncthreads();
-        const uint64_t back = 64ull * threadIdx.x;
-        if (base >= back + 64 && base - back > l && (dbm[(base - back) / 64 - 1] >> 63))
+        const uint64_t back = (uint64_t)step * threadIdx.x;
+        if (base >= back + 1 && base - back > l && dbm_bit(dbm, base - back - 1))
             atomicMin(&best, threadIdx.x);
         __syncthreads();
         const uint32_t t = best;
         __syncthreads();
-        if (t != 0xffffffffu) { found = base - 64ull * t; break; }
-        if (base < 16384ull + l) break;
-        base -= 16384ull;
+        if (t != 0xffffffffu) { found = base - (uint64_t)step * t; break; }
+        if (base < 256ull * step + l) break;
+        base -= 256ull * step;
     }
     if (threadIdx.x == 0) cut[blockIdx.x] = found;
 }
 
 void agh_launch_find_cuts_dbm(const uint64_t *dbm, const uint64_t *bound, const uint64_t *lo,
-                              uint32_t n_bounds, uint64_t *cut, hipStream_t st)
+                              uint32_t n_bounds, uint32_t step, uint64_t *cut, hipStream_t st)
 {
     if (!n_bounds) return;
-    hipLaunchKernelGGL(k_find_cuts_dbm, dim3(n_bounds), dim3(256), 0, st, dbm, bound, lo, cut);
+    hipLaunchKernelGGL(k_find_cuts_dbm, dim3(n_bounds), dim3(256), 0, st, dbm, bound, lo, step, cut);
 }
 
 void agh_launch_find_cuts(const void *text, const uint64_t *bound, const uint64_t *lo,
-                          uint32_t n_bounds, uint32_t delim, uint64_t *cut, hipStream_t st)
+                          uint32_t n_bounds, uint32_t delim, uint32_t step, uint64_t *cut, hipStream_t st)
 {
     if (!n_bounds) return;
     hipLaunchKernelGGL(k_find_cuts, dim3(n_bounds), dim3(256), 0, st, (const uint8_t *)text, bound,
-                       lo, delim, cut);
+                       lo, delim, step, cut);
 }
 
 // ---------------------------------------------------------------------------------------

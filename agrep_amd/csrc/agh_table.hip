@@ -48,6 +48,56 @@ struct TableAutomaton {
         for (int e = 0; e <= K; ++e) B[e] = A[e];
         return ret;
     }
+    // The same with edit costs (-I# -S# -D#, asearch1.c:88-97 on these tables): level e takes the
+    // insertion from level e - ci, the substitution from e - cs, the deletion from the NEW level
+    // e - cd; source levels below 0 are asearch1's zero words (A[k], B[k] for k < D).
+    __device__ __forceinline__ uint32_t feed_costs(uint32_t CM, const agh_dev_tables &T, uint32_t ci,
+                                                   uint32_t cs, uint32_t cd)
+    {
+        uint32_t A[K + 1];
+        A[0] = ((B[0] >> 1) & CM) | (T.Init1 & B[0]);
+#pragma unroll
+        for (int e = 1; e <= K; ++e) {
+            uint32_t ins = 0, via = 0;
+#pragma unroll
+            for (int s = 0; s < e; ++s) {
+                const uint32_t d = (uint32_t)(e - s);
+                if (d == ci) ins = B[s];
+                if (d == cs) via |= B[s];
+                if (d == cd) via |= A[s];
+            }
+            A[e] = ((B[e] >> 1) & CM) | (T.Init1 & B[e]) | ins | ((via >> 1) & T.NO_ERR);
+        }
+        uint32_t ret = 0;
+        if (A[0] & T.D_endpos) {
+            const uint32_t r1 = A[K] & T.endposition;
+            const bool hit = T.AND ? (r1 == T.endposition) : (r1 != 0u);
+            ret = 1u | (hit ? 2u : 0u);
+            // asearch1.c:150-159: all levels Init[0], the byte again, level 0 masked
+            A[0] = (((T.Init0 >> 1) & CM) | (T.Init0 & T.Init1)) & T.D_Mask;
+#pragma unroll
+            for (int e = 1; e <= K; ++e) {
+                uint32_t ins = 0, via = 0;
+#pragma unroll
+                for (int s = 0; s < e; ++s) {
+                    const uint32_t d = (uint32_t)(e - s);
+                    if (d == ci) ins = T.Init0;
+                    if (d == cs) via |= T.Init0;
+                    if (d == cd) via |= A[s];
+                }
+                A[e] = ((T.Init0 >> 1) & CM) | (T.Init1 & T.Init0) | ins | ((via >> 1) & T.NO_ERR);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e <= K; ++e) B[e] = A[e];
+        return ret;
+    }
+    template <bool COSTS>
+    __device__ __forceinline__ uint32_t feed_q(uint32_t CM, const agh_dev_tables &T, const agh_dev_query &q)
+    {
+        if (COSTS) return feed_costs(CM, T, q.ci, q.cs, q.cd);
+        return feed(CM, T);
+    }
 };
 
 // Text feeding as in k_fullscan (agh_fullscan.hip): a lane's chunk is one 1 KiB census strip, a wave
@@ -57,7 +107,7 @@ struct TableAutomaton {
 // the delimiter that closes its last record.
 // LEAN (count-only): no census pass in front -- a record is identified by the offset of its first
 // byte, which the owning lane knows exactly, and goes into the hash set of record starts.
-template <int K, bool LEAN>
+template <int K, bool LEAN, bool COSTS>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, const uint32_t *__restrict__ strip_prefix,
@@ -108,11 +158,11 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
         A.reset(T);
         bool active = false, done = !mine;
         if (mine && cs == 0) {
-            (void)A.feed(lmask[q.head_byte], T);            // asearch.c:69-78 (never a hit: host check)
+            (void)A.template feed_q<COSTS>(lmask[q.head_byte], T, q);   // asearch.c:69-78 (never a hit: host check)
             active = true;
         }
         auto step = [&](uint32_t c, uint64_t pos) {
-            const uint32_t r = A.feed(lmask[c], T);
+            const uint32_t r = A.template feed_q<COSTS>(lmask[c], T, q);
             if (r & 1u) {
                 if (active && (r & 2u)) {
                     if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, pos);
@@ -158,7 +208,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
                 step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, p0 + b);
         }
         if (!done && active && q.tail_virtual) {            // asearch.c:87-91
-            const uint32_t r = A.feed(lmask[q.delim], T);
+            const uint32_t r = A.template feed_q<COSTS>(lmask[q.delim], T, q);
             if ((r & 3u) == 3u) {
                 if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
             }
@@ -174,16 +224,17 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
     const uint64_t want = (n_tiles + (AGH_FS_THREADS / WAVE) - 1) / (AGH_FS_THREADS / WAVE);
     const uint32_t blocks = want > 16384 ? 16384u : (uint32_t)want;
     const bool lean = a.mk.hashset != nullptr;  // count-only: hash set of record starts, no census
+    const bool costs = a.q.ci != 1u || a.q.cs != 1u || a.q.cd != 1u;     // asearch1.c instead of asearch.c
+#define AGH_TS_LAUNCH(KK, LEANV, COSTV)                                                       \
+    hipLaunchKernelGGL((k_tablescan<KK, LEANV, COSTV>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
+                       (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask,    \
+                       a.strip_prefix, a.wave_prefix, a.n_strips, a.mk)
 #define AGH_CASE(KK)                                                                          \
     case KK:                                                                                  \
-        if (lean)                                                                             \
-            hipLaunchKernelGGL((k_tablescan<KK, true>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
-                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);              \
-        else                                                                                  \
-            hipLaunchKernelGGL((k_tablescan<KK, false>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
-                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);              \
+        if (lean && costs) AGH_TS_LAUNCH(KK, true, true);                                     \
+        else if (lean) AGH_TS_LAUNCH(KK, true, false);                                        \
+        else if (costs) AGH_TS_LAUNCH(KK, false, true);                                       \
+        else AGH_TS_LAUNCH(KK, false, false);                                                 \
         break;
     switch (a.q.k) {
         AGH_CASE(0) AGH_CASE(1) AGH_CASE(2) AGH_CASE(3) AGH_CASE(4)
@@ -191,6 +242,7 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
     default: break;
     }
 #undef AGH_CASE
+#undef AGH_TS_LAUNCH
 }
 
 // ---------------------------------------------------------------------------------------

@@ -87,6 +87,9 @@ typedef struct {
     uint32_t n_segments;    /* kernel sequences the text was cut into (<= 8 GiB each, at record boundaries) */
     uint32_t fused_segments;/* of which count-only segments ran as ONE kernel (k_sweep_fused: sweep + verify;
                                sweep_ms then covers that kernel) */
+    uint32_t copied_segments;/* of which segments were scanned from an aligned copy: no record ended on a
+                               16-byte boundary near the cut (fixed-width records behind an odd header) */
+    uint32_t reserved;
 } agh_result;
 
 /* ---- query construction ------------------------------------------------------------- */

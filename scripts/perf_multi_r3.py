@@ -42,6 +42,12 @@ def run(label, pats, k, n, flags, reps=5):
 for lo, hi in ((4, 12), (5, 12), (7, 12), (8, 12)):
     for fl, lab in ((A.COUNT | A.TIME_SWEEP, "count"), (A.TIME_SWEEP, "numbered")):
         run("1024 exact %d..%d B %s" % (lo, hi, lab), pats_of(1024, lo, hi), 0, n_all, fl)
+os.environ["AGH_MP_FUSED"] = "0"              # count-only scans as two kernels (sweep, then verify)
+run("1024 exact 4..12 B count, two kernels", pats_of(1024, 4, 12), 0, n_all, A.COUNT | A.TIME_SWEEP)
+run("1024 exact 8..12 B count, two kernels", pats_of(1024, 8, 12), 0, n_all, A.COUNT | A.TIME_SWEEP)
+run("1024 x 8..12 B k=1 count, two kernels", pats_of(1024, 8, 12), 1, n_all, A.COUNT | A.TIME_SWEEP)
+run("1024 x 12..20 B k=2 count, two kernels", pats_of(1024, 12, 20), 2, n_all, A.COUNT | A.TIME_SWEEP)
+del os.environ["AGH_MP_FUSED"]
 run("1024 x 8..12 B k=1 count", pats_of(1024, 8, 12), 1, n_all, A.COUNT | A.TIME_SWEEP)
 run("1024 x 8..12 B k=1 -l", pats_of(1024, 8, 12), 1, n_all, A.FILENAMEONLY)
 run("1024 x 8..12 B k=1 numbered", pats_of(1024, 8, 12), 1, min(n_all, 1 << 30), A.TIME_SWEEP)

@@ -7,7 +7,9 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base, want, nbytes, outp = os.path.join(R, "gpurun_out", sys.argv[1]), sys.argv[2], float(sys.argv[3]), sys.argv[4]
 note = sys.argv[5] if len(sys.argv) > 5 else ""
 out = {}
-for grp in ("sq1", "tcc", "sq2"):
+for grp in ("sq1", "tcc", "sq2", "tcc2"):
+    if not os.path.exists(os.path.join(base, grp, "p_counter_collection.csv")):
+        continue
     rows = list(csv.DictReader(open(os.path.join(base, grp, "p_counter_collection.csv"))))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
@@ -42,6 +44,10 @@ for k, d in out.items():
             "lds_insts_per_byte": round(d["SQ_INSTS_LDS"] * 64 / nbytes, 3),
             "lds_bank_conflict_frac_of_lds_active": round(d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1), 3),
             "FETCH_SIZE_KiB_x1024_x2_over_bytes": round(d.get("FETCH_SIZE", 0) * 1024 * 2 / nbytes, 3),
+            "ea_read_requests": d.get("TCC_EA0_RDREQ_sum"), "ea_read_requests_32B": d.get("TCC_EA0_RDREQ_32B_sum"),
+            "ea_read_bytes_over_bytes_if_others_are_64B": (round((d["TCC_EA0_RDREQ_32B_sum"] * 32 + (d["TCC_EA0_RDREQ_sum"] - d["TCC_EA0_RDREQ_32B_sum"]) * 64) / nbytes, 3)
+                                                             if "TCC_EA0_RDREQ_sum" in d and "TCC_EA0_RDREQ_32B_sum" in d else None),
+            "l2_hit_frac": (round(d["TCC_HIT_sum"] / max(d["TCC_HIT_sum"] + d["TCC_MISS_sum"], 1), 3) if "TCC_HIT_sum" in d else None),
             "fetch_note": "x2 is the guide's gfx950 correction for 128-byte requests; a kernel that reads 64-byte "
                           "segments (the ring feeder) may issue 64-byte requests, then the true ratio is half of this"}}
 json.dump(res, open(os.path.join(R, outp), "w"), indent=1)

@@ -120,6 +120,15 @@ def asearch_tables(t, k, text, delim=b"\n", cap=0):
     return cnt, _collect(recs, cnt, cap)
 
 
+def asearch_tables_costs(t, k, costs, text, delim=b"\n", cap=0):
+    """asearch1.c's recurrence on given maskgen tables (wildcards / AND / OR together with -I -S -D)"""
+    p, n, keep = _buf(text)
+    recs = _recs(cap)
+    cnt = lib().orc_asearch_costs(C.byref(t), k, costs[0], costs[1], costs[2], p, n, delim,
+                                  len(delim), recs, cap)
+    return cnt, _collect(recs, cnt, cap)
+
+
 def asearch_costs(pat, k, costs, text, delim=b"\n", nocase=False, cap=0):
     """costs = (I, S, D): insertion, substitution, deletion (asearch1.c)"""
     M, t = maskgen(pat, delim, nocase)

@@ -907,3 +907,75 @@ def test_fullscan_fast_form_equals_exact_kernel(agh, monkeypatch):
                 assert r1.engine == agh.ENGINE_FULLSCAN
                 assert (r1.n_matched, [(s, e) for s, e, _ in ms]) == want, (pat, k, fast, len(t))
                 assert r2.n_matched == r3.n_matched == want[0], (pat, k, fast, len(t))
+
+
+def test_table_engine_with_edit_costs(agh):
+    """'#' / ';' / ',' together with -I -S -D: asearch1.c:88-97 runs on the same Init1 / endposition
+    tables; the table engine's feed_costs against the oracle's restatement of asearch1.c on the
+    reference's own tables (tests/golden/pattern_language.json)."""
+    rng = np.random.default_rng(11)
+    words = [b"car", b"cars", b"red", b"fast", b"scar", b"cat", b"a", b"ca r", b"cr", b"caar", b"rad", b" ", b"\n", b"\n"]
+    text = b"".join(words[i] for i in rng.integers(0, len(words), 40000))
+    text += O.corpus(96, seed=31, variants=O.VARIANTS_C2[:5] + (b"approxXXmatch", b"aprxmatch", b"matematch approx"),
+                     plant_period=12)[0].tobytes()
+    n = 0
+    for case in _golden("pattern_language.json"):
+        if case["k"] < 1 or not any(c in case["pattern"] for c in "#;,"):
+            continue
+        tb = case["tables"]
+        M = tb["D_endpos"].bit_length()
+        ot = O.tables_from_golden(tb, M)
+        for costs in ((2, 1, 1), (1, 2, 1), (1, 1, 2), (2, 2, 2), (3, 1, 2)):
+            q = agh.Query.from_maskgen(tb["Mask"], tb["Init0"], tb["Init1"], tb["NO_ERR_MASK"],
+                                       tb["endposition"], tb["D_endpos"], M, b"\n", case["k"], tb["AND"])
+            q.set_costs(*costs)
+            want = O.asearch_tables_costs(ot, case["k"], costs, text, cap=200000)
+            res, ms = q.scan_buffer(text, cap=200000)
+            res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+            q.close()
+            assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (case["pattern"], case["k"], costs)
+            assert res_c.n_matched == want[0]
+            n += 1
+    assert n >= 5
+
+
+def test_segments_cut_at_unaligned_record_ends(agh, monkeypatch):
+    """Inputs above the segment limit are cut where a record ends; where no record ends on a 16-byte
+    boundary -- 64-byte records behind a 1-byte header -- the cut is any record end and the segment
+    is scanned from an aligned copy (agh_result.copied_segments).  Counts, records and record numbers
+    equal the oracle's; the same with a two-byte delimiter (per-segment delimiter bitmap)."""
+    monkeypatch.setenv("AGH_SEG_MAX_MB", "1")
+    rng = random.Random(3)
+    recs = []
+    for i in range(70000):
+        r = bytearray(rng.choice(b"abcdefgh ") for _ in range(63))
+        if i % 97 == 0:
+            v = bytearray(b"approximatematch")
+            if i % 2:
+                v[5] = ord("Z")
+            at = rng.randrange(0, 63 - len(v))
+            r[at:at + len(v)] = v
+        recs.append(bytes(r))
+    text = b"H" + b"\n".join(recs) + b"\n"
+    assert all((1 + 64 * (j + 1)) % 16 for j in range(10))
+    want = O.asearch(b"approximatematch", 2, text, cap=10000)
+    with agh.Query(b"approximatematch", 2) as q:
+        r1, ms = q.scan_buffer(text, cap=10000)
+        r2, _ = q.scan_buffer(text, flags=agh.COUNT)
+        r3, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_FULLSCAN)
+    assert r1.n_segments >= 4 and r1.copied_segments >= 3, (r1.n_segments, r1.copied_segments)
+    assert (r1.n_matched, [(s, e) for s, e, _ in ms]) == want
+    assert [i for _, _, i in ms] == [s // 64 for s, _ in want[1]]
+    assert r2.n_matched == r3.n_matched == want[0]
+    # -f on the same file
+    with agh.Query.multi([b"approximatematch", b"approZimatematch"]) as q:
+        rm, _ = q.scan_buffer(text, flags=agh.COUNT)
+    assert rm.n_matched == want[0]
+    # two-byte delimiter: 62-byte records + "\r\n" behind a 1-byte header never end on a 64-byte boundary
+    t2 = b"H" + b"\r\n".join(r[:62] for r in recs[:50000]) + b"\r\n"
+    want2 = O.asearch(b"approximatematch", 2, t2, delim=b"\r\n", cap=10000)
+    with agh.Query(b"approximatematch", 2, delim=b"\r\n") as q:
+        r4, ms4 = q.scan_buffer(t2, cap=10000)
+        r5, _ = q.scan_buffer(t2, flags=agh.COUNT)
+    assert r4.copied_segments >= 1
+    assert (r4.n_matched, [(s, e) for s, e, _ in ms4]) == want2 and r5.n_matched == want2[0]

@@ -87,6 +87,8 @@ def test_reference_front_end_on_gpu_engines(files, args):
     ("aprxmtch", ["-V0", "-p", "-c"]),                      # -p: I = 0, every position sticky (bitap.c:123)
     ("aprxmtch", ["-V0", "-p", "-1", "-c"]),
     ("aqz", ["-V0", "-p"]),
+    ("approx#match", ["-V0", "-I2", "-2", "-c"]),           # wildcard with edit costs: asearch1.c on the table engine
+    ("approx;match", ["-V0", "-S2", "-D2", "-2", "-c"]),
 ])
 def test_pattern_language_through_the_shim(files, pattern, args):
     for fl in (files[:1], files[:2]):
