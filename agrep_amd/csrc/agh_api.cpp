@@ -119,6 +119,8 @@ struct agh_query {
     hipStream_t aux_stream = nullptr;
     dev_buf cand_b, wave_cand_b, cuts;
     dev_buf seg_copy;                   // aligned copy of a segment whose cut is not 16-byte aligned
+    dev_buf seg_dbm;                    // ... and its own delimiter bitmap (q->dbm holds the whole text's)
+    bool seg_dbm_active = false;
     dev_buf tickets;                    // fused lean kernel: one work counter (own 256-byte line) per segment
     std::vector<hipEvent_t> dep_events, time_events;
     uint64_t *h_cuts = nullptr;         // pinned: bounds, lower limits, cuts
@@ -877,6 +879,7 @@ extern "C" void agh_query_free(agh_query *q)
     q->wave_cand_b.release();
     q->cuts.release();
     q->seg_copy.release();
+    q->seg_dbm.release();
     q->tickets.release();
     if (q->ev0) (void)hipEventDestroy(q->ev0);
     if (q->ev1) (void)hipEventDestroy(q->ev1);
@@ -997,7 +1000,6 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const bool invert = (flags & AGH_INVERT) != 0;
     const bool invert_list = invert && d_match_pos != nullptr;
     if (invert_list && q->multi) return fail("-v with record output is not supported for pattern files");
-    if (invert_list && q_mb(q)) return fail("-v with record output supports single-byte delimiters only");
     const bool pe = q->piece_single && !q->general && !(flags & AGH_FORCE_FULLSCAN) && !invert_list;
     const bool multi = q->multi || pe;
     const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
@@ -1044,15 +1046,18 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const uint64_t *d_dbm = pre_dbm;           // the caller marked the delimiters of the whole text
     if (q_mb(q) && !pre_dbm) {
         const uint64_t n_words = (n + 63) / 64 + 4;     // readers may touch a few words past n
-        if (q->dbm.ensure(n_words * sizeof(uint64_t))) return -1;
+        // (a copied segment of a longer text: the bitmap of the whole text stays intact for the
+        // record bounds that are computed afterwards)
+        dev_buf &dbm_buf = q->seg_dbm_active ? q->seg_dbm : q->dbm;
+        if (dbm_buf.ensure(n_words * sizeof(uint64_t))) return -1;
         HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
-        agh_launch_delim_bitmap(d_text, n, dq, (uint64_t *)q->dbm.p, n_words, q->d_counters, st);
+        agh_launch_delim_bitmap(d_text, n, dq, (uint64_t *)dbm_buf.p, n_words, q->d_counters, st);
         HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (q->h_counters[AGH_C_DELIM_CHAIN])
             return fail("a run of overlapping delimiter occurrences exceeds 4 KiB (unsupported)");
-        d_dbm = (const uint64_t *)q->dbm.p;
+        d_dbm = (const uint64_t *)dbm_buf.p;
     }
 
     // ---- lean pipeline: count-only scans (-c, -l) of a filterable query -------------------
@@ -1107,10 +1112,14 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.tail_only = 1;
             agh_launch_sweep_multi(sa, st);
         } else if (multi) {
-            // AGH_MP_FUSED=0: candidates through the slices, k_verify_multi afterwards (A/B runs)
+            // AGH_MP_FUSED=1: full queues verified inside the sweep instead of going through the
+            // slices to k_verify_multi.  Measured and left off: the sweep is bound by VALU issue and
+            // a wave that verifies stops streaming -- 1024 exact patterns (4..12 B), 4 GiB: 1.44 ms as
+            // two kernels, 1.78 ms in one; k = 1 over 8..12 B: 1.87 vs 2.60 ms (VALU busy 95 % -> 61 %,
+            // waiting on memory 26 % -> 65 %: profiles/r03_pmc_sweep_multi*_fused.json)
             const agh_multi_dev md = multi_dev(q);
             const char *e = getenv("AGH_MP_FUSED");
-            if (!(e && e[0] == '0')) {
+            if (e && e[0] == '1') {
                 sa.fuse_mt = &md;
                 sa.fuse_mk = &va.mk;
             }
@@ -1863,14 +1872,16 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
             HIP_TRY(hipMemcpyAsync(q->seg_copy.p, base + off, end - off, hipMemcpyDeviceToDevice, st));
             seg_text = (const unsigned char *)q->seg_copy.p;
             seg_dbm = nullptr;
+            q->seg_dbm_active = global_dbm != nullptr;
             res->copied_segments += 1;
         }
-        if (scan_segment(q, seg_text, end - off, st, flags,
-                         (i == 0 && is_first) ? '\n' : q->delim[q->dlen - 1], end == len && is_last,
-                         d_match_pos ? d_match_pos + stored : nullptr,
-                         d_match_rec ? d_match_rec + stored : nullptr,
-                         d_match_pos ? cap_left : 0, &sr, seg_dbm))
-            return -1;
+        const int seg_rc = scan_segment(q, seg_text, end - off, st, flags,
+                                        (i == 0 && is_first) ? '\n' : q->delim[q->dlen - 1], end == len && is_last,
+                                        d_match_pos ? d_match_pos + stored : nullptr,
+                                        d_match_rec ? d_match_rec + stored : nullptr,
+                                        d_match_pos ? cap_left : 0, &sr, seg_dbm);
+        q->seg_dbm_active = false;
+        if (seg_rc) return -1;
         if (d_match_pos && sr.stored && off > 0) {
             // the segment's kernels saw positions / record numbers relative to its own start
             agh_launch_offset_matches(d_match_pos + stored, d_match_rec ? d_match_rec + stored : nullptr,
@@ -2249,28 +2260,39 @@ extern "C" int agh_shard_cuts_fd(int fd, const unsigned char *delim, int dlen, i
                                  uint64_t *cuts)
 {
     if (fd < 0 || !delim || nranks < 1 || !cuts) return fail("agh_shard_cuts_fd: bad arguments");
-    if (dlen != 1) return fail("sharding a file supports single-byte delimiters only");
+    if (dlen < 1 || dlen > AGH_MAX_DELIM) return fail("delimiter length %d outside 1..%d", dlen, AGH_MAX_DELIM);
+    // Several bytes: where a record ends must not depend on where the search starts.  That holds for
+    // delimiters no proper prefix of which is also a suffix ("\r\n", "From ", "$$$x"): their
+    // occurrences cannot overlap, every one is selected (asearch.c:54-57).  "\n\n" in "\n\n\n" is
+    // selected by what came before -- such delimiters are not sharded here.
+    for (int b = 1; b < dlen; ++b)
+        if (memcmp(delim, delim + dlen - b, (size_t)b) == 0)
+            return fail("sharding a file by a delimiter that can overlap itself is not supported");
     struct stat sb;
     if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return fail("sharding needs a seekable regular file");
     const uint64_t size = (uint64_t)sb.st_size;
     cuts[0] = 0;
-    std::vector<unsigned char> buf(1 << 16);
+    std::vector<unsigned char> buf((1 << 16) + AGH_MAX_DELIM);
+    const uint64_t dl = (uint64_t)dlen;
     for (int r = 1; r < nranks; ++r) {
         // size * r / nranks without overflow
         uint64_t nominal = size / (uint64_t)nranks * (uint64_t)r + size % (uint64_t)nranks * (uint64_t)r / (uint64_t)nranks;
         if (nominal < cuts[r - 1]) nominal = cuts[r - 1];
         if (nominal >= size) { cuts[r] = size; continue; }
+        if (nominal == 0) { cuts[r] = 0; continue; }
+        // the first delimiter occurrence that ENDS at or after the nominal offset: the cut is its end
+        // (an occurrence that ends exactly at the nominal offset means a record starts right there)
         uint64_t cut = size;
-        // one byte in front of the nominal offset decides whether a record starts right there
-        for (uint64_t off = nominal ? nominal - 1 : 0; off < size && cut == size;) {
+        for (uint64_t off = nominal >= dl ? nominal - dl : 0; off < size && cut == size;) {
             ssize_t got = pread(fd, buf.data(), buf.size(), (off_t)off);
             if (got < 0 && errno == EINTR) continue;
             if (got < 0) return fail("read failed: %s", strerror(errno));
-            if (got == 0) break;
-            if (nominal == 0) { cut = 0; break; }
-            const unsigned char *hit = (const unsigned char *)memchr(buf.data(), delim[0], (size_t)got);
-            if (hit) cut = off + (uint64_t)(hit - buf.data()) + 1;   // (the byte at nominal-1 gives cut == nominal)
-            off += (uint64_t)got;
+            if (got < (ssize_t)dl) break;
+            for (size_t i = 0; i + dl <= (size_t)got; ++i) {
+                if (off + i + dl < nominal) continue;
+                if (buf[i] == delim[0] && memcmp(buf.data() + i, delim, (size_t)dl) == 0) { cut = off + i + dl; break; }
+            }
+            off += (uint64_t)got - (dl - 1);        // keep dlen-1 bytes: an occurrence may straddle the reads
         }
         cuts[r] = cut;
     }

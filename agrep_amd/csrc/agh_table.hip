@@ -251,12 +251,16 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
 // a delimiter closes has the number "delimiters in front of it".  Emits (position of the
 // closing delimiter, record number) for k_match_bounds; one atomic per wave.
 // ---------------------------------------------------------------------------------------
+// Delimiters of several bytes (or a folded letter): the delimiter ends come from the bitmap.
 __global__ __launch_bounds__(256) void k_unmatched(const uint8_t *__restrict__ text, uint64_t n,
                                                    agh_dev_query q,
                                                    const uint32_t *__restrict__ strip_prefix,
                                                    const uint32_t *__restrict__ wave_prefix,
-                                                   uint32_t n_strips, agh_marks mk)
+                                                   uint32_t n_strips, agh_marks mk,
+                                                   const uint64_t *__restrict__ dbm)
 {
+    const bool mb = q.mb != 0;
+    auto is_delim_end = [&](uint64_t p) -> bool { return mb ? dbm_bit(dbm, p) != 0 : text[p] == q.delim; };
     const uint64_t n_chunks = (n + AGH_TS_CHUNK - 1) / AGH_TS_CHUNK;
     const uint32_t dd = q.delim * 0x01010101u;
     const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
@@ -266,7 +270,9 @@ __global__ __launch_bounds__(256) void k_unmatched(const uint8_t *__restrict__ t
         uint64_t ce = cs + AGH_TS_CHUNK;
         if (ce > n) ce = n;
         uint32_t my_delims = 0;
-        if (cs < n) {
+        if (cs < n && mb) {
+            my_delims = dbm_count(dbm, cs, ce);
+        } else if (cs < n) {
             const uint32_t len = (uint32_t)(ce - cs);
             for (uint32_t i = 0; i < (len >> 4); ++i)
                 my_delims += delims_in(*reinterpret_cast<const uint4 *>(text + cs + i * 16), dd);
@@ -290,13 +296,13 @@ __global__ __launch_bounds__(256) void k_unmatched(const uint8_t *__restrict__ t
                            ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] + before
                            : 0u;
         // the last, unterminated record is closed by the delimiter appended at EOF
-        const bool open_tail = cs < n && ce == n && q.tail_virtual && text[n - 1] != q.delim;
+        const bool open_tail = cs < n && ce == n && q.tail_virtual && !is_delim_end(n - 1);
         // pass 1: how many of my records are unmatched
         uint32_t mine = 0;
         if (cs < n) {
             uint32_t r = rec;
             for (uint64_t p = cs; p < ce; ++p)
-                if (text[p] == q.delim) {
+                if (is_delim_end(p)) {
                     if (r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) ++mine;
                     ++r;
                 }
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(256) void k_unmatched(const uint8_t *__restrict__ t
         if (mine) {
             uint32_t r = rec;
             for (uint64_t p = cs; p < ce; ++p)
-                if (text[p] == q.delim) {
+                if (is_delim_end(p)) {
                     if (r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) {
                         if (at < mk.match_cap) {
                             mk.match_pos[at] = p;
@@ -341,5 +347,5 @@ void agh_launch_unmatched(const agh_scan_args &a, hipStream_t st)
     uint64_t want = (n_chunks + 255) / 256;
     const uint32_t blocks = want > 65536 ? 65536u : (uint32_t)want;
     hipLaunchKernelGGL(k_unmatched, dim3(blocks), dim3(256), 0, st, (const uint8_t *)a.text, a.n,
-                       a.q, a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);
+                       a.q, a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm);
 }

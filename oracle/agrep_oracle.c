@@ -5,7 +5,8 @@
  * file:line whose behaviour it follows.  Nothing here is copied from the reference: the
  * algorithms are re-expressed (single-step loops instead of the 2x-unrolled A/B register
  * ping-pong, explicit record bookkeeping instead of output()), and they are pinned against
- * the reference by tests/test_oracle_golden.py and tests/test_oracle_vs_ref.py.
+ * the reference by tests/test_oracle_golden.py (vectors the compiled reference produced:
+ * oracle/gen_golden.py) and tests/test_oracle_fuzz.py (restatement vs DP vs the live reference).
  */
 #include "agrep_oracle.h"
 

@@ -120,3 +120,52 @@ def test_c_abi_shard_cuts_equal_python_rule(world, tmp_path):
             os.close(fd)
         want = shard.record_cuts(np.frombuffer(data, dtype=np.uint8), world)
         assert got == want, (world, i, len(data), got, want)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_c_abi_shard_cuts_multi_byte_delimiter(world, tmp_path):
+    """The same rule for delimiters of several bytes that cannot overlap themselves ("\\r\\n", "From "):
+    inner cut r = end of the first delimiter occurrence that ends at or after size * r / world.
+    Self-overlapping delimiters ("\\n\\n") are refused: which occurrences count depends on the scan's
+    start (asearch.c:54-57)."""
+    import agrep_amd
+    rng = np.random.default_rng(7 + world)
+    for delim in (b"\r\n", b"From ", b"ab"):
+        for trial in range(8):
+            n = int(rng.integers(0, 300000))
+            a = rng.integers(97, 101, size=n).astype(np.uint8).tobytes()
+            pieces = []
+            at = 0
+            while at < n:
+                step = int(rng.integers(1, 4000 if trial % 2 else 200))
+                pieces.append(a[at:at + step].replace(delim, b"zz"))
+                at += step
+            data = delim.join(pieces)
+            f = tmp_path / ("m%d.bin" % trial)
+            f.write_bytes(data)
+            want = [0]
+            for r in range(1, world):
+                nominal = max(want[-1], len(data) * r // world)
+                if nominal >= len(data):
+                    want.append(len(data))
+                    continue
+                if nominal == 0:
+                    want.append(0)
+                    continue
+                i = data.find(delim, max(0, nominal - len(delim)))
+                want.append(len(data) if i < 0 else i + len(delim))
+            want.append(len(data))
+            fd = os.open(str(f), os.O_RDONLY)
+            try:
+                got = agrep_amd.shard_cuts_fd(fd, world, delim=delim)
+            finally:
+                os.close(fd)
+            assert got == want, (delim, trial, got, want)
+    f = tmp_path / "nn.bin"
+    f.write_bytes(b"a\n\n\nb\n\n" * 100)
+    fd = os.open(str(f), os.O_RDONLY)
+    try:
+        with pytest.raises(agrep_amd.AghError):
+            agrep_amd.shard_cuts_fd(fd, 2, delim=b"\n\n")
+    finally:
+        os.close(fd)

@@ -979,3 +979,31 @@ def test_segments_cut_at_unaligned_record_ends(agh, monkeypatch):
         r5, _ = q.scan_buffer(t2, flags=agh.COUNT)
     assert r4.copied_segments >= 1
     assert (r4.n_matched, [(s, e) for s, e, _ in ms4]) == want2 and r5.n_matched == want2[0]
+
+
+def test_inverse_record_list_with_multi_byte_delimiters(agh):
+    """-v with record output where the delimiter has several bytes (or is a folded letter): k_unmatched
+    reads the delimiter-end bitmap.  The complement of the oracle's record set, record by record."""
+    text, _ = O.corpus(64, seed=23, variants=O.VARIANTS_C2, plant_period=5)
+    base = text.tobytes()
+    for delim, tb in ((b"\r\n", base.replace(b"\n", b"\r\n")), (b"$$", base.replace(b"\n", b"$$")[:-2]),
+                      (b"e ", base.replace(b"\n", b" "))):
+        # all records: the text between (leftmost, non-overlapping) delimiter occurrences
+        recs_all, at = [], 0
+        while True:
+            i = tb.find(delim, at)
+            if i < 0:
+                if at < len(tb):
+                    recs_all.append((at, len(tb)))
+                break
+            recs_all.append((at, i))
+            at = i + len(delim)
+        for pat, k in ((O.PATTERN_C2, 2), (b"approxim", 1)):
+            hit = set(O.asearch(pat, k, tb, delim=delim, cap=200000)[1])
+            want = [r for r in recs_all if r not in hit]
+            with agh.Query(pat, k, delim=delim) as q:
+                res, ms = q.scan_buffer(tb, flags=agh.INVERT, cap=200000)
+                rc, _ = q.scan_buffer(tb, flags=agh.INVERT | agh.COUNT)
+            assert res.n_matched == rc.n_matched == len(want), (delim, pat, k)
+            assert [(s, e) for s, e, _ in ms] == want, (delim, pat, k)
+            assert [i for _, _, i in ms][:40] == [recs_all.index(r) for r in want[:40]]
