@@ -703,9 +703,20 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
         off[i] = (uint32_t)pool.size();
         for (int t = 0; t < pcs[i].len; ++t) {
             unsigned char c = src[t];
-            if (c == delim0) usable[i] = 0;   // can never lie inside one record
+            if (q->dlen == 1 && !q->delim_fold && c == delim0) usable[i] = 0;   // can never lie inside one record
             if (nocase && is_upper(c)) c += 32;
             pool.push_back(c);
+        }
+        if (q->dlen > 1 || q->delim_fold) {     // ... nor can an entry that holds the whole delimiter
+            for (int t = 0; t + q->dlen <= pcs[i].len && usable[i]; ++t) {
+                bool same = true;
+                for (int j = 0; j < q->dlen && same; ++j) {
+                    unsigned char c = src[t + j];
+                    if (q->delim_fold && is_upper(c)) c += 32;
+                    same = c == q->delim[j];
+                }
+                if (same) usable[i] = 0;
+            }
         }
         if (!usable[i]) continue;
         for (int o = 0; o < stride; ++o) {
@@ -779,14 +790,21 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
 {
     if (!pats || !lens || npat < 1) { fail("no patterns"); return nullptr; }
     if (guard && D > 0) { fail("-w / -x with a pattern file need exact matching"); return nullptr; }
-    if (!delim || dlen != 1) {
-        fail("multi-pattern scans support single-byte delimiters only");
+    if (!delim || dlen < 1 || dlen > AGH_MAX_DELIM) {
+        fail("delimiter length %d outside 1..%d", dlen, AGH_MAX_DELIM);
         return nullptr;
     }
-    if (nocase && (is_upper(delim[0]) || is_lower(delim[0]))) {
-        fail("-f: -i together with a letter as the delimiter is not supported");
-        return nullptr;
+    // delimiters of several bytes, and letters under -i (maskgen.c:259-266), take their record ends
+    // from the delimiter bitmap like the single-pattern engines
+    bool delim_letters = false;
+    unsigned char dl[AGH_MAX_DELIM];
+    for (int i = 0; i < dlen; ++i) {
+        dl[i] = delim[i];
+        delim_letters = delim_letters || is_upper(delim[i]) || is_lower(delim[i]);
+        if (nocase && is_upper(dl[i])) dl[i] = (unsigned char)(dl[i] + 32);
     }
+    const bool dfold = nocase && delim_letters;
+    const unsigned char dlast = dl[dlen - 1];
     if (D < 0 || D > AGH_MAX_ERRORS) { fail("number of errors %d outside 0..%d", D, AGH_MAX_ERRORS); return nullptr; }
     for (int p = 0; p < npat; ++p) {
         if (lens[p] < 1 || lens[p] > 255) { fail("pattern %d: length %d outside 1..255", p, lens[p]); return nullptr; }
@@ -795,11 +813,13 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
             return nullptr;
         }
         if (D > 0)
-            for (int t = 0; t < lens[p]; ++t)
-                if (pats[p][t] == delim[0] || pats[p][t] == '\n') {
-                    fail("pattern %d holds a delimiter byte (not supported with errors)", p);
+            for (int t = 0; t < lens[p]; ++t) {
+                const unsigned char c = pats[p][t], cf = (dfold && is_upper(c)) ? (unsigned char)(c + 32) : c;
+                if (cf == dlast || c == '\n') {
+                    fail("pattern %d holds the byte that ends a record (not supported with errors)", p);
                     return nullptr;
                 }
+            }
     }
     if (agh_device_count() <= 0) { fail("no usable HIP device: libagrep_hip has no CPU path"); return nullptr; }
 
@@ -808,8 +828,9 @@ static agh_query *build_multi(const unsigned char *const *pats, const int *lens,
     q->npat = npat;
     q->guard = guard;
     q->k = D;
-    q->dlen = 1;
-    q->delim[0] = delim[0];
+    q->dlen = dlen;
+    memcpy(q->delim, dl, (size_t)dlen);
+    q->delim_fold = dfold;
     memset(q->mask, 0, sizeof(q->mask));
     if (fill_multi_tables(q, pats, lens, npat, D, nocase, delim[0], &q->fq, &q->qmask, &q->fold,
                           &q->m) ||
@@ -932,9 +953,11 @@ static bool fs_fast_ok(const agh_query *q)
 {
     const char *e = getenv("AGH_FS_FAST");
     if (e && e[0] == '0') return false;
+    if (q->fs_fast_off || q->multi) return false;
+    // table engine (k_tablescan_fast + k_table_replay): unit costs (its delimiter is one byte anyway)
+    if (q->table) return q->ci == 1 && q->cs == 1 && q->cd == 1;
     // k = 0: one level, nothing to pack -- the one-kernel form is faster there (3.8 vs 3.2 TB/s)
-    return !q->fs_fast_off && q->k >= 1 && !q->multi && !q->table && !q->general &&
-           !(q->dlen > 1 || q->delim_fold) && q->mask[q->delim[0]] == 0;
+    return q->k >= 1 && !q->general && !(q->dlen > 1 || q->delim_fold) && q->mask[q->delim[0]] == 0;
 }
 
 static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
@@ -950,9 +973,10 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     return 0;
 }
 
-static agh_multi_dev multi_dev(const agh_query *q)
+static agh_multi_dev multi_dev(const agh_query *q, const uint64_t *dbm)
 {
     agh_multi_dev m;
+    m.dbm = dbm;
     m.bits = (const uint32_t *)q->d_mp_bits;
     m.bucket_start = (const uint32_t *)q->d_mp_bstart;
     m.items = (const agh_mp_item *)q->d_mp_items;
@@ -1108,7 +1132,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         if (multi && q->multi_dense) {
             // dense hit set: probes and verification of the full strips in one kernel, nothing goes
             // through the slices but the partial last strip
-            agh_launch_dense_multi(sa, multi_dev(q), va.mk, st);
+            agh_launch_dense_multi(sa, multi_dev(q, d_dbm), va.mk, st);
             sa.tail_only = 1;
             agh_launch_sweep_multi(sa, st);
         } else if (multi) {
@@ -1117,7 +1141,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             // a wave that verifies stops streaming -- 1024 exact patterns (4..12 B), 4 GiB: 1.44 ms as
             // two kernels, 1.78 ms in one; k = 1 over 8..12 B: 1.87 vs 2.60 ms (VALU busy 95 % -> 61 %,
             // waiting on memory 26 % -> 65 %: profiles/r03_pmc_sweep_multi*_fused.json)
-            const agh_multi_dev md = multi_dev(q);
+            const agh_multi_dev md = multi_dev(q, d_dbm);
             const char *e = getenv("AGH_MP_FUSED");
             if (e && e[0] == '1') {
                 sa.fuse_mt = &md;
@@ -1142,7 +1166,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.dbm = d_dbm;
         va.gtab = tight_verify_enabled() ? q->d_gtab : nullptr;
         va.gram_spread = q->gram_spread;
-        if (multi) agh_launch_verify_multi(va, multi_dev(q), true, st);
+        if (multi) agh_launch_verify_multi(va, multi_dev(q, d_dbm), true, st);
         else agh_launch_verify_lean(va, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)q->wave_cand.p, (uint32_t)nw, q->d_counters, st);
@@ -1299,7 +1323,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                 mk0.match_rec = d_match_rec;
                 mk0.match_cap = match_cap;
                 sa.ev_begin = sa.ev_end = nullptr;
-                agh_launch_dense_multi(sa, multi_dev(q), mk0, st);
+                agh_launch_dense_multi(sa, multi_dev(q, d_dbm), mk0, st);
                 sa.tail_only = 1;
                 agh_launch_sweep_multi(sa, st);
             } else if (multi) {
@@ -1337,9 +1361,9 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.hashset_mask = 0;
         va.gtab = (tight_verify_enabled() && !multi) ? q->d_gtab : nullptr;
         va.gram_spread = q->gram_spread;
-        if (!multi && !use_filter && !q->table && fs_fast_setup(q, n, &va)) return -1;
+        if (!multi && !use_filter && fs_fast_setup(q, n, &va)) return -1;
         const bool fs_fast = va.fs_fast != 0;
-        if (multi) agh_launch_verify_multi(va, multi_dev(q), false, st);
+        if (multi) agh_launch_verify_multi(va, multi_dev(q, d_dbm), false, st);
         else if (use_filter) agh_launch_verify(va, st);
         else if (q->table) agh_launch_tablescan(va, st);
         else agh_launch_fullscan(va, st);

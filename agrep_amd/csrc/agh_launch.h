@@ -129,6 +129,7 @@ struct agh_multi_dev {
     const agh_mp_item *items;      // grouped by gram bucket
     const uint8_t *pool;           // entry bytes (lower-cased when the query folds case), padded by 16
     const uint32_t *owner_mask;    // k-error queries: [pattern][256] position masks (bit p-1 = position p)
+    const uint64_t *dbm;           // this scan's delimiter-end bitmap (delimiters of several bytes, folded letters) or NULL
 };
 // a.ftab = the bit table; a.tail_only: only the partial last strip (the dense kernel took the rest)
 void agh_launch_sweep_multi(const agh_sweep_args &a, hipStream_t st);

@@ -230,15 +230,17 @@ __device__ __forceinline__ uint64_t mp_item_occurs(const uint8_t *__restrict__ t
 // A verified exact occurrence at j: count its record once.
 template <bool LEAN>
 __device__ __forceinline__ void multi_mark(const uint8_t *__restrict__ text, const agh_dev_query &q,
-                                           const agh_marks &mk, uint64_t j, uint32_t rc_chunk)
+                                           const agh_marks &mk, uint64_t j, uint32_t rc_chunk,
+                                           const uint64_t *__restrict__ dbm)
 {
     if (LEAN) {
-        const uint64_t st = lean_record_start(text, j, q.delim, mk);
+        const uint64_t st = q.mb ? lean_record_start_mb(dbm, j, mk) : lean_record_start(text, j, q.delim, mk);
         if (st != ~0ull) lean_insert(mk, st);
     } else {
         // record number = delimiters in front of the chunk + delimiters in [chunk, j)
         uint32_t rec = rc_chunk;
-        for (uint64_t i = j & ~(uint64_t)15; i < j; ++i) rec += (text[i] == q.delim);
+        if (q.mb) rec += dbm_count(dbm, j & ~(uint64_t)15, j);
+        else for (uint64_t i = j & ~(uint64_t)15; i < j; ++i) rec += (text[i] == q.delim);
         mark_record(mk, rec, j);
     }
 }
@@ -254,10 +256,15 @@ __device__ __forceinline__ void approx_window_k(const uint8_t *__restrict__ text
                                                 const agh_dev_query &q,
                                                 const uint32_t *__restrict__ pmask, uint32_t m,
                                                 uint64_t ws, uint64_t we, uint64_t anchor,
-                                                uint32_t rc_anchor, const agh_marks &mk)
+                                                uint32_t rc_anchor, const agh_marks &mk,
+                                                const uint64_t *__restrict__ dbm)
 {
     const uint32_t finalbit = 1u << (m - 1);
     const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    const bool mb = q.mb != 0;                  // delimiter ends from the bitmap (several bytes / folded)
+    auto before_window = [&]() -> uint64_t {
+        return mb ? lean_record_start_mb(dbm, ws, mk) : lean_record_start(text, ws, q.delim, mk);
+    };
     Automaton<uint32_t, K> A;
     A.reset();
     uint32_t seen = 0;
@@ -276,6 +283,7 @@ __device__ __forceinline__ void approx_window_k(const uint8_t *__restrict__ text
         uint32_t cms[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) cms[t] = (uint32_t)t < nb ? pmask[(dws[t >> 2] >> (8 * (t & 3))) & 0xffu] : 0u;
+        const uint32_t d16 = mb ? (uint32_t)dbm_bits64(dbm, i0) & 0xffffu : 0u;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             if ((uint32_t)t < nb) {
@@ -283,7 +291,7 @@ __device__ __forceinline__ void approx_window_k(const uint8_t *__restrict__ text
                 const uint32_t hit = A.step(cms[t], finalbit) ? 1u : 0u;
                 hitm |= (uint64_t)(hit & ~seen) << (b0 + (uint32_t)t);
                 seen |= hit;
-                if (c == q.delim) {             // patterns never hold the delimiter byte: cm == 0 and
+                if (mb ? ((d16 >> t) & 1u) != 0u : c == q.delim) {   // patterns never hold the delimiter byte: cm == 0 and
                     dm |= 1ull << (b0 + (uint32_t)t);   // the re-fed step leaves level e with its e deletions
                     A.reset();
                     A.step(cms[t], finalbit);
@@ -293,13 +301,14 @@ __device__ __forceinline__ void approx_window_k(const uint8_t *__restrict__ text
         }
     }
     if (we == n && q.tail_virtual) {            // asearch.c:87-91: the appended delimiter is the 65th position at most
-        if (A.step(pmask[q.delim], finalbit) && !seen) {
+        bool tail_hit = false;
+        for (uint32_t jd = 0; jd < q.dlen && !tail_hit; ++jd) tail_hit = A.step(pmask[q.dbytes[jd]], finalbit);
+        if (tail_hit && !seen) {
             // the record that is open at the end of the text
             const uint32_t span = (uint32_t)(we - ws);
             const uint64_t below = span >= 64 ? dm : (dm & ((1ull << span) - 1ull));
             if (LEAN) {
-                const uint64_t st = below ? ws + 64 - (uint64_t)__clzll((long long)below)
-                                          : lean_record_start(text, ws, q.delim, mk);
+                const uint64_t st = below ? ws + 64 - (uint64_t)__clzll((long long)below) : before_window();
                 if (st != ~0ull) lean_insert(mk, st);
             } else {
                 const uint32_t a = (uint32_t)(anchor - ws);
@@ -318,7 +327,7 @@ __device__ __forceinline__ void approx_window_k(const uint8_t *__restrict__ text
             uint64_t st;
             if (below) st = ws + 64 - (uint64_t)__clzll((long long)below);
             else {
-                if (before_ws == ~1ull) before_ws = lean_record_start(text, ws, q.delim, mk);
+                if (before_ws == ~1ull) before_ws = before_window();
                 st = before_ws;
             }
             if (st != ~0ull) lean_insert(mk, st);
@@ -357,13 +366,13 @@ __device__ __forceinline__ void mp_verify_at(const uint8_t *__restrict__ text, u
             // virtual byte in front of the text and the delimiter appended behind it count
             const uint32_t len = item.info & 0xffu;
             const uint32_t before = js ? text[js - 1] : q.head_byte;
-            const uint32_t after = js + len < n ? text[js + len] : q.delim;
+            const uint32_t after = js + len < n ? text[js + len] : q.dbytes[0];
             const bool ok = q.guard == 2u ? (before == '\n' && after == '\n')
                                           : !(dev_isalnum(before) || dev_isalnum(after));
             if (!ok) continue;
         }
         if (K == 0) {
-            multi_mark<LEAN>(text, q, mk, j, rc_chunk);
+            multi_mark<LEAN>(text, q, mk, j, rc_chunk, mt.dbm);
             return;                             // one verbatim entry is enough for the record
         }
         const uint32_t po = item.pom >> 8, m = item.pom & 0xffu;
@@ -374,7 +383,7 @@ __device__ __forceinline__ void mp_verify_at(const uint8_t *__restrict__ text, u
         uint64_t we = js + (m - po) + K;
         if (we > n) we = n;
         approx_window_k<LEAN, K>(text, n, q, mt.owner_mask + (size_t)item.owner * 256u, m, ws, we, anchor,
-                                 rc_chunk, mk);
+                                 rc_chunk, mk, mt.dbm);
     }
 }
 
@@ -396,7 +405,8 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
                                                      uint64_t *__restrict__ cand,
                                                      uint32_t *__restrict__ wave_cand,
                                                      uint32_t *__restrict__ counters,
-                                                     agh_multi_tables mt, agh_marks mk)
+                                                     agh_multi_tables mt, agh_marks mk,
+                                                     const uint16_t *__restrict__ dbm16)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[AGH_MP_WORDS];
     __shared__ uint64_t cq_all[4 * AGH_MP_CQ_LEN];
@@ -475,10 +485,20 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
         // census (numbered scans): delimiters in front of the lane's chunk of every strip
         uint32_t rc[4] = {0u, 0u, 0u, 0u};
         if (!(MODE & 4)) {
-            const uint32_t a0 = nz_popc(v0.x, dd) + nz_popc(v0.y, dd) + nz_popc(v0.z, dd) + nz_popc(v0.w, dd);
-            const uint32_t a1 = nz_popc(v1.x, dd) + nz_popc(v1.y, dd) + nz_popc(v1.z, dd) + nz_popc(v1.w, dd);
-            const uint32_t a2 = nz_popc(v2.x, dd) + nz_popc(v2.y, dd) + nz_popc(v2.z, dd) + nz_popc(v2.w, dd);
-            const uint32_t a3 = nz_popc(v3.x, dd) + nz_popc(v3.y, dd) + nz_popc(v3.z, dd) + nz_popc(v3.w, dd);
+            // ("128 minus the delimiters of the lane's chunk"; bitmap delimiters: 16 bits per chunk)
+            uint32_t a0, a1, a2, a3;
+            if (q.mb) {
+                const uint16_t *d = dbm16 + s * 64 + lane;
+                a0 = 128u - (uint32_t)__popc((uint32_t)d[0]);
+                a1 = 128u - (uint32_t)__popc((uint32_t)d[64]);
+                a2 = 128u - (uint32_t)__popc((uint32_t)d[128]);
+                a3 = 128u - (uint32_t)__popc((uint32_t)d[192]);
+            } else {
+                a0 = nz_popc(v0.x, dd) + nz_popc(v0.y, dd) + nz_popc(v0.z, dd) + nz_popc(v0.w, dd);
+                a1 = nz_popc(v1.x, dd) + nz_popc(v1.y, dd) + nz_popc(v1.z, dd) + nz_popc(v1.w, dd);
+                a2 = nz_popc(v2.x, dd) + nz_popc(v2.y, dd) + nz_popc(v2.z, dd) + nz_popc(v2.w, dd);
+                a3 = nz_popc(v3.x, dd) + nz_popc(v3.y, dd) + nz_popc(v3.z, dd) + nz_popc(v3.w, dd);
+            }
             const uint32_t own01 = a0 | (a1 << 16), own23 = a2 | (a3 << 16);
             const uint32_t sc01 = wave_sum_to_lane63(own01), sc23 = wave_sum_to_lane63(own23);
             const uint32_t p01 = (uint32_t)__builtin_amdgcn_readlane((int)sc01, 63);
@@ -516,7 +536,8 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
         lo >>= 32u - NB;
         uint32_t rc[4] = {0u, 0u, 0u, 0u};
         if (!(MODE & 4)) {
-            const uint32_t a0 = nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
+            const uint32_t a0 = q.mb ? 128u - (uint32_t)__popc((uint32_t)dbm16[st * 64 + lane])
+                                     : nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
             const uint32_t sc = wave_sum_to_lane63(a0);
             rc[0] = run + 128u * (uint32_t)lane - (sc - a0);
             run += 8192u - (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
@@ -563,7 +584,8 @@ __global__ __launch_bounds__(64) void k_sweep_multi_tail(const uint4 *__restrict
                                                          uint64_t *__restrict__ cand,
                                                          uint32_t *__restrict__ wave_cand,
                                                          uint32_t *__restrict__ counters,
-                                                         const uint32_t *__restrict__ strip_prefix)
+                                                         const uint32_t *__restrict__ strip_prefix,
+                                                         const uint16_t *__restrict__ dbm16)
 {
     // strip_prefix != NULL: a census pass already ran (dense numbered scans); wave_totals holds
     // the exclusive prefix per range and strip_prefix the per-strip offsets -- read, not written
@@ -580,7 +602,10 @@ __global__ __launch_bounds__(64) void k_sweep_multi_tail(const uint4 *__restrict
         if (off + 16 > n) v = mask_tail(v, (int)(n - off), fill4);
     }
     uint32_t acc = 0;
-    if (!(MODE & 4)) acc = nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
+    if (!(MODE & 4)) {
+        if (q.mb) acc = 128u - (off < n ? (uint32_t)__popc((uint32_t)dbm16[off >> 4]) : 0u);
+        else acc = nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
+    }
     uint32_t w0[5] = {v.x | fold4, v.y | fold4, v.z | fold4, v.w | fold4, next_lane_dword(v.x, fill4) | fold4};
     constexpr uint32_t NB = 16u / STRIDE;
     uint32_t hits = 0;
@@ -709,7 +734,8 @@ __global__ __launch_bounds__(256) void k_dense_multi(const uint4 *__restrict__ t
         hits >>= 16;
         uint32_t rc[4] = {0u, 0u, 0u, 0u};
         if (!LEAN) {
-            const uint32_t a0 = nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
+            const uint32_t a0 = q.mb ? 128u - (uint32_t)__popc((uint32_t)reinterpret_cast<const uint16_t *>(mt.dbm)[s * 64 + lane])
+                                     : nz_popc(v.x, dd) + nz_popc(v.y, dd) + nz_popc(v.z, dd) + nz_popc(v.w, dd);
             const uint32_t sc = wave_sum_to_lane63(a0);
             rc[0] = run + 128u * (uint32_t)lane - (sc - a0);
             run += 8192u - (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
@@ -737,7 +763,8 @@ static void launch_sweep_multi_ms(const agh_sweep_args &a, hipStream_t st)
 #define AGH_SM_LAUNCH(FKV, MT, MK)                                                            \
     hipLaunchKernelGGL((k_sweep_multi<MODE, STRIDE, Q5, FKV>), dim3((uint32_t)((n_waves + 3) / 4)), \
                        dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,             \
-                       (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand, a.counters, MT, MK)
+                       (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand, a.counters, MT, MK, \
+                       (const uint16_t *)a.dbm)
     if (n_waves && !a.tail_only) {
         // count-only scans with q == 4 and k <= 2: verification inside the sweep
         const bool fuse = (MODE & 4) && (MODE & 2) && a.fuse_mt && a.fuse_mk && a.q.k >= 0 && a.q.k <= 2;
@@ -757,7 +784,8 @@ static void launch_sweep_multi_ms(const agh_sweep_args &a, hipStream_t st)
                            (const uint4 *)a.text, a.n, a.q, (const uint32_t *)a.ftab,
                            a.wave_totals, a.cand, a.wave_cand, a.counters,
                            (a.tail_only && !a.lean) ? (const uint32_t *)a.strip_prefix
-                                                    : (const uint32_t *)nullptr);
+                                                    : (const uint32_t *)nullptr,
+                           (const uint16_t *)a.dbm);
 }
 
 // a.q.fh = the probe stride chosen by the host (fill_multi_tables): 1, 2 or 4; strides > 1 imply q == 4

@@ -216,6 +216,246 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// fast form: branch-free hot loop + exact replay of the records that may match
+// ---------------------------------------------------------------------------------------
+// k_tablescan spends 23 VALU instructions per byte at k = 0 (profiles/r03_pmc_tablescan.json: issue
+// bound) on a loop that is mostly bookkeeping: is this byte a delimiter, does a record of mine close
+// here, which record is it.  Here the hot kernel only advances the reference's recurrence --
+// the reset at a delimiter is a select against the constant state a reset leaves (RF), read together
+// with the byte's mask as (CM, kill) from LDS -- and ORs up "the top level holds an end bit at a
+// record end".  A 16-byte piece where that happened goes to the tile's replay list; k_table_replay
+// then runs asearch.c's recurrence over exactly those records, from their first byte.  Ownership is
+// as in k_tablescan: a lane speaks for the records that START in its 1 KiB chunk (its state is only
+// trusted behind the first delimiter it has seen) and walks on past the chunk's end to the delimiter
+// that closes its last record.  ';' AND patterns are flagged like ',' OR ones (any end bit): the
+// replay decides.  Unit costs, one-byte delimiter.
+template <int K>
+struct TableFast {
+    uint32_t B[K + 1];
+    // one byte: (CM, kb) = (mask of the byte, 0 for the delimiter else ~0) -> A[K] BEFORE the reset
+    __device__ __forceinline__ uint32_t feed(uint32_t CM, uint32_t kb, const agh_dev_tables &T,
+                                             const uint32_t (&RF)[K + 1])
+    {
+        uint32_t A[K + 1];
+        A[0] = ((B[0] >> 1) & CM) | (T.Init1 & B[0]);
+#pragma unroll
+        for (int e = 1; e <= K; ++e)
+            A[e] = ((B[e] >> 1) & CM) | (T.Init1 & B[e]) | B[e - 1] |
+                   (((A[e - 1] | B[e - 1]) >> 1) & T.NO_ERR);
+        const uint32_t top = A[K];
+#pragma unroll
+        for (int e = 0; e <= K; ++e) B[e] = (A[e] & kb) | (RF[e] & ~kb);     // v_bfi: the reset is a select
+        return top;
+    }
+};
+
+// the state asearch.c:175-186 leaves behind a delimiter (all levels Init[0], the delimiter consumed
+// again, level 0 masked)
+template <int K>
+__device__ __forceinline__ void table_reset_state(const agh_dev_tables &T, uint32_t CMd, uint32_t (&RF)[K + 1])
+{
+    RF[0] = (((T.Init0 >> 1) & CMd) | (T.Init0 & T.Init1)) & T.D_Mask;
+#pragma unroll
+    for (int e = 1; e <= K; ++e)
+        RF[e] = ((T.Init0 >> 1) & CMd) | (T.Init1 & T.Init0) | T.Init0 | (((RF[e - 1] | T.Init0) >> 1) & T.NO_ERR);
+}
+
+#define AGH_TF_SLICE 256u       // replay entries per 64 KiB tile
+
+template <int K>
+__global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
+    const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
+    const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
+    uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters)
+{
+    struct MK { uint32_t cm, kb; };
+    __shared__ MK tab[256];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * WAVE * AGH_FS_ROW];
+    tab[threadIdx.x].cm = mask_g[threadIdx.x];
+    tab[threadIdx.x].kb = threadIdx.x == q.delim ? 0u : ~0u;
+    __syncthreads();
+    uint32_t RF[K + 1];
+    table_reset_state<K>(T, mask_g[q.delim & 0xffu], RF);
+    const int lane = lane_id();
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    uint8_t *ring = ring_all + wib * (WAVE * AGH_FS_ROW);
+    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_FS_CHUNK;
+    const uint64_t n_tiles = (n + tile_bytes - 1) / tile_bytes;
+    const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
+    const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    const uint32_t seg_lo = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
+    uint8_t *ring_w = ring + seg_lo * AGH_FS_ROW + part * 16u;
+    const uint8_t *ring_r = ring + (uint32_t)lane * AGH_FS_ROW;
+
+    for (uint64_t tile = (uint64_t)blockIdx.x * (AGH_FS_THREADS / WAVE) + wib; tile < n_tiles;
+         tile += (uint64_t)gridDim.x * (AGH_FS_THREADS / WAVE)) {
+        const uint64_t t0 = tile * tile_bytes;
+        const uint64_t cs = t0 + (uint64_t)lane * AGH_FS_CHUNK;
+        uint64_t ce = cs + AGH_FS_CHUNK;
+        if (ce > n) ce = n;
+        const uint32_t len = cs < n ? (uint32_t)(ce - cs) : 0u;
+        auto gather = [&](uint32_t r, uint4 (&g)[4]) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint64_t a = t0 + (uint64_t)(seg_lo + 16u * i) * AGH_FS_CHUNK + r * AGH_FS_ROUND + part * 16u;
+                g[i] = a < n16 ? *reinterpret_cast<const uint4 *>(text + a) : make_uint4(fill4, fill4, fill4, fill4);
+            }
+        };
+        uint4 g[4];
+        gather(0, g);
+        TableFast<K> A;
+#pragma unroll
+        for (int e = 0; e <= K; ++e) A.B[e] = T.Init0;
+        // trusted: the lane has seen the start of the record it is in (the text's first byte, or a
+        // delimiter inside its chunk)
+        uint32_t trusted = 0u, cnt = 0;
+        if (cs == 0 && len) {                   // the virtual head byte, asearch.c:69-78
+            const MK e = tab[q.head_byte & 0xffu];
+            (void)A.feed(e.cm, e.kb, T, RF);
+            trusted = ~0u;
+        }
+        // 16 bytes: -> "some trusted record end in the piece shows an end bit on the top level"
+        auto piece = [&](uint4 v, uint32_t nbytes) -> uint32_t {
+            const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+            uint32_t flag = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 16; ++b) {
+                if (b < nbytes) {
+                    const MK e = tab[(dws[b >> 2] >> (8u * (b & 3u))) & 0xffu];
+                    const uint32_t top = A.feed(e.cm, e.kb, T, RF);
+                    flag |= top & ~e.kb & trusted;
+                    trusted |= ~e.kb;
+                }
+            }
+            return flag & T.endposition;
+        };
+        auto emit = [&](bool f, uint64_t pos) {  // (uniform call sites: every lane of the wave comes here)
+            const uint64_t fm = __ballot(f);
+            if (!fm) return;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            if (f) {
+                const uint32_t at = cnt + rank;
+                if (at < AGH_TF_SLICE) replay[tile * AGH_TF_SLICE + at] = pos;
+                else counters[AGH_C_OVERFLOW] = 1u;
+            }
+            cnt += (uint32_t)__popcll(fm);
+        };
+        for (uint32_t r = 0; r < AGH_FS_CHUNK / AGH_FS_ROUND; ++r) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i)
+                *reinterpret_cast<uint4 *>(ring_w + 16u * i * AGH_FS_ROW) = g[i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (r + 1 < AGH_FS_CHUNK / AGH_FS_ROUND) gather(r + 1, g);
+#pragma unroll 1
+            for (uint32_t p = 0; p < 4; ++p) {
+                const uint32_t off = r * AGH_FS_ROUND + 16u * p;
+                const uint4 v = *reinterpret_cast<const uint4 *>(ring_r + 16u * p);
+                const uint32_t nb = off + 16u <= len ? 16u : (off < len ? len - off : 0u);
+                uint32_t flag = nb ? piece(v, nb) : 0u;
+                // the piece that holds the last byte of the text: the appended delimiter is the replay's
+                if (nb && cs + off + 16u >= n && trusted) flag = 1u;
+                emit(flag != 0u, cs + off);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all reads done before the next round's writes
+            __builtin_amdgcn_wave_barrier();
+        }
+        // on alone to the delimiter that closes my last record (ce is 16-byte aligned unless ce == n)
+        bool open = len == AGH_FS_CHUNK && trusted != 0u && ce < n;
+        {
+            // (did my chunk end exactly behind a delimiter?  then nothing of mine is open)
+            if (open && text[ce - 1] == q.delim) open = false;
+        }
+        for (uint64_t p0 = ce; __ballot(open); p0 += 16) {
+            uint32_t flag = 0;
+            bool mine = open;
+            if (open) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
+                const uint32_t nb = p0 + 16 <= n ? 16u : (uint32_t)(n - p0);
+                const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+                for (uint32_t b = 0; b < nb && open; ++b) {
+                    const MK e = tab[(dws[b >> 2] >> (8u * (b & 3u))) & 0xffu];
+                    const uint32_t top = A.feed(e.cm, e.kb, T, RF);
+                    if (!e.kb) {                // the delimiter that closes my record
+                        flag = top & T.endposition;
+                        open = false;
+                    }
+                }
+                if (open && p0 + 16 >= n) {     // the text ends inside my record: the last piece
+                    flag = 1u;
+                    open = false;
+                }
+            }
+            // the entry belongs to the tile that holds the piece; entries in another tile's list would
+            // race with its owner, so they go to MY tile's list with the position -- the replay only
+            // needs the position
+            emit(mine && flag != 0u, p0);
+        }
+        if (lane == 0) tile_cnt[tile] = cnt < AGH_TF_SLICE ? cnt : AGH_TF_SLICE;
+    }
+}
+
+// Exact: for every listed piece, every record that ENDS in it (a delimiter inside the piece, or the
+// end of the text) is run through asearch.c's recurrence from its first byte.
+template <int K, bool LEAN>
+__global__ __launch_bounds__(256) void k_table_replay(
+    const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
+    const uint32_t *__restrict__ mask_g, const uint64_t *__restrict__ replay,
+    const uint32_t *__restrict__ tile_cnt, uint32_t n_tiles,
+    const uint32_t *__restrict__ strip_prefix, const uint32_t *__restrict__ wave_prefix,
+    uint32_t n_strips, agh_marks mk)
+{
+    __shared__ uint32_t lmask[256];
+    lmask[threadIdx.x] = mask_g[threadIdx.x];
+    __syncthreads();
+    const uint32_t dd = q.delim * 0x01010101u;
+    for (uint32_t tile = blockIdx.x * 4u + threadIdx.x / WAVE; tile < n_tiles; tile += gridDim.x * 4u) {
+        const uint32_t cnt = tile_cnt[tile];
+        for (uint32_t e = (uint32_t)lane_id(); e < cnt; e += WAVE) {
+            const uint64_t P = replay[(uint64_t)tile * AGH_TF_SLICE + e];
+            uint64_t pend = P + 16;
+            if (pend > n) pend = n;
+            // records that end in [P, pend): one per delimiter there, plus the open one at the text's end
+            uint64_t rs = lean_record_start(text, P, q.delim, mk);      // start of the record that holds byte P
+            if (rs == ~0ull) {                  // more than 1 MiB back: this text belongs to the exact kernel
+                mk.counters[AGH_C_OVERFLOW] = 1u;
+                continue;
+            }
+            uint32_t rec = 0;
+            if (!LEAN) {
+                const uint64_t strip = rs >> AGH_STRIP_SHIFT;
+                rec = strip < n_strips ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] : 0u;
+                for (uint64_t i = strip << AGH_STRIP_SHIFT; i + 16 <= rs; i += 16)
+                    rec += delims_in(*reinterpret_cast<const uint4 *>(text + i), dd);
+                for (uint64_t i = rs & ~(uint64_t)15; i < rs; ++i) rec += text[i] == q.delim;
+            }
+            TableAutomaton<K> A;
+            A.reset(T);
+            // the state at the record's start: what the delimiter (or the virtual head byte) in front
+            // of it left behind
+            if (rs == 0) (void)A.feed(lmask[q.head_byte], T);
+            else (void)A.feed(lmask[q.delim], T);
+            for (uint64_t i = rs; i < pend; ++i) {
+                const uint32_t r = A.feed(lmask[text[i]], T);
+                if (r & 1u) {                   // a record closes at i
+                    if ((r & 2u) && i >= P) {
+                        if (LEAN) lean_insert(mk, rs); else mark_record(mk, rec, i);
+                    }
+                    ++rec;
+                    rs = i + 1;
+                }
+            }
+            if (pend == n && q.tail_virtual && rs < n) {    // asearch.c:87-91: the open record at the end
+                const uint32_t r = A.feed(lmask[q.delim], T);
+                if ((r & 3u) == 3u) {
+                    if (LEAN) lean_insert(mk, rs); else mark_record(mk, rec, n);
+                }
+            }
+        }
+    }
+}
+
 void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
 {
     const uint64_t tile_bytes = (uint64_t)WAVE * AGH_FS_CHUNK;
@@ -225,6 +465,33 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
     const uint32_t blocks = want > 16384 ? 16384u : (uint32_t)want;
     const bool lean = a.mk.hashset != nullptr;  // count-only: hash set of record starts, no census
     const bool costs = a.q.ci != 1u || a.q.cs != 1u || a.q.cd != 1u;     // asearch1.c instead of asearch.c
+    if (a.fs_fast && !costs) {                  // branch-free hot kernel + exact replay (the host checked)
+        const uint32_t nt = (uint32_t)n_tiles;
+        const uint32_t rblocks = (nt + 3u) / 4u > 16384u ? 16384u : (nt + 3u) / 4u;
+#define AGH_TF_CASE(KK)                                                                       \
+    case KK:                                                                                  \
+        hipLaunchKernelGGL((k_tablescan_fast<KK>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
+                           (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                           a.fs_replay, a.fs_tile_cnt, a.mk.counters);                        \
+        if (lean)                                                                             \
+            hipLaunchKernelGGL((k_table_replay<KK, true>), dim3(rblocks), dim3(256), 0, st,   \
+                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                               (const uint64_t *)a.fs_replay, (const uint32_t *)a.fs_tile_cnt, nt, \
+                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);              \
+        else                                                                                  \
+            hipLaunchKernelGGL((k_table_replay<KK, false>), dim3(rblocks), dim3(256), 0, st,  \
+                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                               (const uint64_t *)a.fs_replay, (const uint32_t *)a.fs_tile_cnt, nt, \
+                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);              \
+        break;
+        switch (a.q.k) {
+            AGH_TF_CASE(0) AGH_TF_CASE(1) AGH_TF_CASE(2) AGH_TF_CASE(3) AGH_TF_CASE(4)
+            AGH_TF_CASE(5) AGH_TF_CASE(6) AGH_TF_CASE(7) AGH_TF_CASE(8)
+        default: break;
+        }
+#undef AGH_TF_CASE
+        return;
+    }
 #define AGH_TS_LAUNCH(KK, LEANV, COSTV)                                                       \
     hipLaunchKernelGGL((k_tablescan<KK, LEANV, COSTV>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
                        (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask,    \

@@ -234,3 +234,48 @@ def test_multi_pattern_with_errors_strided(agh, npat, lo, hi, k, stride):
     text = _plant(base.tobytes(), planted, rng, every=6)
     res = _check_approx(agh, pats, k, text)
     assert res.n_matched > 0
+
+
+@pytest.mark.parametrize("delim", [b"\r\n", b"$$", b"; ", b"\n\n"])
+def test_multi_pattern_with_multi_byte_delimiters(agh, delim):
+    """-f (exact and with errors) where records are separated by several bytes: record ends come from
+    the delimiter bitmap, as in the single-pattern engines (preproce.c:181-224, delim.c:49-96 for
+    mgrep's record bounds).  Records, record numbers and counts against the oracle."""
+    rng = random.Random(len(delim) * 31 + delim[0])
+    pats = _rand_patterns(rng, 40, 5, 11)
+    base, _ = O.corpus(40, seed=9, variants=(), plant_period=0)
+    planted = [_mutate(rng.choice(pats), rng.randint(0, 2), rng) for _ in range(64)]
+    text = _plant(base.tobytes(), planted, rng, every=5).replace(b"\n", delim)
+    for t in (text, text[:-len(delim)], text[:100000] + delim + delim + text[100000:200000]):
+        want = O.multi_exact_count(pats, t, delim=delim, cap=200000)
+        with agh.Query.multi(pats, delim=delim) as q:
+            res, ms = q.scan_buffer(t, cap=200000)
+            res_c, _ = q.scan_buffer(t, flags=agh.COUNT)
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (delim, len(t))
+        assert res_c.n_matched == want[0]
+        recs = set()
+        for p in pats:
+            recs.update(O.asearch(p, 1, t, delim=delim, cap=400000)[1])
+        want1 = sorted(recs)
+        with agh.Query.multi(pats, delim=delim, k=1) as q:
+            res, ms = q.scan_buffer(t, cap=400000)
+            res_c, _ = q.scan_buffer(t, flags=agh.COUNT)
+            res_n, _ = q.scan_buffer(t, flags=agh.COUNT | agh.FORCE_NUMBERED)
+        assert [(s, e) for s, e, _ in ms] == want1, (delim, len(t))
+        assert res.n_matched == res_c.n_matched == res_n.n_matched == len(want1)
+
+
+def test_multi_pattern_nocase_letter_delimiter(agh):
+    """-i -d q -f: 'Q' ends a record as well (maskgen.c:259-266 aliases the delimiter's rows too)."""
+    rng = random.Random(17)
+    pats = [b"needle", b"haystack", b"stall"]
+    base, _ = O.corpus(24, seed=3, variants=(b"Needle", b"HAYSTACK", b"needle"), plant_period=6, upper_permille=200)
+    t = base.tobytes().replace(b"\n", b"q")
+    recs = set()
+    for p in pats:
+        recs.update(O.asearch(p, 0, t, delim=b"q", nocase=True, cap=100000)[1])
+    want = sorted(recs)
+    with agh.Query.multi(pats, nocase=True, delim=b"q") as q:
+        res, ms = q.scan_buffer(t, cap=100000)
+        res_c, _ = q.scan_buffer(t, flags=agh.COUNT)
+    assert [(s, e) for s, e, _ in ms] == want and res.n_matched == res_c.n_matched == len(want)
