@@ -343,6 +343,30 @@ __device__ __forceinline__ void approx_window_k(const uint8_t *__restrict__ text
     }
 }
 
+// -f with ONE error, patterns of two pieces: with one piece verbatim the other side has to lie
+// within one edit of the text next to it -- a question about <= 8 bytes that two 64-bit words answer
+// (no automaton, no per-byte mask gathers: the verifier waits on its dependent loads).
+// S = the text bytes next to the piece, nearest first; B = the pattern bytes of the other side in the
+// same order; L <= 7 of them.  Up to the first mismatch i both agree; one edit there and the rest has
+// to agree again: the pattern byte is missing in the text (B[i+1..] == S[i..]), replaced
+// (B[i+1..] == S[i+1..]) or a text byte stands in front of it (B[i..] == S[i+1..]).  A delimiter can
+// only be the replaced or the extra text byte (patterns hold none): the automaton resets there, so
+// that is no match.
+__device__ __forceinline__ bool side_within_one_edit(uint64_t S, uint64_t B, uint32_t L, uint32_t delim)
+{
+    const uint64_t maskL = (1ull << (8u * L)) - 1ull;
+    const uint64_t x = (S ^ B) & maskL;
+    if (!x) return true;
+    const uint32_t i8 = (uint32_t)__builtin_ctzll(x) & ~7u;         // 8 * (first mismatching byte)
+    const uint64_t tail = maskL >> i8;                              // bytes i .. L-1, moved down
+    if (!(((S ^ (B >> 8)) >> i8) & (tail >> 8))) return true;      // the pattern byte is missing
+    if (((uint32_t)(S >> i8) & 0xffu) == delim) return false;
+    if (!((x >> i8) >> 8)) return true;                             // replaced
+    return !((((S >> 8) ^ B) >> i8) & tail);                        // an extra text byte
+}
+
+typedef uint64_t u64_u __attribute__((aligned(1)));
+
 // Everything that can match at candidate position j: the bucket of entries with the gram at j.
 // K = 0: an entry that occurs is a match; K > 0: a verbatim PIECE at text position js sends its
 // pattern's automaton over [js - po - K, js + (m - po) + K).
@@ -376,6 +400,27 @@ __device__ __forceinline__ void mp_verify_at(const uint8_t *__restrict__ text, u
             return;                             // one verbatim entry is enough for the record
         }
         const uint32_t po = item.pom >> 8, m = item.pom & 0xffu;
+        if constexpr (K == 1) {
+            // two pieces: [0, len) and [po, m); the side that is not the piece has L bytes
+            const uint32_t len = item.info & 0xffu, L = po ? po : m - len;
+            if (!q.mb && L <= 7u && (po ? js >= 8u : js + len + 8u <= n)) {
+                const uint8_t *pat = mt.pool + (item.info >> 8) - po;       // the pieces of a pattern lie in a row
+                uint64_t S, B;
+                if (po == 0) {                  // the rest of the pattern behind the piece
+                    S = *reinterpret_cast<const u64_u *>(text + js + len);
+                    B = *reinterpret_cast<const u64_u *>(pat + len);
+                } else {                        // the head of the pattern in front of it: nearest byte first
+                    S = __builtin_bswap64(*reinterpret_cast<const u64_u *>(text + js - 8));
+                    B = __builtin_bswap64(*reinterpret_cast<const u64_u *>(pat) << (8u * (8u - L)));
+                }
+                if (q.fold) S = (uint64_t)swar_lower((uint32_t)S) | ((uint64_t)swar_lower((uint32_t)(S >> 32)) << 32);
+                if (side_within_one_edit(S, B, L, q.delim)) {
+                    multi_mark<LEAN>(text, q, mk, j, rc_chunk, mt.dbm);
+                    return;                     // the record of j is counted: nothing else to find here
+                }
+                continue;
+            }
+        }
         const uint64_t anchor = j & ~(uint64_t)15;          // rc_chunk = delimiters in front of it
         const uint64_t back = (uint64_t)po + K;
         uint64_t ws = js > back ? js - back : 0;
@@ -406,8 +451,9 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
                                                      uint32_t *__restrict__ wave_cand,
                                                      uint32_t *__restrict__ counters,
                                                      agh_multi_tables mt, agh_marks mk,
-                                                     const uint16_t *__restrict__ dbm16)
+                                                     const uint16_t *__restrict__ dbm16, uint32_t w_base)
 {
+    // this launch sweeps the wave ranges w_base .. up to strip n_full_strips (a part of the text)
     __shared__ __attribute__((aligned(16))) uint32_t tab[AGH_MP_WORDS];
     __shared__ uint64_t cq_all[4 * AGH_MP_CQ_LEN];
     {
@@ -424,7 +470,7 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
     const uint8_t *tab8 = reinterpret_cast<const uint8_t *>(tab);
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + wib;
+    const uint64_t w = (uint64_t)w_base + (uint64_t)blockIdx.x * 4 + wib;
     const uint64_t s0 = w * AGH_WAVE_STRIPS;
     if (s0 >= n_full_strips) return;
     uint64_t s1 = s0 + AGH_WAVE_STRIPS;
@@ -649,9 +695,9 @@ __global__ __launch_bounds__(256) void k_verify_multi(const uint8_t *__restrict_
                                                       const uint64_t *__restrict__ cand,
                                                       const uint32_t *__restrict__ wave_cand,
                                                       const uint32_t *__restrict__ wave_prefix,
-                                                      uint32_t nw, agh_marks mk)
+                                                      uint32_t w_begin, uint32_t nw, agh_marks mk)
 {
-    for (uint32_t w = blockIdx.x; w < nw; w += gridDim.x) {
+    for (uint32_t w = w_begin + blockIdx.x; w < nw; w += gridDim.x) {
         const uint32_t cnt = wave_cand[w];
         const uint64_t *slice = cand + (uint64_t)w * AGH_MP_SLICE_CAP;
         const uint32_t wp = LEAN ? 0u : wave_prefix[w];
@@ -671,39 +717,37 @@ __global__ __launch_bounds__(256) void k_verify_multi(const uint8_t *__restrict_
 // the stride would have skipped still names real entries), hits are queued as in the sweep, and
 // a full queue is verified on the spot -- one candidate per lane, so the lanes stay busy however
 // the hits are spread over the text.  Run-time mode (fold, q, 5-byte grams): the probes are not
-// what this kernel spends its time on.  Numbered scans: wave_totals holds the exclusive prefix of
-// a census pass (k_sweep<0> + scan) that ran in front of this kernel.
+// what this kernel spends its time on.  Numbered scans: wave_totals / strip_prefix hold the
+// exclusive prefixes of a census pass (k_sweep<0> + scan) that ran in front of this kernel.
+// A wave takes AGH_DENSE_STRIPS strips (16 KiB), not a whole 256 KiB range: the kernel waits on
+// the verifier's dependent loads, and 256 MiB in 256 KiB ranges are one wave per SIMD.
+#define AGH_DENSE_STRIPS 16u
 template <bool LEAN, int K>
 __global__ __launch_bounds__(256) void k_dense_multi(const uint4 *__restrict__ text, uint64_t n,
                                                      uint64_t n_full_strips, agh_dev_query q,
                                                      agh_multi_tables mt,
                                                      const uint32_t *__restrict__ wave_totals,
+                                                     const uint32_t *__restrict__ strip_prefix,
                                                      uint32_t *__restrict__ wave_cand, agh_marks mk)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tab[AGH_MP_WORDS];
+    // The bit table stays in global memory (32 KiB: L2 / L1 resident): this kernel waits on the
+    // verifier's dependent loads, not on probes, and without the table in LDS seven waves per SIMD are
+    // resident instead of four
     __shared__ uint64_t cq_all[4 * AGH_MP_CQ_LEN];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(mt.bits);
-        uint4 *dst = reinterpret_cast<uint4 *>(tab);
-        constexpr int PER = AGH_MP_WORDS / 4 / 256;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) dst[threadIdx.x + i * 256] = src[threadIdx.x + i * 256];
-        __syncthreads();
-    }
-    const uint8_t *tab8 = reinterpret_cast<const uint8_t *>(tab);
+    const uint8_t *tab8 = reinterpret_cast<const uint8_t *>(mt.bits);
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + wib;
-    const uint64_t s0 = w * AGH_WAVE_STRIPS;
+    const uint64_t s0 = ((uint64_t)blockIdx.x * 4 + wib) * AGH_DENSE_STRIPS;
     if (s0 >= n_full_strips) return;
-    uint64_t s1 = s0 + AGH_WAVE_STRIPS;
+    const uint64_t w = s0 / AGH_WAVE_STRIPS;    // the 256 KiB range the census numbers are kept for
+    uint64_t s1 = s0 + AGH_DENSE_STRIPS;
     if (s1 > n_full_strips) s1 = n_full_strips;
     const uint8_t *text8 = reinterpret_cast<const uint8_t *>(text);
     const uint32_t dd = q.delim * 0x01010101u;
     const uint32_t fold4 = q.fold ? 0x20202020u : 0u;
     const bool q4 = q.fq == 4, q5 = q.mp_q5 != 0;
     const uint64_t n_dw = ((n + 15) & ~(uint64_t)15) / 4;
-    uint32_t run = LEAN ? 0u : wave_totals[w], qn = 0;
+    uint32_t run = LEAN ? 0u : wave_totals[w] + strip_prefix[s0], qn = 0;
     uint64_t *cq = cq_all + wib * AGH_MP_CQ_LEN;
     // verify the first `take` queued candidates, one per lane; keep the rest
     auto verify_queue = [&](uint32_t take) {
@@ -744,7 +788,7 @@ __global__ __launch_bounds__(256) void k_dense_multi(const uint4 *__restrict__ t
         emit_rounds<1>(hits, 0u, s, rc, cq, qn, [&]() { verify_queue(64u); });
     }
     if (qn) verify_queue(qn);
-    if (lane == 0) wave_cand[w] = 0u;           // nothing went through the slices
+    if (lane == 0 && s0 % AGH_WAVE_STRIPS == 0) wave_cand[w] = 0u;      // nothing went through the slices
 }
 
 // ---------------------------------------------------------------------------------------
@@ -753,8 +797,13 @@ __global__ __launch_bounds__(256) void k_dense_multi(const uint4 *__restrict__ t
 template <int MODE, int STRIDE, bool Q5>
 static void launch_sweep_multi_ms(const agh_sweep_args &a, hipStream_t st)
 {
-    const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
-    const uint64_t n_waves = (n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+    // a part [w_begin, w_end) of the wave ranges (count-only scans: the verifier of one part runs
+    // under the sweep of the next), or everything
+    const uint64_t n_full_all = a.n >> AGH_STRIP_SHIFT;
+    const bool to_end = a.w_end == 0 || (uint64_t)a.w_end * AGH_WAVE_STRIPS >= n_full_all;
+    const uint64_t n_full = to_end ? n_full_all : (uint64_t)a.w_end * AGH_WAVE_STRIPS;
+    const uint64_t w_hi = (n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+    const uint64_t n_waves = w_hi > a.w_begin ? w_hi - a.w_begin : 0;
     if (a.ev_begin) (void)hipEventRecord(a.ev_begin, st);
     agh_multi_dev none_mt;
     agh_marks none_mk;
@@ -764,7 +813,7 @@ static void launch_sweep_multi_ms(const agh_sweep_args &a, hipStream_t st)
     hipLaunchKernelGGL((k_sweep_multi<MODE, STRIDE, Q5, FKV>), dim3((uint32_t)((n_waves + 3) / 4)), \
                        dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,             \
                        (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand, a.counters, MT, MK, \
-                       (const uint16_t *)a.dbm)
+                       (const uint16_t *)a.dbm, a.w_begin)
     if (n_waves && !a.tail_only) {
         // count-only scans with q == 4 and k <= 2: verification inside the sweep
         const bool fuse = (MODE & 4) && (MODE & 2) && a.fuse_mt && a.fuse_mk && a.q.k >= 0 && a.q.k <= 2;
@@ -779,6 +828,7 @@ static void launch_sweep_multi_ms(const agh_sweep_args &a, hipStream_t st)
     }
 #undef AGH_SM_LAUNCH
     if (a.ev_end) (void)hipEventRecord(a.ev_end, st);
+    if (!to_end) return;                        // the partial last strip belongs to the last part
     if (a.n & (AGH_STRIP - 1))
         hipLaunchKernelGGL((k_sweep_multi_tail<MODE, STRIDE, Q5>), dim3(1), dim3(64), 0, st,
                            (const uint4 *)a.text, a.n, a.q, (const uint32_t *)a.ftab,
@@ -828,7 +878,7 @@ void agh_launch_dense_multi(const agh_sweep_args &a, const agh_multi_dev &m, con
                             hipStream_t st)
 {
     const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
-    const uint64_t n_waves = (n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
+    const uint64_t n_waves = (n_full + AGH_DENSE_STRIPS - 1) / AGH_DENSE_STRIPS;
     if (!n_waves) return;
     const uint32_t blocks = (uint32_t)((n_waves + 3) / 4);
     const bool lean = a.lean != 0;
@@ -837,11 +887,11 @@ void agh_launch_dense_multi(const agh_sweep_args &a, const agh_multi_dev &m, con
         if (lean)                                                                             \
             hipLaunchKernelGGL((k_dense_multi<true, KK>), dim3(blocks), dim3(256), 0, st,     \
                                (const uint4 *)a.text, a.n, n_full, a.q, m, a.wave_totals,     \
-                               a.wave_cand, mk);                                              \
+                               (const uint32_t *)a.strip_prefix, a.wave_cand, mk);            \
         else                                                                                  \
             hipLaunchKernelGGL((k_dense_multi<false, KK>), dim3(blocks), dim3(256), 0, st,    \
                                (const uint4 *)a.text, a.n, n_full, a.q, m, a.wave_totals,     \
-                               a.wave_cand, mk);                                              \
+                               (const uint32_t *)a.strip_prefix, a.wave_cand, mk);            \
         break;
     AGH_K_SWITCH(AGH_DM_CASE)
 #undef AGH_DM_CASE
@@ -850,18 +900,20 @@ void agh_launch_dense_multi(const agh_sweep_args &a, const agh_multi_dev &m, con
 void agh_launch_verify_multi(const agh_scan_args &a, const agh_multi_dev &m, bool lean,
                              hipStream_t st)
 {
-    if (!a.nw) return;
-    const uint32_t blocks = a.nw > 65536u ? 65536u : a.nw;
+    // slices [w_begin, w_end) of a part, else all
+    const uint32_t w_hi = (a.w_end && a.w_end < a.nw) ? a.w_end : a.nw;
+    if (w_hi <= a.w_begin) return;
+    const uint32_t blocks = w_hi - a.w_begin > 65536u ? 65536u : w_hi - a.w_begin;
 #define AGH_VM_CASE(KK)                                                                       \
     case KK:                                                                                  \
         if (lean)                                                                             \
             hipLaunchKernelGGL((k_verify_multi<true, KK>), dim3(blocks), dim3(256), 0, st,    \
                                (const uint8_t *)a.text, a.n, a.q, m, a.cand, a.wave_cand,     \
-                               a.wave_prefix, a.nw, a.mk);                                    \
+                               a.wave_prefix, a.w_begin, w_hi, a.mk);                         \
         else                                                                                  \
             hipLaunchKernelGGL((k_verify_multi<false, KK>), dim3(blocks), dim3(256), 0, st,   \
                                (const uint8_t *)a.text, a.n, a.q, m, a.cand, a.wave_cand,     \
-                               a.wave_prefix, a.nw, a.mk);                                    \
+                               a.wave_prefix, a.w_begin, w_hi, a.mk);                         \
         break;
     AGH_K_SWITCH(AGH_VM_CASE)
 #undef AGH_VM_CASE

@@ -226,9 +226,9 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
 // with the byte's mask as (CM, kill) from LDS -- and ORs up "the top level holds an end bit at a
 // record end".  A 16-byte piece where that happened goes to the tile's replay list; k_table_replay
 // then runs asearch.c's recurrence over exactly those records, from their first byte.  Ownership is
-// as in k_tablescan: a lane speaks for the records that START in its 1 KiB chunk (its state is only
-// trusted behind the first delimiter it has seen) and walks on past the chunk's end to the delimiter
-// that closes its last record.  ';' AND patterns are flagged like ',' OR ones (any end bit): the
+// as in k_tablescan: a lane speaks for the records whose preceding delimiter lies in its 1 KiB chunk
+// (its state is only trusted behind the first delimiter it has seen) and walks on past the chunk's
+// end to the first delimiter there.  ';' AND patterns are flagged like ',' OR ones (any end bit): the
 // replay decides.  Unit costs, one-byte delimiter.
 template <int K>
 struct TableFast {
@@ -261,7 +261,12 @@ __device__ __forceinline__ void table_reset_state(const agh_dev_tables &T, uint3
         RF[e] = ((T.Init0 >> 1) & CMd) | (T.Init1 & T.Init0) | T.Init0 | (((RF[e - 1] | T.Init0) >> 1) & T.NO_ERR);
 }
 
-#define AGH_TF_SLICE 256u       // replay entries per 64 KiB tile
+// A lane's chunk is 4 KiB here (k_tablescan: 1 KiB): the walk past the chunk's end costs a wave the
+// LONGEST of its 64 lanes' walks (~300 bytes with 80-byte records), a third of a 1 KiB chunk's work
+// but a twelfth of this one's.  Record numbers do not depend on it (the replay takes them from the
+// census strips).
+#define AGH_TF_CHUNK 4096u
+#define AGH_TF_SLICE 1024u      // replay entries per tile (64 chunks = 256 KiB)
 
 template <int K>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     uint8_t *ring = ring_all + wib * (WAVE * AGH_FS_ROW);
-    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_FS_CHUNK;
+    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_TF_CHUNK;
     const uint64_t n_tiles = (n + tile_bytes - 1) / tile_bytes;
     const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
     const uint64_t n16 = (n + 15) & ~(uint64_t)15;
@@ -291,14 +296,14 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     for (uint64_t tile = (uint64_t)blockIdx.x * (AGH_FS_THREADS / WAVE) + wib; tile < n_tiles;
          tile += (uint64_t)gridDim.x * (AGH_FS_THREADS / WAVE)) {
         const uint64_t t0 = tile * tile_bytes;
-        const uint64_t cs = t0 + (uint64_t)lane * AGH_FS_CHUNK;
-        uint64_t ce = cs + AGH_FS_CHUNK;
+        const uint64_t cs = t0 + (uint64_t)lane * AGH_TF_CHUNK;
+        uint64_t ce = cs + AGH_TF_CHUNK;
         if (ce > n) ce = n;
         const uint32_t len = cs < n ? (uint32_t)(ce - cs) : 0u;
         auto gather = [&](uint32_t r, uint4 (&g)[4]) {
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
-                const uint64_t a = t0 + (uint64_t)(seg_lo + 16u * i) * AGH_FS_CHUNK + r * AGH_FS_ROUND + part * 16u;
+                const uint64_t a = t0 + (uint64_t)(seg_lo + 16u * i) * AGH_TF_CHUNK + r * AGH_FS_ROUND + part * 16u;
                 g[i] = a < n16 ? *reinterpret_cast<const uint4 *>(text + a) : make_uint4(fill4, fill4, fill4, fill4);
             }
         };
@@ -316,6 +321,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
             trusted = ~0u;
         }
         // 16 bytes: -> "some trusted record end in the piece shows an end bit on the top level"
+        uint32_t dseen = 0;                     // ~0 once a delimiter went through piece()
         auto piece = [&](uint4 v, uint32_t nbytes) -> uint32_t {
             const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
             uint32_t flag = 0;
@@ -326,6 +332,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
                     const uint32_t top = A.feed(e.cm, e.kb, T, RF);
                     flag |= top & ~e.kb & trusted;
                     trusted |= ~e.kb;
+                    dseen |= ~e.kb;
                 }
             }
             return flag & T.endposition;
@@ -341,13 +348,13 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
             }
             cnt += (uint32_t)__popcll(fm);
         };
-        for (uint32_t r = 0; r < AGH_FS_CHUNK / AGH_FS_ROUND; ++r) {
+        for (uint32_t r = 0; r < AGH_TF_CHUNK / AGH_FS_ROUND; ++r) {
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i)
                 *reinterpret_cast<uint4 *>(ring_w + 16u * i * AGH_FS_ROW) = g[i];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (r + 1 < AGH_FS_CHUNK / AGH_FS_ROUND) gather(r + 1, g);
+            if (r + 1 < AGH_TF_CHUNK / AGH_FS_ROUND) gather(r + 1, g);
 #pragma unroll 1
             for (uint32_t p = 0; p < 4; ++p) {
                 const uint32_t off = r * AGH_FS_ROUND + 16u * p;
@@ -362,34 +369,26 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
             __builtin_amdgcn_wave_barrier();
         }
         // on alone to the delimiter that closes my last record (ce is 16-byte aligned unless ce == n)
-        bool open = len == AGH_FS_CHUNK && trusted != 0u && ce < n;
-        {
-            // (did my chunk end exactly behind a delimiter?  then nothing of mine is open)
-            if (open && text[ce - 1] == q.delim) open = false;
-        }
+        // (a record that starts exactly at the chunk's end is mine as well: I saw the delimiter in
+        // front of it, the next lane trusts its state only behind the first delimiter IT sees)
+        bool open = len == AGH_TF_CHUNK && trusted != 0u && ce < n;
+        dseen = 0;
         for (uint64_t p0 = ce; __ballot(open); p0 += 16) {
+            // whole 16-byte pieces until one holds a delimiter: what it flags behind that delimiter
+            // belongs to the next lane, which flags it as well -- the replay does not mind
             uint32_t flag = 0;
-            bool mine = open;
+            const bool mine = open;
             if (open) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
                 const uint32_t nb = p0 + 16 <= n ? 16u : (uint32_t)(n - p0);
-                const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
-                for (uint32_t b = 0; b < nb && open; ++b) {
-                    const MK e = tab[(dws[b >> 2] >> (8u * (b & 3u))) & 0xffu];
-                    const uint32_t top = A.feed(e.cm, e.kb, T, RF);
-                    if (!e.kb) {                // the delimiter that closes my record
-                        flag = top & T.endposition;
-                        open = false;
-                    }
-                }
-                if (open && p0 + 16 >= n) {     // the text ends inside my record: the last piece
+                flag = piece(v, nb);
+                if (dseen) open = false;
+                else if (p0 + 16 >= n) {         // the text ends inside my record: the last piece
                     flag = 1u;
                     open = false;
                 }
             }
-            // the entry belongs to the tile that holds the piece; entries in another tile's list would
-            // race with its owner, so they go to MY tile's list with the position -- the replay only
-            // needs the position
+            // (into MY tile's list, whatever tile the piece lies in: the replay only needs the position)
             emit(mine && flag != 0u, p0);
         }
         if (lane == 0) tile_cnt[tile] = cnt < AGH_TF_SLICE ? cnt : AGH_TF_SLICE;
@@ -466,11 +465,13 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
     const bool lean = a.mk.hashset != nullptr;  // count-only: hash set of record starts, no census
     const bool costs = a.q.ci != 1u || a.q.cs != 1u || a.q.cd != 1u;     // asearch1.c instead of asearch.c
     if (a.fs_fast && !costs) {                  // branch-free hot kernel + exact replay (the host checked)
-        const uint32_t nt = (uint32_t)n_tiles;
-        const uint32_t rblocks = (nt + 3u) / 4u > 16384u ? 16384u : (nt + 3u) / 4u;
+        const uint64_t tf_tile = (uint64_t)WAVE * AGH_TF_CHUNK;             // 256 KiB tiles here
+        const uint32_t nt = (uint32_t)((a.n + tf_tile - 1) / tf_tile);
+        const uint32_t fblocks = (nt + 3u) / 4u > 16384u ? 16384u : (nt + 3u) / 4u;
+        const uint32_t rblocks = fblocks;
 #define AGH_TF_CASE(KK)                                                                       \
     case KK:                                                                                  \
-        hipLaunchKernelGGL((k_tablescan_fast<KK>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
+        hipLaunchKernelGGL((k_tablescan_fast<KK>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
                            (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
                            a.fs_replay, a.fs_tile_cnt, a.mk.counters);                        \
         if (lean)                                                                             \

@@ -37,3 +37,25 @@ for pat, k, nocase in cases:
           "exact: numbered %.3f ms %.0f GB/s, count-only %.3f ms %.0f GB/s (matched %d/%d)"
           % (len(pat), k, " -i" if nocase else "", row[0][0], n / 1e6 / row[0][0], row[0][1], n / 1e6 / row[0][1], row[0][2], row[0][3],
              row[0][4], row[1][0], n / 1e6 / row[1][0], row[1][1], n / 1e6 / row[1][1], row[1][2], row[1][3]), flush=True)
+
+# table engine ('#', ';', ',' on the reference's own tables): fast form (k_tablescan_fast + k_table_replay) vs k_tablescan
+import json
+gold = json.load(open(os.path.join(ROOT, "tests", "golden", "pattern_language.json")))["cases"]
+for c in gold:
+    if c["pattern"] in ("approx#match", "approxi;matematch", "scar,cat") and c["k"] <= 1:
+        tb = c["tables"]
+        M = tb["D_endpos"].bit_length()
+        row = []
+        for fast in ("1", "0"):
+            os.environ["AGH_FS_FAST"] = fast
+            q = A.Query.from_maskgen(tb["Mask"], tb["Init0"], tb["Init1"], tb["NO_ERR_MASK"], tb["endposition"],
+                                     tb["D_endpos"], M, b"\n", c["k"], tb["AND"])
+            ms_n, r_n = med(q, 0, 3)
+            ms_c, r_c = med(q, A.COUNT, 3)
+            q.close()
+            row.append((ms_n, ms_c, r_n.n_matched, r_c.n_matched))
+        print("table '%s' k=%d  fast: numbered %.3f ms %.0f GB/s, count-only %.3f ms %.0f GB/s (matched %d/%d) | "
+              "k_tablescan: numbered %.3f ms %.0f GB/s, count-only %.3f ms %.0f GB/s (matched %d/%d)"
+              % (c["pattern"], c["k"], row[0][0], n / 1e6 / row[0][0], row[0][1], n / 1e6 / row[0][1], row[0][2], row[0][3],
+                 row[1][0], n / 1e6 / row[1][0], row[1][1], n / 1e6 / row[1][1], row[1][2], row[1][3]), flush=True)
+os.environ.pop("AGH_FS_FAST", None)
