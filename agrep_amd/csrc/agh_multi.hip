@@ -31,6 +31,12 @@
 typedef agh_multi_dev agh_multi_tables;
 
 #define AGH_MP_WORDS ((1u << AGH_MP_BITS) / 32u)
+// k_sweep_multi: threads per workgroup (512: two workgroups per CU instead of four, same 16 waves --
+// within the run-to-run noise of 256)
+#ifndef AGH_MP_BLOCK
+#define AGH_MP_BLOCK 256
+#endif
+#define AGH_MP_WPB (AGH_MP_BLOCK / 64)
 #define AGH_MP_CQ_LEN 128u          // a round adds at most 64 entries to fewer than 64 queued ones
 
 // ---------------------------------------------------------------------------------------
@@ -443,7 +449,7 @@ __device__ __forceinline__ void mp_verify_at(const uint8_t *__restrict__ text, u
 // the verifier's waits, where two kernels pay for both one after the other (-f with k = 1, 4 GiB:
 // sweep 1.25 ms + verify 0.62 ms as two kernels).
 template <int MODE, int STRIDE, bool Q5, int FK>
-__global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ text, uint64_t n,
+__global__ __launch_bounds__(AGH_MP_BLOCK) void k_sweep_multi(const uint4 *__restrict__ text, uint64_t n,
                                                      uint64_t n_full_strips, agh_dev_query q,
                                                      const uint32_t *__restrict__ bits_g,
                                                      uint32_t *__restrict__ wave_totals,
@@ -455,22 +461,22 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
 {
     // this launch sweeps the wave ranges w_base .. up to strip n_full_strips (a part of the text)
     __shared__ __attribute__((aligned(16))) uint32_t tab[AGH_MP_WORDS];
-    __shared__ uint64_t cq_all[4 * AGH_MP_CQ_LEN];
+    __shared__ uint64_t cq_all[AGH_MP_WPB * AGH_MP_CQ_LEN];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(bits_g);
         uint4 *dst = reinterpret_cast<uint4 *>(tab);
-        constexpr int PER = AGH_MP_WORDS / 4 / 256;
+        constexpr int PER = AGH_MP_WORDS / 4 / AGH_MP_BLOCK;
         uint4 tmp[PER];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) tmp[i] = src[threadIdx.x + i * 256];
+        for (int i = 0; i < PER; ++i) tmp[i] = src[threadIdx.x + i * AGH_MP_BLOCK];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) dst[threadIdx.x + i * 256] = tmp[i];
+        for (int i = 0; i < PER; ++i) dst[threadIdx.x + i * AGH_MP_BLOCK] = tmp[i];
         __syncthreads();
     }
     const uint8_t *tab8 = reinterpret_cast<const uint8_t *>(tab);
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const uint64_t w = (uint64_t)w_base + (uint64_t)blockIdx.x * 4 + wib;
+    const uint64_t w = (uint64_t)w_base + (uint64_t)blockIdx.x * AGH_MP_WPB + wib;
     const uint64_t s0 = w * AGH_WAVE_STRIPS;
     if (s0 >= n_full_strips) return;
     uint64_t s1 = s0 + AGH_WAVE_STRIPS;
@@ -517,18 +523,9 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
                           next_lane_dword(v2.x, (uint32_t)__builtin_amdgcn_readlane((int)v3.x, 0)) | fold4};
         uint32_t w3[5] = {v3.x | fold4, v3.y | fold4, v3.z | fold4, v3.w | fold4,
                           next_lane_dword(v3.x, nx3) | fold4};
-        uint32_t lo = 0, hi = 0;
-        probe_chunk_l1<MODE, STRIDE, Q5>(w0, q, tab8, lo);
-        probe_chunk_l1<MODE, STRIDE, Q5>(w1, q, tab8, lo);
-        if (STRIDE == 1) {
-            probe_chunk_l1<MODE, STRIDE, Q5>(w2, q, tab8, hi);
-            probe_chunk_l1<MODE, STRIDE, Q5>(w3, q, tab8, hi);
-        } else {
-            probe_chunk_l1<MODE, STRIDE, Q5>(w2, q, tab8, lo);
-            probe_chunk_l1<MODE, STRIDE, Q5>(w3, q, tab8, lo);
-            if (STRIDE == 4) lo >>= 16;         // 16 pushes only
-        }
-        // census (numbered scans): delimiters in front of the lane's chunk of every strip
+        // census (numbered scans): delimiters in front of the lane's chunk of every strip.  In front
+        // of the probes: behind them its bitmap branch splits the block, and the compiler parks all 64
+        // table reads of a supertile in registers across it (181 VGPRs, two waves per SIMD)
         uint32_t rc[4] = {0u, 0u, 0u, 0u};
         if (!(MODE & 4)) {
             // ("128 minus the delimiters of the lane's chunk"; bitmap delimiters: 16 bits per chunk)
@@ -558,8 +555,24 @@ __global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ t
             rc[3] = run + z0 + z1 + z2 + lb - (ex23 >> 16);
             run += z0 + z1 + z2 + z3;
         }
+        uint32_t lo = 0, hi = 0;
+        probe_chunk_l1<MODE, STRIDE, Q5>(w0, q, tab8, lo);
+        probe_chunk_l1<MODE, STRIDE, Q5>(w1, q, tab8, lo);
+        if (STRIDE == 1) {
+            probe_chunk_l1<MODE, STRIDE, Q5>(w2, q, tab8, hi);
+            probe_chunk_l1<MODE, STRIDE, Q5>(w3, q, tab8, hi);
+        } else {
+            probe_chunk_l1<MODE, STRIDE, Q5>(w2, q, tab8, lo);
+            probe_chunk_l1<MODE, STRIDE, Q5>(w3, q, tab8, lo);
+            if (STRIDE == 4) lo >>= 16;         // 16 pushes only
+        }
         if (!__ballot((lo | hi) != 0u)) return;
-        if (MODE & 2) {                          // second Bloom probe, strip by strip (static registers)
+        // second Bloom probe, strip by strip: the gram of a run-time position wants an indexed read,
+        // which registers do not have, and a loop per strip keeps the indices static.  (Measured: the
+        // supertile parked in LDS and ONE loop over all its first-level hits -- 5 rounds instead of 8 --
+        // is within the noise of this, 3 % either way by set; it is not where the time goes: 368 of the
+        // 396 VALU instructions of a stride-1 supertile are the 64 first-level probes.)
+        if (MODE & 2) {
             constexpr uint32_t M = NB == 16 ? 0xffffu : (NB == 8 ? 0xffu : 0xfu);
             const uint32_t h0 = lo & M, h1 = (lo >> NB) & M;
             const uint32_t h2 = STRIDE == 1 ? (hi & M) : ((lo >> (2 * NB)) & M);
@@ -810,8 +823,9 @@ static void launch_sweep_multi_ms(const agh_sweep_args &a, hipStream_t st)
     memset(&none_mt, 0, sizeof(none_mt));
     memset(&none_mk, 0, sizeof(none_mk));
 #define AGH_SM_LAUNCH(FKV, MT, MK)                                                            \
-    hipLaunchKernelGGL((k_sweep_multi<MODE, STRIDE, Q5, FKV>), dim3((uint32_t)((n_waves + 3) / 4)), \
-                       dim3(256), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,             \
+    hipLaunchKernelGGL((k_sweep_multi<MODE, STRIDE, Q5, FKV>),                                 \
+                       dim3((uint32_t)((n_waves + AGH_MP_WPB - 1) / AGH_MP_WPB)),             \
+                       dim3(AGH_MP_BLOCK), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,    \
                        (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand, a.counters, MT, MK, \
                        (const uint16_t *)a.dbm, a.w_begin)
     if (n_waves && !a.tail_only) {

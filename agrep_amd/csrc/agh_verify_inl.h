@@ -17,6 +17,8 @@ __device__ __forceinline__ void mark_record(const agh_marks &mk, uint32_t r, uin
         return;
     }
     const uint32_t bit = 1u << (r & 31u);
+    // (dense hit sets mark the same record again and again: a plain load settles those)
+    if (__atomic_load_n(&mk.bitmap[r >> 5], __ATOMIC_RELAXED) & bit) return;
     uint32_t old = atomicOr(&mk.bitmap[r >> 5], bit);
     if (mk.match_pos && !(old & bit)) {
         uint32_t idx = atomicAdd(&mk.counters[AGH_C_STORED], 1u);

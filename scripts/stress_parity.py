@@ -8,9 +8,61 @@ import numpy as np
 import agrep_amd as A
 import _oracle as O
 
+import json
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = random.Random(seed)
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "pattern_language.json")))["cases"]
+
+
+def table_case():
+    """'#' / ';' / ',' / -p patterns on the reference's own tables (table engine, fast form and
+    k_tablescan, with and without edit costs) against the oracle's asearch on the same tables."""
+    global fails
+    case = rng.choice(GOLD)
+    tb = case["tables"]
+    M = tb["D_endpos"].bit_length()
+    letters = bytes(sorted(set(c for c in case["pattern"].encode() if chr(c).isalnum()))) or b"a"
+    alpha = letters + rng.choice([b"\n", b" \n", b"xyz \n", b"\n\n"])
+    n = rng.choice([0, 1, 17, 300, 4095, 4096, 4097, 70000, 262144, 300000, 1 << 20])
+    text = bytearray(rng.choice(alpha) for _ in range(min(n, 8192)))
+    if n > 8192:
+        arr = np.tile(np.frombuffer(bytes(text), dtype=np.uint8), n // 8192 + 1)[:n].copy()
+        g = np.random.default_rng(rng.randrange(1 << 30))
+        idx = g.integers(0, n, size=n // 20)
+        arr[idx] = np.frombuffer(alpha, dtype=np.uint8)[g.integers(0, len(alpha), size=len(idx))]
+        if rng.random() < 0.3:                  # a few very long records
+            lo = rng.randrange(0, n // 2)
+            seg = arr[lo:lo + rng.choice([5000, 70000, 300000])]
+            seg[seg == 10] = letters[0]
+        text = bytearray(arr.tobytes())
+    text = bytes(text)
+    costs = None
+    if case["k"] > 0 and rng.random() < 0.4:
+        costs = (rng.randint(1, 2), rng.randint(1, 2), rng.randint(1, 2))
+    ot = O.tables_from_golden(tb, M)
+    want = (O.asearch_tables_costs(ot, case["k"], costs, text, cap=400000) if costs
+            else O.asearch_tables(ot, case["k"], text, cap=400000))
+    q = A.Query.from_maskgen(tb["Mask"], tb["Init0"], tb["Init1"], tb["NO_ERR_MASK"], tb["endposition"],
+                             tb["D_endpos"], M, b"\n", case["k"], tb["AND"])
+    try:
+        if costs:
+            q.set_costs(*costs)
+        for fast in ("1", "0"):
+            os.environ["AGH_FS_FAST"] = fast
+            r1, ms = q.scan_buffer(text, cap=400000)
+            r2, _ = q.scan_buffer(text, flags=A.COUNT)
+            r3, _ = q.scan_buffer(text, flags=A.COUNT | A.FORCE_NUMBERED)
+            got = (r1.n_matched, [(s_, e_) for s_, e_, _ in ms])
+            if got != want or not (r2.n_matched == r3.n_matched == want[0]):
+                fails += 1
+                print("MISMATCH table", case["pattern"], case["opts"], "k", case["k"], "costs", costs, "fast", fast, "n", len(text),
+                      "want", want[0], "got", r1.n_matched, r2.n_matched, r3.n_matched, "seed", seed, "case", n_cases, flush=True)
+    finally:
+        os.environ.pop("AGH_FS_FAST", None)
+        q.close()
+
+
 t_end = time.time() + budget
 n_cases = 0
 fails = 0
@@ -24,10 +76,14 @@ while time.time() < t_end:
     letters = bytes(c for c in alpha if c != 10) or b"a"
     pat = bytes(rng.choice(letters) for _ in range(m))
     nocase = rng.random() < 0.3
-    kind = rng.choice(["single"] * 5 + ["costs", "costs", "mbdelim", "wide", "multi", "multi"])
+    kind = rng.choice(["single"] * 5 + ["costs", "costs", "mbdelim", "wide", "multi", "multi", "multi", "table", "table"])
+    if kind == "table":
+        table_case()
+        n_cases += 1
+        continue
     delim = b"\n" if rng.random() < 0.8 else bytes([rng.choice(b";|\t")])
-    if kind == "mbdelim":
-        delim = rng.choice([b"\n\n", b";;", b"\r\n", b"ab\n", b"$$"])
+    if kind == "mbdelim" or (kind == "multi" and rng.random() < 0.25):
+        delim = rng.choice([b"\n\n", b";;", b"\r\n", b"ab\n", b"$$"]) if kind == "mbdelim" else rng.choice([b"\n\n", b";;", b"\r\n", b"$$"])
         alpha = alpha + delim
     if kind == "wide":
         m = rng.choice([30, 33, 40, 48, 64])
@@ -81,7 +137,7 @@ while time.time() < t_end:
     if kind == "multi":
         npat = rng.choice([1, 2, 5, 20])
         pats = sorted({bytes(rng.choice(letters) for _ in range(rng.randint(max(2, k + 1), 10))) for _ in range(npat)})
-        if len(delim) != 1 or any(delim[0] in x for x in pats) or len(text) > 300000:
+        if any(delim[-1] in x for x in pats) or len(text) > 300000:
             continue
         recs = set()
         for x in pats:

@@ -195,6 +195,23 @@ def test_multi_pattern_with_errors_edges(agh):
         agh.Query.multi([b"nee\ndle"], k=1)
 
 
+@pytest.mark.parametrize("alphabet,lo,hi,nocase", [(b"ab", 2, 14, False), (b"abc", 3, 9, False), (b"aB", 4, 16, True),
+                                                  (b"ab", 15, 20, False)])
+def test_multi_pattern_one_error_small_alphabet(agh, alphabet, lo, hi, nocase):
+    """k = 1: the side next to a verbatim piece is checked in two 64-bit words (agh_multi.hip
+    side_within_one_edit) when it has <= 7 bytes, by the automaton otherwise.  Texts over the patterns'
+    own tiny alphabet with short records: every position is a near miss, delimiters land on the
+    replaced / extra byte, occurrences touch both ends of the text."""
+    rng = random.Random(len(alphabet) * 100 + lo)
+    pats = _rand_patterns(rng, 12, lo, hi, alphabet=alphabet)
+    talpha = (alphabet + alphabet.swapcase() if nocase else alphabet) + b"\n"
+    for n in (1, 7, 300, 70000):
+        text = bytes(rng.choice(talpha) for _ in range(n))
+        _check_approx(agh, pats, 1, text, nocase=nocase)
+    text = bytes(rng.choice(alphabet + b"z") if i % 23 else 10 for i in range(200000))
+    _check_approx(agh, pats, 1, text, nocase=nocase)
+
+
 @pytest.mark.parametrize("npat,lo,hi,stride,nocase", [(100, 5, 9, 2, False), (500, 7, 12, 4, False),
                                                       (1024, 8, 12, 4, False), (64, 5, 6, 2, True),
                                                       (200, 7, 30, 4, True), (3, 25, 38, 4, False)])
