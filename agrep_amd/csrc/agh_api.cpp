@@ -996,7 +996,6 @@ static const uint64_t AGH_LEAN_SEG_MAX = (uint64_t)64 << 30;     // lean scans: 
 #define AGH_PART_MB_DEFAULT 0
 #define AGH_OVERLAP_DEFAULT 0
 #define AGH_FUSED_DEFAULT 1
-#define AGH_MP_PARTS_DEFAULT 1  // count-only -f scans: parts of a segment (verifier of part p under the sweep of p+1); measured: 1
 // ... from this segment size on (MiB; AGH_FUSED_MIN_MB overrides, the tests run with 0).  The
 // persistent kernel pays ~70 us once (the candidates queued last are verified after the stream has
 // ended, and 4096 waves drawing 256 KiB tickets finish less evenly than hardware-dispatched
@@ -1147,7 +1146,6 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.dbm = d_dbm;
         va.gtab = tight_verify_enabled() ? q->d_gtab : nullptr;
         va.gram_spread = q->gram_spread;
-        bool verified = false;                  // the verifier has been queued already (parts)
         if (multi && q->multi_dense) {
             // dense hit set: probes and verification of the full strips in one kernel, nothing goes
             // through the slices but the partial last strip
@@ -1155,56 +1153,13 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.tail_only = 1;
             agh_launch_sweep_multi(sa, st);
         } else if (multi) {
-            // AGH_MP_FUSED=1: full queues verified inside the sweep instead of going through the
-            // slices to k_verify_multi.  Measured and left off: the sweep is bound by VALU issue and
-            // a wave that verifies stops streaming -- 1024 exact patterns (4..12 B), 4 GiB: 1.44 ms as
-            // two kernels, 1.78 ms in one; k = 1 over 8..12 B: 1.87 vs 2.60 ms (VALU busy 95 % -> 61 %,
-            // waiting on memory 26 % -> 65 %: profiles/r03_pmc_sweep_multi*_fused.json)
-            const agh_multi_dev md = multi_dev(q, d_dbm);
-            const char *e = getenv("AGH_MP_FUSED");
-            // AGH_MP_PARTS=p: the segment is swept in p parts and the verifier of a part -- bound by the
-            // latency of its dependent loads, next to no VALU work -- runs on a second stream under the
-            // sweep of the next part.  Measured and left at 1 (profiles/r03_perf_multi.log): 1024 exact
-            // patterns (4..12 B), 4 GiB: 1.45 ms in one part, 1.52 in two, 1.84 in four, 2.84 in eight;
-            // k = 1 over 8..12 B: 1.87 / 2.04 / 2.11 / 3.16 ms -- the verifier's waves take LDS and
-            // wave slots from a sweep that is bound by VALU issue, and every part pays a launch tail
-            uint32_t parts = (uint32_t)env_mb("AGH_MP_PARTS", AGH_MP_PARTS_DEFAULT);
-            if (parts < 1 || nw < 64ull * parts) parts = 1;
-            if (e && e[0] == '1') {
-                sa.fuse_mt = &md;
-                sa.fuse_mk = &va.mk;
-                agh_launch_sweep_multi(sa, st);
-                sa.fuse_mt = nullptr;
-                sa.fuse_mk = nullptr;
-            } else if (parts > 1) {
-                if (!q->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&q->aux_stream, hipStreamNonBlocking));
-                if (get_events(q->dep_events, 4, hipEventDisableTiming)) return -1;
-                // (what was queued on st so far -- the counter / hash set memsets -- comes first)
-                HIP_TRY(hipEventRecord(q->dep_events[2], st));
-                HIP_TRY(hipStreamWaitEvent(q->aux_stream, q->dep_events[2], 0));
-                for (uint32_t p = 0; p < parts; ++p) {
-                    const uint32_t w0 = (uint32_t)(nw * p / parts) & ~3u;
-                    const uint32_t w1 = p + 1 == parts ? 0u : (uint32_t)(nw * (p + 1) / parts) & ~3u;
-                    sa.w_begin = va.w_begin = w0;
-                    sa.w_end = va.w_end = w1;
-                    agh_launch_sweep_multi(sa, st);
-                    hipEvent_t ev = q->dep_events[p & 1];
-                    HIP_TRY(hipEventRecord(ev, st));
-                    HIP_TRY(hipStreamWaitEvent(q->aux_stream, ev, 0));
-                    agh_launch_verify_multi(va, md, true, q->aux_stream);
-                }
-                HIP_TRY(hipEventRecord(q->dep_events[3], q->aux_stream));
-                HIP_TRY(hipStreamWaitEvent(st, q->dep_events[3], 0));
-                sa.w_begin = sa.w_end = va.w_begin = va.w_end = 0;
-                verified = true;
-            } else {
-                agh_launch_sweep_multi(sa, st);
-            }
+            // (sweep, then verify: verifying inside the sweep, verifying waves next to the sweeping ones and
+            // the verifier of one part under the sweep of the next were all measured slower -- agh_multi.hip)
+            agh_launch_sweep_multi(sa, st);
         } else {
             agh_launch_sweep(sa, q->fh, st);
         }
-        if (verified) { /* nothing */ }
-        else         if (multi) agh_launch_verify_multi(va, multi_dev(q, d_dbm), true, st);
+        if (multi) agh_launch_verify_multi(va, multi_dev(q, d_dbm), true, st);
         else agh_launch_verify_lean(va, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)q->wave_cand.p, (uint32_t)nw, q->d_counters, st);

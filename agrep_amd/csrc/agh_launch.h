@@ -39,8 +39,6 @@ struct agh_sweep_args {
     int tail_only = 0;       // 1: only the partial last strip (the fused kernel swept the rest)
     // multi-pattern count-only sweeps: verify full queues inside the sweep (tables and marks of the
     // verifier; NULL: candidates go to the slices)
-    const struct agh_multi_dev *fuse_mt = nullptr;
-    const struct agh_marks *fuse_mk = nullptr;
 };
 
 struct agh_scan_args {

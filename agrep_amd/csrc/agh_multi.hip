@@ -31,12 +31,6 @@
 typedef agh_multi_dev agh_multi_tables;
 
 #define AGH_MP_WORDS ((1u << AGH_MP_BITS) / 32u)
-// k_sweep_multi: threads per workgroup (512: two workgroups per CU instead of four, same 16 waves --
-// within the run-to-run noise of 256)
-#ifndef AGH_MP_BLOCK
-#define AGH_MP_BLOCK 256
-#endif
-#define AGH_MP_WPB (AGH_MP_BLOCK / 64)
 #define AGH_MP_CQ_LEN 128u          // a round adds at most 64 entries to fewer than 64 queued ones
 
 // ---------------------------------------------------------------------------------------
@@ -443,40 +437,41 @@ __device__ __forceinline__ void mp_verify_at(const uint8_t *__restrict__ text, u
 // ---------------------------------------------------------------------------------------
 // One wave per 256 KiB range, 4 KiB supertiles, next supertile prefetched -- as k_sweep.
 // MODE: bit 0 fold case, bit 1 q == 4, bit 2 lean (no census).
-// FK >= 0 (count-only scans, FK = the number of errors): a full queue is not written to the wave's
-// slice but verified on the spot, one candidate per lane.  The sweep is bound by VALU issue and the
-// verifier by the latency of its dependent loads; in one kernel the other waves of the SIMD fill
-// the verifier's waits, where two kernels pay for both one after the other (-f with k = 1, 4 GiB:
-// sweep 1.25 ms + verify 0.62 ms as two kernels).
-template <int MODE, int STRIDE, bool Q5, int FK>
-__global__ __launch_bounds__(AGH_MP_BLOCK) void k_sweep_multi(const uint4 *__restrict__ text, uint64_t n,
+// Hits go to the wave's private slice of the candidate buffer; k_verify_multi reads them back.
+// Measured and dropped (round 3; profiles/r03_perf_multi_verifier_waves*.log, r03_pmc_sweep_multi*_fused.json):
+// verifying a full queue inside the sweeping wave (1.78 vs 1.44 ms per 4 GiB, exact 4..12 B; k = 1: 2.60
+// vs 1.87), two verifying waves per workgroup fed through an LDS ring as in k_sweep_fused (1.55 vs 1.45;
+// k = 1: 1.65 vs 1.65; 8..12 B exact: 1.09 vs 0.93) and the verifier of one part of the text on a second
+// stream under the sweep of the next (1.52 / 1.84 / 2.84 ms in 2 / 4 / 8 parts) -- the sweep is bound by
+// VALU issue and LDS reads, and whatever shares its SIMDs costs it what it would have cost alone.
+template <int MODE, int STRIDE, bool Q5>
+__global__ __launch_bounds__(256) void k_sweep_multi(const uint4 *__restrict__ text, uint64_t n,
                                                      uint64_t n_full_strips, agh_dev_query q,
                                                      const uint32_t *__restrict__ bits_g,
                                                      uint32_t *__restrict__ wave_totals,
                                                      uint64_t *__restrict__ cand,
                                                      uint32_t *__restrict__ wave_cand,
                                                      uint32_t *__restrict__ counters,
-                                                     agh_multi_tables mt, agh_marks mk,
                                                      const uint16_t *__restrict__ dbm16, uint32_t w_base)
 {
     // this launch sweeps the wave ranges w_base .. up to strip n_full_strips (a part of the text)
     __shared__ __attribute__((aligned(16))) uint32_t tab[AGH_MP_WORDS];
-    __shared__ uint64_t cq_all[AGH_MP_WPB * AGH_MP_CQ_LEN];
+    __shared__ uint64_t cq_all[4 * AGH_MP_CQ_LEN];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(bits_g);
         uint4 *dst = reinterpret_cast<uint4 *>(tab);
-        constexpr int PER = AGH_MP_WORDS / 4 / AGH_MP_BLOCK;
+        constexpr int PER = AGH_MP_WORDS / 4 / 256;
         uint4 tmp[PER];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) tmp[i] = src[threadIdx.x + i * AGH_MP_BLOCK];
+        for (int i = 0; i < PER; ++i) tmp[i] = src[threadIdx.x + i * 256];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) dst[threadIdx.x + i * AGH_MP_BLOCK] = tmp[i];
+        for (int i = 0; i < PER; ++i) dst[threadIdx.x + i * 256] = tmp[i];
         __syncthreads();
     }
     const uint8_t *tab8 = reinterpret_cast<const uint8_t *>(tab);
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const uint64_t w = (uint64_t)w_base + (uint64_t)blockIdx.x * AGH_MP_WPB + wib;
+    const uint64_t w = (uint64_t)w_base + (uint64_t)blockIdx.x * 4 + wib;
     const uint64_t s0 = w * AGH_WAVE_STRIPS;
     if (s0 >= n_full_strips) return;
     uint64_t s1 = s0 + AGH_WAVE_STRIPS;
@@ -487,26 +482,7 @@ __global__ __launch_bounds__(AGH_MP_BLOCK) void k_sweep_multi(const uint4 *__res
     uint32_t run = 0, ncand = 0, qn = 0;
     uint64_t *cq = cq_all + wib * AGH_MP_CQ_LEN;
     uint64_t *slice = cand + w * AGH_MP_SLICE_CAP;
-    // fused form: the first `take` queued candidates are verified, one per lane; the rest stay queued
-    auto verify_queue = [&](uint32_t take) {
-        if constexpr (FK >= 0) {
-            if ((uint32_t)lane < take) {
-                const uint64_t ent = cq[lane];
-                mp_verify_at<true, (FK >= 0 ? FK : 0)>(reinterpret_cast<const uint8_t *>(text), n, q, mt,
-                                                        ent & 0xffffffffull, 0u, mk);
-            }
-            ncand += take;
-            const uint32_t rest = qn - take;
-            uint64_t keep = 0;
-            if ((uint32_t)lane < rest) keep = cq[take + (uint32_t)lane];
-            if ((uint32_t)lane < rest) cq[lane] = keep;
-            qn = rest;
-        }
-    };
-    auto flush64 = [&]() {
-        if constexpr (FK >= 0) verify_queue(64u);
-        else flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, 64u, slice, ncand, counters);
-    };
+    auto flush64 = [&]() { flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, 64u, slice, ncand, counters); };
     // the dword right behind strip st-1 (uniform; 0 past the readable text)
     auto first_dword_of = [&](uint64_t st) -> uint32_t {
         const uint64_t i = st * 256u;
@@ -619,18 +595,10 @@ __global__ __launch_bounds__(AGH_MP_BLOCK) void k_sweep_multi(const uint4 *__res
         s += 4;
     }
     for (; s < s1; ++s) single(ld_stream(text + s * 64 + lane), s, first_dword_of(s + 1));
-    if constexpr (FK >= 0) {
-        if (qn) verify_queue(qn);
-        if (lane == 0) {
-            wave_cand[w] = 0u;                  // nothing went through the slice
-            if (ncand) atomicAdd(&counters[AGH_C_CAND], ncand);
-        }
-    } else {
-        if (qn) flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, qn, slice, ncand, counters);
-        if (lane == 0) {
-            wave_totals[w] = run;
-            wave_cand[w] = ncand < AGH_MP_SLICE_CAP ? ncand : AGH_MP_SLICE_CAP;
-        }
+    if (qn) flush_candidates<AGH_MP_SLICE_CAP>(cq, qn, qn, slice, ncand, counters);
+    if (lane == 0) {
+        wave_totals[w] = run;
+        wave_cand[w] = ncand < AGH_MP_SLICE_CAP ? ncand : AGH_MP_SLICE_CAP;
     }
 }
 
@@ -818,29 +786,10 @@ static void launch_sweep_multi_ms(const agh_sweep_args &a, hipStream_t st)
     const uint64_t w_hi = (n_full + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
     const uint64_t n_waves = w_hi > a.w_begin ? w_hi - a.w_begin : 0;
     if (a.ev_begin) (void)hipEventRecord(a.ev_begin, st);
-    agh_multi_dev none_mt;
-    agh_marks none_mk;
-    memset(&none_mt, 0, sizeof(none_mt));
-    memset(&none_mk, 0, sizeof(none_mk));
-#define AGH_SM_LAUNCH(FKV, MT, MK)                                                            \
-    hipLaunchKernelGGL((k_sweep_multi<MODE, STRIDE, Q5, FKV>),                                 \
-                       dim3((uint32_t)((n_waves + AGH_MP_WPB - 1) / AGH_MP_WPB)),             \
-                       dim3(AGH_MP_BLOCK), 0, st, (const uint4 *)a.text, a.n, n_full, a.q,    \
-                       (const uint32_t *)a.ftab, a.wave_totals, a.cand, a.wave_cand, a.counters, MT, MK, \
-                       (const uint16_t *)a.dbm, a.w_begin)
-    if (n_waves && !a.tail_only) {
-        // count-only scans with q == 4 and k <= 2: verification inside the sweep
-        const bool fuse = (MODE & 4) && (MODE & 2) && a.fuse_mt && a.fuse_mk && a.q.k >= 0 && a.q.k <= 2;
-        if constexpr ((MODE & 6) == 6) {
-            if (fuse && a.q.k == 0) AGH_SM_LAUNCH(0, *a.fuse_mt, *a.fuse_mk);
-            else if (fuse && a.q.k == 1) AGH_SM_LAUNCH(1, *a.fuse_mt, *a.fuse_mk);
-            else if (fuse) AGH_SM_LAUNCH(2, *a.fuse_mt, *a.fuse_mk);
-            else AGH_SM_LAUNCH(-1, none_mt, none_mk);
-        } else {
-            AGH_SM_LAUNCH(-1, none_mt, none_mk);
-        }
-    }
-#undef AGH_SM_LAUNCH
+    if (n_waves && !a.tail_only)
+        hipLaunchKernelGGL((k_sweep_multi<MODE, STRIDE, Q5>), dim3((uint32_t)((n_waves + 3) / 4)), dim3(256), 0, st,
+                           (const uint4 *)a.text, a.n, n_full, a.q, (const uint32_t *)a.ftab, a.wave_totals,
+                           a.cand, a.wave_cand, a.counters, (const uint16_t *)a.dbm, a.w_begin);
     if (a.ev_end) (void)hipEventRecord(a.ev_end, st);
     if (!to_end) return;                        // the partial last strip belongs to the last part
     if (a.n & (AGH_STRIP - 1))

@@ -42,16 +42,6 @@ def run(label, pats, k, n, flags, reps=5):
 for lo, hi in ((4, 12), (5, 12), (7, 12), (8, 12)):
     for fl, lab in ((A.COUNT | A.TIME_SWEEP, "count"), (A.TIME_SWEEP, "numbered")):
         run("1024 exact %d..%d B %s" % (lo, hi, lab), pats_of(1024, lo, hi), 0, n_all, fl)
-for parts in ("1", "2", "8"):                 # (default 4: the verifier of a part under the sweep of the next)
-    os.environ["AGH_MP_PARTS"] = parts
-    run("1024 exact 4..12 B count, %s part(s)" % parts, pats_of(1024, 4, 12), 0, n_all, A.COUNT)
-    run("1024 x 8..12 B k=1 count, %s part(s)" % parts, pats_of(1024, 8, 12), 1, n_all, A.COUNT)
-    run("1024 x 12..20 B k=2 count, %s part(s)" % parts, pats_of(1024, 12, 20), 2, n_all, A.COUNT)
-del os.environ["AGH_MP_PARTS"]
-os.environ["AGH_MP_FUSED"] = "1"              # verification inside the sweep (measured and left off)
-run("1024 exact 4..12 B count, fused", pats_of(1024, 4, 12), 0, n_all, A.COUNT | A.TIME_SWEEP)
-run("1024 x 8..12 B k=1 count, fused", pats_of(1024, 8, 12), 1, n_all, A.COUNT | A.TIME_SWEEP)
-del os.environ["AGH_MP_FUSED"]
 run("1024 x 8..12 B k=1 count", pats_of(1024, 8, 12), 1, n_all, A.COUNT | A.TIME_SWEEP)
 run("1024 x 8..12 B k=1 -l", pats_of(1024, 8, 12), 1, n_all, A.FILENAMEONLY)
 run("1024 x 8..12 B k=1 numbered", pats_of(1024, 8, 12), 1, min(n_all, 1 << 30), A.TIME_SWEEP)
