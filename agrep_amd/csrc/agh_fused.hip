@@ -4,7 +4,7 @@
 // The two-kernel lean pipeline (k_sweep, then k_verify) spends ~7 % of a 64 GiB scan in k_verify,
 // and running the verifier on a second stream only displaces sweep workgroups.  Here the verifiers
 // are two EXTRA waves of each sweep workgroup: they take no LDS or wave slot away from the
-// sweepers (4 workgroups x 6 waves = 24 of a CU's 32 wave slots), their line fetches ride along
+// sweepers (3 workgroups x 6 waves = 18 of a CU's 32 wave slots), their line fetches ride along
 // the stream, and candidates never go through HBM -- they are handed over 64 at a time through a
 // small LDS ring.  Measured (scripts/ab_fused.py, same process, same corpus): 64 GiB, k = 2:
 // 11.0-11.3 ms for the two kernels, 10.6-10.8 ms fused; with the verifier switched off the kernel
@@ -17,11 +17,13 @@
 // 128 KiB 0 ... -2 %, 512 KiB -1 ... -3 %, 1024 KiB +0.5 % at 64 GiB and -5 % at 16 GiB; 64 KiB and
 // below saturate the counter near 70 requests/us: 14.7 ms); streaming across range boundaries with
 // the ticket read deferred behind the stream (+1 %: the boundary bubble is not what costs); 1, 3 or
-// 4 verifying waves (within 0.1 %).  Only three of the four workgroups launched per CU are resident
-// (the trace shows a quarter of them starting when the first ones leave): 4 x 38 KiB of LDS do not
-// fit next to whatever the CU keeps for itself, k_sweep's 4 x 35 KiB do; the late workgroups find
-// no tickets left and exit.  A 36 KiB layout (e.g. 2^17 filter bits) would put 16 instead of 12
-// sweeping waves on a CU -- not tried yet.
+// 4 verifying waves (within 0.1 %).  Only three workgroups per CU are resident: 4 x 38 KiB of LDS do
+// not fit next to whatever the CU keeps for itself, k_sweep's 4 x 35 KiB do (with four launched, the
+// trace shows a quarter of them starting when the first ones leave).  Round 3 launches three per CU
+// (launch_fused): since every wave's first range is its own number, a late workgroup had real work
+// left and did it alone at the end.  A 36 KiB layout (2^17 filter bits: make FT_BITS=14) puts 16
+// instead of 12 sweeping waves on a CU -- measured, not faster (more chance candidates, and twelve
+// streaming waves saturate the HBM).
 // Two things mattered on the way (kept in mind for any kernel built like this one):
 //   * the work counter needs a cache line of its own: on the scan counters' line the sweepers'
 //     ticket atomics queued behind the verifiers' stores and the kernel took 14 ms;
@@ -51,8 +53,8 @@
 #ifndef AGH_FU_K
 #error "compile with -DAGH_FU_K=0..3"
 #endif
-// Verifying waves per workgroup.  Four workgroups of 4 + NV waves must fit a CU: with NV = 2 that is
-// 6 waves per SIMD (<= 80 VGPRs, <= 128 SGPRs; the kernels use 53-67 / ~106).  Measured on the
+// Verifying waves per workgroup.  Three workgroups of 4 + NV waves per CU: with NV = 2 that is
+// 4.5 waves per SIMD (the kernels use 53-67 VGPRs / ~106 SGPRs).  Measured on the
 // 64 GiB bench corpus, NV = 1, 2, 3, 4 and three or four workgroups per CU are all within 0.1 %
 // (a build-time A/B hook, since removed): the kernel sits at the HBM ceiling either way; two keeps
 // headroom for candidate-dense text without giving up sweeping waves.
@@ -320,8 +322,16 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     if (!tail_total) tail_strips = range_strips;
     const uint32_t n_ranges = (uint32_t)(n_big64 + n_small);
     if (!n_ranges) return;
-    // persistent workgroups: four per CU (LDS), fewer when the text has fewer ranges
-    uint32_t blocks = a.n_cu * 4u;
+    // persistent workgroups: THREE per CU, fewer when the text has fewer ranges.  Four fit by the
+    // arithmetic (4 x 38 KiB of 160 KiB) but not on the chip: with four launched, the fourth of every CU
+    // starts when another one leaves -- at the end of the scan -- and sweeps its statically assigned first
+    // ranges alone.  profiles/r03_ab_headline_workgroups.log, 4 -> 3 per CU: 8 GiB k = 2 / k = 0 1.407 ->
+    // 1.371 / 1.359 -> 1.339 ms, 64 GiB unchanged (10.27 / 10.10 ms); five per CU as four.
+    // ... and two where a 16-byte chunk takes two probes or fewer (H >= 8: k = 0): eight streaming waves per
+    // CU keep the HBM busy there and disturb each other less -- 64 GiB k = 0 10.07 -> 9.97 ms, 8 GiB 1.334 ->
+    // 1.309 (profiles/r03_ab_headline_final.log); with eight probes per chunk (H = 2) two are far too few
+    // (10.17 -> 11.14 ms).
+    uint32_t blocks = a.n_cu * (H >= 8 ? 2u : 3u);
     const uint32_t need = (n_ranges + 3u) / 4u;
     if (blocks > need) blocks = need;
     if (const char *e = getenv("AGH_FUSED_BLOCKS")) {                        // (A/B runs)

@@ -227,7 +227,10 @@ int agh_reduce_file_hits_all(agh_comm *const *comms, int n, unsigned char *const
  * is the nominal offset r * size / nranks itself if a record starts there (the byte in front of it is
  * the delimiter), else the offset just after the next delimiter at or after it -- the rule of
  * agrep_amd/shard.py:record_cuts, so callers that derive the cuts themselves get the same shards as
- * `agrep-hip --gpus`.  fd must be seekable (pread).  delim/dlen as in agh_query_literal. */
+ * `agrep-hip --gpus`.  fd must be seekable (pread).  delim/dlen as in agh_query_literal; a delimiter of
+ * several bytes must not overlap itself (no proper prefix that is also a suffix: "\r\n", "; ", "$$$" is
+ * refused with errno 123) -- only then does the leftmost non-overlapping reading of the delimiters not
+ * depend on where the search starts. */
 int agh_shard_cuts_fd(int fd, const unsigned char *delim, int dlen, int nranks, uint64_t *cuts);
 
 /* agh_scan_fd restricted to the byte range [begin, end) of a seekable file -- one rank's shard. */

@@ -10,7 +10,7 @@ python bench.py 2>gpurun_out/r03_bench.err | tail -1 > gpurun_out/r03_bench_line
     python $R/bench.py --steps 10 --warmup 2 --no-traffic --no-cpu-baseline > $R/gpurun_out/r03_bench_line_under_rocprof.json 2>/dev/null)
 f=$(find gpurun_out/prof_r03_bench -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/r03_bench_kernel_stats.csv
 # the headline A/B (fused vs two kernels, ticket tail, H = 2) on the final build, 64 and 8 GiB
-python scripts/ab_round3.py 64 10 2>&1 | grep -v "^/opt" | grep -E " 64.0 GiB| 8.0 GiB" | grep -E "two kernels|fused  |fused tail 512M/128K|fused H2" > gpurun_out/r03_ab_headline_final.log
+python scripts/ab_final_r3.py 64 10 2>&1 | grep -v "^/opt" > gpurun_out/r03_ab_headline_final.log
 python scripts/config_runs.py c3 2>&1 | grep -v "^/opt" > gpurun_out/r03_c3.log
 python scripts/perf_fullscan.py 4 2>&1 | grep -v "^/opt" > gpurun_out/r03_perf_fallback_engines.log
 AGH_FS_FAST=0 python scripts/perf_fullscan.py 4 2>&1 | grep -E "tablescan" > gpurun_out/r03_perf_tablescan_exact_kernel.log
