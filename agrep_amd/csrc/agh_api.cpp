@@ -534,20 +534,27 @@ static uint32_t table_feed(const agh_dev_tables &T, const uint32_t *Mask, int k,
 // and run by the table engine (agh_table.hip).
 static agh_query *table_query(const uint32_t Mask[256], uint32_t Init0, uint32_t Init1,
                               uint32_t NO_ERR_MASK, uint32_t endposition, uint32_t D_endpos,
-                              int M, const unsigned char *old_D_pat, int D_length, int D, int AND)
+                              int M, const unsigned char *old_D_pat, int D_length, int D, int AND,
+                              bool delim_fold)
 {
-    if (D_length != 1) {
-        fail("wildcard / AND / OR patterns support single-byte delimiters only");
+    // delimiter position p lives at bit M - p and accepts the byte old_D_pat[p - 1] (its case pair
+    // under -i: the caller checked the classes); D_endpos is the last of them
+    unsigned char dl[AGH_MAX_DELIM];
+    for (int i = 0; i < D_length; ++i) {
+        unsigned char c = old_D_pat[i];
+        if (c == '^' || c == '$') c = '\n';                         // bitap.c:92-94
+        if (delim_fold && is_upper(c)) c = (unsigned char)(c + 32);
+        dl[i] = c;
+        if (!((Mask[c] >> (M - 1 - i)) & 1u)) {
+            fail("delimiter position %d of the tables does not accept the byte 0x%02x", i + 1, c);
+            return nullptr;
+        }
+    }
+    if (D_endpos != (1u << (M - D_length))) {
+        fail("D_endpos is not the last delimiter position");
         return nullptr;
     }
-    unsigned char dc = old_D_pat[0];
-    if (dc == '^' || dc == '$') dc = '\n';                          // bitap.c:92-94
-    int members = 0;
-    for (int c = 0; c < 256; ++c) members += (Mask[c] & D_endpos) ? 1 : 0;
-    if (members != 1 || !(Mask[dc] & D_endpos)) {
-        fail("the delimiter position of the tables is not the single byte 0x%02x", dc);
-        return nullptr;
-    }
+    const unsigned char dc = dl[D_length - 1];
     agh_query *q = new agh_query();
     q->table = true;
     q->tab.Init0 = Init0;
@@ -555,12 +562,17 @@ static agh_query *table_query(const uint32_t Mask[256], uint32_t Init0, uint32_t
     q->tab.NO_ERR = NO_ERR_MASK;
     q->tab.endposition = endposition;
     q->tab.D_endpos = D_endpos;
-    q->tab.D_Mask = ~D_endpos;                                      // asearch.c:54-57, D_length 1
+    {
+        uint32_t dm = D_endpos;                                     // asearch.c:54-57
+        for (int i = 1; i < D_length; ++i) dm = (dm << 1) | dm;
+        q->tab.D_Mask = ~dm;
+    }
     q->tab.AND = AND ? 1u : 0u;
     q->m = M - D_length - 1;
     q->k = D;
-    q->dlen = 1;
-    q->delim[0] = dc;
+    q->dlen = D_length;
+    memcpy(q->delim, dl, (size_t)D_length);
+    q->delim_fold = delim_fold;
     memset(q->mask, 0, sizeof(q->mask));
     for (int c = 0; c < 256; ++c) q->mask[c] = Mask[c];             // uploaded unchanged
     // An empty record must not match (the virtual '\n' in front of the text and the delimiter
@@ -568,10 +580,11 @@ static agh_query *table_query(const uint32_t Mask[256], uint32_t Init0, uint32_t
     {
         uint32_t B[AGH_MAX_ERRORS + 1];
         for (int e = 0; e <= D; ++e) B[e] = Init0;
-        uint32_t r0 = table_feed(q->tab, Mask, D, B, '\n');
-        uint32_t r1 = table_feed(q->tab, Mask, D, B, dc);
-        uint32_t r2 = table_feed(q->tab, Mask, D, B, dc);
-        if ((r0 & 2u) || (r1 & 2u) || (r2 & 2u)) {
+        uint32_t r = table_feed(q->tab, Mask, D, B, '\n');
+        for (int rep = 0; rep < 2; ++rep)
+            for (int i = 0; i < D_length; ++i) r |= table_feed(q->tab, Mask, D, B, dl[i]);
+        (void)dc;
+        if (r & 2u) {
             delete q;
             fail("the pattern matches the empty record with %d errors", D);
             return nullptr;
@@ -624,7 +637,7 @@ extern "C" agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t 
     if (AND || endposition != 1u || Init0 != (pad | sep) || Init1 != (Init0 | 1u | D_endpos) ||
         D_endpos != (1u << (M - D_length)))
         return table_query(Mask, Init0, Init1, NO_ERR_MASK, endposition, D_endpos, M, old_D_pat,
-                           D_length, D, AND);
+                           D_length, D, AND, delim_fold);
     // NO_ERR_MASK: 0-bits forbid error transitions into a position (<exact> segments,
     // maskgen.c:80-95, 222-223); pattern position p is reference bit (m - p) -> device bit p-1
     uint64_t no_err = 0;
@@ -954,8 +967,8 @@ static bool fs_fast_ok(const agh_query *q)
     const char *e = getenv("AGH_FS_FAST");
     if (e && e[0] == '0') return false;
     if (q->fs_fast_off || q->multi) return false;
-    // table engine (k_tablescan_fast + k_table_replay): unit costs (its delimiter is one byte anyway)
-    if (q->table) return q->ci == 1 && q->cs == 1 && q->cd == 1;
+    // table engine (k_tablescan_fast + k_table_replay): unit costs, one-byte delimiter
+    if (q->table) return q->ci == 1 && q->cs == 1 && q->cd == 1 && !(q->dlen > 1 || q->delim_fold);
     // k = 0: one level, nothing to pack -- the one-kernel form is faster there (3.8 vs 3.2 TB/s)
     return q->k >= 1 && !q->general && !(q->dlen > 1 || q->delim_fold) && q->mask[q->delim[0]] == 0;
 }

@@ -37,8 +37,6 @@ struct agh_sweep_args {
     // verifier of one part run while the next part is swept, and let -l stop early.
     uint32_t w_begin = 0, w_end = 0;
     int tail_only = 0;       // 1: only the partial last strip (the fused kernel swept the rest)
-    // multi-pattern count-only sweeps: verify full queues inside the sweep (tables and marks of the
-    // verifier; NULL: candidates go to the slices)
 };
 
 struct agh_scan_args {

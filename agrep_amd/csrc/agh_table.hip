@@ -9,6 +9,12 @@
 // in its 1 KiB chunk and runs each of them from its start (reset + re-fed delimiter,
 // asearch.c:175-186) to the delimiter that closes it, wherever that is.  Record numbers come
 // from the same delimiter census the full scan uses (count-only scans need neither).
+// Delimiters of several bytes (and letters under -i): the tables carry the delimiter in their first
+// D_length positions (preproce.c:181-224) and level 0 finds its leftmost non-overlapping occurrences
+// -- but only for a run that started in front of them.  So WHERE records end is read from the
+// delimiter bitmap the other engines use; a lane that learns of a boundary its own state missed takes
+// the state a boundary leaves (TableAutomaton::force_boundary) and is exact from there.  k_tablescan
+// only; the fast form below keeps to one byte.
 #include "agh_verify_inl.h"
 
 #define AGH_TS_CHUNK 256u       // k_unmatched: bytes per lane
@@ -98,6 +104,31 @@ struct TableAutomaton {
         if (COSTS) return feed_costs(CM, T, q.ci, q.cs, q.cd);
         return feed(CM, T);
     }
+    // The state a record boundary at a byte with mask CM leaves (the reset branch of feed / feed_costs),
+    // for a lane that has just learnt from the delimiter bitmap that a delimiter of several bytes ended
+    // here: it started inside that delimiter, so its own level 0 could not know.
+    template <bool COSTS>
+    __device__ __forceinline__ void force_boundary(uint32_t CM, const agh_dev_tables &T, const agh_dev_query &q)
+    {
+        B[0] = (((T.Init0 >> 1) & CM) | (T.Init0 & T.Init1)) & T.D_Mask;
+#pragma unroll
+        for (int e = 1; e <= K; ++e) {
+            if (COSTS) {
+                uint32_t ins = 0, via = 0;
+#pragma unroll
+                for (int s = 0; s < e; ++s) {
+                    const uint32_t d = (uint32_t)(e - s);
+                    if (d == q.ci) ins = T.Init0;
+                    if (d == q.cs) via |= T.Init0;
+                    if (d == q.cd) via |= B[s];
+                }
+                B[e] = ((T.Init0 >> 1) & CM) | (T.Init1 & T.Init0) | ins | ((via >> 1) & T.NO_ERR);
+            } else {
+                B[e] = ((T.Init0 >> 1) & CM) | (T.Init1 & T.Init0) | T.Init0 |
+                       (((B[e - 1] | T.Init0) >> 1) & T.NO_ERR);
+            }
+        }
+    }
 };
 
 // Text feeding as in k_fullscan (agh_fullscan.hip): a lane's chunk is one 1 KiB census strip, a wave
@@ -111,8 +142,14 @@ template <int K, bool LEAN, bool COSTS>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, const uint32_t *__restrict__ strip_prefix,
-    const uint32_t *__restrict__ wave_prefix, uint32_t n_strips, agh_marks mk)
+    const uint32_t *__restrict__ wave_prefix, uint32_t n_strips, agh_marks mk,
+    const uint64_t *__restrict__ dbm)
 {
+    // q.mb (delimiters of several bytes, letters under -i): WHERE a record ends comes from the delimiter
+    // bitmap (the leftmost non-overlapping occurrences, which is also what level 0 of the automaton
+    // selects when it runs from the start of the text) -- a lane that starts inside a delimiter cannot
+    // know from its own state.  What the boundary does to the state stays the automaton's business.
+    const bool mb = q.mb != 0;
     __shared__ uint32_t lmask[256];
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * WAVE * AGH_FS_ROW];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
@@ -161,8 +198,16 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
             (void)A.template feed_q<COSTS>(lmask[q.head_byte], T, q);   // asearch.c:69-78 (never a hit: host check)
             active = true;
         }
-        auto step = [&](uint32_t c, uint64_t pos) {
-            const uint32_t r = A.template feed_q<COSTS>(lmask[c], T, q);
+        auto step = [&](uint32_t c, uint64_t pos, uint32_t dbit) {
+            uint32_t r = A.template feed_q<COSTS>(lmask[c], T, q);
+            if (mb) {
+                if (dbit && !(r & 1u)) {        // (only before my first boundary: I started inside the delimiter)
+                    A.template force_boundary<COSTS>(lmask[c], T, q);
+                    r = 1u;
+                } else if (!dbit) {
+                    r = 0u;                     // (an occurrence my untrusted state selected differently)
+                }
+            }
             if (r & 1u) {
                 if (active && (r & 2u)) {
                     if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, pos);
@@ -189,13 +234,14 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
             for (uint32_t p = 0; p < 4; ++p) {
                 const uint32_t off = r * AGH_FS_ROUND + 16u * p;
                 const uint32_t dws[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+                const uint32_t d16 = (mb && off < len) ? (uint32_t)dbm_bits64(dbm, cs + off) & 0xffffu : 0u;
                 if (off + 16u <= len) {
 #pragma unroll
                     for (uint32_t b = 0; b < 16; ++b)
-                        step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, cs + off + b);
+                        step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, cs + off + b, (d16 >> b) & 1u);
                 } else if (off < len) {
                     for (uint32_t b = 0; off + b < len; ++b)
-                        step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, cs + off + b);
+                        step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, cs + off + b, (d16 >> b) & 1u);
                 }
             }
         }
@@ -204,11 +250,14 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
         for (uint64_t p0 = ce; !done && p0 < n; p0 += 16) {
             const uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
             const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t d16 = mb ? (uint32_t)dbm_bits64(dbm, p0) & 0xffffu : 0u;
             for (uint32_t b = 0; b < 16 && !done && p0 + b < n; ++b)
-                step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, p0 + b);
+                step((dws[b >> 2] >> (8u * (b & 3u))) & 0xffu, p0 + b, (d16 >> b) & 1u);
         }
-        if (!done && active && q.tail_virtual) {            // asearch.c:87-91
-            const uint32_t r = A.template feed_q<COSTS>(lmask[q.delim], T, q);
+        if (!done && active && q.tail_virtual) {            // asearch.c:87-91: the delimiter appended at EOF
+            uint32_t r = 0;
+            for (uint32_t jd = 0; jd < q.dlen && !(r & 1u); ++jd)
+                r = A.template feed_q<COSTS>(lmask[q.dbytes[jd]], T, q);
             if ((r & 3u) == 3u) {
                 if (LEAN) lean_insert(mk, rstart); else mark_record(mk, rec, n);
             }
@@ -496,7 +545,7 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
 #define AGH_TS_LAUNCH(KK, LEANV, COSTV)                                                       \
     hipLaunchKernelGGL((k_tablescan<KK, LEANV, COSTV>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
                        (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask,    \
-                       a.strip_prefix, a.wave_prefix, a.n_strips, a.mk)
+                       a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm)
 #define AGH_CASE(KK)                                                                          \
     case KK:                                                                                  \
         if (lean && costs) AGH_TS_LAUNCH(KK, true, true);                                     \

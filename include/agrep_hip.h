@@ -125,8 +125,9 @@ agh_query *agh_query_literal_ex(const unsigned char *pat, int m, int D, unsigned
  * Literals, [classes], -w / -x guards and <exact> segments (NO_ERR_MASK) run on the byte-
  * parallel engines; tables with '#' wildcards (sticky Init1 bits, maskgen.c:231-232) or
  * ';' AND / ',' OR (several endposition bits, maskgen.c:136-163) are kept unchanged and run
- * record-parallel by the table engine (single-byte delimiter, unit costs).  NULL for a
- * pattern that matches the empty record and for malformed tables. */
+ * record-parallel by the table engine (delimiters of 1..8 bytes, also letters under -i; edit costs
+ * through agh_query_set_costs).  NULL for a pattern that matches the empty record and for malformed
+ * tables. */
 agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint32_t Init1,
                                   uint32_t NO_ERR_MASK, uint32_t endposition,
                                   uint32_t D_endpos, int M, const unsigned char *old_D_pat,

@@ -223,6 +223,36 @@ def gen_pattern_language():
     print("pattern_language.json:", [(c["pattern"], c["opts"], c["count"], c["tables"]["ret"]) for c in cases])
 
 
+def gen_pattern_language_delims():
+    """The table-engine patterns ('#', ';', ',') under delimiters of several bytes (-d): tables and
+    counts from the reference.  `delim` is what separates the records in the text ('$' and '^' in the
+    option mean newline, bitap.c:92-94)."""
+    cases = []
+    text, _ = O.corpus(8, seed=77, variants=O.VARIANTS_C2, plant_period=3)
+    words = (b"the car is red\ncars are fast\na scar\ncar\ncharacter\nmy car.\ncat\n"
+             b"approximatematch\nxapproxQmatch\napprox match x\nred car\nfast cars\n")
+    base = text.tobytes() + words
+    for dopt, delim, more in ((";;", b";;", []), ("\r\n", b"\r\n", []), ("$$", b"\n\n", []), ("; ", b"; ", []),
+                              ("XY", b"xy", ["-i"]), (":::", b":::", []), ("@@@@", b"@@@@", [])):
+        tb = base.replace(b"\n", delim)
+        if delim == b"xy":                      # -i: the delimiter's letters in both cases
+            tb = tb.replace(b"xy", b"xY", 7).replace(b"xy", b"XY", 5)
+        for pat, k in (("approx#match", 0), ("approx#match", 1), ("appr#mate#ch", 2), ("approxi;matematch", 1),
+                       ("cars;fast", 0), ("scar,cat", 0), ("aproxi,matemmat", 1), ("car;red", 1)):
+            opts = more + ["-d", dopt]
+            kopt = ["-%d" % k] if k else []
+            rc, out, err = run([HARNESS, "tables"] + kopt + ["-n"] + opts + [pat])
+            t = json.loads(out)
+            cnt, lines = ref_scan(tb, pat, k, ["-n"] + opts, "file")
+            cases.append({"pattern": pat, "k": k, "opts": opts, "delim_latin1": delim.decode("latin1"),
+                          "nocase": "-i" in more, "tables": t, "count": cnt,
+                          "text": {"kind": "corpus+words, newlines replaced by the delimiter", "pages": 8, "seed": 77,
+                                   "period": 3, "words_latin1": words.decode("latin1")}})
+    with open(os.path.join(OUT, "pattern_language_delims.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "cases": cases}, f, indent=0)
+    print("pattern_language_delims.json:", [(c["pattern"], c["opts"], c["count"]) for c in cases])
+
+
 def gen_quirks():
     q = []
     pat = "approximatematch"
@@ -258,3 +288,4 @@ if __name__ == "__main__":
     gen_costs()
     gen_exact_segments()
     gen_pattern_language()
+    gen_pattern_language_delims()

@@ -13,17 +13,25 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = random.Random(seed)
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "pattern_language.json")))["cases"]
+GOLD_D = json.load(open(os.path.join(ROOT, "tests", "golden", "pattern_language_delims.json")))["cases"]
 
 
 def table_case():
     """'#' / ';' / ',' / -p patterns on the reference's own tables (table engine, fast form and
     k_tablescan, with and without edit costs) against the oracle's asearch on the same tables."""
     global fails
-    case = rng.choice(GOLD)
+    multi_d = rng.random() < 0.4                # ... under a delimiter of several bytes (round 3)
+    case = rng.choice(GOLD_D if multi_d else GOLD)
     tb = case["tables"]
-    M = tb["D_endpos"].bit_length()
+    delim = case["delim_latin1"].encode("latin1") if multi_d else b"\n"
+    dopt = case["opts"][case["opts"].index("-d") + 1].encode("latin1") if multi_d else b"\n"
+    M = tb["D_endpos"].bit_length() + len(delim) - 1
     letters = bytes(sorted(set(c for c in case["pattern"].encode() if chr(c).isalnum()))) or b"a"
-    alpha = letters + rng.choice([b"\n", b" \n", b"xyz \n", b"\n\n"])
+    if multi_d:
+        dset = delim + (delim.upper() if case.get("nocase") else b"")
+        alpha = letters + rng.choice([dset, dset + b" ", dset + dset + b"xyz "])
+    else:
+        alpha = letters + rng.choice([b"\n", b" \n", b"xyz \n", b"\n\n"])
     n = rng.choice([0, 1, 17, 300, 4095, 4096, 4097, 70000, 262144, 300000, 1 << 20])
     text = bytearray(rng.choice(alpha) for _ in range(min(n, 8192)))
     if n > 8192:
@@ -34,17 +42,19 @@ def table_case():
         if rng.random() < 0.3:                  # a few very long records
             lo = rng.randrange(0, n // 2)
             seg = arr[lo:lo + rng.choice([5000, 70000, 300000])]
-            seg[seg == 10] = letters[0]
+            seg[seg == delim[-1]] = letters[0]
         text = bytearray(arr.tobytes())
     text = bytes(text)
     costs = None
     if case["k"] > 0 and rng.random() < 0.4:
         costs = (rng.randint(1, 2), rng.randint(1, 2), rng.randint(1, 2))
-    ot = O.tables_from_golden(tb, M)
-    want = (O.asearch_tables_costs(ot, case["k"], costs, text, cap=400000) if costs
-            else O.asearch_tables(ot, case["k"], text, cap=400000))
+    if not text and multi_d:
+        return                                  # (empty text: only the appended delimiter could match, Q11)
+    ot = O.tables_from_golden(tb, M, dlen=len(delim))
+    want = (O.asearch_tables_costs(ot, case["k"], costs, text, delim=delim, cap=400000) if costs
+            else O.asearch_tables(ot, case["k"], text, delim=delim, cap=400000))
     q = A.Query.from_maskgen(tb["Mask"], tb["Init0"], tb["Init1"], tb["NO_ERR_MASK"], tb["endposition"],
-                             tb["D_endpos"], M, b"\n", case["k"], tb["AND"])
+                             tb["D_endpos"], M, dopt, case["k"], tb["AND"])
     try:
         if costs:
             q.set_costs(*costs)
@@ -56,7 +66,7 @@ def table_case():
             got = (r1.n_matched, [(s_, e_) for s_, e_, _ in ms])
             if got != want or not (r2.n_matched == r3.n_matched == want[0]):
                 fails += 1
-                print("MISMATCH table", case["pattern"], case["opts"], "k", case["k"], "costs", costs, "fast", fast, "n", len(text),
+                print("MISMATCH table", case["pattern"], case["opts"], "delim", delim, "k", case["k"], "costs", costs, "fast", fast, "n", len(text),
                       "want", want[0], "got", r1.n_matched, r2.n_matched, r3.n_matched, "seed", seed, "case", n_cases, flush=True)
     finally:
         os.environ.pop("AGH_FS_FAST", None)

@@ -499,6 +499,56 @@ def test_table_engine_adversarial_texts(agh):
         q.close()
 
 
+def test_table_engine_with_multi_byte_delimiters(agh):
+    """'#', ';' and ',' under delimiters of several bytes and letters under -i: record ends from the
+    delimiter bitmap, the reference's tables run literally (agh_table.hip).  The reference's own counts
+    on its golden texts, and the oracle on texts built to hurt: delimiters across strip / tile borders,
+    runs of a delimiter that overlaps itself, no delimiter at the end, nothing but delimiters."""
+    from test_oracle_golden import lang_delims_text
+    rng = np.random.default_rng(23)
+    for ci, case in enumerate(_golden("pattern_language_delims.json")):
+        text, delim = lang_delims_text(case)
+        tb = case["tables"]
+        M = tb["D_endpos"].bit_length() + len(delim) - 1        # D_endpos = the LAST delimiter position, bit M - D_length
+        opt = case["opts"][case["opts"].index("-d") + 1].encode("latin1")
+        q = agh.Query.from_maskgen(tb["Mask"], tb["Init0"], tb["Init1"], tb["NO_ERR_MASK"], tb["endposition"],
+                                   tb["D_endpos"], M, opt, case["k"], tb["AND"])
+        ot = O.tables_from_golden(tb, M, dlen=len(delim))
+        texts = [text]
+        if ci % 8 in (0, 4, 5):                 # one '#', one ';' and one ',' pattern per delimiter
+            letters = np.frombuffer(b"acrestpoxim h", dtype=np.uint8)
+            body = letters[rng.integers(0, len(letters), 150000)].tobytes()
+            pieces, pos = [], 0
+            while pos < len(body):
+                step = int(rng.integers(1, 400))
+                pieces.append(body[pos:pos + step])
+                pos += step
+            joined = delim.join(pieces)
+            # delimiters moved onto the 1 KiB / 64 KiB borders, a run of delimiter bytes, both ends
+            b = bytearray(joined)
+            for border in (1024, 4096, 65536, 131072):
+                for shift in range(len(delim) + 1):
+                    at = border - shift + 7 * 1024 * shift
+                    if at + len(delim) < len(b):
+                        b[at:at + len(delim)] = delim
+            run_of = (delim[:1] * (2 * len(delim) + 1))
+            b[70000:70000 + len(run_of)] = run_of
+            texts += [bytes(b), delim + bytes(b[:5000]), bytes(b[:3000]) + b"approxQmatch cars fast scar",
+                      delim * 5, b"car", b""]
+        for ti, t in enumerate(texts):
+            if not t and len(delim) > 1:
+                continue                        # (empty text: only the appended delimiter, Q11)
+            want = O.asearch_tables(ot, case["k"], t, delim=delim, cap=300000)
+            if ti == 0:
+                assert want[0] == case["count"]
+            res, ms = q.scan_buffer(t, cap=300000)
+            assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (case["pattern"], case["opts"], ti)
+            res_c, _ = q.scan_buffer(t, flags=agh.COUNT)
+            res_n, _ = q.scan_buffer(t, flags=agh.COUNT | agh.FORCE_NUMBERED)
+            assert res_c.n_matched == res_n.n_matched == want[0], (case["pattern"], case["opts"], ti)
+        q.close()
+
+
 def test_piece_engine_for_short_patterns(agh):
     """Patterns the sample lemma cannot filter (m < 5k+6) run through the piece engine: k+1
     verbatim pieces found by the multi-pattern sweep, the pattern's automaton on the window.

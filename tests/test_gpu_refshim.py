@@ -114,6 +114,10 @@ def test_delimiters_through_the_shim(files, tmp_path, delim):
         matrix += [["-V0", "-d", delim, "-2", "-c"], ["-V0", "-d", delim, "-2"]]
     for args in matrix:
         _same(args + ["approximatematch"], [str(f)])
+    # '#', ';' and ',' (table engine; since round 3 also under delimiters of several bytes)
+    for pat in ("approx#match", "approxi;matematch", "aproxi,matemmat"):
+        for args in (["-V0", "-d", delim, "-1", "-c"], ["-V0", "-d", delim, "-1"], ["-V0", "-d", delim, "-n", "-1"]):
+            _same(args + [pat], [str(f)])
 
 
 @needs

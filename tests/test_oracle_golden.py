@@ -185,3 +185,26 @@ def test_pattern_language_tables_match_reference(case):
     maskgen.c:86-170): the oracle automaton driven by those tables gives the reference count."""
     t = O.tables_from_golden(case["tables"], _lang_M(case["tables"]))
     assert O.asearch_tables(t, case["k"], _lang_text(case))[0] == case["count"]
+
+
+def lang_delims_text(case):
+    """Text of a pattern_language_delims.json case (oracle/gen_golden.py:gen_pattern_language_delims)."""
+    spec = case["text"]
+    text, _ = O.corpus(spec["pages"], seed=spec["seed"], variants=O.VARIANTS_C2, plant_period=spec["period"])
+    delim = case["delim_latin1"].encode("latin1")
+    tb = (text.tobytes() + spec["words_latin1"].encode("latin1")).replace(b"\n", delim)
+    if delim == b"xy":
+        tb = tb.replace(b"xy", b"xY", 7).replace(b"xy", b"XY", 5)
+    return tb, delim
+
+
+@pytest.mark.parametrize("case", _load("pattern_language_delims.json"),
+                         ids=lambda c: "%s_k%d_%s" % (c["pattern"], c["k"], "".join(c["opts"]).replace("\r\n", "CRLF")))
+def test_pattern_language_with_multi_byte_delimiters_matches_reference(case):
+    """'#', ';' and ',' under -d delimiters of several bytes (also letters under -i): the oracle automaton on the
+    reference's tables -- delimiter positions in front, D_Mask over all of them (asearch.c:54-57) -- gives
+    the reference's count, including where the delimiter's own bytes take part in an occurrence (Q11)."""
+    text, delim = lang_delims_text(case)
+    tb = case["tables"]
+    t = O.tables_from_golden(tb, _lang_M(tb) + len(delim) - 1, dlen=len(delim))
+    assert O.asearch_tables(t, case["k"], text, delim=delim)[0] == case["count"]
