@@ -327,11 +327,12 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     // starts when another one leaves -- at the end of the scan -- and sweeps its statically assigned first
     // ranges alone.  profiles/r03_ab_headline_workgroups.log, 4 -> 3 per CU: 8 GiB k = 2 / k = 0 1.407 ->
     // 1.371 / 1.359 -> 1.339 ms, 64 GiB unchanged (10.27 / 10.10 ms); five per CU as four.
-    // ... and two where a 16-byte chunk takes two probes or fewer (H >= 8: k = 0): eight streaming waves per
-    // CU keep the HBM busy there and disturb each other less -- 64 GiB k = 0 10.07 -> 9.97 ms, 8 GiB 1.334 ->
-    // 1.309 (profiles/r03_ab_headline_final.log); with eight probes per chunk (H = 2) two are far too few
-    // (10.17 -> 11.14 ms).
-    uint32_t blocks = a.n_cu * (H >= 8 ? 2u : 3u);
+    // ... and two where a 16-byte chunk takes four probes or fewer (H >= 4: k = 0, k = 1, config C3): eight
+    // streaming waves per CU keep the HBM busy there and disturb each other less -- 64 GiB k = 0 10.07 ->
+    // 9.97 ms, 8 GiB 1.334 -> 1.309; k = 1 10.31 -> 10.20 ms, 8 GiB 1.361 -> 1.342 (profiles/
+    // r03_ab_headline_final.log, r03_ab_k1_workgroups.log); with the eight probes of H = 2 two are far too
+    // few (10.17 -> 11.14 ms).
+    uint32_t blocks = a.n_cu * (H >= 4 ? 2u : 3u);
     const uint32_t need = (n_ranges + 3u) / 4u;
     if (blocks > need) blocks = need;
     if (const char *e = getenv("AGH_FUSED_BLOCKS")) {                        // (A/B runs)

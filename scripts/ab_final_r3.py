@@ -43,6 +43,14 @@ def run(label, k, n, env):
 
 
 OLD = {"AGH_SHAPE_H2": "0", "AGH_FUSED_TAIL_MB": "0"}
+if len(sys.argv) > 3 and sys.argv[3] == "k1":       # k = 1 (4-byte samples every 4 bytes): workgroups per CU only
+    for sz in [s for s in (64, 8) if s <= gib]:
+        for label, env in (("shipped default", {}), ("2 workgroups per CU", {"AGH_FUSED_BLOCKS": str(2 * n_cu)}),
+                           ("3 workgroups per CU", {"AGH_FUSED_BLOCKS": str(3 * n_cu)}),
+                           ("4 workgroups per CU", {"AGH_FUSED_BLOCKS": str(4 * n_cu)}), ("two kernels", {"AGH_FUSED": "0"}),
+                           ("shipped default again", {})):
+            run(label, 1, sz << 30, env)
+    sys.exit(0)
 for sz in [s for s in (64, 8, 4, 2, 1) if s <= gib]:
     n = sz << 30
     for k in (2, 0):
