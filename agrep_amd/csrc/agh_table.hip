@@ -138,7 +138,7 @@ struct TableAutomaton {
 // the delimiter that closes its last record.
 // LEAN (count-only): no census pass in front -- a record is identified by the offset of its first
 // byte, which the owning lane knows exactly, and goes into the hash set of record starts.
-template <int K, bool LEAN, bool COSTS>
+template <int K, bool LEAN, bool COSTS, bool MB>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, const uint32_t *__restrict__ strip_prefix,
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan(
     // bitmap (the leftmost non-overlapping occurrences, which is also what level 0 of the automaton
     // selects when it runs from the start of the text) -- a lane that starts inside a delimiter cannot
     // know from its own state.  What the boundary does to the state stays the automaton's business.
-    const bool mb = q.mb != 0;
+    constexpr bool mb = MB;
     __shared__ uint32_t lmask[256];
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * WAVE * AGH_FS_ROW];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
@@ -542,22 +542,25 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
 #undef AGH_TF_CASE
         return;
     }
-#define AGH_TS_LAUNCH(KK, LEANV, COSTV)                                                       \
-    hipLaunchKernelGGL((k_tablescan<KK, LEANV, COSTV>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
+#define AGH_TS_LAUNCH(KK, LEANV, COSTV, MBV)                                                  \
+    hipLaunchKernelGGL((k_tablescan<KK, LEANV, COSTV, MBV>), dim3(blocks), dim3(AGH_FS_THREADS), 0, st, \
                        (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask,    \
                        a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, a.dbm)
+#define AGH_CASE_MB(KK, MBV)                                                                  \
+        if (lean && costs) AGH_TS_LAUNCH(KK, true, true, MBV);                                \
+        else if (lean) AGH_TS_LAUNCH(KK, true, false, MBV);                                   \
+        else if (costs) AGH_TS_LAUNCH(KK, false, true, MBV);                                  \
+        else AGH_TS_LAUNCH(KK, false, false, MBV);
 #define AGH_CASE(KK)                                                                          \
     case KK:                                                                                  \
-        if (lean && costs) AGH_TS_LAUNCH(KK, true, true);                                     \
-        else if (lean) AGH_TS_LAUNCH(KK, true, false);                                        \
-        else if (costs) AGH_TS_LAUNCH(KK, false, true);                                       \
-        else AGH_TS_LAUNCH(KK, false, false);                                                 \
+        if (a.q.mb) { AGH_CASE_MB(KK, true) } else { AGH_CASE_MB(KK, false) }                 \
         break;
     switch (a.q.k) {
         AGH_CASE(0) AGH_CASE(1) AGH_CASE(2) AGH_CASE(3) AGH_CASE(4)
         AGH_CASE(5) AGH_CASE(6) AGH_CASE(7) AGH_CASE(8)
     default: break;
     }
+#undef AGH_CASE_MB
 #undef AGH_CASE
 #undef AGH_TS_LAUNCH
 }
