@@ -1015,9 +1015,9 @@ static const uint64_t AGH_LEAN_SEG_MAX = (uint64_t)64 << 30;     // lean scans: 
 // workgroups): measured against the two-kernel form (scripts/ab_fused.py, k = 2 / k = 0) it is
 // -3 % / -3 % at 4 GiB, even at 8 GiB, +1.8 % / +1.6 % at 16 GiB, +5 % / 0 % at 64 GiB in round 2;
 // round 3 (H = 2 samples at k = 2, small tickets at the end; profiles/r03_ab_headline.log): -3 % / -4 %
-// at 4 GiB, +1.9 % / +0.2 % at 8 GiB, +3.5 % / +3.5 % at 16 GiB, +6.7 % / +3.7 % at 64 GiB; with three
-// instead of four workgroups per CU (agh_fused.hip; profiles/r03_ab_headline_final.log): -10 % / -12 % at
-// 1 GiB, -3 % / -7 % at 2 GiB, +2.7 % / -1.3 % at 4 GiB, +4.5 % / +2.4 % at 8 GiB, +7 % / +4.5 % at 64 GiB.
+// at 4 GiB, +1.9 % / +0.2 % at 8 GiB, +3.5 % / +3.5 % at 16 GiB, +6.7 % / +3.7 % at 64 GiB; with the final
+// grid (agh_fused.hip launch_fused; profiles/r03_ab_headline_final.log): -10 % / -13 % at 1 GiB,
+// -4 % / -3 % at 2 GiB, +3.3 % / +2.5 % at 4 GiB, +4.9 % / +3.7 % at 8 GiB, +6 % / +4.8 % at 64 GiB.
 #define AGH_FUSED_MIN_MB_DEFAULT 4096
 
 static uint64_t env_mb(const char *name, uint64_t dflt_mb);

@@ -1,10 +1,10 @@
-// agh_fused.hip -- count-only (lean) scans in ONE kernel: four sweeping waves and two verifying
+// agh_fused.hip -- count-only (lean) scans in ONE kernel: six or eight sweeping waves and two verifying
 // waves per workgroup.
 //
 // The two-kernel lean pipeline (k_sweep, then k_verify) spends ~7 % of a 64 GiB scan in k_verify,
 // and running the verifier on a second stream only displaces sweep workgroups.  Here the verifiers
 // are two EXTRA waves of each sweep workgroup: they take no LDS or wave slot away from the
-// sweepers (3 workgroups x 6 waves = 18 of a CU's 32 wave slots), their line fetches ride along
+// sweepers (16 or 10 of a CU's 32 wave slots in all), their line fetches ride along
 // the stream, and candidates never go through HBM -- they are handed over 64 at a time through a
 // small LDS ring.  Measured (scripts/ab_fused.py, same process, same corpus): 64 GiB, k = 2:
 // 11.0-11.3 ms for the two kernels, 10.6-10.8 ms fused; with the verifier switched off the kernel
@@ -17,13 +17,13 @@
 // 128 KiB 0 ... -2 %, 512 KiB -1 ... -3 %, 1024 KiB +0.5 % at 64 GiB and -5 % at 16 GiB; 64 KiB and
 // below saturate the counter near 70 requests/us: 14.7 ms); streaming across range boundaries with
 // the ticket read deferred behind the stream (+1 %: the boundary bubble is not what costs); 1, 3 or
-// 4 verifying waves (within 0.1 %).  Only three workgroups per CU are resident: 4 x 38 KiB of LDS do
-// not fit next to whatever the CU keeps for itself, k_sweep's 4 x 35 KiB do (with four launched, the
-// trace shows a quarter of them starting when the first ones leave).  Round 3 launches three per CU
-// (launch_fused): since every wave's first range is its own number, a late workgroup had real work
-// left and did it alone at the end.  A 36 KiB layout (2^17 filter bits: make FT_BITS=14) puts 16
-// instead of 12 sweeping waves on a CU -- measured, not faster (more chance candidates, and twelve
-// streaming waves saturate the HBM).
+// 4 verifying waves (within 0.1 %).  Round 2 launched four workgroups of 4 + 2 waves per CU, of which only
+// three are resident (4 x 38 KiB of LDS do not fit next to whatever the CU keeps for itself, k_sweep's
+// 4 x 35 KiB do; the trace shows a quarter of them starting when the first ones leave).  Round 3 measured
+// the shape of the grid -- sweeping waves per workgroup x workgroups per CU -- and ships 2 x (6 + 2) waves
+// per CU for H = 2 and 1 x (8 + 2) for the lighter sample shapes (launch_fused has the numbers).  A 36 KiB
+// layout (2^17 filter bits: make FT_BITS=14) with 16 sweeping waves on a CU was measured as well: not
+// faster (more chance candidates, and twelve streaming waves saturate the HBM).
 // Two things mattered on the way (kept in mind for any kernel built like this one):
 //   * the work counter needs a cache line of its own: on the scan counters' line the sweepers'
 //     ticket atomics queued behind the verifiers' stores and the kernel took 14 ms;
@@ -53,11 +53,10 @@
 #ifndef AGH_FU_K
 #error "compile with -DAGH_FU_K=0..3"
 #endif
-// Verifying waves per workgroup.  Three workgroups of 4 + NV waves per CU: with NV = 2 that is
-// 4.5 waves per SIMD (the kernels use 53-67 VGPRs / ~106 SGPRs).  Measured on the
-// 64 GiB bench corpus, NV = 1, 2, 3, 4 and three or four workgroups per CU are all within 0.1 %
-// (a build-time A/B hook, since removed): the kernel sits at the HBM ceiling either way; two keeps
-// headroom for candidate-dense text without giving up sweeping waves.
+// Verifying waves per workgroup (next to 6 or 8 sweeping ones, launch_fused; the kernels use 53-67 VGPRs /
+// ~106 SGPRs).  Measured on the 64 GiB bench corpus in round 2 with four sweeping waves per workgroup,
+// NV = 1, 2, 3, 4 were all within 0.1 % (a build-time A/B hook, since removed): the kernel sits at the HBM
+// ceiling either way; two keeps headroom for candidate-dense text.
 #define AGH_FU_NV 2
 #define AGH_FU_CHUNKS 4u                 // LDS ring: 4 chunks of 64 candidates (2 KiB)
 // a wave's private queue: handed over at 64, one emit round adds at most 16 (one lane's hit bits;
@@ -86,8 +85,8 @@ __device__ __forceinline__ uint32_t lds_peek(const uint32_t *p)
     return __atomic_load_n(p, __ATOMIC_RELAXED);
 }
 
-template <typename WT, int H, int MODE, int K, int NCH, int NV>
-__global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
+template <typename WT, int H, int MODE, int K, int NCH, int NV, int NS>
+__global__ __launch_bounds__(64 * (NS + NV)) void k_sweep_fused(
     const uint4 *__restrict__ text, uint64_t n, uint64_t n_full_strips, agh_dev_query q,
     const uint8_t *__restrict__ ftab_g, const WT *__restrict__ mask_g, agh_marks mk,
     const uint64_t *__restrict__ gtab, uint32_t tspan, uint32_t n_ranges,
@@ -95,7 +94,7 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
 {
     static_assert((MODE & 4) && !(MODE & 8), "lean sweeps with one-byte delimiters only");
         __shared__ __attribute__((aligned(16))) uint8_t ftab[AGH_FT_SIZE];
-    __shared__ uint64_t cq_all[4 * AGH_FU_CQ_LEN];
+    __shared__ uint64_t cq_all[NS * AGH_FU_CQ_LEN];
     __shared__ uint64_t ring[AGH_FU_CHUNKS * 64];
     __shared__ WT lmask[256];
     __shared__ uint32_t ring_ready[AGH_FU_CHUNKS];   // ticket + 1 of the chunk that is published
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
         for (int i = 0; i < PER; ++i) dst[threadIdx.x + i * 256] = tmp[i];
     } else {
         const uint32_t t = threadIdx.x - 256u;
-        for (uint32_t i = t; i < 256u; i += 64u * NV) lmask[i] = mask_g[i];
+        for (uint32_t i = t; i < 256u; i += 64u * (NS + NV - 4)) lmask[i] = mask_g[i];
         if (t < AGH_FU_CHUNKS) ring_ready[t] = ring_freed[t] = 0u;
         if (t == 0) tickets = done = next_chunk = 0u;
     }
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     AGH_FU_STAMP(0);
 
-    if (wib < 4) {
+    if (wib < (uint32_t)NS) {
         // ---------------------------------------------------------------- a sweeping wave
         // (the verifier takes the address of q, which sends the kernel-argument copy to scratch: the
         // sweepers probe with a register copy of the two fields they read)
@@ -186,8 +185,8 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
 
         // the first range is the wave's own number (4096 waves asking one counter at the same
         // moment would wait ~45 us for the last answer); the counter hands out the rest
-        const uint32_t first_dynamic = gridDim.x * 4u;
-        uint32_t r = blockIdx.x * 4u + wib;
+        const uint32_t first_dynamic = gridDim.x * (uint32_t)NS;
+        uint32_t r = blockIdx.x * (uint32_t)NS + wib;
         uint32_t n_done = 0;
         while (r < n_ranges) {
             ++n_done;
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(256 + 64 * NV) void k_sweep_fused(
         bool more = true;
         for (uint32_t spins = 0;; ++spins) {
             if (lds_peek(&ring_ready[slot]) == v + 1u) break;
-            if (lds_peek(&done) == 4u && lds_peek(&tickets) <= v) { more = false; break; }
+            if (lds_peek(&done) == (uint32_t)NS && lds_peek(&tickets) <= v) { more = false; break; }
             if (spins > AGH_FU_SPIN_LIMIT) {        // never seen; a stuck protocol must not hang the GPU
                 mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
                 more = false;
@@ -287,6 +286,7 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
 {
     constexpr int K = AGH_FU_K;
     constexpr int NV = AGH_FU_NV;
+    constexpr int NS = H == 2 ? 6 : 8;          // sweeping waves per workgroup (below)
     const uint64_t n_full = a.n >> AGH_STRIP_SHIFT;
     // KiB per ticket (a multiple of 8: the ticket for the next range is requested half-way); the
     // diagnostics overrides are clamped -- a zero grid or a wrapped range size must not reach the launch
@@ -322,24 +322,26 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     if (!tail_total) tail_strips = range_strips;
     const uint32_t n_ranges = (uint32_t)(n_big64 + n_small);
     if (!n_ranges) return;
-    // persistent workgroups: THREE per CU, fewer when the text has fewer ranges.  Four fit by the
-    // arithmetic (4 x 38 KiB of 160 KiB) but not on the chip: with four launched, the fourth of every CU
-    // starts when another one leaves -- at the end of the scan -- and sweeps its statically assigned first
-    // ranges alone.  profiles/r03_ab_headline_workgroups.log, 4 -> 3 per CU: 8 GiB k = 2 / k = 0 1.407 ->
-    // 1.371 / 1.359 -> 1.339 ms, 64 GiB unchanged (10.27 / 10.10 ms); five per CU as four.
-    // ... and two where a 16-byte chunk takes four probes or fewer (H >= 4: k = 0, k = 1, config C3): eight
-    // streaming waves per CU keep the HBM busy there and disturb each other less -- 64 GiB k = 0 10.07 ->
-    // 9.97 ms, 8 GiB 1.334 -> 1.309; k = 1 10.31 -> 10.20 ms, 8 GiB 1.361 -> 1.342 (profiles/
-    // r03_ab_headline_final.log, r03_ab_k1_workgroups.log); with the eight probes of H = 2 two are far too
-    // few (10.17 -> 11.14 ms).
-    uint32_t blocks = a.n_cu * (H >= 4 ? 2u : 3u);
-    const uint32_t need = (n_ranges + 3u) / 4u;
+    // Shape of the persistent grid.  Sweeping waves per CU decide: H = 2 (eight probes per 16-byte chunk)
+    // needs twelve -- eight leave the VALU short (10.2 -> 11.1-11.4 ms per 64 GiB) --, the lighter shapes
+    // (H >= 4: k = 0, k = 1, config C3) want SIX TO EIGHT: more streams only disturb each other at the HBM
+    // (k = 0: 8 sweeping waves 9.96 ms, 12 10.08-10.13, 16 10.11-10.15, 24 10.16-10.31).  And for the same
+    // number of sweeping waves fewer, larger workgroups are better: 2 x 6 sweepers against 3 x 4 at k = 2
+    // 10.14 vs 10.46 ms per 64 GiB and 1.360 vs 1.415 per 8 GiB in the same call, 1 x 8 against 2 x 4 at
+    // k = 0 9.96 vs 10.14 and 1.310 vs 1.335 (profiles/r03_ab_sweepers_per_workgroup.log; fewer copies of
+    // the filter table, fewer verifying waves polling).  History: round 2 launched four workgroups of 4 + 2
+    // waves per CU, of which three were resident (4 x 38 KiB of LDS do not fit next to what the CU keeps for
+    // itself) -- the fourth started when another one left and swept its statically assigned first ranges
+    // alone at the end (r03_ab_headline_workgroups.log: 4 -> 3 per CU 1.407 -> 1.371 ms per 8 GiB).
+    constexpr uint32_t WG_PER_CU = H == 2 ? 2u : 1u;
+    uint32_t blocks = a.n_cu * WG_PER_CU;
+    const uint32_t need = (n_ranges + (uint32_t)NS - 1u) / (uint32_t)NS;
     if (blocks > need) blocks = need;
     if (const char *e = getenv("AGH_FUSED_BLOCKS")) {                        // (A/B runs)
         const unsigned long v = strtoul(e, nullptr, 10);
         blocks = (uint32_t)(v < 1ul ? 1ul : (v > (unsigned long)a.n_cu * 8ul ? (unsigned long)a.n_cu * 8ul : v));
     }
-    hipLaunchKernelGGL((k_sweep_fused<WT, H, MODE, K, NCH, NV>), dim3(blocks), dim3(256 + 64 * NV), 0,
+    hipLaunchKernelGGL((k_sweep_fused<WT, H, MODE, K, NCH, NV, NS>), dim3(blocks), dim3(64 * (NS + NV)), 0,
                        st, (const uint4 *)a.text, a.n, n_full, a.q, a.ftab, (const WT *)a.mask,
                        a.mk, a.gtab, tspan, n_ranges, a.ticket, range_strips, n_big, tail_strips);
 }

@@ -1,7 +1,8 @@
 """Final round-3 A/B of the headline count-only scan, ONE process on one corpus: every step from the
 round-2 kernel to the shipped default as an explicit row (the defaults changed during the round, so
 scripts/ab_round3.py's unlabelled 'fused' row is the final form), plus the number of persistent
-workgroups (AGH_FUSED_BLOCKS; default 3 per CU).
+workgroups (AGH_FUSED_BLOCKS; shipped: 2 per CU of 6 sweeping + 2 verifying waves for H = 2 samples,
+1 per CU of 8 + 2 waves else).
 usage: scripts/ab_final_r3.py [total GiB, default 64] [steps, default 10]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,9 +46,9 @@ def run(label, k, n, env):
 OLD = {"AGH_SHAPE_H2": "0", "AGH_FUSED_TAIL_MB": "0"}
 if len(sys.argv) > 3 and sys.argv[3] == "k1":       # k = 1 (4-byte samples every 4 bytes): workgroups per CU only
     for sz in [s for s in (64, 8) if s <= gib]:
-        for label, env in (("shipped default", {}), ("2 workgroups per CU", {"AGH_FUSED_BLOCKS": str(2 * n_cu)}),
-                           ("3 workgroups per CU", {"AGH_FUSED_BLOCKS": str(3 * n_cu)}),
-                           ("4 workgroups per CU", {"AGH_FUSED_BLOCKS": str(4 * n_cu)}), ("two kernels", {"AGH_FUSED": "0"}),
+        for label, env in (("shipped default", {}), ("1 workgroup per CU", {"AGH_FUSED_BLOCKS": str(1 * n_cu)}),
+                           ("2 workgroups per CU", {"AGH_FUSED_BLOCKS": str(2 * n_cu)}),
+                           ("3 workgroups per CU", {"AGH_FUSED_BLOCKS": str(3 * n_cu)}), ("two kernels", {"AGH_FUSED": "0"}),
                            ("shipped default again", {})):
             run(label, 1, sz << 30, env)
     sys.exit(0)
@@ -60,11 +61,12 @@ for sz in [s for s in (64, 8, 4, 2, 1) if s <= gib]:
                 ("fused + H=2 samples = shipped default", {}),
                 ("two kernels, shipped shape", {"AGH_FUSED": "0"}),
                 ("shipped, without the small tickets", {"AGH_FUSED_TAIL_MB": "0"}),
-                ("shipped, 4 workgroups per CU (was default)", {"AGH_FUSED_BLOCKS": str(4 * n_cu)}),
+                ("shipped, 1 workgroup per CU", {"AGH_FUSED_BLOCKS": str(1 * n_cu)}),
                 ("shipped, 2 workgroups per CU", {"AGH_FUSED_BLOCKS": str(2 * n_cu)}),
+                ("shipped, 3 workgroups per CU", {"AGH_FUSED_BLOCKS": str(3 * n_cu)}),
                 ("shipped default again", {})]
         if sz < 8:          # where does the fused kernel start to pay?  (AGH_FUSED_MIN_MB)
-            rows = [rows[4], rows[3], rows[6]]
+            rows = [rows[4], rows[3]]
         want = None
         for label, env in rows:
             got = run(label, k, n, env)
