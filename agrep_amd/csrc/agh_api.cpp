@@ -150,6 +150,10 @@ struct agh_query {
     int npat = 0;
     void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_pool = nullptr,
          *d_mp_omask = nullptr;
+    // one-pass count-only -f scan (agh_mscan.hip): pair table, exact gram table, entry directory
+    bool ms_ok = false;
+    uint32_t ms_rb = 0, ms_dbg = 0;
+    void *d_ms_ptab = nullptr, *d_ms_gtab = nullptr, *d_ms_mdir = nullptr, *d_ms_ment = nullptr;
 };
 
 // delimiter ends come from the delimiter bitmap: several bytes, or one letter under -i
@@ -790,6 +794,92 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
         up(&q->d_mp_pool, pool.data(), pool.size()) ||
         up(&q->d_mp_omask, omask.data(), omask.size() * 4))
         return -1;
+
+    // ---- tables of the one-pass count-only scan (agh_mscan.hip) ---------------------------------
+    // Sets it takes: 4-byte grams, a one-byte delimiter, no -w / -x, and entries it can check out of two
+    // 16-byte text loads -- k = 0: patterns of 4..15 bytes; k = 1: patterns of 8..14 bytes (two pieces of
+    // 4..7 bytes; the side next to a verbatim piece has <= 7 bytes: side_within_one_edit).  Everything
+    // else (and numbered scans of these sets) stays on k_sweep_multi + k_verify_multi.
+    q->ms_ok = false;
+    // ... and those probed at every or every second position: with entries of >= 7 bytes the strided sweep
+    // (4 probes per 16 bytes) is the faster one (profiles/r04_perf_c5_b.log: 0.91 vs 1.00 ms per 4 GiB).
+    bool ms = fq == 4 && q->dlen == 1 && !q->delim_fold && !q->guard && D <= 1 && q->multi && stride <= 2;
+    {
+        const char *e = getenv("AGH_MSCAN");
+        if (e && e[0] == '0') ms = false;
+    }
+    for (int p = 0; p < npat && ms && D == 1; ++p) ms = lens[p] >= 8 && lens[p] <= 14;
+    for (int i = 0; i < npc && ms && D == 0; ++i) ms = !usable[i] || pcs[i].len <= 15;
+    if (ms) {
+        struct ms_entry { uint32_t key; uint32_t w[4]; };
+        std::vector<ms_entry> es;
+        auto pb = [&](int i, int t) -> uint32_t { return t < pcs[i].len ? pool[off[i] + t] : 0u; };
+        for (int i = 0; i < npc; ++i) {
+            if (!usable[i]) continue;
+            ms_entry e;
+            e.w[0] = pb(i, 0) | pb(i, 1) << 8 | pb(i, 2) << 16 | pb(i, 3) << 24;
+            e.key = e.w[0] | fold;
+            if (D == 0) {
+                e.w[1] = pb(i, 4) | pb(i, 5) << 8 | pb(i, 6) << 16 | pb(i, 7) << 24;
+                e.w[2] = pb(i, 8) | pb(i, 9) << 8 | pb(i, 10) << 16 | pb(i, 11) << 24;
+                e.w[3] = pb(i, 12) | pb(i, 13) << 8 | pb(i, 14) << 16 | (uint32_t)pcs[i].len << 24;
+            } else {
+                // the other side of the pattern, nearest byte first, in the case the pool has
+                const int m = lens[pcs[i].owner], po = pcs[i].po, len = pcs[i].len;
+                const bool before = po > 0;
+                const int L = before ? po : m - len;
+                uint8_t B[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int t = 0; t < L; ++t) {
+                    unsigned char c = before ? pats[pcs[i].owner][po - 1 - t] : pats[pcs[i].owner][len + t];
+                    if (nocase && is_upper(c)) c += 32;
+                    B[t] = c;
+                }
+                const uint32_t meta = (uint32_t)L | (uint32_t)(len - 4) << 3 | (before ? 32u : 0u);
+                e.w[1] = B[0] | B[1] << 8 | B[2] << 16 | (uint32_t)B[3] << 24;
+                e.w[2] = B[4] | B[5] << 8 | B[6] << 16 | meta << 24;
+                e.w[3] = pb(i, 4) | pb(i, 5) << 8 | pb(i, 6) << 16;
+            }
+            if (e.key == 0) ms = false;
+            es.push_back(e);
+        }
+        std::stable_sort(es.begin(), es.end(), [](const ms_entry &a, const ms_entry &b) { return a.key < b.key; });
+        uint32_t rb = 13;
+        {
+            const char *e = getenv("AGH_MSCAN_RB");
+            if (e && e[0] == '1' && e[1] == '2') rb = 12;
+        }
+        std::vector<uint32_t> ptab((size_t)2 << rb, 0), gtab(AGH_MS_GSLOTS, 0), mdir(AGH_MS_GSLOTS, 0);
+        std::vector<uint32_t> ment(es.size() * 4 + 4, 0);
+        size_t n_grams = 0;
+        for (size_t a = 0; a < es.size() && ms;) {
+            size_t b = a;
+            while (b < es.size() && es[b].key == es[a].key) ++b;
+            const uint32_t g = es[a].key;
+            if (b - a > 255 || ++n_grams > AGH_MS_GSLOTS * 6 / 10) { ms = false; break; }
+            const uint32_t k0 = g & 0xffu, k3 = g >> 24;
+            ptab[2 * agh_ms_row(g >> 8, rb)] |= 1u << (k0 & 31u);            // pre of (k1 k2 k3)
+            ptab[2 * agh_ms_row(g & 0xffffffu, rb) + 1] |= 1u << (k3 & 31u);     // suf of (k0 k1 k2)
+            const uint32_t gh = agh_ms_ghash(g), b1 = AGH_MS_GB1(gh), b2 = AGH_MS_GB2(gh);
+            auto load_of = [&](uint32_t bk) { int c = 0; while (c < 4 && gtab[4 * bk + c]) ++c; return c; };
+            const int l1 = load_of(b1), l2 = load_of(b2);
+            if (l1 >= 4 && l2 >= 4) { ms = false; break; }     // (both buckets full: the set stays on the two-kernel form)
+            const uint32_t sl = l1 <= l2 ? 4 * b1 + (uint32_t)l1 : 4 * b2 + (uint32_t)l2;
+            gtab[sl] = g;
+            mdir[sl] = (uint32_t)a << 8 | (uint32_t)(b - a);
+            a = b;
+        }
+        if (es.size() >= (1u << 24)) ms = false;
+        for (size_t i = 0; i < es.size(); ++i) memcpy(&ment[4 * i], es[i].w, 16);
+        if (ms) {
+            if (up(&q->d_ms_ptab, ptab.data(), ptab.size() * 4) || up(&q->d_ms_gtab, gtab.data(), gtab.size() * 4) ||
+                up(&q->d_ms_mdir, mdir.data(), mdir.size() * 4) || up(&q->d_ms_ment, ment.data(), ment.size() * 4))
+                return -1;
+            q->ms_ok = true;
+            q->ms_rb = rb;
+            const char *dbg = getenv("AGH_MSCAN_DBG");
+            q->ms_dbg = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u;
+        }
+    }
     return 0;
 }
 
@@ -902,6 +992,10 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_mp_items) (void)hipFree(q->d_mp_items);
     if (q->d_mp_pool) (void)hipFree(q->d_mp_pool);
     if (q->d_mp_omask) (void)hipFree(q->d_mp_omask);
+    if (q->d_ms_ptab) (void)hipFree(q->d_ms_ptab);
+    if (q->d_ms_gtab) (void)hipFree(q->d_ms_gtab);
+    if (q->d_ms_mdir) (void)hipFree(q->d_ms_mdir);
+    if (q->d_ms_ment) (void)hipFree(q->d_ms_ment);
     if (q->d_counters) (void)hipFree(q->d_counters);
     if (q->d_chunk_totals) (void)hipFree(q->d_chunk_totals);
     if (q->h_counters) (void)hipHostFree(q->h_counters);
@@ -1845,6 +1939,120 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// count-only (-c, -l) scans of a pattern file whose set the one-pass kernel takes (agh_mscan.hip,
+// tables: fill_multi_tables): one launch per segment of up to 64 GiB, nothing read back until every
+// segment is queued.  A segment whose scan gave up (a record start more than AGH_LEAN_BACK_CAP bytes
+// in front of a match, hash set full) is run again on the numbered two-kernel pipeline.
+// ---------------------------------------------------------------------------------------
+static bool mscan_applies(const agh_query *q, unsigned flags, bool want_list)
+{
+    return q->multi && q->ms_ok && !want_list && (flags & (AGH_COUNT | AGH_FILENAMEONLY)) &&
+           !(flags & (AGH_INVERT | AGH_FORCE_FULLSCAN | AGH_FORCE_NUMBERED));
+}
+
+static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<uint64_t> &cuts,
+                     hipStream_t st, unsigned flags, agh_result *res, bool is_first, bool is_last)
+{
+    const int nseg = (int)cuts.size() - 1;
+    const bool timing = (flags & (AGH_TIME_SWEEP | AGH_TIME_SCAN)) != 0;
+    uint64_t max_n = 0;
+    for (int i = 0; i < nseg; ++i) max_n = std::max(max_n, cuts[i + 1] - cuts[i]);
+    uint64_t slots = 1u << 17;
+    if (!q->hashset_slots_hint) while (slots < (max_n >> 13) && slots < (1u << 26)) slots <<= 1;
+    while (slots < q->hashset_slots_hint) slots <<= 1;
+    {
+        const size_t cap_before = q->hashset.cap;
+        if (q->hashset.ensure(slots * sizeof(uint64_t))) return -1;
+        if (q->hashset.cap != cap_before || q->hashset_dirty)
+            HIP_TRY(hipMemsetAsync(q->hashset.p, 0, q->hashset.cap, st));
+        q->hashset_dirty = true;
+    }
+    if (q->tickets.ensure((size_t)nseg * 256u)) return -1;
+    HIP_TRY(hipMemsetAsync(q->tickets.p, 0, (size_t)nseg * 256u, st));
+    if (timing && get_events(q->time_events, 3 * (size_t)nseg, hipEventDefault)) return -1;
+
+    agh_dev_query dq;
+    memset(&dq, 0, sizeof(dq));
+    dq.m = q->m;
+    dq.k = q->k;
+    dq.delim = q->delim[0];
+    dq.dlen = 1;
+    dq.dbytes[0] = q->delim[0];
+    dq.mp_q5 = q->mp_q5 ? 1u : 0u;
+    dq.fq = q->fq;
+    dq.fh = q->mp_stride;
+    dq.qmask = q->qmask;
+    dq.fold = q->fold;
+    dq.ci = dq.cs = dq.cd = 1;
+    dq.no_err = q->no_err;
+    uint32_t *d_cnt = q->d_counters + AGH_C_COUNT;      // (block 0 belongs to scan_segment)
+    for (int i = 0; i < nseg; ++i) {
+        uint32_t *h_cnt = q->h_counters + (size_t)(1 + i) * AGH_C_COUNT;
+        dq.head_byte = (i == 0 && is_first) ? '\n' : q->delim[0];
+        dq.tail_virtual = (i == nseg - 1 && is_last) ? 1 : 0;
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+        agh_mscan_args a;
+        a.text = base + cuts[i];
+        a.n = cuts[i + 1] - cuts[i];
+        a.q = dq;
+        a.ms.ptab = (const uint2 *)q->d_ms_ptab;
+        a.ms.gtab = (const uint32_t *)q->d_ms_gtab;
+        a.ms.mdir = (const uint32_t *)q->d_ms_mdir;
+        a.ms.ment = (const uint4 *)q->d_ms_ment;
+        a.ms.rb = q->ms_rb;
+        a.mt = multi_dev(q, nullptr);
+        memset(&a.mk, 0, sizeof(a.mk));
+        a.mk.counters = d_cnt;
+        a.mk.hashset = (uint64_t *)q->hashset.p;
+        a.mk.hashset_mask = (uint32_t)(slots - 1);
+        a.ticket = (uint32_t *)((char *)q->tickets.p + (size_t)i * 256u);
+        a.n_cu = device_cus();
+        a.dbg = q->ms_dbg;
+        if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i], st));
+        if (!agh_launch_mscan(a, st)) return fail("internal error: no one-pass kernel for this pattern set");
+        if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i + 1], st));
+        agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8), nullptr, 0u, d_cnt, st);
+        HIP_TRY(hipGetLastError());
+        if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i + 2], st));
+        HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, AGH_C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    q->hashset_dirty = false;
+
+    res->engine = AGH_ENGINE_FILTER;
+    uint64_t max_matched = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const uint32_t *h = q->h_counters + (size_t)(1 + i) * AGH_C_COUNT;
+        if (timing) {
+            float ms = 0.f, all = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, q->time_events[3 * i], q->time_events[3 * i + 1]));
+            HIP_TRY(hipEventElapsedTime(&all, q->time_events[3 * i], q->time_events[3 * i + 2]));
+            res->sweep_ms += ms;               // the one kernel that reads every byte (+ its edge positions)
+            res->device_ms += all;
+            res->sweep_launches += 1;
+        }
+        if (!(h[AGH_C_LEAN_FALLBACK] || h[AGH_C_OVERFLOW])) {
+            res->n_matched += h[AGH_C_MATCHED];
+            res->n_candidates += h[AGH_C_CAND];
+            res->fused_segments += 1;
+            max_matched = std::max<uint64_t>(max_matched, h[AGH_C_MATCHED]);
+            continue;
+        }
+        max_matched = std::max<uint64_t>(max_matched, 2ull * (h[AGH_C_MATCHED] + 1024));
+        agh_result rr;
+        if (scan_device_impl(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED, &rr,
+                             nullptr, nullptr, 0, i == 0 && is_first, i == nseg - 1 && is_last))
+            return -1;
+        res->n_matched += rr.n_matched;
+        res->n_candidates += rr.n_candidates;
+        res->lean_reruns += 1;
+    }
+    res->n_segments = (uint32_t)nseg;
+    q->hashset_slots_hint = 4ull * max_matched;
+    return 0;
+}
+
 static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
                             unsigned flags, agh_result *res, uint64_t *d_match_pos,
                             uint32_t *d_match_rec, size_t match_cap, bool is_first, bool is_last)
@@ -1881,10 +2089,12 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
             return fail("a run of overlapping delimiter occurrences exceeds 4 KiB (unsupported)");
         global_dbm = (const uint64_t *)q->dbm.p;
     }
-    if (plan_segments(q, base, len, st, &cuts, lean, global_dbm)) return -1;
-    if (lean) {
+    const bool ms = mscan_applies(q, flags, d_match_pos != nullptr);
+    if (plan_segments(q, base, len, st, &cuts, lean || ms, global_dbm)) return -1;
+    if (lean || ms) {
         bool aligned = true;                    // (the segment STARTS: the last entry is the end of the text)
         for (size_t i = 0; i + 1 < cuts.size(); ++i) aligned = aligned && (cuts[i] & 15u) == 0;
+        if (aligned && ms) return mscan_run(q, base, cuts, st, flags, res, is_first, is_last);
         if (aligned) return lean_run(q, base, cuts, st, flags, res, is_first, is_last);
         // a cut that is not 16-byte aligned: segment by segment through aligned copies (below), in
         // the segment sizes of that path

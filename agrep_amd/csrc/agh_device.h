@@ -165,6 +165,34 @@ AGH_HD uint32_t agh_mp_bucket(uint32_t s)
     uint32_t x = s * 0x9E3779B1u;
     return (x ^ (x >> 15)) >> (32 - AGH_MP_BUCKET_BITS);
 }
+// ---- one-pass -f scan (agh_mscan.hip): pair table + exact gram table --------------------------
+// Two neighbouring text positions p, p+1 hold the 4-grams (a, xyz) and (xyz, d) around the SAME
+// 3-gram xyz = t[p+1..p+3], so ONE 8-byte row -- selected by a hash of xyz -- answers both:
+//   row.x bit (a & 31): some key gram is a followed by xyz   ("pre" role of xyz)
+//   row.y bit (d & 31): some key gram is xyz followed by d   ("suf" role of xyz)
+// Every key gram (k0 k1 k2 k3) is entered twice: pre of (k1 k2 k3) with a = k0, suf of (k0 k1 k2)
+// with d = k3.  Half the LDS reads of one probe per position, and ds_read_b64 spreads over 64 banks.
+// Row of a 3-gram held in the low 24 bits of y (the top byte is ignored by the 24-bit multiply):
+// the middle bits [31:19] of y * C; the device takes them as a byte address with
+// ((v_mul_u32_u24 y, C) >> 16) & ((rows - 1) << 3)  (one v_and_b32_sdwa src0_sel:WORD_1).
+#define AGH_MS_C 0xC2B2AEu
+#define AGH_MS_RB_MAX 13u                   // rows <= 2^13 (64 KiB)
+AGH_HD uint32_t agh_ms_row(uint32_t y, uint32_t rb)
+{
+    const uint32_t h = (uint32_t)((uint64_t)(y & 0xffffffu) * AGH_MS_C);
+    return (h >> 19) & ((1u << rb) - 1u);
+}
+// exact gram table: AGH_MS_GSLOTS 32-bit grams (0 = empty) in buckets of four, two-choice hashing: a
+// gram lives in one of the two buckets its hash names (the host puts it into the emptier one), a lookup
+// reads both
+#define AGH_MS_GSLOTS 4096u
+#define AGH_MS_GBUCKETS (AGH_MS_GSLOTS / 4u)
+AGH_HD uint32_t agh_ms_ghash(uint32_t g)
+{
+    return g * 0x9E3779B1u;
+}
+#define AGH_MS_GB1(h) ((h) >> 22)                    // 10 bits each
+#define AGH_MS_GB2(h) (((h) >> 12) & (AGH_MS_GBUCKETS - 1u))
 // q <= 3: the sample already fits 24 bits.
 AGH_HD uint32_t agh_sample_prod_q3(uint32_t s)
 {

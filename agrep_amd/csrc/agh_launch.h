@@ -135,3 +135,24 @@ void agh_launch_dense_multi(const agh_sweep_args &a, const agh_multi_dev &m, con
 void agh_launch_verify_multi(const agh_scan_args &a, const agh_multi_dev &m, bool lean,
                              hipStream_t st);
 void agh_launch_census_scan(const agh_sweep_args &a, bool with_cand, hipStream_t st);
+
+// one-pass count-only -f scan (agh_mscan.hip): every table it probes on the way lives in LDS
+struct agh_mscan_dev {
+    const uint2 *ptab;       // pair table, 1 << rb rows (agh_device.h)
+    const uint32_t *gtab;    // AGH_MS_GSLOTS key grams (0 = empty), buckets of 4
+    const uint32_t *mdir;    // per gram slot: (first entry << 8) | number of entries with that gram
+    const uint4 *ment;       // entries: a whole pattern (k = 0) or a piece + the other side of its pattern (k = 1)
+    uint32_t rb;             // log2 rows of ptab: 12 or 13
+};
+struct agh_mscan_args {
+    const void *text;
+    uint64_t n;
+    agh_dev_query q;
+    agh_mscan_dev ms;
+    agh_multi_dev mt;        // the general tables: candidates next to the ends of the text
+    agh_marks mk;            // hash set + counters
+    uint32_t *ticket;        // zeroed work counter in a cache line of its own
+    uint32_t n_cu;
+    uint32_t dbg;            // AGH_MSCAN_DBG: measurement switches of the kernel (0 in production)
+};
+bool agh_launch_mscan(const agh_mscan_args &a, hipStream_t st);

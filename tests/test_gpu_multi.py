@@ -296,3 +296,111 @@ def test_multi_pattern_nocase_letter_delimiter(agh):
         res, ms = q.scan_buffer(t, cap=100000)
         res_c, _ = q.scan_buffer(t, flags=agh.COUNT)
     assert [(s, e) for s, e, _ in ms] == want and res.n_matched == res_c.n_matched == len(want)
+
+
+# ---- the one-pass count-only scan (agh_mscan.hip): sets it takes, every boundary it has ----------
+def _one_pass_count(agh, pats, k, text, nocase=False, expect=True):
+    """COUNT scan (the one-pass kernel where the set qualifies) == numbered two-kernel pipeline."""
+    with agh.Query.multi(pats, nocase=nocase, k=k) as q:
+        c, _ = q.scan_buffer(text, flags=agh.COUNT)
+        n, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
+    assert c.n_matched == n.n_matched, (len(text), k, nocase)
+    if len(text):
+        assert (c.fused_segments == 1) == expect, "one-pass kernel %s" % ("did not run" if expect else "ran")
+        assert c.lean_reruns == 0
+    return c.n_matched
+
+
+@pytest.mark.parametrize("rb", ["13", "12"])
+def test_one_pass_scan_takes_the_sets_it_should(agh, rb, monkeypatch):
+    monkeypatch.setenv("AGH_MSCAN_RB", rb)
+    rng = random.Random(41 + int(rb))
+    base, _ = O.corpus(160, seed=7, variants=(), plant_period=0)            # 640 KiB: three wave ranges
+    p812 = _rand_patterns(rng, 300, 8, 12)
+    planted = [_mutate(rng.choice(p812), rng.randint(0, 2), rng) for _ in range(200)]
+    text = _plant(base.tobytes(), planted, rng, every=4)
+    want1 = len(_approx_want(p812, 1, text))
+    assert _one_pass_count(agh, p812, 1, text) == want1 > 100
+    # (exact entries of >= 7 bytes are probed at every 4th position by the two-kernel form: faster there)
+    assert _one_pass_count(agh, p812, 0, text, expect=False) == O.multi_exact_count(p812, text)[0] > 10
+    p512 = _rand_patterns(rng, 300, 5, 12)
+    text5 = _plant(base.tobytes(), p512, rng, every=5)
+    assert _one_pass_count(agh, p512, 0, text5) == O.multi_exact_count(p512, text5)[0] > 100
+    p414 = _rand_patterns(rng, 200, 4, 15)
+    text0 = _plant(base.tobytes(), p414, rng, every=5)
+    assert _one_pass_count(agh, p414, 0, text0) == O.multi_exact_count(p414, text0)[0] > 100
+    # -i: mixed-case text, patterns with capitals
+    up = [bytes(c - 32 if rng.random() < 0.3 else c for c in p) for p in p812[:100]]
+    mixed = bytes(c - 32 if (97 <= c <= 122 and rng.random() < 0.3) else c for c in text)
+    assert _one_pass_count(agh, up, 1, mixed, nocase=True) == len(_approx_want(up, 1, mixed, nocase=True)) > 50
+    # sets it leaves to the two-kernel form: k = 2, patterns above 14 bytes with an error, above 15 without,
+    # entries below 4 bytes
+    _one_pass_count(agh, _rand_patterns(rng, 40, 9, 12), 2, text, expect=False)
+    _one_pass_count(agh, _rand_patterns(rng, 40, 10, 16), 1, text, expect=False)
+    _one_pass_count(agh, _rand_patterns(rng, 40, 6, 20), 0, text, expect=False)
+    _one_pass_count(agh, _rand_patterns(rng, 40, 3, 9), 0, text, expect=False)
+    monkeypatch.setenv("AGH_MSCAN", "0")
+    _one_pass_count(agh, p812, 1, text, expect=False)
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_one_pass_scan_boundaries(agh, k):
+    """Occurrences at every offset around the kernel's seams: position 0 (queued by hand), the first 8 and
+    last 24 bytes (k_mscan_edges), chunk / strip / supertile / range starts (position 16 of one lane is
+    position 0 of the next), a partial last strip, texts below one strip, hits in every chunk."""
+    rng = random.Random(k)
+    # (k = 0: a 5-byte entry keeps the set on the one-pass kernel -- entries of >= 7 bytes go to the strided sweep)
+    pats = [b"needlework", b"haystacks", b"abcdefgh", b"zyxwvutsrqpo"] + ([b"vwxyz"] if k == 0 else [])
+    near = {0: [b"needlework", b"haystacks", b"abcdefgh"], 1: [b"needlewrk", b"haYstacks", b"abcdxefgh", b"bcdefgh"]}[k]
+    for t in (b"", b"n", b"needlework", b"needlework\n", b"\nneedlework", b"xneedlework", b"abcdefgh" * 3,
+              b"x" * 7 + b"abcdefgh" + b"y" * 23, b"x" * 8 + b"abcdefgh" + b"y" * 24, b"abcdefg", b"haystack"):
+        _one_pass_count(agh, pats, k, t)
+    for boundary in (16, 1024, 4096, 8192, 262144, 262144 + 4096):
+        for tail in (0, 5, 16, 700):
+            t = bytearray(b"q" * (boundary + 60 + tail))
+            for i in range(41, len(t), 97):
+                t[i] = 10
+            for j, shift in enumerate(range(-14, 6)):
+                at = boundary + shift
+                w = near[j % len(near)]
+                if at < 0 or at + len(w) > len(t):
+                    continue
+                s = bytearray(t)
+                s[at:at + len(w)] = w
+                for p in range(max(0, at - 2), min(len(s), at + len(w) + 2)):
+                    if s[p] == 10:
+                        s[p] = ord("q")
+                got = _one_pass_count(agh, pats, k, bytes(s))
+                assert got == 1, (boundary, tail, shift, w)
+    # an occurrence in every 16-byte chunk of a range: queue A full for every supertile, queue B drained
+    # in the middle of level 2
+    dense = (b"abcdefgh" + b"\n" + b"r" * 7) * 40000
+    assert _one_pass_count(agh, pats, k, dense) == 40000
+    dense2 = (b"xabcdefgh" + b"rr\n") * 50000 + b"abcdefg"
+    assert _one_pass_count(agh, pats, k, dense2) == 50000 + k      # ("abcdefg" at the end: one deletion)
+    # long records: a match whose record started in another supertile / range (look-back through the text)
+    longrec = b"w" * 300000 + b"abcdefgh" + b"w" * 10 + b"\n" + b"v" * 5000 + b"haystacks\n"
+    assert _one_pass_count(agh, pats, k, longrec) == 2
+
+
+def test_one_pass_scan_fuzz(agh):
+    """Random sets, texts over small alphabets (everything is a near miss, shared prefixes, several entries
+    per gram), random lengths: one-pass count == numbered count, spot-checked against the oracle."""
+    rng = random.Random(2024)
+    for it in range(40):
+        k = rng.randint(0, 1)
+        alpha = rng.choice([b"ab", b"abc", b"abcdefghijklmnopqrstuvwxyz", b"aA", b"abcd "])
+        lo, hi = (8, 14) if k else (4, 15)
+        nocase = rng.random() < 0.3
+        pats = _rand_patterns(rng, rng.choice([1, 3, 30, 200]), lo, rng.randint(lo, hi), alphabet=alpha.replace(b" ", b"e"))
+        n = rng.choice([0, 1, 9, 100, 1023, 1024, 1025, 4097, 70000, 263000, 600000])
+        talpha = alpha + b"\n" if rng.random() < 0.7 else alpha + b"\n\n\n\n"
+        text = bytes(rng.choice(talpha) for _ in range(n))
+        with agh.Query.multi(pats, nocase=nocase, k=k) as q:
+            ok = q.scan_buffer(b"x" * 64, flags=agh.COUNT)[0].fused_segments == 1
+        if not ok:
+            continue                            # (sets of > 255 entries per gram and the like)
+        got = _one_pass_count(agh, pats, k, text, nocase=nocase)
+        if n <= 70000 and len(pats) <= 30:
+            want = len(_approx_want(pats, k, text, nocase)) if k else O.multi_exact_count(pats, text, nocase=nocase)[0]
+            assert got == want, (it, k, alpha, n)
