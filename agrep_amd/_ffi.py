@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("AGH_LIB_PATH") or os.path.join(_HERE, "libagrep_hip.s
 COUNT = 0x01
 FILENAMEONLY = 0x02
 INVERT = 0x04
+NO_BYTES = 0x200
 TIME_SWEEP = 0x80
 TIME_SCAN = 0x100
 FORCE_FULLSCAN = 0x10
@@ -35,6 +36,9 @@ class Result(C.Structure):
                 ("n_segments", C.c_uint32), ("fused_segments", C.c_uint32),
                 ("copied_segments", C.c_uint32), ("reserved", C.c_uint32)]
 
+
+# agh_emit_fn: int (*)(void *ctx, const agh_match *m, size_t n, const unsigned char *bytes, size_t n_bytes)
+EMIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Match), C.c_size_t, C.POINTER(C.c_ubyte), C.c_size_t)
 
 _LIB = None
 
@@ -87,6 +91,12 @@ def lib():
     L.agh_scan_fd.argtypes = [vp, C.c_int, C.c_uint, C.POINTER(Result), C.POINTER(Match),
                               C.c_size_t]
     L.agh_scan_fd.restype = C.c_int
+    L.agh_scan_fd_emit.argtypes = [vp, C.c_int, C.c_uint, C.POINTER(Result), EMIT_FN, vp]
+    L.agh_scan_fd_emit.restype = C.c_int
+    L.agh_scan_fd_range_emit.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint, C.POINTER(Result), EMIT_FN, vp]
+    L.agh_scan_fd_range_emit.restype = C.c_int
+    L.agh_scan_device_emit.argtypes = [vp, vp, C.c_size_t, C.c_uint, C.POINTER(Result), EMIT_FN, vp]
+    L.agh_scan_device_emit.restype = C.c_int
     L.agh_rescan_staged.argtypes = [vp, C.c_uint, C.POINTER(Result), C.POINTER(Match), C.c_size_t]
     L.agh_rescan_staged.restype = C.c_int
     L.agh_fetch_records.argtypes = [vp, C.POINTER(Match), C.c_size_t, vp, C.c_size_t,
@@ -232,6 +242,47 @@ class Query:
         _check(lib().agh_scan_fd_range(self._h, fd, begin, end, flags, C.byref(res),
                                        ms if cap else None, cap))
         return res, [(ms[i].start, ms[i].end, ms[i].index) for i in range(int(res.n_stored))]
+
+    def _emit_collector(self, on_batch, stop_after, summarize=False):
+        """-> (callback object, list of batches); a batch = ([(start, end, index)], [record bytes] or None),
+        or with summarize (timing runs: no Python object per record) (records, bytes, first start, last end)"""
+        batches = []
+
+        def cb(ctx, m, n, bytes_, n_bytes):
+            if summarize:
+                batches.append((n, n_bytes, m[0].start if n else 0, m[n - 1].end if n else 0))
+                return 0
+            ms = [(m[i].start, m[i].end, m[i].index) for i in range(n)]
+            recs = None
+            if bytes_:
+                raw = C.string_at(bytes_, n_bytes)
+                recs, o = [], 0
+                for s_, e_, _ in ms:
+                    recs.append(raw[o:o + (e_ - s_)])
+                    o += e_ - s_
+            batches.append((ms, recs))
+            if on_batch:
+                on_batch(ms, recs)
+            return 1 if (stop_after is not None and len(batches) >= stop_after) else 0
+        return EMIT_FN(cb), batches
+
+    def scan_fd_emit(self, fd, flags=0, on_batch=None, stop_after=None, byte_range=None, summarize=False):
+        """agh_scan_fd_emit / agh_scan_fd_range_emit -> (Result, batches): record output while the input
+        streams through bounded device segments; one batch per segment, in file order."""
+        cb, batches = self._emit_collector(on_batch, stop_after, summarize)
+        res = Result()
+        if byte_range is None:
+            _check(lib().agh_scan_fd_emit(self._h, fd, flags, C.byref(res), cb, None))
+        else:
+            _check(lib().agh_scan_fd_range_emit(self._h, fd, byte_range[0], byte_range[1], flags, C.byref(res), cb, None))
+        return res, batches
+
+    def scan_device_emit(self, dev_ptr, n, flags=0, on_batch=None, summarize=False):
+        """agh_scan_device_emit: matched records (offsets, numbers, bytes) of text resident in HBM"""
+        cb, batches = self._emit_collector(on_batch, None, summarize)
+        res = Result()
+        _check(lib().agh_scan_device_emit(self._h, dev_ptr, n, flags, C.byref(res), cb, None))
+        return res, batches
 
     def fetch_records(self, matches):
         """matches: [(start, end, index)] from the last scan_fd / scan_buffer -> list of bytes"""

@@ -1,29 +1,15 @@
-// agh_api.cpp -- the C-ABI of libagrep_hip.so (include/agrep_hip.h): query compilation,
-// workspace management, staging and kernel orchestration.  No CPU scan path exists here:
-// if HIP is unusable every entry point fails with -1 / errno = 123.
-#include <errno.h>
-#include <hip/hip_runtime.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <sys/stat.h>
-#include <unistd.h>
-
-#include <algorithm>
-#include <thread>
-#include <vector>
-
-#include "../../include/agrep_hip.h"
-#include "agh_device.h"
-#include "agh_launch.h"
+// agh_api.cpp -- the C-ABI of libagrep_hip.so (include/agrep_hip.h): query compilation, workspace
+// management and kernel orchestration for text resident in HBM (staging, files and record output:
+// agh_stage.cpp).  No CPU scan path exists here: if HIP is unusable every entry point fails with
+// -1 / errno = 123.
+#include "agh_internal.h"
 
 // ---------------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(const char *fmt, ...)
+int agh_fail(const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -32,14 +18,6 @@ static int fail(const char *fmt, ...)
     errno = AGH_ERRNO;
     return -1;
 }
-
-#define HIP_TRY(expr)                                                                     \
-    do {                                                                                  \
-        hipError_t e__ = (expr);                                                          \
-        if (e__ != hipSuccess)                                                            \
-            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
-                        __LINE__);                                                        \
-    } while (0)
 
 extern "C" const char *agh_last_error(void) { return g_err; }
 // (internal: agh_comm.cpp reports through the same text; not part of the ABI, hence hidden)
@@ -62,102 +40,6 @@ extern "C" int agh_set_device(int ordinal)
     return 0;
 }
 
-// ---------------------------------------------------------------------------------------
-// query
-// ---------------------------------------------------------------------------------------
-struct dev_buf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes)
-    {
-        if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 8 + 4096;
-        HIP_TRY(hipMalloc(&p, want));
-        cap = want;
-        return 0;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-#define AGH_LEAN_SLOTS 2      // segments of the lean pipeline in flight (sweep i+1 | verify i)
-#define AGH_MAX_SEGS 256      // segments of one scan (8 GiB each: 2 TiB)
-
-struct agh_query {
-    int m = 0, k = 0, dlen = 1, wide = 0;
-    bool delim_fold = false;            // -i with letters in a multi-byte delimiter
-    unsigned char delim[AGH_MAX_DELIM] = {'\n'};
-    uint64_t mask[256];                 // bit (p-1) set iff byte is in the class of position p
-    int fq = 0, fh = 0;                 // filter sample shape (0: no filter)
-    int run_a = 0, run_len = 0;         // the literal run of positions the samples are taken from
-    uint32_t qmask = 0, fold = 0;
-    // device-resident tables
-    void *d_mask = nullptr;             // 256 x uint32_t or uint64_t
-    uint8_t *d_ftab = nullptr;          // AGH_FT_SIZE bytes
-    uint64_t *d_gtab = nullptr;         // AGH_FT_SIZE x (gram, first/last offset): tight verify windows
-    uint32_t gram_spread = 0;           // max (last - first offset) over the grams in d_gtab
-    // per-query workspace (grown lazily, reused across scans)
-    dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, hashset, dbm, staging, match_pos,
-        match_rec, match_start, match_end, match_off, gather;
-    uint64_t staged_len = 0;            // bytes of the text currently held in `staging`
-    bool staged_first = true, staged_last = true;   // ... is the head / the tail of its file (agh_scan_fd_range)
-    hipStream_t stage_stream = nullptr; // H2D copies of agh_scan_fd
-    unsigned char *pinned[2] = {nullptr, nullptr};
-    hipEvent_t pinned_ev[2] = {nullptr, nullptr};
-    uint32_t *d_counters = nullptr;     // AGH_LEAN_SLOTS + 1 counter blocks (block 0: everything but the pipeline)
-    uint32_t *d_chunk_totals = nullptr; // scratch of the prefix scan
-    uint32_t *h_counters = nullptr;     // pinned: block 0 + one block per pipelined segment
-    // lean pipeline (lean_run): a second stream for the verifier, a second set of candidate
-    // buffers, dependency / timing events, the device scratch of the segment cutter
-    hipStream_t aux_stream = nullptr;
-    dev_buf cand_b, wave_cand_b, cuts;
-    dev_buf seg_copy;                   // aligned copy of a segment whose cut is not 16-byte aligned
-    dev_buf seg_dbm;                    // ... and its own delimiter bitmap (q->dbm holds the whole text's)
-    bool seg_dbm_active = false;
-    dev_buf tickets;                    // fused lean kernel: one work counter (own 256-byte line) per segment
-    std::vector<hipEvent_t> dep_events, time_events;
-    uint64_t *h_cuts = nullptr;         // pinned: bounds, lower limits, cuts
-    uint64_t bitmap_bits_hint = 0;      // records seen by the previous scan (+25 %)
-    bool bitmap_dirty = false;          // a scan was queued but its count-and-clear did not finish
-    uint64_t hashset_slots_hint = 0;    // lean scans: slots wanted by the previous scan
-    bool hashset_dirty = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-    // multi-pattern (-f) queries
-    // general automaton (asearch1.c costs, <exact> segments): full scan only
-    bool general = false;
-    bool table = false;                 // table engine: mask[] holds the reference's Mask[]
-    agh_dev_tables tab;
-    int ci = 1, cs = 1, cd = 1;
-    uint64_t no_err = ~0ull;
-    bool multi = false;
-    // piece engine for a single literal pattern the sample filter cannot take (short pattern /
-    // many errors): the multi-pattern tables hold its k+1 pieces (or the pattern itself, k = 0)
-    bool piece_single = false;
-    int pe_fq = 0, pe_minlen = 0;
-    int guard = 0;                      // -f with -w (1) / -x (2): checked by the exact verifier
-    int mp_stride = 1;                  // multi-pattern sweep: probe every 1 / 2 / 4 bytes (fill_multi_tables)
-    bool mp_q5 = false;                 // ... with 5-byte grams (stride 4, entries of >= 8 bytes)
-    uint32_t pe_qmask = 0, pe_fold = 0;
-    bool multi_dense = false;           // hits are too dense for the candidate slices
-    bool fs_fast_off = false;           // full scan: the replay lists overflowed once (match-dense text): exact kernel from now on
-    int npat = 0;
-    void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_pool = nullptr,
-         *d_mp_omask = nullptr;
-    // one-pass count-only -f scan (agh_mscan.hip): pair table, exact gram table, entry directory
-    bool ms_ok = false;
-    uint32_t ms_rb = 0, ms_dbg = 0;
-    void *d_ms_ptab = nullptr, *d_ms_gtab = nullptr, *d_ms_mdir = nullptr, *d_ms_ment = nullptr;
-};
-
-// delimiter ends come from the delimiter bitmap: several bytes, or one letter under -i
-static bool q_mb(const agh_query *q) { return q->dlen > 1 || q->delim_fold; }
 
 static bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
 static bool is_lower(int c) { return c >= 'a' && c <= 'z'; }
@@ -1027,7 +909,8 @@ extern "C" void agh_query_free(agh_query *q)
     q->match_end.release();
     q->match_off.release();
     q->gather.release();
-    for (int b = 0; b < 2; ++b) {
+    q->staging_b.release();
+    for (int b = 0; b < AGH_PIN_RING; ++b) {
         if (q->pinned[b]) (void)hipHostFree(q->pinned[b]);
         if (q->pinned_ev[b]) (void)hipEventDestroy(q->pinned_ev[b]);
     }
@@ -1114,7 +997,7 @@ static const uint64_t AGH_LEAN_SEG_MAX = (uint64_t)64 << 30;     // lean scans: 
 // -4 % / -3 % at 2 GiB, +3.3 % / +2.5 % at 4 GiB, +4.9 % / +3.7 % at 8 GiB, +6 % / +4.8 % at 64 GiB.
 #define AGH_FUSED_MIN_MB_DEFAULT 4096
 
-static uint64_t env_mb(const char *name, uint64_t dflt_mb);
+
 static int get_events(std::vector<hipEvent_t> &pool, size_t want, unsigned evflags);
 
 struct seg_result {
@@ -1624,7 +1507,7 @@ static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, 
 //   * AGH_FILENAMEONLY (-l, asearch.c:130-161 returns at the first match): parts grow from
 //     64 MiB, the host looks at the hit flag after each and stops at the first part with a hit.
 // ---------------------------------------------------------------------------------------
-static uint64_t env_mb(const char *name, uint64_t dflt_mb)
+uint64_t agh_env_mb(const char *name, uint64_t dflt_mb)
 {
     const char *e = getenv(name);
     if (e && *e) return strtoull(e, nullptr, 10);
@@ -1666,9 +1549,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                         unsigned flags, uint32_t head_byte, int tail_virtual,
                         uint64_t *d_match_pos, uint32_t *d_match_rec, uint32_t match_cap,
                         seg_result *out, const uint64_t *pre_dbm = nullptr);
-static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
-                            unsigned flags, agh_result *res, uint64_t *d_match_pos,
-                            uint32_t *d_match_rec, size_t match_cap, bool is_first, bool is_last);
+
 
 static int get_events(std::vector<hipEvent_t> &pool, size_t want, unsigned evflags)
 {
@@ -1688,11 +1569,11 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     const bool timing = (flags & AGH_TIME_SWEEP) != 0;
     // part size: a multiple of 8 wave ranges (2 MiB) so verify workgroups never straddle parts
     const uint64_t part_unit = (uint64_t)AGH_WAVE_STRIPS * AGH_STRIP * 8u;
-    uint64_t part_bytes = env_mb("AGH_PART_MB", AGH_PART_MB_DEFAULT) << 20;
+    uint64_t part_bytes = agh_env_mb("AGH_PART_MB", AGH_PART_MB_DEFAULT) << 20;
     part_bytes = part_bytes / part_unit * part_unit;
     uint64_t max_n = 0;
     for (int i = 0; i < nseg; ++i) max_n = std::max(max_n, cuts[i + 1] - cuts[i]);
-    const bool overlap = env_mb("AGH_OVERLAP", AGH_OVERLAP_DEFAULT) != 0 && !early &&
+    const bool overlap = agh_env_mb("AGH_OVERLAP", AGH_OVERLAP_DEFAULT) != 0 && !early &&
                          (nseg > 1 || (part_bytes && part_bytes < max_n));
     const uint64_t max_strips = (max_n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint64_t max_nw = (max_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
@@ -1719,7 +1600,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     }
     // work counters of the fused kernel: a line of their own each -- on the counters' line the
     // sweepers' ticket atomics would queue behind the verifier's ANYHIT stores
-    const uint64_t fused_min = env_mb("AGH_FUSED_MIN_MB", AGH_FUSED_MIN_MB_DEFAULT) << 20;
+    const uint64_t fused_min = agh_env_mb("AGH_FUSED_MIN_MB", AGH_FUSED_MIN_MB_DEFAULT) << 20;
     const bool may_fuse = !early && !overlap && !part_bytes && fused_enabled() && max_n >= fused_min &&
                           tight_verify_enabled() && q->d_gtab;
     if (may_fuse) {
@@ -1926,7 +1807,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         max_matched = std::max<uint64_t>(max_matched, 2ull * (h[AGH_C_MATCHED] + 1024));
         q->hashset_slots_hint = 4ull * max_matched;
         agh_result rr;
-        if (scan_device_impl(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED, &rr,
+        if (agh_scan_device_impl(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED, &rr,
                              nullptr, nullptr, 0, i == 0 && is_first, i == nseg - 1 && is_last))
             return -1;
         if (jobs[i].done_early) res->n_bytes = cuts[i + 1];    // the rerun read the whole segment
@@ -2041,7 +1922,7 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
         }
         max_matched = std::max<uint64_t>(max_matched, 2ull * (h[AGH_C_MATCHED] + 1024));
         agh_result rr;
-        if (scan_device_impl(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED, &rr,
+        if (agh_scan_device_impl(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED, &rr,
                              nullptr, nullptr, 0, i == 0 && is_first, i == nseg - 1 && is_last))
             return -1;
         res->n_matched += rr.n_matched;
@@ -2053,9 +1934,9 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
     return 0;
 }
 
-static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
-                            unsigned flags, agh_result *res, uint64_t *d_match_pos,
-                            uint32_t *d_match_rec, size_t match_cap, bool is_first, bool is_last)
+int agh_scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
+                         unsigned flags, agh_result *res, uint64_t *d_match_pos,
+                         uint32_t *d_match_rec, size_t match_cap, bool is_first, bool is_last)
 {
     if (!q || !res) return fail("null argument");
     memset(res, 0, sizeof(*res));
@@ -2145,445 +2026,12 @@ static int scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hi
     return 0;
 }
 
-static int scan_device_range(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
-                             unsigned flags, agh_result *res, bool is_first, bool is_last)
-{
-    return scan_device_impl(q, dev_text, len, st, flags, res, nullptr, nullptr, 0, is_first, is_last);
-}
-
 extern "C" int agh_scan_device(agh_query *q, const void *dev_text, size_t len, void *stream,
                                unsigned flags, agh_result *res, void *dev_match_pos,
                                size_t match_cap)
 {
-    return scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res,
+    return agh_scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res,
                             (uint64_t *)dev_match_pos, nullptr, dev_match_pos ? match_cap : 0, true, true);
-}
-
-// Matches of the text staged in q->staging: bounds computed on the device, sorted into file
-// order on the host.
-static int collect_matches(agh_query *q, uint64_t len, const agh_result *res, agh_match *matches)
-{
-    const size_t ns = (size_t)res->n_stored;
-    if (!ns) return 0;
-    if (q->match_start.ensure(ns * sizeof(uint64_t))) return -1;
-    if (q->match_end.ensure(ns * sizeof(uint64_t))) return -1;
-    agh_dev_query dq;
-    memset(&dq, 0, sizeof(dq));
-    dq.delim = q->delim[q->dlen - 1];
-    dq.dlen = (uint32_t)q->dlen;
-    memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
-    dq.dfold = q->delim_fold ? 1u : 0u;
-    dq.mb = q_mb(q) ? 1u : 0u;
-    agh_launch_match_bounds(q->staging.p, len, dq, (const uint64_t *)q->dbm.p,
-                            (const uint64_t *)q->match_pos.p, (uint32_t)ns,
-                            (uint64_t *)q->match_start.p, (uint64_t *)q->match_end.p, nullptr);
-    HIP_TRY(hipGetLastError());
-    std::vector<uint64_t> st(ns), en(ns);
-    std::vector<uint32_t> rec(ns);
-    HIP_TRY(hipMemcpy(st.data(), q->match_start.p, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(en.data(), q->match_end.p, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(rec.data(), q->match_rec.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::vector<size_t> order(ns);
-    for (size_t i = 0; i < ns; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st[a] < st[b]; });
-    for (size_t i = 0; i < ns; ++i) {
-        matches[i].start = st[order[i]];
-        matches[i].end = en[order[i]];
-        matches[i].index = rec[order[i]];
-    }
-    return 0;
-}
-
-static int scan_staged(agh_query *q, uint64_t len, unsigned flags, agh_result *res,
-                       agh_match *matches, size_t cap, bool is_first = true, bool is_last = true)
-{
-    uint64_t *d_pos = nullptr;
-    uint32_t *d_rec = nullptr;
-    if (matches && cap) {
-        if (q->match_pos.ensure(cap * sizeof(uint64_t))) return -1;
-        if (q->match_rec.ensure(cap * sizeof(uint32_t))) return -1;
-        d_pos = (uint64_t *)q->match_pos.p;
-        d_rec = (uint32_t *)q->match_rec.p;
-    }
-    q->staged_len = len;
-    q->staged_first = is_first;                 // (agh_rescan_staged scans the same shard again)
-    q->staged_last = is_last;
-    if (scan_device_impl(q, q->staging.p, len, nullptr, flags, res, d_pos, d_rec, cap, is_first, is_last)) return -1;
-    return d_pos ? collect_matches(q, len, res, matches) : 0;
-}
-
-extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t len,
-                               unsigned flags, agh_result *res, agh_match *matches, size_t cap)
-{
-    if (!q || !res || (!text && len)) return fail("null argument");
-    if (q->staging.ensure(((len + 15) & ~(size_t)15) + 16)) return -1;
-    if (len) HIP_TRY(hipMemcpy(q->staging.p, text, len, hipMemcpyHostToDevice));
-    return scan_staged(q, len, flags, res, matches, cap);
-}
-
-// File mode: read() lands directly in pinned memory and is copied to HBM asynchronously while
-// the next chunk is being read (two chunks in flight) -- the staging role of fill_buf
-// (bitap.c:450-477), without an intermediate pageable copy.
-static const size_t AGH_STAGE_CHUNK = (size_t)32 << 20;
-
-// Sequential reader of an fd (or of the byte range [pos, pos + left) of a regular file): a
-// regular file is read by up to 16 pread threads per chunk (one read(2) stream copies ~10 GB/s
-// out of the page cache, PCIe takes five times that), a pipe by read(2).
-struct fd_reader {
-    int fd = -1;
-    bool regular = false;
-    off_t pos = 0;                  // regular files: next byte to read
-    uint64_t left = 0;              // regular files: bytes still to read
-    bool ranged = false;            // an explicit range: never read past it
-    unsigned n_readers = 1;
-
-    int open_fd(int fd_, bool with_range, uint64_t begin, uint64_t end)
-    {
-        fd = fd_;
-        ranged = with_range;
-        struct stat sb;
-        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
-            off_t cur = with_range ? (off_t)begin : lseek(fd, 0, SEEK_CUR);
-            if (cur < 0) cur = 0;
-            uint64_t stop = with_range ? std::min<uint64_t>(end, (uint64_t)sb.st_size) : (uint64_t)sb.st_size;
-            regular = true;
-            pos = cur;
-            left = (uint64_t)cur < stop ? stop - (uint64_t)cur : 0;
-        } else if (with_range) {
-            return fail("a byte range needs a seekable regular file");
-        }
-        n_readers = std::thread::hardware_concurrency();
-        if (n_readers > 16) n_readers = 16;
-        if (const char *e = getenv("AGH_READERS")) n_readers = (unsigned)atoi(e);
-        if (n_readers < 1) n_readers = 1;
-        return 0;
-    }
-    uint64_t size_hint() const { return regular ? left : 0; }
-
-    // up to `want` bytes into dst; 0 = end of input; -1 = error (message set)
-    ssize_t fill(unsigned char *dst, size_t want)
-    {
-        size_t got = 0;
-        if (regular && left >= want / 2 && n_readers > 1) {
-            const size_t take = (size_t)std::min<uint64_t>(want, left);
-            const size_t piece = ((take + n_readers - 1) / n_readers + 4095) & ~(size_t)4095;
-            std::vector<std::thread> th;
-            std::vector<ssize_t> done(n_readers, 0);
-            std::vector<int> rd_errno(n_readers, 0);
-            for (unsigned t = 0; t < n_readers; ++t) {
-                const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
-                if (lo >= hi) break;
-                th.emplace_back([&, t, lo, hi]() {
-                    size_t at = lo;
-                    while (at < hi) {
-                        ssize_t r = pread(fd, dst + at, hi - at, pos + (off_t)at);
-                        if (r < 0 && errno == EINTR) continue;
-                        if (r < 0) { rd_errno[t] = errno; break; }   // EIO, ESTALE ...: not a truncation
-                        if (r == 0) break;                           // the file got shorter meanwhile
-                        at += (size_t)r;
-                    }
-                    done[t] = (ssize_t)(at - lo);
-                });
-            }
-            for (auto &x : th) x.join();
-            for (unsigned t = 0; t < th.size(); ++t)
-                if (rd_errno[t]) return fail("read failed: %s", strerror(rd_errno[t]));
-            // contiguous prefix that really arrived (a file truncated meanwhile ends the scan)
-            for (unsigned t = 0; t < th.size(); ++t) {
-                const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
-                got += (size_t)done[t];
-                if ((size_t)done[t] < hi - lo) break;
-            }
-            pos += (off_t)got;
-            left -= std::min<uint64_t>(left, got);
-            if (got < take) left = 0;
-            if (!ranged) (void)lseek(fd, pos, SEEK_SET);
-            return (ssize_t)got;
-        }
-        if (regular) want = (size_t)std::min<uint64_t>(want, left);
-        while (got < want) {
-            ssize_t r = regular ? pread(fd, dst + got, want - got, pos + (off_t)got)
-                                : read(fd, dst + got, want - got);
-            if (r < 0) {
-                if (errno == EINTR) continue;
-                return fail("read failed: %s", strerror(errno));
-            }
-            if (r == 0) break;
-            got += (size_t)r;
-        }
-        if (regular) {
-            pos += (off_t)got;
-            left -= std::min<uint64_t>(left, got);
-            if (!ranged) (void)lseek(fd, pos, SEEK_SET);
-        }
-        return (ssize_t)got;
-    }
-};
-
-static int ensure_stage_resources(agh_query *q)
-{
-    if (q->stage_stream) return 0;
-    HIP_TRY(hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) {
-        HIP_TRY(hipHostMalloc((void **)&q->pinned[b], AGH_STAGE_CHUNK));
-        HIP_TRY(hipEventCreateWithFlags(&q->pinned_ev[b], hipEventDisableTiming));
-    }
-    return 0;
-}
-
-static int scan_device_range(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
-                             unsigned flags, agh_result *res, bool is_first, bool is_last);
-
-// Count-only scans (-c, -l) of a stream: the input passes through ONE device segment
-// (AGH_STREAM_SEG_MB, default 1 GiB) that is scanned whenever it is full, cut after the last
-// delimiter that has arrived; the unfinished record is carried to the front of the next
-// segment -- fill_buf's residue carry (bitap.c:450-477, sgrep.c:465-471) at HBM scale.  HBM use
-// is bounded whatever the input size, a pipe never needs a second copy, and -l stops READING at
-// the first segment with a match (asearch.c:130-161: print the name, return).  The scan of a
-// segment (~0.2 ms per GiB) is not overlapped with the staging (~20 ms per GiB over PCIe).
-static int stream_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *res, bool is_first,
-                       bool is_last)
-{
-    memset(res, 0, sizeof(*res));
-    const uint64_t seg_cap = std::max<uint64_t>(env_mb("AGH_STREAM_SEG_MB", 1024), 1) << 20;
-    const bool early = (flags & AGH_FILENAMEONLY) != 0;
-    // -l: small first segments (1 MiB, x4 each time) so that a hit near the top of a file is
-    // reported after the first megabyte has been read and scanned, whatever the engine costs
-    uint64_t target = early ? std::min<uint64_t>(seg_cap, (uint64_t)1 << 20) : seg_cap;
-    const uint64_t hint = rd.size_hint();
-    if (q->staging.ensure(std::min<uint64_t>(seg_cap, hint ? hint : seg_cap) + 2 * AGH_STAGE_CHUNK + 64))
-        return -1;
-    q->staged_len = 0;                          // what stays in HBM is not the whole input
-    uint64_t used = 0;                          // bytes of the current segment staged so far
-    // a shard with begin > 0 follows a delimiter (not the virtual '\n' in front of a file) and one
-    // that ends before EOF gets no delimiter appended: both only at the real ends of the file
-    bool first = is_first, eof = false;
-    int b = 0;
-    bool busy[2] = {false, false};
-    const unsigned char dl = q->delim[0];
-    while (!eof) {
-        if (busy[b]) HIP_TRY(hipEventSynchronize(q->pinned_ev[b]));
-        busy[b] = false;
-        // (-l reads no further ahead than its current segment target)
-        const size_t ask = early ? (size_t)std::min<uint64_t>(AGH_STAGE_CHUNK, std::max<uint64_t>(target > used ? target - used : 0, 65536))
-                                 : AGH_STAGE_CHUNK;
-        const ssize_t got = rd.fill(q->pinned[b], ask);
-        if (got < 0) return -1;
-        if (got == 0) eof = true;
-        if (got > 0) {
-            if (used + (uint64_t)got + 64 > q->staging.cap) {   // a record longer than the segment: grow
-                dev_buf bigger;
-                if (bigger.ensure((used + (uint64_t)got) * 2 + 64)) return -1;
-                HIP_TRY(hipStreamSynchronize(q->stage_stream));
-                if (used) HIP_TRY(hipMemcpy(bigger.p, q->staging.p, used, hipMemcpyDeviceToDevice));
-                q->staging.release();
-                q->staging = bigger;
-            }
-            HIP_TRY(hipMemcpyAsync((unsigned char *)q->staging.p + used, q->pinned[b], (size_t)got,
-                                   hipMemcpyHostToDevice, q->stage_stream));
-            HIP_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
-            busy[b] = true;
-            used += (uint64_t)got;
-        }
-        if (!eof && used < target) { b ^= 1; continue; }
-        // cut after the last delimiter of the chunk that has just arrived
-        uint64_t cut = used;
-        const unsigned char *tail_src = nullptr;
-        uint64_t tail_len = 0;
-        if (!eof) {
-            const unsigned char *hit = (const unsigned char *)memrchr(q->pinned[b], dl, (size_t)got);
-            if (!hit) { b ^= 1; continue; }     // no record ends here yet: the segment grows
-            const uint64_t idx = (uint64_t)(hit - q->pinned[b]) + 1;
-            cut = used - (uint64_t)got + idx;
-            tail_src = q->pinned[b] + idx;
-            tail_len = (uint64_t)got - idx;
-        }
-        HIP_TRY(hipStreamSynchronize(q->stage_stream));
-        if (cut) {
-            agh_result r;
-            if (scan_device_range(q, q->staging.p, cut, nullptr, flags, &r, first, eof && is_last)) return -1;
-            res->n_matched += r.n_matched;
-            res->n_records += r.n_records;
-            res->n_candidates += r.n_candidates;
-            res->n_bytes += r.n_bytes;
-            res->device_ms += r.device_ms;
-            res->sweep_ms += r.sweep_ms;
-            res->sweep_launches += r.sweep_launches;
-            res->lean_reruns += r.lean_reruns;
-            res->n_segments += r.n_segments;
-            res->engine = r.engine;
-            first = false;
-            if (early && res->n_matched) return 0;      // -l: the rest of the input is never read
-        }
-        if (tail_len)                            // the unfinished record opens the next segment
-            HIP_TRY(hipMemcpyAsync(q->staging.p, tail_src, (size_t)tail_len, hipMemcpyHostToDevice,
-                                   q->stage_stream));
-        if (tail_len) {
-            HIP_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
-            busy[b] = true;
-        }
-        used = tail_len;
-        if (early && target < seg_cap) target = std::min<uint64_t>(seg_cap, target * 4);
-        b ^= 1;
-    }
-    return 0;
-}
-
-static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, uint64_t end,
-                        unsigned flags, agh_result *res, agh_match *matches, size_t cap)
-{
-    if (!q || !res) return fail("null argument");
-    if (fd < 0) return fail("agh_scan_fd needs fd >= 0 (memory mode is agh_scan_buffer)");
-    if (with_range && end < begin) return fail("empty byte range");
-    if (ensure_stage_resources(q)) return -1;
-    fd_reader rd;
-    if (rd.open_fd(fd, with_range, begin, end)) return -1;
-    const bool count_only = (flags & (AGH_COUNT | AGH_FILENAMEONLY)) && !(matches && cap);
-    // one rank's shard of a file: the virtual head byte / the appended delimiter (asearch.c:69-91)
-    // belong to the shards that hold the file's first / last byte
-    bool is_first = true, is_last = true;
-    if (with_range) {
-        struct stat sb;
-        is_first = begin == 0;
-        is_last = !(fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && end < (uint64_t)sb.st_size);
-    }
-    if (count_only && !q_mb(q) && env_mb("AGH_STREAM", 1) != 0)
-        return stream_scan(q, rd, flags, res, is_first, is_last);
-
-    // records wanted: the whole input is staged, then scanned (agh_fetch_records gathers from it)
-    size_t want = rd.regular ? (size_t)rd.left + 64 : AGH_STAGE_CHUNK * 2;
-    if (q->staging.ensure(want + 32)) return -1;
-    size_t used = 0;
-    int b = 0;
-    bool busy[2] = {false, false};
-    for (;;) {
-        if (busy[b]) HIP_TRY(hipEventSynchronize(q->pinned_ev[b]));   // its H2D copy finished
-        busy[b] = false;
-        const ssize_t r = rd.fill(q->pinned[b], AGH_STAGE_CHUNK);
-        if (r < 0) return -1;
-        const size_t got = (size_t)r;
-        if (got == 0) break;
-        if (used + got + 32 > q->staging.cap) {     // unknown length (pipe): grow, keep contents
-            dev_buf bigger;
-            if (bigger.ensure((used + got) * 2 + 64)) return -1;
-            HIP_TRY(hipStreamSynchronize(q->stage_stream));
-            if (used) HIP_TRY(hipMemcpy(bigger.p, q->staging.p, used, hipMemcpyDeviceToDevice));
-            q->staging.release();
-            q->staging = bigger;
-        }
-        HIP_TRY(hipMemcpyAsync((unsigned char *)q->staging.p + used, q->pinned[b], got,
-                               hipMemcpyHostToDevice, q->stage_stream));
-        HIP_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
-        busy[b] = true;
-        used += got;
-        b ^= 1;
-    }
-    HIP_TRY(hipStreamSynchronize(q->stage_stream));
-    return scan_staged(q, used, flags, res, matches, cap, is_first, is_last);
-}
-
-extern "C" int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res,
-                           agh_match *matches, size_t cap)
-{
-    return scan_fd_impl(q, fd, false, 0, 0, flags, res, matches, cap);
-}
-
-extern "C" int agh_scan_fd_range(agh_query *q, int fd, uint64_t begin, uint64_t end,
-                                 unsigned flags, agh_result *res, agh_match *matches, size_t cap)
-{
-    return scan_fd_impl(q, fd, true, begin, end, flags, res, matches, cap);
-}
-
-// cut a file into nranks record-aligned shards (a record belongs to the shard that
-// holds its first byte).  Inner cut r = the nominal offset size * r / nranks if a record starts
-// there, else just after the next delimiter -- the rule of agrep_amd/shard.py:record_cuts.
-// Host-only code (pread); single-byte delimiters.
-extern "C" int agh_shard_cuts_fd(int fd, const unsigned char *delim, int dlen, int nranks,
-                                 uint64_t *cuts)
-{
-    if (fd < 0 || !delim || nranks < 1 || !cuts) return fail("agh_shard_cuts_fd: bad arguments");
-    if (dlen < 1 || dlen > AGH_MAX_DELIM) return fail("delimiter length %d outside 1..%d", dlen, AGH_MAX_DELIM);
-    // Several bytes: where a record ends must not depend on where the search starts.  That holds for
-    // delimiters no proper prefix of which is also a suffix ("\r\n", "From ", "$$$x"): their
-    // occurrences cannot overlap, every one is selected (asearch.c:54-57).  "\n\n" in "\n\n\n" is
-    // selected by what came before -- such delimiters are not sharded here.
-    for (int b = 1; b < dlen; ++b)
-        if (memcmp(delim, delim + dlen - b, (size_t)b) == 0)
-            return fail("sharding a file by a delimiter that can overlap itself is not supported");
-    struct stat sb;
-    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return fail("sharding needs a seekable regular file");
-    const uint64_t size = (uint64_t)sb.st_size;
-    cuts[0] = 0;
-    std::vector<unsigned char> buf((1 << 16) + AGH_MAX_DELIM);
-    const uint64_t dl = (uint64_t)dlen;
-    for (int r = 1; r < nranks; ++r) {
-        // size * r / nranks without overflow
-        uint64_t nominal = size / (uint64_t)nranks * (uint64_t)r + size % (uint64_t)nranks * (uint64_t)r / (uint64_t)nranks;
-        if (nominal < cuts[r - 1]) nominal = cuts[r - 1];
-        if (nominal >= size) { cuts[r] = size; continue; }
-        if (nominal == 0) { cuts[r] = 0; continue; }
-        // the first delimiter occurrence that ENDS at or after the nominal offset: the cut is its end
-        // (an occurrence that ends exactly at the nominal offset means a record starts right there)
-        uint64_t cut = size;
-        for (uint64_t off = nominal >= dl ? nominal - dl : 0; off < size && cut == size;) {
-            ssize_t got = pread(fd, buf.data(), buf.size(), (off_t)off);
-            if (got < 0 && errno == EINTR) continue;
-            if (got < 0) return fail("read failed: %s", strerror(errno));
-            if (got < (ssize_t)dl) break;
-            for (size_t i = 0; i + dl <= (size_t)got; ++i) {
-                if (off + i + dl < nominal) continue;
-                if (buf[i] == delim[0] && memcmp(buf.data() + i, delim, (size_t)dl) == 0) { cut = off + i + dl; break; }
-            }
-            off += (uint64_t)got - (dl - 1);        // keep dlen-1 bytes: an occurrence may straddle the reads
-        }
-        cuts[r] = cut;
-    }
-    cuts[nranks] = size;
-    return 0;
-}
-
-// Scan again what the last agh_scan_fd / agh_scan_buffer staged (e.g. with a larger match
-// array after `truncated`, or with other flags) without touching the input again.
-extern "C" int agh_rescan_staged(agh_query *q, unsigned flags, agh_result *res,
-                                 agh_match *matches, size_t cap)
-{
-    if (!q || !res) return fail("null argument");
-    return scan_staged(q, q->staged_len, flags, res, matches, cap, q->staged_first, q->staged_last);
-}
-
-// Bytes of matched records of the most recent agh_scan_fd / agh_scan_buffer, concatenated in
-// the order given (no delimiters in between): device-side gather + one D2H copy.
-extern "C" int agh_fetch_records(agh_query *q, const agh_match *m, size_t n_matches,
-                                 unsigned char *out, size_t out_cap, size_t *out_len)
-{
-    if (!q || (!m && n_matches) || (!out && out_cap)) return fail("null argument");
-    std::vector<uint64_t> st(n_matches), en(n_matches), off(n_matches);
-    uint64_t total = 0;
-    for (size_t i = 0; i < n_matches; ++i) {
-        if (m[i].end < m[i].start || m[i].end > q->staged_len)
-            return fail("match %zu lies outside the staged text", i);
-        st[i] = m[i].start;
-        en[i] = m[i].end;
-        off[i] = total;
-        total += m[i].end - m[i].start;
-    }
-    if (out_len) *out_len = (size_t)total;
-    if (total > out_cap) return fail("output buffer too small (%llu bytes needed)",
-                                     (unsigned long long)total);
-    if (!n_matches || !total) return 0;
-    const size_t bytes = n_matches * sizeof(uint64_t);
-    if (q->match_start.ensure(bytes) || q->match_end.ensure(bytes) || q->match_off.ensure(bytes) ||
-        q->gather.ensure((size_t)total))
-        return -1;
-    HIP_TRY(hipMemcpy(q->match_start.p, st.data(), bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(q->match_end.p, en.data(), bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(q->match_off.p, off.data(), bytes, hipMemcpyHostToDevice));
-    agh_launch_gather_records(q->staging.p, (const uint64_t *)q->match_start.p,
-                              (const uint64_t *)q->match_end.p, (const uint64_t *)q->match_off.p,
-                              (uint32_t)n_matches, q->gather.p, nullptr);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, q->gather.p, (size_t)total, hipMemcpyDeviceToHost));
-    return 0;
 }
 
 // ---------------------------------------------------------------------------------------

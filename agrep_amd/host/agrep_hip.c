@@ -231,33 +231,40 @@ static unsigned char *slurp(int fd, size_t *len)
     return buf;
 }
 
-/* One file through the device engines; count-only unless records have to be printed.  The
- * file is streamed to HBM by the library (pinned double buffering); only the matched
- * records come back. */
-static int scan_one(agh_query *q, int fd, int want_records, struct filehit *out)
+/* One file through the device engines; count-only unless records have to be printed.  The file is
+ * streamed to HBM by the library (pinned ring, two bounded device segments); matched records are
+ * printed from emit_records() after every segment, while the rest of the file is still being read --
+ * as output() is called from inside the reference's block loop (asearch.c:66-324). */
+struct emit_ctx {
+    const char *name;
+    int with_name;
+};
+static void print_records(const struct filehit *h, const char *name, int with_name);
+
+static int emit_records(void *vctx, const agh_match *m, size_t n, const unsigned char *bytes, size_t n_bytes)
 {
-    size_t cap = 65536, total = 0;
+    const struct emit_ctx *c = (const struct emit_ctx *)vctx;
+    struct filehit h;
+    (void)n_bytes;
+    memset(&h, 0, sizeof(h));
+    h.res.n_stored = n;
+    h.matches = (agh_match *)m;
+    h.bytes = (unsigned char *)bytes;
+    print_records(&h, c->name, c->with_name);
+    return 0;
+}
+
+static int scan_one(agh_query *q, int fd, int want_records, struct filehit *out, const char *name, int with_name)
+{
+    struct emit_ctx c;
     memset(out, 0, sizeof(*out));
     if (!want_records) {
         unsigned flags = (opt.FILENAMEONLY ? AGH_FILENAMEONLY : AGH_COUNT) | (opt.INVERSE ? AGH_INVERT : 0u);
         return agh_scan_fd(q, fd, flags, &out->res, NULL, 0);
     }
-    out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
-    if (!out->matches) return -1;
-    if (agh_scan_fd(q, fd, opt.INVERSE ? AGH_INVERT : 0u, &out->res, out->matches, cap)) return -1;
-    if (out->res.truncated) {                   /* more matches than guessed: scan the staged text again */
-        free(out->matches);
-        cap = (size_t)out->res.n_matched + 16;
-        out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
-        if (!out->matches) return -1;
-        if (agh_rescan_staged(q, opt.INVERSE ? AGH_INVERT : 0u, &out->res, out->matches, cap)) return -1;
-    }
-    if (agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, NULL, 0, &total) == 0 &&
-        total == 0)
-        return 0;                               /* nothing to print */
-    out->bytes = (unsigned char *)malloc(total ? total : 1);
-    if (!out->bytes) return -1;
-    return agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, out->bytes, total, &total);
+    c.name = name;
+    c.with_name = with_name;
+    return agh_scan_fd_emit(q, fd, opt.INVERSE ? AGH_INVERT : 0u, &out->res, emit_records, &c);
 }
 
 /* agrep.c:3805-3956 output(): [file: ][N: ]record\n for newline-delimited records.  With a
@@ -310,7 +317,7 @@ static long run_pass(agh_query *q, char **files, int nfiles, int print, int coun
             fprintf(stderr, "%s: '%s' no such file or directory\n", Progname, name);
             continue;
         }
-        if (scan_one(q, fd, want_records, &h)) {
+        if (scan_one(q, fd, want_records, &h, name, nfiles > 1 && !opt.NOFILENAME)) {
             fprintf(stderr, "%s: %s: %s\n", Progname, name, agh_last_error());
             exit(2);
         }
@@ -323,9 +330,7 @@ static long run_pass(agh_query *q, char **files, int nfiles, int print, int coun
                     printf("%llu\n", (unsigned long long)h.res.n_matched);
             } else if (opt.FILENAMEONLY) {      /* asearch.c:130-161 */
                 if (h.res.n_matched) printf("%s\n", name);
-            } else if (want_records) {
-                print_records(&h, name, nfiles > 1 && !opt.NOFILENAME);
-            }
+            }                                   /* (records: printed by emit_records() during the scan) */
         }
         if (h.res.n_matched) (*files_matched)++;
         /* -l counts files, everything else counts records (sgrep.c:1188, Appendix A) */

@@ -23,6 +23,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with
                   a child process (or null)
   cpu_baseline -- the unmodified reference (oracle/_ref/agrep, 1 core and all cores) on a
                   bounded sample of the same corpus, N = 1 only
+  c2_records / c3 / c5 -- the other BASELINE.json configs on resident text, N = 1 only, measured after
+                  (outside) the headline's timed region with their own steps: C2 = m=16 k=2, 4 GiB, numbered
+                  scan + device gather of the matched records (agh_scan_device_emit); C3 = m=48 k=3 -i,
+                  16 GiB, count-only and numbered; C5 = -f 1024 patterns (8..12 B) k=1, 8 GiB (one GPU's
+                  share of 32 GiB / 4), count-only.  Each block: value (GB/s), ms_per_step, matched vs
+                  planted, and a roofline sub-block for the kernel that reads every byte (HIP events on the
+                  scan's stream; C5 with its own in-run FETCH_SIZE pass)
 """
 import argparse
 import csv
@@ -173,7 +180,7 @@ def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes, q=None
             "seconds": round(dt, 3), "count": int(cnt)}
 
 
-def measure_traffic(seg_gib, k, timeout_s):
+def measure_traffic(seg_gib, k, timeout_s, config="headline", kernels=("void k_sweep<", "void k_sweep_fused<")):
     """HBM read bytes of ONE launch of the dominant kernel, measured now: a child process runs a few scans of
     one segment of the same corpus under `rocprofv3 --pmc FETCH_SIZE` (its own pass, with
     --kernel-trace only, as MI355X_MICROARCH.md prescribes); FETCH_SIZE is in KiB and counts the
@@ -187,8 +194,8 @@ def measure_traffic(seg_gib, k, timeout_s):
         for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "AGH_BENCH_FORCE_DIST"):
             env.pop(v, None)
         cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p",
-               "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--total-gib", str(seg_gib),
-               "-k", str(k), "--steps", "3", "--warmup", "0"]
+               "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--pmc-config", config,
+               "--total-gib", str(seg_gib), "-k", str(k), "--steps", "3", "--warmup", "0"]
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            timeout=timeout_s)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -196,10 +203,10 @@ def measure_traffic(seg_gib, k, timeout_s):
             return None, "rocprofv3 pass failed (rc %d)" % r.returncode
         vals = []
         for row in csv.DictReader(open(files[0])):
-            if row.get("Counter_Name") == "FETCH_SIZE" and row.get("Kernel_Name", "").startswith(("void k_sweep<", "void k_sweep_fused<")):
+            if row.get("Counter_Name") == "FETCH_SIZE" and row.get("Kernel_Name", "").startswith(tuple(kernels)):
                 vals.append(float(row["Counter_Value"]))
         if not vals:
-            return None, "no k_sweep / k_sweep_fused rows in the counter file"
+            return None, "no %s rows in the counter file" % " / ".join(kernels)
         # one row per launch (the counter is summed over the XCDs by rocprofv3); drop nothing
         per_launch = sum(vals) / len(vals)
         return int(per_launch * 1024 * 2), "rocprofv3 --pmc FETCH_SIZE, %d launches of %g GiB, KiB x 1024 x 2" % (len(vals), seg_gib)
@@ -207,6 +214,162 @@ def measure_traffic(seg_gib, k, timeout_s):
         return None, "traffic pass failed: %s" % str(e)[:120]
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+# ---- the other BASELINE.json configs (N = 1, resident text, outside the headline's timed region) ----------
+def c3_pattern_and_variants():
+    """m = 48 pattern and its 0..4-edit variants (tests/test_gpu_fullsize.py::test_c3_*: the same recipe)"""
+    import random
+    rng = random.Random(48)
+    pat = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(48))
+    vs = [pat]
+    for edits in (1, 2, 3, 4):
+        v = bytearray(pat)
+        for _ in range(edits):
+            op, pos = rng.randint(0, 2), rng.randrange(4, len(v) - 4)
+            if op == 0:
+                v[pos] = ord("Q")
+            elif op == 1:
+                del v[pos]
+            else:
+                v.insert(pos, ord("Z"))
+        vs.append(bytes(v))
+    return pat, tuple(vs)
+
+
+def c5_patterns_and_variants():
+    """1024 patterns of 8..12 bytes and planted 0-, 1- and 3-edit variants (test_c5_1024_patterns_k1_8gib)"""
+    import random
+    rng = random.Random(1024)
+    pats = set()
+    while len(pats) < 1024:
+        pats.add(bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(8, 12))))
+    pats = sorted(pats)
+    rng = random.Random(7)
+
+    def edit(p, edits):
+        a = bytearray(p)
+        for _ in range(edits):
+            op, at = rng.randint(0, 2), rng.randrange(1, len(a) - 1)
+            if op == 0:
+                a[at] = ord("Q")
+            elif op == 1:
+                del a[at]
+            else:
+                a.insert(at, ord("Z"))
+        return bytes(a)
+    base = [pats[3], pats[500], pats[900]]
+    variants = (base[0], base[1], edit(base[0], 1), edit(base[1], 1), edit(base[2], 1), edit(base[0], 3), edit(base[2], 3))
+    return pats, variants
+
+
+def timed_steps(torch, fn, steps, warmup=2):
+    """-> (seconds per step, last result, sum of sweep_ms, sweep launches, sum of device_ms)"""
+    for _ in range(warmup):
+        r = fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sweep = dev = 0.0
+    launches = 0
+    for _ in range(steps):
+        r = fn()
+        sweep += r.sweep_ms
+        dev += r.device_ms
+        launches += r.sweep_launches
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, r, sweep, launches, dev
+
+
+def roofline_block(kernel, n_bytes, steps, sweep_ms, launches):
+    per_launch = n_bytes * steps / max(launches, 1)
+    avg = sweep_ms / max(launches, 1)
+    ach = per_launch / 1e6 / max(avg, 1e-9)
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_ms": round(avg, 4), "launches_timed": int(launches)}
+
+
+def config_blocks(A, torch, steps):
+    out = {}
+    buf = torch.empty(16 << 30, dtype=torch.uint8, device="cuda")
+    F = A.TIME_SWEEP | A.TIME_SCAN
+
+    # C2: m = 16, k = 2, 4 GiB, the match SET: numbered scan + device gather of the matched records
+    n = 4 << 30
+    planted = A.corpus_fill_device(buf.data_ptr(), n // 4096, seed=SEED, variants=VARIANTS, plant_period=500)
+    want = sum(c for c, e in zip(planted, VARIANT_EDITS) if e <= 2)
+    with A.Query(PATTERN, 2) as q:
+        got = {}
+
+        def step():
+            # (summarize: the callback only counts -- no Python object per record inside the timed region)
+            res, batches = q.scan_device_emit(buf.data_ptr(), n, flags=F, summarize=True)
+            got["records"] = sum(b[0] for b in batches)
+            got["bytes"] = sum(b[1] for b in batches)
+            return res
+        sec, r, sweep, launches, dev = timed_steps(torch, step, steps)
+        info = q.info()
+    out["c2_records"] = {
+        "workload": "BASELINE configs[1]: m=16 k=2, 4 GiB resident, numbered scan + match bounds + device gather of the "
+                    "matched records, records copied back (agh_scan_device_emit)",
+        "value": round(n / 1e9 / sec, 2), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4), "steps": steps,
+        "device_ms_scan_only": round(dev / steps, 4), "matched_records": int(r.n_matched), "records_returned": got["records"],
+        "record_bytes_returned": got["bytes"], "planted_records": int(want),
+        "matched_equals_planted": bool(r.n_matched == want == got["records"]), "segments": int(r.n_segments),
+        "roofline": roofline_block("k_sweep<H=%d, census> (the kernel of the numbered pipeline that reads every byte)" % info["filter_h"],
+                                   n, steps, sweep, launches)}
+
+    # C3: m = 48, k = 3, -i, 16 GiB: count-only (one fused launch) and with record numbers
+    n = 16 << 30
+    pat, vs = c3_pattern_and_variants()
+    planted = A.corpus_fill_device(buf.data_ptr(), n // 4096, seed=9, variants=vs, plant_period=500, upper_permille=500)
+    want = int(sum(planted[:4]))
+    nsteps = max(steps // 2, 3)
+    with A.Query(pat, 3, nocase=True) as q:
+        info = q.info()
+        sec, r, sweep, launches, dev = timed_steps(torch, lambda: q.scan_device(buf.data_ptr(), n, flags=A.COUNT | F), steps)
+        secn, rn, sweepn, launchesn, devn = timed_steps(torch, lambda: q.scan_device(buf.data_ptr(), n, flags=F), nsteps)
+    out["c3"] = {
+        "workload": "BASELINE configs[2]: m=48 k=3 -i, 16 GiB resident (64-bit state words; the reference rejects m > 29: "
+                    "anchored on the planted 0..3-edit records)",
+        "value": round(n / 1e9 / sec, 2), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4), "steps": steps,
+        "matched_records": int(r.n_matched), "planted_records": want, "matched_equals_planted": bool(r.n_matched == want),
+        "filter_sample": "q=%d bytes every h=%d bytes" % (info["filter_q"], info["filter_h"]),
+        "fused_segments": int(r.fused_segments), "lean_reruns": int(r.lean_reruns),
+        "roofline": roofline_block(("k_sweep_fused<H=%d> (64-bit words)" if r.fused_segments else "k_sweep<H=%d>") % info["filter_h"],
+                                   n, steps, sweep, launches),
+        "numbered": {"value": round(n / 1e9 / secn, 2), "unit": "GB/s", "ms_per_step": round(secn * 1e3, 4),
+                     "steps": nsteps, "matched_records": int(rn.n_matched), "segments": int(rn.n_segments),
+                     "matched_equals_planted": bool(rn.n_matched == want),
+                     "roofline": roofline_block("k_sweep<H=%d, census>" % info["filter_h"], n, nsteps, sweepn, launchesn)}}
+
+    # C5: -f, 1024 patterns of 8..12 bytes, k = 1, 8 GiB (one GPU's share of 32 GiB over 4), count-only
+    n = 8 << 30
+    pats, variants = c5_patterns_and_variants()
+    planted = A.corpus_fill_device(buf.data_ptr(), n // 4096, seed=55, variants=variants, plant_period=500)
+    want_le1 = int(sum(planted[:5]))
+    q = A.Query.multi(pats, k=1)
+    try:
+        sec, r, sweep, launches, dev = timed_steps(torch, lambda: q.scan_device(buf.data_ptr(), n, flags=A.COUNT | F), steps)
+        lean2 = q.scan_device(buf.data_ptr(), 2 << 30, flags=A.COUNT)
+        numb2 = q.scan_device(buf.data_ptr(), 2 << 30, flags=A.COUNT | A.FORCE_NUMBERED)
+    finally:
+        q.close()
+    one_pass = bool(r.fused_segments)
+    out["c5"] = {
+        "workload": "BASELINE configs[4]: -f 1024 patterns (8..12 bytes), k=1, 8 GiB resident = one GPU's share of 32 GiB / 4, "
+                    "count-only (-c / -l).  The reference ignores -# with -f (compat.c:34-37): the predicate is the union "
+                    "of the single-pattern one",
+        "value": round(n / 1e9 / sec, 2), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4), "steps": steps,
+        "matched_records": int(r.n_matched), "planted_records_0_1_edits": want_le1,
+        "matched_ge_planted": bool(r.n_matched >= want_le1 > 0),
+        "count_only_equals_numbered_on_2gib": bool(lean2.n_matched == numb2.n_matched),
+        "candidates_per_step": int(r.n_candidates), "segments": int(r.n_segments), "lean_reruns": int(r.lean_reruns),
+        "roofline": roofline_block("k_mscan (one pass: pair-table probes, exact gram table, k=1 side check)" if one_pass
+                                   else "k_sweep_multi (+ k_verify_multi)", n, steps, sweep, launches)}
+    del buf
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -223,6 +386,9 @@ def main():
                     help="skip the reference run over every shard of the corpus (N = 1 only, ~1 min)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 FETCH_SIZE pass")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-config", default="headline", help=argparse.SUPPRESS)
+    ap.add_argument("--no-configs", action="store_true", help="skip the c2_records / c3 / c5 blocks (N = 1 only, ~30 s)")
+    ap.add_argument("--config-steps", type=int, default=20)
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -272,6 +438,17 @@ def main():
             comm = A.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank)
         else:
             dist.init_process_group(backend)
+
+    if args.pmc_child and args.pmc_config == "c5":       # under rocprofv3 --pmc: the C5 scan, nothing else
+        n5 = int(args.total_gib * (1 << 30)) // 4096 * 4096
+        t5 = torch.empty(n5, dtype=torch.uint8, device="cuda")
+        pats, variants = c5_patterns_and_variants()
+        A.corpus_fill_device(t5.data_ptr(), n5 // 4096, seed=55, variants=variants, plant_period=500)
+        with A.Query.multi(pats, k=1) as q5:
+            for _ in range(args.steps):
+                q5.scan_device(t5.data_ptr(), n5, flags=A.COUNT, time_sweep=False, time_scan=False)
+        torch.cuda.synchronize()
+        return
 
     total_pages = int(args.total_gib * (1 << 30)) // 4096
     first_page, n_pages = shard.shard_pages(total_pages, world, rank)
@@ -405,6 +582,11 @@ def main():
     q.close()
     q0.close()
     if rank == 0:
+        if world == 1 and not args.no_configs:
+            try:
+                out.update(config_blocks(A, torch, args.config_steps))
+            except Exception as e:                              # never lose the headline over this
+                out["configs_error"] = str(e)[:300]
         if world == 1 and not args.no_traffic:
             del text
             torch.cuda.empty_cache()
@@ -414,6 +596,14 @@ def main():
             out["roofline"]["traffic_source"] = note
             if tr:
                 out["roofline"]["traffic_over_algorithmic"] = round(tr / per_launch_bytes, 4)
+            if "c5" in out and "roofline" in out["c5"]:
+                r5 = out["c5"]["roofline"]
+                g5 = r5["algorithmic_bytes_per_launch"] / 2**30
+                tr5, note5 = measure_traffic(g5, 1, 240, config="c5", kernels=("void k_mscan<", "void k_sweep_multi<"))
+                r5["traffic"] = tr5
+                r5["traffic_source"] = note5
+                if tr5:
+                    r5["traffic_over_algorithmic"] = round(tr5 / r5["algorithmic_bytes_per_launch"], 4)
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()

@@ -53,6 +53,7 @@ extern "C" {
 #define AGH_TIME_SCAN      0x100u /* time the whole kernel sequence of the scan (agh_result.device_ms): two HIP
                                      events as well */
 #define AGH_FORCE_NUMBERED 0x40u  /* diagnostics: compute record numbers even for -c / -l scans */
+#define AGH_NO_BYTES       0x200u /* agh_scan_*_emit: offsets and record numbers only, no record bytes */
 
 /* engine that produced a result */
 #define AGH_ENGINE_FULLSCAN 1u    /* k-error automaton over every byte (asearch.c:94-116) */
@@ -168,10 +169,30 @@ int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q, int *filte
 int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t len, unsigned flags,
                     agh_result *res, agh_match *matches, size_t cap);
 
-/* File mode (fd >= 0, asearch.c:66-324 / sgrep.c:334-547): reads fd to EOF through two pinned
- * buffers (read() of chunk i+1 overlaps the H2D copy of chunk i); works for pipes too. */
+/* File mode (fd >= 0, asearch.c:66-324 / sgrep.c:334-547): reads fd to EOF through a ring of pinned
+ * buffers (read() of the next chunks overlaps the H2D copy of chunk i); works for pipes too.  Count-only
+ * scans (matches == NULL) stream through two device segments of bounded size; with a match ARRAY the whole
+ * input is staged in HBM (agh_fetch_records / agh_rescan_staged work on that copy) -- for record output of
+ * inputs of any size use agh_scan_fd_emit. */
 int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res, agh_match *matches,
                 size_t cap);
+
+/* Record output while the input is still being read -- what asearch.c:66-324 / bitap.c:169-284 do when they
+ * call output() from inside their block loop.  The input streams through two device segments of bounded
+ * size (the scan of one overlaps the read + H2D copy of the next); after every segment emit() receives that
+ * segment's matched records in file order: m[0..n) (offsets relative to the start of the input, index = the
+ * record number), and bytes[0..n_bytes) = the records themselves back to back (record i has m[i].end -
+ * m[i].start bytes; NULL / 0 with AGH_NO_BYTES).  emit() is called from a worker thread of the library, never
+ * concurrently; a non-zero return stops the scan (the call returns 0 with res->truncated = 1).  HBM use does
+ * not grow with the input, pipes work, records of any number come out.  flags: AGH_INVERT, AGH_NO_BYTES. */
+typedef int (*agh_emit_fn)(void *ctx, const agh_match *m, size_t n, const unsigned char *bytes, size_t n_bytes);
+int agh_scan_fd_emit(agh_query *q, int fd, unsigned flags, agh_result *res, agh_emit_fn emit, void *ctx);
+int agh_scan_fd_range_emit(agh_query *q, int fd, uint64_t begin, uint64_t end, unsigned flags,
+                           agh_result *res, agh_emit_fn emit, void *ctx);
+/* The same for text already resident in HBM (dev_text as for agh_scan_device): numbered scan, record bounds
+ * and the gather of the record bytes on the device, one emit() call. */
+int agh_scan_device_emit(agh_query *q, const void *dev_text, size_t len, unsigned flags, agh_result *res,
+                         agh_emit_fn emit, void *ctx);
 
 /* Scan again the text the last agh_scan_fd / agh_scan_buffer staged in HBM (a pipe cannot be
  * read twice): used after `truncated` with a larger match array. */

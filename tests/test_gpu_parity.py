@@ -370,6 +370,123 @@ def test_scan_fd_streams_files_and_pipes(agh, tmp_path):
         assert res_c.n_matched == want_n
 
 
+def _emit_all(batches):
+    ms = [m for b in batches for m in b[0]]
+    recs = [r for b in batches for r in (b[1] or [])]
+    return ms, recs
+
+
+@pytest.mark.parametrize("seg_mb", ["1024", "16"])
+def test_scan_fd_emit_streams_records(agh, tmp_path, monkeypatch, seg_mb):
+    """agh_scan_fd_emit: the input streams through two bounded device segments (16 MiB here: six segments,
+    the residue carried five times), matched records come out per segment in file order -- the same
+    offsets, record numbers and bytes as the oracle / the whole-file path, from a file and from a pipe;
+    stopping from inside emit(); offsets only (AGH_NO_BYTES); -v; a byte range."""
+    import threading
+    monkeypatch.setenv("AGH_STREAM_SEG_MB", seg_mb)
+    text, _ = O.corpus((80 << 20) // 4096, seed=31, variants=O.VARIANTS_C2, plant_period=3000)
+    tb = text.tobytes()
+    want_n, want_recs = O.asearch(O.PATTERN_C2, 2, tb, cap=100000)
+    nl = np.flatnonzero(text == 10)
+    want_idx = np.searchsorted(nl, [s for s, _ in want_recs]).tolist()
+    p = tmp_path / "big.txt"
+    p.write_bytes(tb)
+    with agh.Query(O.PATTERN_C2, 2) as q:
+        fd = os.open(str(p), os.O_RDONLY)
+        try:
+            res, batches = q.scan_fd_emit(fd)
+        finally:
+            os.close(fd)
+        ms, recs = _emit_all(batches)
+        assert res.n_matched == want_n and not res.truncated
+        assert [(s, e) for s, e, _ in ms] == want_recs and [i for _, _, i in ms] == want_idx
+        assert recs == [tb[s:e] for s, e in want_recs]
+        assert len(batches) >= (5 if seg_mb == "16" else 1)
+        assert res.n_bytes == len(tb) and res.n_records == len(nl)
+        # a pipe
+        r, w = os.pipe()
+
+        def feed():
+            with os.fdopen(w, "wb") as f:
+                for i in range(0, len(tb), 1 << 20):
+                    f.write(tb[i:i + (1 << 20)])
+        th = threading.Thread(target=feed)
+        th.start()
+        try:
+            res_p, bp = q.scan_fd_emit(r)
+        finally:
+            th.join()
+            os.close(r)
+        assert _emit_all(bp)[0] == ms and _emit_all(bp)[1] == recs
+        # offsets only; stop after the first batch
+        fd = os.open(str(p), os.O_RDONLY)
+        try:
+            res_o, bo = q.scan_fd_emit(fd, flags=agh.NO_BYTES)
+            os.lseek(fd, 0, os.SEEK_SET)
+            res_s, bs = q.scan_fd_emit(fd, stop_after=1)
+            os.lseek(fd, 0, os.SEEK_SET)
+            half = int(nl[len(nl) // 2]) + 1                  # a record-aligned byte range
+            res_r, br = q.scan_fd_emit(fd, byte_range=(half, len(tb)))
+        finally:
+            os.close(fd)
+        assert _emit_all(bo)[0] == ms and _emit_all(bo)[1] == []
+        assert len(bs) == 1 and (res_s.truncated == 1 or len(batches) == 1)
+        assert [(s + half, e + half) for s, e, _ in _emit_all(br)[0]] == [x for x in want_recs if x[0] >= half]
+        # count-only scans of the same file take the same pipeline
+        fd = os.open(str(p), os.O_RDONLY)
+        try:
+            assert q.scan_fd(fd, flags=agh.COUNT)[0].n_matched == want_n
+        finally:
+            os.close(fd)
+    # -v on a small file in many segments: every record that does not match
+    small = tb[:3 << 20]
+    ps = tmp_path / "small.txt"
+    ps.write_bytes(small)
+    monkeypatch.setenv("AGH_STREAM_SEG_MB", "1")
+    got_n, got = O.asearch(O.PATTERN_C2, 2, small, cap=100000)
+    all_recs, pos = [], 0
+    for e in np.flatnonzero(np.frombuffer(small, dtype=np.uint8) == 10).tolist():
+        all_recs.append((pos, e))
+        pos = e + 1
+    want_inv = [x for x in all_recs if x not in set(got)]
+    with agh.Query(O.PATTERN_C2, 2) as q:
+        fd = os.open(str(ps), os.O_RDONLY)
+        try:
+            res_v, bv = q.scan_fd_emit(fd, flags=agh.INVERT)
+        finally:
+            os.close(fd)
+    assert [(s, e) for s, e, _ in _emit_all(bv)[0]] == want_inv and res_v.n_matched == len(want_inv)
+
+
+@pytest.mark.parametrize("delim", [b"\r\n", b"\n\n", b"aa", b"From "])
+def test_scan_fd_emit_multi_byte_delimiters(agh, tmp_path, monkeypatch, delim):
+    """The streaming pipeline with delimiters of several bytes (also ones that overlap themselves: a
+    segment is cut only behind an occurrence no other occurrence overlaps from the left), count-only and
+    with records, 1 MiB segments."""
+    monkeypatch.setenv("AGH_STREAM_SEG_MB", "1")
+    rng = random.Random(len(delim) + delim[0])
+    text, _ = O.corpus((6 << 20) // 4096, seed=77, variants=O.VARIANTS_C2, plant_period=200)
+    tb = text.tobytes().replace(b"\n", delim)
+    if delim == b"\n\n":                                   # runs of the delimiter's own byte
+        tb = tb.replace(b" e", b"\n\n\ne", 2000)
+    want_n, want_recs = O.asearch(O.PATTERN_C2, 2, tb, delim=delim, cap=200000)
+    p = tmp_path / "mb.txt"
+    p.write_bytes(tb)
+    with agh.Query(O.PATTERN_C2, 2, delim=delim) as q:
+        fd = os.open(str(p), os.O_RDONLY)
+        try:
+            rc, _ = q.scan_fd(fd, flags=agh.COUNT)
+            os.lseek(fd, 0, os.SEEK_SET)
+            res, batches = q.scan_fd_emit(fd)
+        finally:
+            os.close(fd)
+    ms, recs = _emit_all(batches)
+    assert rc.n_matched == want_n == res.n_matched > 10
+    assert [(s, e) for s, e, _ in ms] == want_recs
+    assert recs == [tb[s:e] for s, e in want_recs]
+    assert len(batches) >= 3
+
+
 @pytest.mark.parametrize("delim", [b"FROM ", b"\n\n", b"#%", b"@@@", b"ab", b"aa", b"\n.\n"])
 def test_multi_byte_delimiters(agh, delim):
     """-d with 2..8 byte delimiters (-d 'From ', -d '$$'): leftmost non-overlapping delimiter
