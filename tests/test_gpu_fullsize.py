@@ -27,6 +27,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(O.REF_DIR, "agrep")
 
 
+def _oracle_union(pats, k, host, threads=32):
+    """Record starts of the union over the patterns of the oracle's k-error scan, patterns spread over
+    host threads (the C calls release the GIL): 1024 patterns x 64 MiB in well under a minute."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(p):
+        return [s for s, _ in O.asearch(p, k, host, cap=400000)[1]]
+    out = set()
+    with ThreadPoolExecutor(max_workers=min(threads, os.cpu_count() or 1)) as ex:
+        for part in ex.map(one, pats):
+            out.update(part)
+    return out
+
+
 def _log(rec):
     d = os.path.join(ROOT, "gpurun_out")
     try:
@@ -67,6 +81,15 @@ def test_c2_match_set_equals_reference_at_4gib():
             h = hashlib.sha256()
             for r in recs:
                 h.update(r + b"\n")
+            # the same records through the streaming pipeline (bounded HBM, output while reading)
+            he = hashlib.sha256()
+            fd = os.open(path, os.O_RDONLY)
+            try:
+                t0 = time.time()
+                re_, batches = q.scan_fd_emit(fd, on_batch=lambda ms_, recs_: [he.update(x + b"\n") for x in recs_])
+                emit_s = time.time() - t0
+            finally:
+                os.close(fd)
             # the count-only pipelines on the same file: streaming -c and -l
             fd = os.open(path, os.O_RDONLY)
             try:
@@ -81,9 +104,11 @@ def test_c2_match_set_equals_reference_at_4gib():
     _log({"test": "c2_match_set", "bytes": n, "reference_lines": ref_lines, "gpu_records": len(recs),
           "sha256_reference": ref_sha, "sha256_gpu": h.hexdigest(), "planted": int(sum(planted)),
           "reference_seconds": round(ref_s, 2), "gpu_file_to_records_seconds": round(gpu_s, 2),
+          "gpu_file_to_records_streaming_seconds": round(emit_s, 2), "streaming_batches": len(batches),
           "count_only_matched": int(rc.n_matched), "l_scan_bytes_read": int(rl.n_bytes)})
     assert not res.truncated and res.n_matched == len(recs) == ref_lines == sum(planted)
     assert h.hexdigest() == ref_sha, "matched records differ from the reference's printed lines"
+    assert he.hexdigest() == ref_sha and re_.n_matched == ref_lines, "the streaming pipeline's records differ"
     assert [m[0] for m in ms] == sorted(m[0] for m in ms)                  # file order
     assert rc.n_matched == res.n_matched
     # -l stops reading at the first segment with a match (asearch.c:130-161)
@@ -123,7 +148,7 @@ def test_c3_long_pattern_nocase_16gib():
         r_full = q.scan_device(t.data_ptr(), 2 << 30, flags=A.FORCE_FULLSCAN)
         r_filt = q.scan_device(t.data_ptr(), 2 << 30)
         # a slice against the oracle's 64-bit-word automaton
-        sl = 8 << 20
+        sl = 64 << 20
         host = t[:sl].cpu().numpy()
         want = O.wm_count(pat, 3, host, nocase=True)[0]
         got = q.scan_device(t.data_ptr(), sl).n_matched
@@ -160,9 +185,9 @@ def test_c5_1024_exact_patterns_8gib():
             t0 = time.perf_counter()
             q.scan_device(t.data_ptr(), n, flags=A.COUNT, time_sweep=False, time_scan=False)
             xs.append(time.perf_counter() - t0)
-        sl = 16 << 20
+        sl = 64 << 20
         host = t[:sl].cpu().numpy()
-        want = O.multi_exact_count(pats, host)[0]
+        want = len(_oracle_union(pats, 0, host))            # (the k = 0 automaton per pattern, on the host's threads)
         got = q.scan_device(t.data_ptr(), sl, flags=A.COUNT).n_matched
     finally:
         q.close()
@@ -237,12 +262,10 @@ def test_c5_1024_patterns_k1_8gib():
                 r1 = q1.scan_device(t.data_ptr(), sl, match_pos_ptr=pos.data_ptr(), match_cap=cap)
                 assert not r1.truncated
                 want.update(np.searchsorted(nl, pos[:int(r1.n_stored)].cpu().numpy()).tolist())
-        # (a) the oracle on the first 2 MiB
-        osl = 2 << 20
-        orc = set()
-        for p in pats:
-            orc.update(s for s, _ in O.asearch(p, 1, host[:osl], cap=100000)[1])
-        ro = q.scan_buffer(host[:osl].tobytes(), cap=100000)
+        # (a) the oracle on the same 64 MiB (1024 scalar scans on the host's threads)
+        osl = sl
+        orc = _oracle_union(pats, 1, host[:osl])
+        ro = q.scan_buffer(host[:osl].tobytes(), cap=400000)
     finally:
         q.close()
     planted_le1 = int(sum(planted[:5]))
@@ -250,7 +273,7 @@ def test_c5_1024_patterns_k1_8gib():
           "planted_3_edits": int(sum(planted[5:])), "candidates": int(r.n_candidates), "segments": int(r.n_segments),
           "count_only_GBps": round(n / 1e9 / sorted(xs)[1], 1), "count_only_ms": round(sorted(xs)[1] * 1e3, 3),
           "numbered_2gib": int(rn.n_matched), "lean_2gib": int(rl.n_matched), "slice_records_multi": len(got),
-          "slice_records_single_union": len(want), "oracle_2mib_records": len(orc)})
+          "slice_records_single_union": len(want), "oracle_64mib_records": len(orc)})
     assert r.n_matched >= planted_le1 > 0 and r.lean_reruns == 0
     assert rn.n_matched == rl.n_matched
     assert not rm.truncated and got == want
@@ -276,15 +299,13 @@ def test_c5_as_worded_4_to_12_bytes_k1_dense():
             xs.append(time.perf_counter() - t0)
         rn = q.scan_device(t.data_ptr(), 64 << 20)
         rl = q.scan_device(t.data_ptr(), 64 << 20, flags=A.COUNT)
-        osl = 256 << 10
+        osl = 8 << 20
         host = t[:osl].cpu().numpy()
-        orc = set()
-        for p in pats:
-            orc.update(s for s, _ in O.asearch(p, 1, host, cap=100000)[1])
-        ro = q.scan_buffer(host.tobytes(), cap=100000)
+        orc = _oracle_union(pats, 1, host)
+        ro = q.scan_buffer(host.tobytes(), cap=400000)
     ms = sorted(xs)[1] * 1e3
     _log({"test": "c5_1024x4..12_k1_dense_256mib", "bytes": n, "matched": int(r.n_matched), "count_only_ms": round(ms, 2),
-          "count_only_GBps": round(n / 1e6 / ms, 2), "oracle_256kib_records": len(orc)})
+          "count_only_GBps": round(n / 1e6 / ms, 2), "oracle_8mib_records": len(orc)})
     assert rn.n_matched == rl.n_matched > 0
     assert sorted(s for s, _, _ in ro[1]) == sorted(orc)
     assert ms < 50.0, ms

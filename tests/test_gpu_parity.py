@@ -1174,3 +1174,16 @@ def test_inverse_record_list_with_multi_byte_delimiters(agh):
             assert res.n_matched == rc.n_matched == len(want), (delim, pat, k)
             assert [(s, e) for s, e, _ in ms] == want, (delim, pat, k)
             assert [i for _, _, i in ms][:40] == [recs_all.index(r) for r in want[:40]]
+
+
+def test_stress_parity_slice():
+    """A seeded 60-second slice of scripts/stress_parity.py (random patterns / k / -i / delimiters / texts /
+    -f sets / table-engine cases, every device engine against the oracle) inside the suite, so that the
+    driver's own run executes it; longer runs: profiles/r04_stress_parity*.log."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "stress_parity.py")
+    p = subprocess.run([sys.executable, script, "60", "20260926"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = p.stdout.decode(errors="replace").strip().splitlines()[-5:]
+    assert p.returncode == 0 and tail and tail[-1].endswith("failures 0"), tail
+    assert int(tail[-1].split()[1]) > 300, tail
