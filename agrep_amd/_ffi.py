@@ -97,6 +97,8 @@ def lib():
     L.agh_scan_fd_range_emit.restype = C.c_int
     L.agh_scan_device_emit.argtypes = [vp, vp, C.c_size_t, C.c_uint, C.POINTER(Result), EMIT_FN, vp]
     L.agh_scan_device_emit.restype = C.c_int
+    L.agh_scan_device_reduce.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_uint, C.POINTER(Result), C.POINTER(C.c_uint64)]
+    L.agh_scan_device_reduce.restype = C.c_int
     L.agh_rescan_staged.argtypes = [vp, C.c_uint, C.POINTER(Result), C.POINTER(Match), C.c_size_t]
     L.agh_rescan_staged.restype = C.c_int
     L.agh_fetch_records.argtypes = [vp, C.POINTER(Match), C.c_size_t, vp, C.c_size_t,
@@ -314,6 +316,16 @@ class Query:
         _check(lib().agh_scan_device(self._h, dev_ptr, n, stream, flags, C.byref(res),
                                      match_pos_ptr, match_cap))
         return res
+
+    def scan_device_reduce(self, comm, dev_ptr, n, flags=COUNT, stream=None, time_sweep=False):
+        """agh_scan_device_reduce: this rank's count-only scan + the sum of (matched, records) over all ranks
+        of the communicator, all-reduced on the scan's stream (one host sync) -> (Result, (matched, records))"""
+        if time_sweep:
+            flags |= TIME_SWEEP
+        res = Result()
+        tot = (C.c_uint64 * 2)()
+        _check(lib().agh_scan_device_reduce(self._h, comm._h, dev_ptr, n, stream, flags, C.byref(res), tot))
+        return res, (int(tot[0]), int(tot[1]))
 
     def close(self):
         if self._h:

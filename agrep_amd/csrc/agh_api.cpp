@@ -878,6 +878,8 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_ms_gtab) (void)hipFree(q->d_ms_gtab);
     if (q->d_ms_mdir) (void)hipFree(q->d_ms_mdir);
     if (q->d_ms_ment) (void)hipFree(q->d_ms_ment);
+    if (q->d_acc) (void)hipFree(q->d_acc);
+    if (q->h_acc) (void)hipHostFree(q->h_acc);
     if (q->d_counters) (void)hipFree(q->d_counters);
     if (q->d_chunk_totals) (void)hipFree(q->d_chunk_totals);
     if (q->h_counters) (void)hipHostFree(q->h_counters);
@@ -1769,6 +1771,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         if (!stop) scanned += n;
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)wcand[slot]->p, nw, d_cnt, aux);
+        if (q->reduce_comm) agh_launch_accumulate_counts(d_cnt, q->d_acc, aux);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, AGH_C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, aux));
         if (overlap) HIP_TRY(hipEventRecord(q->dep_events[2 + slot], aux));
@@ -1777,6 +1780,13 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         const int last_slot = (queued - 1) & 1;
         HIP_TRY(hipStreamWaitEvent(st, q->dep_events[2 + last_slot], 0));
         if (queued >= 2) HIP_TRY(hipStreamWaitEvent(st, q->dep_events[2 + (last_slot ^ 1)], 0));
+    }
+    if (q->reduce_comm && !stop) {
+        // the counts never leave the device before they are summed over the ranks: the all-reduce is queued
+        // behind the last segment's kernels, the host waits once for everything
+        if (agh_comm_allreduce_dev(q->reduce_comm, q->d_acc, 3, st)) return -1;
+        HIP_TRY(hipMemcpyAsync(q->h_acc, q->d_acc, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        q->reduce_done = true;
     }
     HIP_TRY(hipStreamSynchronize(st));
     if (overlap) HIP_TRY(hipStreamSynchronize(aux));
@@ -1894,9 +1904,15 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
         if (!agh_launch_mscan(a, st)) return fail("internal error: no one-pass kernel for this pattern set");
         if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i + 1], st));
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8), nullptr, 0u, d_cnt, st);
+        if (q->reduce_comm) agh_launch_accumulate_counts(d_cnt, q->d_acc, st);
         HIP_TRY(hipGetLastError());
         if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i + 2], st));
         HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, AGH_C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
+    if (q->reduce_comm) {
+        if (agh_comm_allreduce_dev(q->reduce_comm, q->d_acc, 3, st)) return -1;
+        HIP_TRY(hipMemcpyAsync(q->h_acc, q->d_acc, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        q->reduce_done = true;
     }
     HIP_TRY(hipStreamSynchronize(st));
     q->hashset_dirty = false;
@@ -2032,6 +2048,44 @@ extern "C" int agh_scan_device(agh_query *q, const void *dev_text, size_t len, v
 {
     return agh_scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res,
                             (uint64_t *)dev_match_pos, nullptr, dev_match_pos ? match_cap : 0, true, true);
+}
+
+// One step of a sharded count-only scan (the only exchange is the -c aggregate): the scan of this
+// rank's shard and the all-reduce of the counts.  On the count-only pipelines the per-segment counts are
+// summed on the device and ncclAllReduce is enqueued on the scan's stream right behind the kernels -- the
+// host waits ONCE per step (round 3: scan sync, H2D of 16 bytes, all-reduce, D2H, sync).  Every rank issues
+// the same collectives whatever path its own scan took: one all-reduce of (matched, records, gave-up), and
+// -- only if some rank's count-only scan gave up and was rerun -- a second one with the final counts.
+extern "C" int agh_scan_device_reduce(agh_query *q, agh_comm *c, const void *dev_text, size_t len, void *stream,
+                                      unsigned flags, agh_result *res, uint64_t totals[2])
+{
+    if (!q || !c || !res || !totals) return fail("null argument");
+    if (!q->d_acc) {
+        HIP_TRY(hipMalloc((void **)&q->d_acc, 4 * sizeof(uint64_t)));
+        HIP_TRY(hipHostMalloc((void **)&q->h_acc, 4 * sizeof(uint64_t)));
+    }
+    HIP_TRY(hipMemsetAsync(q->d_acc, 0, 4 * sizeof(uint64_t), (hipStream_t)stream));
+    q->reduce_comm = c;
+    q->reduce_done = false;
+    const int rc = agh_scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res, nullptr, nullptr, 0, true, true);
+    q->reduce_comm = nullptr;
+    if (rc) return -1;
+    uint64_t v[3] = {res->n_matched, res->n_records, 0};
+    if (q->reduce_done) {
+        v[0] = q->h_acc[0];
+        v[1] = q->h_acc[1];
+        v[2] = q->h_acc[2];
+    } else if (agh_comm_allreduce_host(c, v, 3)) {      // (a path without the device-side sum: same collective)
+        return -1;
+    }
+    if (v[2]) {                                         // some rank reran a segment: the final counts, once more
+        v[0] = res->n_matched;
+        v[1] = res->n_records;
+        if (agh_comm_allreduce_host(c, v, 2)) return -1;
+    }
+    totals[0] = v[0];
+    totals[1] = v[1];
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------

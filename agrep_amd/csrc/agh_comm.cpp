@@ -270,6 +270,29 @@ static int all_reduce_many(agh_comm *const *cs, int n, void *const *host, size_t
     return 0;
 }
 
+// internal (agh_api.cpp, agh_scan_device_reduce): uint64 sums in place -- on a device buffer, enqueued on the
+// caller's stream behind the scan's kernels (no host round trip), or from host memory
+extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_dev(agh_comm *c, uint64_t *d_buf, size_t count,
+                                                                            hipStream_t st)
+{
+    if (!c || !d_buf) return cfail("null argument");
+    if (need_rccl()) return -1;
+    NCCL_TRY(R.AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->comm, st));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_host(agh_comm *c, uint64_t *v, size_t count)
+{
+    if (!c || !v) return cfail("null argument");
+    if (need_rccl()) return -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void *h = v;
+    const int rc = all_reduce_many(&c, 1, &h, count, ncclUint64, ncclSum, sizeof(uint64_t));
+    (void)hipSetDevice(dev);
+    return rc;
+}
+
 extern "C" int agh_reduce_counts(agh_comm *c, uint64_t counts[2])
 {
     if (!c || !counts) return cfail("null argument");

@@ -124,6 +124,10 @@ struct agh_query {
     int npat = 0;
     void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_pool = nullptr,
          *d_mp_omask = nullptr;
+    // agh_scan_device_reduce: the communicator of the step in progress, its totals on the device / pinned
+    struct agh_comm *reduce_comm = nullptr;
+    uint64_t *d_acc = nullptr, *h_acc = nullptr;        // matched, records, segments that gave up (+ 1 spare)
+    bool reduce_done = false;
     // one-pass count-only -f scan (agh_mscan.hip): pair table, exact gram table, entry directory
     bool ms_ok = false;
     uint32_t ms_rb = 0, ms_dbg = 0;
@@ -132,6 +136,11 @@ struct agh_query {
 
 // delimiter ends come from the delimiter bitmap: several bytes, or one letter under -i
 static inline bool q_mb(const agh_query *q) { return q->dlen > 1 || q->delim_fold; }
+
+// ---- agh_comm.cpp (internal) --------------------------------------------------------------------
+extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_dev(struct agh_comm *c, uint64_t *d_buf, size_t count,
+                                                                            hipStream_t st);
+extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_host(struct agh_comm *c, uint64_t *v, size_t count);
 
 // ---- agh_api.cpp ------------------------------------------------------------------------------
 uint64_t agh_env_mb(const char *name, uint64_t dflt_mb) __attribute__((visibility("hidden")));

@@ -91,6 +91,7 @@ void agh_launch_bitmap_count(uint32_t *bitmap, uint32_t n_words, uint32_t *count
                              hipStream_t st);
 void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *wave_cand,
                               uint32_t nw, uint32_t *counters, hipStream_t st);
+void agh_launch_accumulate_counts(const uint32_t *counters, uint64_t *acc, hipStream_t st);
 void agh_launch_verify_lean(const agh_scan_args &a, hipStream_t st);
 void agh_launch_find_cuts(const void *text, const uint64_t *bound, const uint64_t *lo,
                           uint32_t n_bounds, uint32_t delim, uint32_t step, uint64_t *cut, hipStream_t st);

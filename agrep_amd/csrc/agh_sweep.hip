@@ -757,6 +757,20 @@ void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *w
                        nw, counters);
 }
 
+// A sharded count-only scan leaves its totals on the device for the all-reduce that follows on the same
+// stream: acc[0] += matched, acc[1] += records (0: lean scans do not number records), acc[2] += "this
+// segment's count-only scan gave up" (the host reruns it and the ranks reduce once more).
+__global__ void k_accumulate_counts(const uint32_t *__restrict__ counters, unsigned long long *__restrict__ acc)
+{
+    acc[0] += counters[AGH_C_MATCHED];
+    acc[2] += (counters[AGH_C_LEAN_FALLBACK] | counters[AGH_C_OVERFLOW]) ? 1ull : 0ull;
+}
+
+void agh_launch_accumulate_counts(const uint32_t *counters, uint64_t *acc, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_accumulate_counts, dim3(1), dim3(1), 0, st, counters, (unsigned long long *)acc);
+}
+
 void agh_launch_read_probe(const void *text, uint64_t n, uint32_t *counters, hipStream_t st)
 {
     const uint64_t n_strips = n >> AGH_STRIP_SHIFT;

@@ -6,8 +6,8 @@ newline-delimited corpus at 1/2/4/8 GPUs.  STRONG scaling: the job is always the
 (16 shards x 4 GiB of SURVEY 8d's generator, seed 12345); rank r of N owns the contiguous
 64/N GiB page range r (N = 8: 8 GiB per GPU = BASELINE configs[3]), resident in HBM before the
 timed region starts.  A "step" is one complete `-c` scan of the rank's range through the C-ABI
-(agh_scan_device: sweep + verify + count of every <= 8 GiB segment, one host sync) followed by
-the RCCL all-reduce of the counts through the C-ABI (agh_reduce_counts, N > 1).
+(agh_scan_device: sweep + verify + count, one host sync); with N > 1 the RCCL all-reduce of the
+counts is part of the same call (agh_scan_device_reduce: enqueued on the scan's stream, still one sync).
 
     python bench.py                     # 1 GPU, the whole 64 GiB
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -478,12 +478,14 @@ def main():
 
         def step():
             # AGH_TIME_SWEEP: HIP events around every k_sweep launch on the scan's stream
+            if dist_on and comm is not None:
+                # scan + the -c aggregate in one call: the counts stay on the device, ncclAllReduce is queued on
+                # the scan's stream behind the kernels, one host synchronisation per step (agh_scan_device_reduce)
+                res, (agg[0], agg[1]) = q.scan_device_reduce(comm, text.data_ptr(), n, flags=A.COUNT, time_sweep=True)
+                return res
             res = q.scan_device(text.data_ptr(), n, flags=A.COUNT | A.TIME_SWEEP, time_scan=False)
-            if dist_on:                         # the -c aggregate: ncclAllReduce through the C-ABI
-                if comm is not None:
-                    agg[0], agg[1] = comm.reduce_counts(res.n_matched, res.n_records)
-                else:
-                    agg[0], agg[1] = shard.reduce_counts(res.n_matched, res.n_records, device="cpu")
+            if dist_on:
+                agg[0], agg[1] = shard.reduce_counts(res.n_matched, res.n_records, device="cpu")
             return res
 
         for _ in range(args.warmup):
@@ -541,7 +543,8 @@ def main():
                        "segments_per_gpu": int(res.n_segments),
                        "sharding": "contiguous page range per rank; the only exchange is the RCCL all-reduce of "
                                    "the counts (agh_reduce_counts)" if world > 1 else "one GPU holds the whole corpus",
-                       "count_reduction": ("agh_reduce_counts (RCCL ncclAllReduce inside the C-ABI)" if comm is not None
+                       "count_reduction": ("agh_scan_device_reduce (RCCL ncclAllReduce inside the C-ABI, enqueued on the scan's "
+                                           "stream with the counts in device memory: one host sync per step)" if comm is not None
                                            else ("torch.distributed/" + backend if dist_on else "none (one rank)")),
                        "engine": {1: "fullscan", 2: "q-gram sample filter + verify"}[res.engine],
                        "filter_sample": "q=%d bytes every h=%d bytes" % (info["filter_q"], info["filter_h"]),

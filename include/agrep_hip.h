@@ -238,6 +238,13 @@ void agh_comm_free(agh_comm *c);
 int agh_reduce_counts(agh_comm *c, uint64_t counts[2]);
 int agh_reduce_counts_all(agh_comm *const *comms, int n, uint64_t (*counts)[2]);
 
+/* One step of a sharded count-only scan: agh_scan_device(flags with AGH_COUNT / AGH_FILENAMEONLY) on this
+ * rank's shard + the sum of (n_matched, n_records) over all ranks in totals[0..1].  The counts stay in device
+ * memory and the all-reduce is enqueued on the scan's stream behind its kernels: one host synchronisation per
+ * step.  Collective: every rank of the communicator calls it (agrep.c:3444-3558 prints one count per file). */
+int agh_scan_device_reduce(agh_query *q, agh_comm *c, const void *dev_text, size_t len, void *stream,
+                           unsigned flags, agh_result *res, uint64_t totals[2]);
+
 /* hits[f] != 0 iff this rank found a match in file f -> the OR over all ranks (ncclMax over
  * bytes): the -l file list of files that were sharded or dealt out across ranks. */
 int agh_reduce_file_hits(agh_comm *c, unsigned char *hits, size_t n_files);

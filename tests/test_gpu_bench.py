@@ -77,12 +77,46 @@ def test_bench_launches_its_own_ranks():
 def test_bench_rccl_code_path_with_one_rank():
     """The nccl branch of bench.py end to end on the one GPU there is: torch.distributed over RCCL,
     rank 0's ncclUniqueId broadcast, the C-ABI's own communicator (agh_comm_init_rank) and
-    agh_reduce_counts (ncclAllReduce) in every timed step -- with a world of one rank."""
+    agh_scan_device_reduce (scan + ncclAllReduce on the scan's stream, one host sync) in every timed step --
+    with a world of one rank."""
     env = dict(os.environ, AGH_BENCH_FORCE_DIST="1", MASTER_PORT="29541")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--total-gib", "0.5", "--steps", "3",
                         "--warmup", "1", "--no-cpu-baseline", "--no-traffic"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     a = _last_json(r.stdout)
-    assert a["config"]["count_reduction"].startswith("agh_reduce_counts")
+    assert a["config"]["count_reduction"].startswith("agh_scan_device_reduce")
     assert a["matched_equals_planted"] is True and a["n_gpus"] == 1
+
+
+def test_scan_device_reduce_one_rank():
+    """agh_scan_device_reduce on a communicator of one rank: the totals are the scan's own counts -- on the
+    fused count-only kernel (device-side sum + ncclAllReduce on the scan's stream), on a text whose count-only
+    scan gives up (a 3 MiB record in front of a match: rerun, second all-reduce), on the one-pass -f kernel
+    and on a query without a count-only pipeline of its own (host-side all-reduce of the same shape)."""
+    import torch
+    import numpy as np
+    import agrep_amd as A
+    import _oracle as O
+    comm = A.Comm(A.Comm.unique_id(), 1, 0)
+    try:
+        text, planted = O.corpus(2048, seed=3, variants=O.VARIANTS_C2, plant_period=40)
+        want = O.asearch(O.PATTERN_C2, 2, text)[0]
+        t = torch.from_numpy(text).cuda()
+        with A.Query(O.PATTERN_C2, 2) as q:
+            res, tot = q.scan_device_reduce(comm, t.data_ptr(), t.numel())
+            assert res.n_matched == tot[0] == want and res.fused_segments == 1
+            # a record longer than the look-back of the count-only verifier, a match at its end
+            long = np.concatenate([np.full(3 << 20, ord("x"), dtype=np.uint8), np.frombuffer(b" approximatematch\n", dtype=np.uint8), text])
+            tl = torch.from_numpy(long).cuda()
+            res2, tot2 = q.scan_device_reduce(comm, tl.data_ptr(), tl.numel())
+            assert res2.lean_reruns == 1 and res2.n_matched == tot2[0] == want + 1
+            res3, tot3 = q.scan_device_reduce(comm, t.data_ptr(), t.numel(), flags=A.COUNT | A.FORCE_NUMBERED)
+            assert res3.n_matched == tot3[0] == want and tot3[1] == res3.n_records > 0
+        pats = [b"approxim", b"matematch", b"zzzzqqqq"]
+        with A.Query.multi(pats, k=1) as qm:
+            r4, tot4 = qm.scan_device_reduce(comm, t.data_ptr(), t.numel())
+            r5 = qm.scan_device(t.data_ptr(), t.numel(), flags=A.COUNT | A.FORCE_NUMBERED)
+            assert r4.fused_segments == 1 and r4.n_matched == tot4[0] == r5.n_matched > 0
+    finally:
+        comm.close()
