@@ -335,6 +335,10 @@ extern "C" agh_query *agh_query_literal_ex(const unsigned char *pat, int m, int 
                                            const unsigned char *delim, int dlen)
 {
     const int nocase = (qflags & AGH_Q_NOCASE) ? 1 : 0;
+    if ((qflags & AGH_Q_WORD) && (qflags & AGH_Q_WHOLELINE)) {          // agrep.c:2188-2196
+        fail("illegal option combination (-x and -w)");
+        return nullptr;
+    }
     // guard positions around the pattern: -x wraps it into '\n' (sgrep.c:252-259), -w into the class
     // of non-alphanumeric bytes (the test bm() makes on the bytes next to an occurrence, sgrep.c:750-756)
     const int guard = (qflags & AGH_Q_WHOLELINE) ? 2 : ((qflags & AGH_Q_WORD) ? 1 : 0);
@@ -836,6 +840,10 @@ extern "C" agh_query *agh_query_multi(const unsigned char *const *pats, const in
 extern "C" agh_query *agh_query_multi_ex(const unsigned char *const *pats, const int *lens, int npat,
                                          unsigned qflags, const unsigned char *delim, int dlen)
 {
+    if ((qflags & AGH_Q_WORD) && (qflags & AGH_Q_WHOLELINE)) {          // agrep.c:2188-2196
+        fail("illegal option combination (-x and -w)");
+        return nullptr;
+    }
     return build_multi(pats, lens, npat, 0, (qflags & AGH_Q_NOCASE) ? 1 : 0, delim, dlen,
                        (qflags & AGH_Q_WHOLELINE) ? 2 : ((qflags & AGH_Q_WORD) ? 1 : 0));
 }
@@ -930,12 +938,7 @@ extern "C" int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q,
     return 0;
 }
 
-// AGH_TIGHT_VERIFY=0: offset-blind verify windows, no false-positive rejection (A/B runs).
-static bool tight_verify_enabled()
-{
-    const char *e = getenv("AGH_TIGHT_VERIFY");
-    return !(e && e[0] == '0');
-}
+// (AGH_TIGHT_VERIFY=0: offset-blind verify windows, no false-positive rejection -- A/B runs; q->tune)
 
 // Full scan, fast form (k_fullscan_fast + k_fullscan_replay): unit costs, a one-byte delimiter that
 // no pattern position accepts.  The replay lists live in the candidate buffers a full scan does not
@@ -943,9 +946,7 @@ static bool tight_verify_enabled()
 #define AGH_FF_SLICE_HOST 256u      // = AGH_FF_SLICE (agh_fullscan.hip)
 static bool fs_fast_ok(const agh_query *q)
 {
-    const char *e = getenv("AGH_FS_FAST");
-    if (e && e[0] == '0') return false;
-    if (q->fs_fast_off || q->multi) return false;
+    if (!q->tune.fs_fast || q->fs_fast_off || q->multi) return false;
     // table engine (k_tablescan_fast + k_table_replay): unit costs, one-byte delimiter
     if (q->table) return q->ci == 1 && q->cs == 1 && q->cd == 1 && !(q->dlen > 1 || q->delim_fold);
     // k = 0: one level, nothing to pack -- the one-kernel form is faster there (3.8 vs 3.2 TB/s)
@@ -1124,6 +1125,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         if (!(flags & AGH_TIME_SWEEP)) sa.ev_begin = sa.ev_end = nullptr;   // two events cost ~11 us per scan
         agh_scan_args va;
         memset(&va, 0, sizeof(va));
+        va.verify_blocks = q->tune.verify_blocks;
         va.mk.counters = q->d_counters;
         va.mk.hashset = (uint64_t *)q->hashset.p;
         va.mk.hashset_mask = (uint32_t)(slots - 1);
@@ -1138,7 +1140,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.nw = (uint32_t)nw;
         va.wave_prefix = (const uint32_t *)q->wave_totals.p;
         va.dbm = d_dbm;
-        va.gtab = tight_verify_enabled() ? q->d_gtab : nullptr;
+        va.gtab = q->tune.tight_verify ? q->d_gtab : nullptr;
         va.gram_spread = q->gram_spread;
         if (multi && q->multi_dense) {
             // dense hit set: probes and verification of the full strips in one kernel, nothing goes
@@ -1206,6 +1208,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
         agh_scan_args va;
         memset(&va, 0, sizeof(va));
+        va.verify_blocks = q->tune.verify_blocks;
         va.text = d_text;
         va.n = n;
         va.q = dq;
@@ -1323,6 +1326,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         }
         agh_scan_args va;
         memset(&va, 0, sizeof(va));
+        va.verify_blocks = q->tune.verify_blocks;
         va.text = d_text;
         va.n = n;
         va.q = dq;
@@ -1346,7 +1350,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.match_cap = invert_list ? 0u : match_cap;
         va.mk.hashset = nullptr;
         va.mk.hashset_mask = 0;
-        va.gtab = (tight_verify_enabled() && !multi) ? q->d_gtab : nullptr;
+        va.gtab = (q->tune.tight_verify && !multi) ? q->d_gtab : nullptr;
         va.gram_spread = q->gram_spread;
         if (!multi && !use_filter && fs_fast_setup(q, n, &va)) return -1;
         const bool fs_fast = va.fs_fast != 0;
@@ -1374,7 +1378,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         swept = true;
 
         const uint32_t n_delims = q->h_counters[AGH_C_NDELIM];
-        if (getenv("AGH_DEBUG"))
+        if (q->tune.debug)
             fprintf(stderr, "[agh] attempt %d multi %d dense %d filter %d: ndelim %u cand %u overflow %u "
                             "bm_overflow %u matched %u bm_bits %llu\n", attempt, (int)multi,
                     (int)q->multi_dense, (int)use_filter, n_delims, q->h_counters[AGH_C_CAND],
@@ -1430,10 +1434,11 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
 // ---------------------------------------------------------------------------------------
 static uint64_t seg_nominal(const agh_query *q)
 {
-    const char *e = getenv("AGH_SEG_MAX_MB");           // tests: tiny segments
-    if (e && *e) {
-        uint64_t mb = strtoull(e, nullptr, 10);
-        if (mb >= 1 && mb <= 8192) return mb << 20;
+    if (q->tune.seg_max_mb) {                                       // AGH_SEG_MAX_MB (tests: tiny segments)
+        // (H = 2 candidates are 32-bit halfword indices: 8 GiB reach, so 4 GiB nominal at most)
+        const uint64_t mb = (q->fh == 2 && !q->multi && !q->piece_single) ? std::min<uint64_t>(q->tune.seg_max_mb, 4096)
+                                                                         : q->tune.seg_max_mb;
+        return mb << 20;
     }
     if (q->multi || q->piece_single) return (uint64_t)2 << 30;
     // H == 2 candidates are 32-bit HALFWORD indices in numbered scans: 8 GiB reach, 4 GiB nominal
@@ -1449,7 +1454,7 @@ static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, 
     // entries and need no record numbers, so ONE kernel sequence covers up to 64 GiB (bounded only by
     // the candidate slices: 1/8 of the text); everything else is limited by 32-bit indices.
     uint64_t nominal = seg_nominal(q);
-    if (lean && !getenv("AGH_SEG_MAX_MB")) nominal = AGH_LEAN_SEG_MAX;
+    if (lean && !q->tune.seg_max_mb) nominal = AGH_LEAN_SEG_MAX;
     if (len > nominal) {
         const uint64_t nb = (len - 1) / nominal;        // boundaries strictly inside the text
         if (nb + 1 > AGH_MAX_SEGS) return fail("input too large: more than %d segments", AGH_MAX_SEGS);
@@ -1478,7 +1483,7 @@ static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, 
         if (find(global_dbm ? 64u : 16u, h_cut)) return -1;
         bool missing = false;
         for (uint64_t i = 0; i < nb; ++i) missing = missing || !h_cut[i];
-        if (missing && !getenv("AGH_ALIGNED_CUTS_ONLY")) {
+        if (missing && !q->tune.aligned_cuts_only) {
             std::vector<uint64_t> any(nb, 0);
             if (find(1u, any.data())) return -1;
             for (uint64_t i = 0; i < nb; ++i)
@@ -1509,11 +1514,47 @@ static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, 
 //   * AGH_FILENAMEONLY (-l, asearch.c:130-161 returns at the first match): parts grow from
 //     64 MiB, the host looks at the hit flag after each and stops at the first part with a hit.
 // ---------------------------------------------------------------------------------------
-uint64_t agh_env_mb(const char *name, uint64_t dflt_mb)
+static uint64_t env_u64(const char *name, uint64_t dflt)
 {
     const char *e = getenv(name);
     if (e && *e) return strtoull(e, nullptr, 10);
-    return dflt_mb;
+    return dflt;
+}
+static long env_long(const char *name)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? (long)strtoul(e, nullptr, 10) : -1;
+}
+static bool env_on(const char *name, bool dflt)
+{
+    const char *e = getenv(name);
+    return e && *e ? e[0] != '0' : dflt;
+}
+
+// The environment switches, once per query (agh_tuning, agh_launch.h).
+void agh_read_tuning(agh_tuning *t)
+{
+    t->live = env_on("AGH_ENV_LIVE", false);
+    t->tight_verify = env_on("AGH_TIGHT_VERIFY", true);
+    t->fs_fast = env_on("AGH_FS_FAST", true);
+    t->fused = env_on("AGH_FUSED", AGH_FUSED_DEFAULT != 0);
+    t->debug = getenv("AGH_DEBUG") != nullptr;
+    t->aligned_cuts_only = getenv("AGH_ALIGNED_CUTS_ONLY") != nullptr;
+    t->stream = env_u64("AGH_STREAM", 1) != 0;
+    {
+        const uint64_t mb = env_u64("AGH_SEG_MAX_MB", 0);
+        t->seg_max_mb = (mb >= 1 && mb <= 8192) ? mb : 0;
+    }
+    t->part_mb = env_u64("AGH_PART_MB", AGH_PART_MB_DEFAULT);
+    t->overlap = env_u64("AGH_OVERLAP", AGH_OVERLAP_DEFAULT) != 0;
+    t->fused_min_mb = env_u64("AGH_FUSED_MIN_MB", AGH_FUSED_MIN_MB_DEFAULT);
+    t->stream_seg_mb = std::max<uint64_t>(env_u64("AGH_STREAM_SEG_MB", 1024), 1);
+    t->readers = (unsigned)env_u64("AGH_READERS", 0);
+    t->fused_range_kb = env_long("AGH_FUSED_RANGE_KB");
+    t->fused_tail_kb = env_long("AGH_FUSED_TAIL_KB");
+    t->fused_tail_mb = env_long("AGH_FUSED_TAIL_MB");
+    t->fused_blocks = env_long("AGH_FUSED_BLOCKS");
+    t->verify_blocks = env_long("AGH_VERIFY_BLOCKS");
 }
 
 // CUs of the current device (the fused lean kernel launches persistent workgroups)
@@ -1532,12 +1573,7 @@ static uint32_t device_cus()
     return cached;
 }
 
-// AGH_FUSED=0: count-only scans as two kernels (k_sweep, then k_verify) instead of the fused one
-static bool fused_enabled()
-{
-    const char *e = getenv("AGH_FUSED");
-    return e ? e[0] != '0' : AGH_FUSED_DEFAULT != 0;
-}
+// (AGH_FUSED=0: count-only scans as two kernels -- k_sweep, then k_verify -- instead of the fused one; q->tune)
 
 static bool lean_pipeline_ok(const agh_query *q, unsigned flags, bool want_list)
 {
@@ -1571,11 +1607,11 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     const bool timing = (flags & AGH_TIME_SWEEP) != 0;
     // part size: a multiple of 8 wave ranges (2 MiB) so verify workgroups never straddle parts
     const uint64_t part_unit = (uint64_t)AGH_WAVE_STRIPS * AGH_STRIP * 8u;
-    uint64_t part_bytes = agh_env_mb("AGH_PART_MB", AGH_PART_MB_DEFAULT) << 20;
+    uint64_t part_bytes = q->tune.part_mb << 20;
     part_bytes = part_bytes / part_unit * part_unit;
     uint64_t max_n = 0;
     for (int i = 0; i < nseg; ++i) max_n = std::max(max_n, cuts[i + 1] - cuts[i]);
-    const bool overlap = agh_env_mb("AGH_OVERLAP", AGH_OVERLAP_DEFAULT) != 0 && !early &&
+    const bool overlap = q->tune.overlap && !early &&
                          (nseg > 1 || (part_bytes && part_bytes < max_n));
     const uint64_t max_strips = (max_n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint64_t max_nw = (max_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
@@ -1602,9 +1638,9 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     }
     // work counters of the fused kernel: a line of their own each -- on the counters' line the
     // sweepers' ticket atomics would queue behind the verifier's ANYHIT stores
-    const uint64_t fused_min = agh_env_mb("AGH_FUSED_MIN_MB", AGH_FUSED_MIN_MB_DEFAULT) << 20;
-    const bool may_fuse = !early && !overlap && !part_bytes && fused_enabled() && max_n >= fused_min &&
-                          tight_verify_enabled() && q->d_gtab;
+    const uint64_t fused_min = q->tune.fused_min_mb << 20;
+    const bool may_fuse = !early && !overlap && !part_bytes && q->tune.fused && max_n >= fused_min &&
+                          q->tune.tight_verify && q->d_gtab;
     if (may_fuse) {
         if (q->tickets.ensure((size_t)nseg * 256u)) return -1;
         HIP_TRY(hipMemsetAsync(q->tickets.p, 0, (size_t)nseg * 256u, st));
@@ -1672,6 +1708,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         sa.lean = 1;
         agh_scan_args va;
         memset(&va, 0, sizeof(va));
+        va.verify_blocks = q->tune.verify_blocks;
         va.mk.counters = d_cnt;
         va.mk.hashset = (uint64_t *)q->hashset.p;
         va.mk.hashset_mask = (uint32_t)(slots - 1);
@@ -1685,7 +1722,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         va.wave_cand = (const uint32_t *)wcand[slot]->p;
         va.nw = nw;
         va.wave_prefix = (const uint32_t *)q->wave_totals.p;
-        va.gtab = tight_verify_enabled() ? q->d_gtab : nullptr;
+        va.gtab = q->tune.tight_verify ? q->d_gtab : nullptr;
         va.gram_spread = q->gram_spread;
 
         // one kernel for sweep + verify where the query's shape has a fused instance; the partial
@@ -1704,6 +1741,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
             fa.mk = va.mk;
             fa.n_cu = device_cus();
             fa.ticket = (uint32_t *)((char *)q->tickets.p + (size_t)i * 256u);
+            fa.tune = &q->tune;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (timing) {
                 if (get_events(q->time_events, n_time + 2, hipEventDefault)) return -1;
@@ -2046,6 +2084,7 @@ extern "C" int agh_scan_device(agh_query *q, const void *dev_text, size_t len, v
                                unsigned flags, agh_result *res, void *dev_match_pos,
                                size_t match_cap)
 {
+    if (q) agh_refresh_tuning(q);
     return agh_scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res,
                             (uint64_t *)dev_match_pos, nullptr, dev_match_pos ? match_cap : 0, true, true);
 }
@@ -2060,6 +2099,7 @@ extern "C" int agh_scan_device_reduce(agh_query *q, agh_comm *c, const void *dev
                                       unsigned flags, agh_result *res, uint64_t totals[2])
 {
     if (!q || !c || !res || !totals) return fail("null argument");
+    agh_refresh_tuning(q);
     if (!q->d_acc) {
         HIP_TRY(hipMalloc((void **)&q->d_acc, 4 * sizeof(uint64_t)));
         HIP_TRY(hipHostMalloc((void **)&q->h_acc, 4 * sizeof(uint64_t)));

@@ -291,8 +291,8 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     // KiB per ticket (a multiple of 8: the ticket for the next range is requested half-way); the
     // diagnostics overrides are clamped -- a zero grid or a wrapped range size must not reach the launch
     uint32_t range_strips = AGH_WAVE_STRIPS;
-    if (const char *e = getenv("AGH_FUSED_RANGE_KB")) {
-        const unsigned long v = strtoul(e, nullptr, 10);
+    if (a.tune && a.tune->fused_range_kb >= 0) {
+        const unsigned long v = (unsigned long)a.tune->fused_range_kb;
         range_strips = (uint32_t)((v > 65536ul ? 65536ul : v) + 7ul) & ~7u;
     }
     if (range_strips < 16u) range_strips = 16u;
@@ -303,12 +303,12 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     // neutral (1.413 -> 1.419 ms) and 64 KiB ones cost 1-5 %
     uint32_t tail_strips = AGH_FU_TAIL_KB_DEFAULT;
     uint64_t tail_total = (uint64_t)AGH_FU_TAIL_MB_DEFAULT << 10;            // in strips (KiB)
-    if (const char *e = getenv("AGH_FUSED_TAIL_KB")) {
-        const unsigned long v = strtoul(e, nullptr, 10);
+    if (a.tune && a.tune->fused_tail_kb >= 0) {
+        const unsigned long v = (unsigned long)a.tune->fused_tail_kb;
         tail_strips = (uint32_t)((v > 65536ul ? 65536ul : v) + 7ul) & ~7u;
     }
-    if (const char *e = getenv("AGH_FUSED_TAIL_MB")) {
-        const unsigned long v = strtoul(e, nullptr, 10);
+    if (a.tune && a.tune->fused_tail_mb >= 0) {
+        const unsigned long v = (unsigned long)a.tune->fused_tail_mb;
         tail_total = (uint64_t)(v > (1ul << 20) ? (1ul << 20) : v) << 10;
     }
     if (tail_strips < 8u) tail_strips = 8u;
@@ -337,8 +337,8 @@ static void launch_fused(const agh_fused_args &a, uint32_t tspan, hipStream_t st
     uint32_t blocks = a.n_cu * WG_PER_CU;
     const uint32_t need = (n_ranges + (uint32_t)NS - 1u) / (uint32_t)NS;
     if (blocks > need) blocks = need;
-    if (const char *e = getenv("AGH_FUSED_BLOCKS")) {                        // (A/B runs)
-        const unsigned long v = strtoul(e, nullptr, 10);
+    if (a.tune && a.tune->fused_blocks >= 0) {                               // (A/B runs)
+        const unsigned long v = (unsigned long)a.tune->fused_blocks;
         blocks = (uint32_t)(v < 1ul ? 1ul : (v > (unsigned long)a.n_cu * 8ul ? (unsigned long)a.n_cu * 8ul : v));
     }
     hipLaunchKernelGGL((k_sweep_fused<WT, H, MODE, K, NCH, NV, NS>), dim3(blocks), dim3(64 * (NS + NV)), 0,

@@ -62,7 +62,10 @@ struct dev_buf {
 #define AGH_LEAN_SLOTS 2      // segments of the lean pipeline in flight (sweep i+1 | verify i)
 #define AGH_MAX_SEGS 256      // segments of one scan (8 GiB each: 2 TiB)
 
+__attribute__((visibility("hidden"))) void agh_read_tuning(agh_tuning *t);
+
 struct agh_query {
+    agh_query() { agh_read_tuning(&tune); }
     int m = 0, k = 0, dlen = 1, wide = 0;
     bool delim_fold = false;            // -i with letters in a multi-byte delimiter
     unsigned char delim[AGH_MAX_DELIM] = {'\n'};
@@ -124,6 +127,7 @@ struct agh_query {
     int npat = 0;
     void *d_mp_bits = nullptr, *d_mp_bstart = nullptr, *d_mp_items = nullptr, *d_mp_pool = nullptr,
          *d_mp_omask = nullptr;
+    agh_tuning tune;                    // the environment switches as they were when the query was created
     // agh_scan_device_reduce: the communicator of the step in progress, its totals on the device / pinned
     struct agh_comm *reduce_comm = nullptr;
     uint64_t *d_acc = nullptr, *h_acc = nullptr;        // matched, records, segments that gave up (+ 1 spare)
@@ -143,7 +147,8 @@ extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_dev(stru
 extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_host(struct agh_comm *c, uint64_t *v, size_t count);
 
 // ---- agh_api.cpp ------------------------------------------------------------------------------
-uint64_t agh_env_mb(const char *name, uint64_t dflt_mb) __attribute__((visibility("hidden")));
+// at the start of every public scan call: AGH_ENV_LIVE=1 re-reads the switches (tests, A/B scripts)
+static inline void agh_refresh_tuning(agh_query *q) { if (q->tune.live) agh_read_tuning(&q->tune); }
 // one scan of text resident in HBM, cut into segments as the query needs; d_match_pos / d_match_rec
 // (device, match_cap entries) receive one position / the record number per matched record
 __attribute__((visibility("hidden"))) int agh_scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,

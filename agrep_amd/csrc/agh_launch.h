@@ -6,6 +6,26 @@
 
 #include "agh_device.h"
 
+// Environment switches (DESIGN.md "Environment switches"), read ONCE when a query is created -- no getenv on
+// a scan path.  AGH_ENV_LIVE=1 (the test suite, A/B scripts) re-reads them at the start of every scan call.
+struct agh_tuning {
+    bool live = false;              // AGH_ENV_LIVE
+    bool tight_verify = true;       // AGH_TIGHT_VERIFY
+    bool fs_fast = true;            // AGH_FS_FAST
+    bool fused = true;              // AGH_FUSED
+    bool debug = false;             // AGH_DEBUG
+    bool aligned_cuts_only = false; // AGH_ALIGNED_CUTS_ONLY
+    bool stream = true;             // AGH_STREAM
+    uint64_t seg_max_mb = 0;        // AGH_SEG_MAX_MB (0: unset)
+    uint64_t part_mb = 0;           // AGH_PART_MB
+    bool overlap = false;           // AGH_OVERLAP
+    uint64_t fused_min_mb = 4096;   // AGH_FUSED_MIN_MB
+    uint64_t stream_seg_mb = 1024;  // AGH_STREAM_SEG_MB
+    unsigned readers = 0;           // AGH_READERS (0: unset)
+    long fused_range_kb = -1, fused_tail_kb = -1, fused_tail_mb = -1, fused_blocks = -1;   // AGH_FUSED_* (-1: unset)
+    long verify_blocks = -1;        // AGH_VERIFY_BLOCKS (-1: unset)
+};
+
 struct agh_marks {
     uint32_t *bitmap;        // one bit per record
     uint32_t bitmap_bits;    // capacity; larger record numbers raise AGH_C_BM_OVERFLOW
@@ -64,6 +84,7 @@ struct agh_scan_args {
     int fs_fast;
     uint64_t *fs_replay;
     uint32_t *fs_tile_cnt;
+    long verify_blocks;      // AGH_VERIFY_BLOCKS: grid cap of k_verify (-1: the default)
 };
 
 void agh_launch_sweep(const agh_sweep_args &a, int H, hipStream_t st);
@@ -81,6 +102,7 @@ struct agh_fused_args {
     agh_marks mk;            // hash set + counters
     uint32_t *ticket;        // zeroed work counter in a cache line of its own
     uint32_t n_cu;
+    const agh_tuning *tune;  // AGH_FUSED_RANGE_KB / _TAIL_KB / _TAIL_MB / _BLOCKS overrides (A/B runs)
 };
 bool agh_launch_sweep_fused(const agh_fused_args &a, int H, hipStream_t st);
 void agh_launch_verify(const agh_scan_args &a, hipStream_t st);

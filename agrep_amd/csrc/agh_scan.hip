@@ -164,7 +164,7 @@ static void launch_verify_n(const agh_scan_args &a, const uint64_t *gtab, uint32
     uint32_t blocks = (w_hi - g_base + AGH_VGROUP - 1u) / AGH_VGROUP;
     {   // grid cap (workgroups loop over the groups); AGH_VERIFY_BLOCKS=0: one workgroup per group
         uint32_t cap = 16384u;                  // A/B on 64 GiB: 0 / 4096 / 8192 / 16384 all within 0.5 %
-        if (const char *e = getenv("AGH_VERIFY_BLOCKS")) cap = (uint32_t)strtoul(e, nullptr, 10);
+        if (a.verify_blocks >= 0) cap = (uint32_t)a.verify_blocks;
         if (cap && blocks > cap) blocks = cap;
     }
     if (a.general)                          // single-byte delimiters only (the host checks)

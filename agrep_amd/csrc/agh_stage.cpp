@@ -65,6 +65,7 @@ extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t l
                                unsigned flags, agh_result *res, agh_match *matches, size_t cap)
 {
     if (!q || !res || (!text && len)) return fail("null argument");
+    agh_refresh_tuning(q);
     if (q->staging.ensure(((len + 15) & ~(size_t)15) + 16)) return -1;
     if (len) HIP_TRY(hipMemcpy(q->staging.p, text, len, hipMemcpyHostToDevice));
     return scan_staged(q, len, flags, res, matches, cap);
@@ -84,7 +85,7 @@ struct fd_reader {
     bool ranged = false;            // an explicit range: never read past it
     unsigned n_readers = 1;
 
-    int open_fd(int fd_, bool with_range, uint64_t begin, uint64_t end)
+    int open_fd(int fd_, bool with_range, uint64_t begin, uint64_t end, unsigned readers_override = 0)
     {
         fd = fd_;
         ranged = with_range;
@@ -101,7 +102,7 @@ struct fd_reader {
         }
         n_readers = std::thread::hardware_concurrency();
         if (n_readers > 16) n_readers = 16;
-        if (const char *e = getenv("AGH_READERS")) n_readers = (unsigned)atoi(e);
+        if (readers_override) n_readers = readers_override;      // AGH_READERS
         if (n_readers < 1) n_readers = 1;
         return 0;
     }
@@ -276,6 +277,7 @@ extern "C" int agh_scan_device_emit(agh_query *q, const void *dev_text, size_t l
                                     agh_result *res, agh_emit_fn emit, void *ctx)
 {
     if (!q || !res || !emit) return fail("null argument");
+    agh_refresh_tuning(q);
     memset(res, 0, sizeof(*res));
     res->n_bytes = len;
     if (!len) return 0;
@@ -409,7 +411,7 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
                      const rec_sink *sink)
 {
     memset(res, 0, sizeof(*res));
-    const uint64_t seg_cap = std::max<uint64_t>(agh_env_mb("AGH_STREAM_SEG_MB", 1024), 1) << 20;
+    const uint64_t seg_cap = q->tune.stream_seg_mb << 20;
     const bool early = !sink && (flags & AGH_FILENAMEONLY) != 0;
     // -l: small first segments (1 MiB, x4 each time) so that a hit near the top of a file is reported after
     // the first megabyte has been read and scanned, whatever the engine costs
@@ -525,7 +527,8 @@ static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, u
     if (with_range && end < begin) return fail("empty byte range");
     if (ensure_stage_resources(q)) return -1;
     fd_reader rd;
-    if (rd.open_fd(fd, with_range, begin, end)) return -1;
+    agh_refresh_tuning(q);
+    if (rd.open_fd(fd, with_range, begin, end, q->tune.readers)) return -1;
     const bool count_only = (flags & (AGH_COUNT | AGH_FILENAMEONLY)) && !(matches && cap) && !sink;
     // one rank's shard of a file: the virtual head byte / the appended delimiter (asearch.c:69-91)
     // belong to the shards that hold the file's first / last byte
@@ -535,7 +538,7 @@ static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, u
         is_first = begin == 0;
         is_last = !(fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && end < (uint64_t)sb.st_size);
     }
-    if ((count_only || sink) && agh_env_mb("AGH_STREAM", 1) != 0)
+    if ((count_only || sink) && q->tune.stream)
         return pipe_scan(q, rd, flags, res, is_first, is_last, sink);
 
     // a match ARRAY wanted (agh_scan_fd with matches / cap; or AGH_STREAM=0): the whole input is staged,
@@ -662,6 +665,7 @@ extern "C" int agh_rescan_staged(agh_query *q, unsigned flags, agh_result *res,
                                  agh_match *matches, size_t cap)
 {
     if (!q || !res) return fail("null argument");
+    agh_refresh_tuning(q);
     return scan_staged(q, q->staged_len, flags, res, matches, cap, q->staged_first, q->staged_last);
 }
 

@@ -9,9 +9,9 @@
  *   -B best match       agrep.c:3582-3728
  *   Grand Total, exit   agrep.c:3229-3231, main.c:78-96
  *
- * Everything outside the hot path (regular expressions, boolean patterns, character classes,
- * -r, -f, -v, weighted costs ...) is rejected with exit status 2: this binary is the
- * hot-path driver, not a re-implementation of agrep's control plane.  There is no CPU scan
+ * Everything outside the hot path (regular expressions, boolean patterns, character classes, -r ...)
+ * is rejected with exit status 2: this binary is the hot-path driver, not a re-implementation of
+ * agrep's control plane (the reference's own front end linked onto the same engines: ref_shim.c).  There is no CPU scan
  * engine here; without a HIP device the library calls fail and so does this program.
  */
 #include <errno.h>
@@ -177,6 +177,19 @@ static int parse_options(int argc, char **argv, char **files)
         }
     }
     if (opt.pattern == NULL) die_usage("no pattern");
+    /* agrep.c:2188-2196 (and :2661-2664): "illegal option combination (-x and -w)" */
+    if (opt.WORDBOUND && opt.WHOLELINE) die_usage("illegal option combination (-x and -w)");
+    /* -f with errors checks an occurrence by edit distance, the -w / -x tests need a verbatim one */
+    if (opt.pattern_file && opt.approx_f && opt.D > 0 && (opt.WORDBOUND || opt.WHOLELINE))
+        die_usage("-w / -x with a pattern file need exact matching (drop --approx-f or -#)");
+    /* a delimiter of several bytes with letters under -i: where a record ends is decided on folded bytes,
+     * which agh_shard_cuts_fd (raw bytes) does not see -- such files are not cut into shards */
+    if (opt.gpus && opt.NOUPPER && opt.dlen > 1) {
+        int j, letters = 0;
+        for (j = 0; j < opt.dlen; j++)
+            letters |= (opt.delim[j] >= 'a' && opt.delim[j] <= 'z') || (opt.delim[j] >= 'A' && opt.delim[j] <= 'Z');
+        if (letters) die_usage("--gpus with -i and a multi-byte delimiter that holds letters is not supported");
+    }
     if (opt.pattern_file) {
         /* compat.c:26-37: -B is ignored with -f; -# is not supported with -f (warning only) */
         if (opt.BESTMATCH) opt.BESTMATCH = 0;
@@ -426,9 +439,25 @@ static void *gpu_worker(void *arg)
     return NULL;
 }
 
+struct comm_init {
+    agh_comm **comms;
+    int n, rc;
+    char err[256];
+};
+
+static void *comm_init_thread(void *arg)
+{
+    struct comm_init *c = (struct comm_init *)arg;
+    c->rc = agh_comm_init_all(c->comms, c->n, NULL);
+    if (c->rc) snprintf(c->err, sizeof(c->err), "%s", agh_last_error());
+    return NULL;
+}
+
 static long run_multi_gpu(query_builder build, char **files, int nfiles, long *files_matched)
 {
     const int G = opt.gpus;
+    struct comm_init ci;
+    pthread_t ci_th;
     const int want_records = !opt.COUNT && !opt.FILENAMEONLY && !opt.SILENT;
     struct gpu_task *tasks = (struct gpu_task *)calloc((size_t)G, sizeof(*tasks));
     pthread_t *th = (pthread_t *)calloc((size_t)G, sizeof(*th));
@@ -440,10 +469,13 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
         fprintf(stderr, "%s: --gpus %d but only %d HIP device(s) are visible\n", Progname, G, agh_device_count());
         exit(2);
     }
-    if (agh_comm_init_all(comms, G, NULL)) {
-        fprintf(stderr, "%s: RCCL: %s\n", Progname, agh_last_error());
-        exit(2);
-    }
+    /* the communicators are needed only for the reductions at the end: ncclCommInitAll (~2 s) runs on a
+     * thread of its own while the workers read and scan their shards */
+    ci.comms = comms;
+    ci.n = G;
+    ci.rc = 0;
+    ci.err[0] = 0;
+    pthread_create(&ci_th, NULL, comm_init_thread, &ci);
     for (r = 0; r < G; r++) {
         tasks[r].rank = r;
         tasks[r].ngpus = G;
@@ -456,6 +488,11 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
         pthread_create(&th[r], NULL, gpu_worker, &tasks[r]);
     }
     for (r = 0; r < G; r++) pthread_join(th[r], NULL);
+    pthread_join(ci_th, NULL);
+    if (ci.rc) {
+        fprintf(stderr, "%s: RCCL: %s\n", Progname, ci.err);
+        exit(2);
+    }
     for (r = 0; r < G; r++)
         if (tasks[r].failed) { fprintf(stderr, "%s: %s\n", Progname, tasks[r].err); exit(2); }
 

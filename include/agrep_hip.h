@@ -82,7 +82,7 @@ typedef struct {
     double   sweep_ms;      /* AGH_TIME_SWEEP (else 0): of which the k_sweep / k_sweep_fused kernel launches (the kernel that
                                reads every byte), hipEvents recorded right around them on the scan stream */
     uint32_t sweep_launches;/* AGH_TIME_SWEEP: number of k_sweep launches sweep_ms is the sum of */
-    uint32_t lean_reruns;   /* segments whose count-only (lean) scan gave up (a record start more than 64 KiB
+    uint32_t lean_reruns;   /* segments whose count-only (lean) scan gave up (a record start more than 1 MiB
                                in front of a match, hash set full, candidate slices full) and were scanned
                                again on the numbered pipeline: the result is exact, the time doubled */
     uint32_t n_segments;    /* kernel sequences the text was cut into (<= 8 GiB each, at record boundaries) */
@@ -111,7 +111,8 @@ agh_query *agh_query_literal(const unsigned char *pat, int m, int D, int nocase,
  *   AGH_Q_WHOLELINE  -x   WHOLELINE: char_tr() wraps the pattern into "\n pat \n" (sgrep.c:252-259):
  *                         the occurrence is a whole line
  * With D > 0 no error may touch the guard positions (maskgen.c:171-187 sets their NO_ERR_MASK bits).
- * m <= AGH_MAX_PATTERN - 2 with a guard. */
+ * m <= AGH_MAX_PATTERN - 2 with a guard.  AGH_Q_WORD together with AGH_Q_WHOLELINE is refused, as the
+ * reference refuses -w with -x (agrep.c:2188-2196). */
 #define AGH_Q_NOCASE    0x1u
 #define AGH_Q_WORD      0x2u
 #define AGH_Q_WHOLELINE 0x4u
@@ -259,7 +260,9 @@ int agh_reduce_file_hits_all(agh_comm *const *comms, int n, unsigned char *const
  * `agrep-hip --gpus`.  fd must be seekable (pread).  delim/dlen as in agh_query_literal; a delimiter of
  * several bytes must not overlap itself (no proper prefix that is also a suffix: "\r\n", "; ", "$$$" is
  * refused with errno 123) -- only then does the leftmost non-overlapping reading of the delimiters not
- * depend on where the search starts. */
+ * depend on where the search starts.  The search is on raw bytes: under -i a delimiter of several bytes that
+ * holds letters ends records on its case variants too, which this function does not see -- do not shard such
+ * inputs (agrep-hip --gpus refuses them). */
 int agh_shard_cuts_fd(int fd, const unsigned char *delim, int dlen, int nranks, uint64_t *cuts);
 
 /* agh_scan_fd restricted to the byte range [begin, end) of a seekable file -- one rank's shard. */

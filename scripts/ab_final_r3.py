@@ -5,6 +5,7 @@ workgroups (AGH_FUSED_BLOCKS; shipped: 2 per CU of 6 sweeping + 2 verifying wave
 1 per CU of 8 + 2 waves else).
 usage: scripts/ab_final_r3.py [total GiB, default 64] [steps, default 10]"""
 import os, sys, time
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 os.environ["AGH_FUSED_MIN_MB"] = "0"

@@ -3,6 +3,7 @@ k_verify) against AGH_FUSED=1 (sweep + verify in one kernel, agh_fused.hip), k =
 corpus, plus ragged sizes for the tail path.  usage: scripts/ab_fused.py [total GiB, default 64] [steps]
 AGH_LIB_PATH=<variant .so> runs the same against another build (e.g. make -C agrep_amd/csrc FT_BITS=14)."""
 import os, sys, time
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 os.environ["AGH_FUSED_MIN_MB"] = "0"      # compare the two forms at every size (the default picks by size)

@@ -1,6 +1,7 @@
 """Fused against two-kernel count-only scans when candidates are dense: patterns cut out of the
 corpus itself (its vocabulary is small, so their grams are everywhere).  usage: [GiB, default 4]"""
 import os, sys, time
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 os.environ["AGH_FUSED_MIN_MB"] = "0"      # compare the two forms at every size (the default picks by size)

@@ -2,6 +2,7 @@
 AGH_PART_MB (sweep launches per segment) x AGH_OVERLAP (verifier on a second stream), k = 2 and 0,
 on the bench corpus.  usage: scripts/ab_pipeline.py [total GiB, default 64] [steps, default 10]"""
 import os, sys, time
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import torch

@@ -4,6 +4,7 @@ q = 4 sample shape (AGH_SHAPE_H2, read when the query is built) against H = 4 / 
 usage: scripts/ab_round3.py [total GiB, default 64] [steps, default 10]
 AGH_LIB_PATH=<variant .so> runs the same against another build (make -C agrep_amd/csrc FT_BITS=14)."""
 import os, sys, time
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 os.environ["AGH_FUSED_MIN_MB"] = "0"

@@ -2,6 +2,7 @@
 workgroups per CU (AGH_FUSED_BLOCKS), k = 2 (H = 2 samples) and k = 0, 64 GiB and 8 GiB, one process per library.
 usage: AGH_LIB_PATH=<lib> scripts/ab_sweepers_r3.py <sweepers per workgroup of that build> [GiB] [steps]"""
 import os, sys, time
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 os.environ["AGH_FUSED_MIN_MB"] = "0"

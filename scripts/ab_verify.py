@@ -1,6 +1,7 @@
 """A/B inside one process: gram-offset-tight verify windows + false-positive rejection
 (AGH_TIGHT_VERIFY=1, default) vs the offset-blind window.  usage: ab_verify.py [gib] [k] [m]"""
 import os, sys, time
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import torch

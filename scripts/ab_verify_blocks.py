@@ -1,6 +1,7 @@
 """A/B of the verifier's grid (AGH_VERIFY_BLOCKS; 0 = one workgroup per group of 8 slices) on the
 bench corpus, inside one process.  usage: scripts/ab_verify_blocks.py [GiB, default 64]"""
 import os, sys, time
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import torch

@@ -1,6 +1,7 @@
 """(needs the diagnostics build: make -C agrep_amd/csrc EXP=1.)  When did each wave of the fused kernel stop
 sweeping and when did it leave?  usage: scripts/fused_trace.py [GiB, default 8]"""
 import ctypes, os, sys
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 os.environ["AGH_FUSED_MIN_MB"] = "0"

@@ -2,6 +2,7 @@
 (AGH_FS_FAST=0) on the 4 GiB C2 corpus: the queries that really land there (short cores) and the
 headline pattern forced onto it.  usage: scripts/perf_fullscan_r3.py [GiB, default 4]"""
 import os, sys
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import torch

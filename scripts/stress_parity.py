@@ -4,6 +4,7 @@ import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 os.environ["AGH_FUSED_MIN_MB"] = "0"          # count-only scans: the fused kernel at every size ...
+os.environ["AGH_ENV_LIVE"] = "1"              # (switches are flipped between scans of one query)
 import numpy as np
 import agrep_amd as A
 import _oracle as O

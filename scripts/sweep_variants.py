@@ -3,6 +3,7 @@ The env hook is not in the library by default: it is a ten-line dispatch over
 k_sweep<H, MODE, BLOCK, PREFETCH> in launch_sweep_hm (agh_sweep.hip) that was added for the
 tuning rounds recorded in DESIGN.md (d) and removed again."""
 import os
+os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)

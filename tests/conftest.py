@@ -4,10 +4,13 @@ import sys
 
 import pytest
 
-# Count-only scans of a filterable query run as ONE kernel (k_sweep_fused) from 12 GiB on and as two
+# Count-only scans of a filterable query run as ONE kernel (k_sweep_fused) from 4 GiB on and as two
 # kernels below; the test texts are small, so the tests ask for the fused kernel at every
 # size -- _check() in test_gpu_parity.py runs the two-kernel form explicitly beside it.
 os.environ.setdefault("AGH_FUSED_MIN_MB", "0")
+# The library reads its environment switches once per query; the tests flip them between scans of one
+# query (AGH_FUSED, AGH_FS_FAST, ...): AGH_ENV_LIVE=1 makes every scan call read them again.
+os.environ.setdefault("AGH_ENV_LIVE", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -266,3 +266,23 @@ def test_cli_pattern_file_with_errors(files, tmp_path):
     for g in ("1",):
         assert _run(CLI, ["--gpus", g, "--approx-f", "-V0", "-2", "-l", "-f", str(pf)] + files)[1] == \
             _run(CLI, ["--approx-f", "-V0", "-2", "-l", "-f", str(pf)] + files)[1]
+
+
+def test_cli_refuses_what_the_library_cannot_honour(files, tmp_path):
+    """Option combinations that must not be dropped silently: -w with -x (the reference: "illegal option
+    combination", agrep.c:2188-2196), -w / -x with --approx-f and errors (the guards need a verbatim
+    occurrence), --gpus with -i and a multi-byte letter delimiter (shards are cut on raw bytes)."""
+    pf = tmp_path / "p.txt"
+    pf.write_bytes(b"approximatematch\n")
+    for a in (["-w", "-x", "-c", "match", files[0]],
+              ["--approx-f", "-1", "-w", "-c", "-f", str(pf), files[0]],
+              ["--approx-f", "-2", "-x", "-l", "-f", str(pf), files[0]],
+              ["--gpus", "1", "-i", "-d", "From ", "-c", "match", files[0]]):
+        rc, out, err = _run(CLI, a)
+        assert rc == 2 and out == b"" and err, a
+    # ... while the same guards with an exact pattern file are served
+    rc, out, err = _run(CLI, ["-V0", "-w", "-c", "-f", str(pf), files[0]])
+    assert rc != 2 and err == b""
+    import agrep_amd as A
+    with pytest.raises(A.AghError):
+        A.Query(b"match", 0, word=True, wholeline=True)
