@@ -901,6 +901,7 @@ extern "C" void agh_query_free(agh_query *q)
     q->seg_copy.release();
     q->seg_dbm.release();
     q->tickets.release();
+    q->giveups.release();
     if (q->ev0) (void)hipEventDestroy(q->ev0);
     if (q->ev1) (void)hipEventDestroy(q->ev1);
     if (q->ev2) (void)hipEventDestroy(q->ev2);
@@ -1002,6 +1003,21 @@ static const uint64_t AGH_LEAN_SEG_MAX = (uint64_t)64 << 30;     // lean scans: 
 
 
 static int get_events(std::vector<hipEvent_t> &pool, size_t want, unsigned evflags);
+
+// Lean scans with a one-byte delimiter: room for the matches whose record starts further back than the
+// verifier looks; resolved after the scan by k_resolve_giveups instead of a rerun of the segment.
+#define AGH_GIVEUP_CAP 4096u
+static int attach_giveups(agh_query *q, agh_marks *mk)
+{
+    mk->giveups = nullptr;
+    mk->giveup_cap = 0;
+    if (q_mb(q) || q->tune.giveup_cap == 0) return 0;
+    const uint32_t cap = q->tune.giveup_cap < 0 ? AGH_GIVEUP_CAP : (uint32_t)q->tune.giveup_cap;
+    if (q->giveups.ensure((size_t)cap * sizeof(uint64_t))) return -1;
+    mk->giveups = (uint64_t *)q->giveups.p;
+    mk->giveup_cap = cap;
+    return 0;
+}
 
 struct seg_result {
     uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
@@ -1129,6 +1145,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.counters = q->d_counters;
         va.mk.hashset = (uint64_t *)q->hashset.p;
         va.mk.hashset_mask = (uint32_t)(slots - 1);
+        if (attach_giveups(q, &va.mk)) return -1;
         va.text = d_text;
         va.n = n;
         va.q = dq;
@@ -1157,6 +1174,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         }
         if (multi) agh_launch_verify_multi(va, multi_dev(q, d_dbm), true, st);
         else agh_launch_verify_lean(va, st);
+        agh_launch_resolve_giveups(d_text, dq.delim, va.mk, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)q->wave_cand.p, (uint32_t)nw, q->d_counters, st);
         HIP_TRY(hipGetLastError());
@@ -1219,12 +1237,14 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.counters = q->d_counters;
         va.mk.hashset = (uint64_t *)q->hashset.p;
         va.mk.hashset_mask = (uint32_t)(slots - 1);
+        if (attach_giveups(q, &va.mk)) return -1;
         va.table = q->table;
         va.tab = q->tab;
         if (fs_fast_setup(q, n, &va)) return -1;
         const bool fs_fast = va.fs_fast != 0;
         if (q->table) agh_launch_tablescan(va, st);
         else agh_launch_fullscan(va, st);
+        agh_launch_resolve_giveups(d_text, dq.delim, va.mk, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8), nullptr, 0u,
                                  q->d_counters, st);
         HIP_TRY(hipGetLastError());
@@ -1555,6 +1575,7 @@ void agh_read_tuning(agh_tuning *t)
     t->fused_tail_mb = env_long("AGH_FUSED_TAIL_MB");
     t->fused_blocks = env_long("AGH_FUSED_BLOCKS");
     t->verify_blocks = env_long("AGH_VERIFY_BLOCKS");
+    t->giveup_cap = env_long("AGH_GIVEUP_CAP");
 }
 
 // CUs of the current device (the fused lean kernel launches persistent workgroups)
@@ -1712,6 +1733,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         va.mk.counters = d_cnt;
         va.mk.hashset = (uint64_t *)q->hashset.p;
         va.mk.hashset_mask = (uint32_t)(slots - 1);
+        if (attach_giveups(q, &va.mk)) return -1;
         va.text = text;
         va.n = n;
         va.q = dq;
@@ -1807,6 +1829,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
             }
         }
         if (!stop) scanned += n;
+        agh_launch_resolve_giveups(text, dq.delim, va.mk, aux);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8),
                                  (const uint32_t *)wcand[slot]->p, nw, d_cnt, aux);
         if (q->reduce_comm) agh_launch_accumulate_counts(d_cnt, q->d_acc, aux);
@@ -1935,12 +1958,14 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
         a.mk.counters = d_cnt;
         a.mk.hashset = (uint64_t *)q->hashset.p;
         a.mk.hashset_mask = (uint32_t)(slots - 1);
+        if (attach_giveups(q, &a.mk)) return -1;
         a.ticket = (uint32_t *)((char *)q->tickets.p + (size_t)i * 256u);
         a.n_cu = device_cus();
         a.dbg = q->ms_dbg;
         if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i], st));
         if (!agh_launch_mscan(a, st)) return fail("internal error: no one-pass kernel for this pattern set");
         if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i + 1], st));
+        agh_launch_resolve_giveups(a.text, dq.delim, a.mk, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8), nullptr, 0u, d_cnt, st);
         if (q->reduce_comm) agh_launch_accumulate_counts(d_cnt, q->d_acc, st);
         HIP_TRY(hipGetLastError());

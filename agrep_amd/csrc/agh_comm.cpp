@@ -133,6 +133,7 @@ struct agh_comm {
     hipStream_t stream = nullptr;
     uint64_t *d_buf = nullptr;              // counts (2 x uint64) or file hits (bytes)
     size_t d_cap = 0;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;   // agh_comm_allreduce_dev: the caller's stream <-> ours
 };
 
 static int comm_setup(agh_comm *c, size_t bytes)
@@ -220,6 +221,8 @@ extern "C" void agh_comm_free(agh_comm *c)
     (void)hipSetDevice(c->device);
     if (c->comm && R_ok) (void)R.CommDestroy(c->comm);
     if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -277,7 +280,20 @@ extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_dev(agh_
 {
     if (!c || !d_buf) return cfail("null argument");
     if (need_rccl()) return -1;
-    NCCL_TRY(R.AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->comm, st));
+    // RCCL runs on the communicator's own non-blocking stream, never on the caller's (which may be the legacy
+    // default stream, with its implicit synchronisation against every blocking stream): the caller's stream
+    // hands over through an event and takes the result back through another -- stream-ordered on both sides,
+    // no host wait in between
+    if (comm_setup(c, 64)) return -1;
+    if (!c->ev_in) {
+        HIPC_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        HIPC_TRY(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    }
+    HIPC_TRY(hipEventRecord(c->ev_in, st));
+    HIPC_TRY(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    NCCL_TRY(R.AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->comm, c->stream));
+    HIPC_TRY(hipEventRecord(c->ev_out, c->stream));
+    HIPC_TRY(hipStreamWaitEvent(st, c->ev_out, 0));
     return 0;
 }
 

@@ -43,6 +43,7 @@ enum agh_counter {
     AGH_C_LEAN_FALLBACK = 8,
     AGH_C_DELIM_CHAIN = 9, // multi-byte delimiter: overlapping occurrences chain > 4 KiB (unsupported) // lean scan gave up (record start too far back / hash set full)
     AGH_C_ANYHIT = 10,   // lean scans: some record matched (what -l needs to stop early)
+    AGH_C_GIVEUPS = 11,  // lean scans: matches whose record starts further back than the verifier looks (agh_marks.giveups)
     AGH_C_COUNT = 12
 };
 

@@ -86,6 +86,7 @@ struct agh_query {
     hipStream_t stage_stream = nullptr; // H2D copies of agh_scan_fd
     unsigned char *pinned[AGH_PIN_RING] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pinned_ev[AGH_PIN_RING] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pinned_cap[AGH_PIN_RING] = {0, 0, 0, 0};     // (allocated on first use, no larger than the input needs)
     dev_buf staging_b;                  // the second device segment of the streaming pipeline
     size_t match_cap_hint = 0;          // record output: matches of the previous segment (+25 %)
     uint32_t *d_counters = nullptr;     // AGH_LEAN_SLOTS + 1 counter blocks (block 0: everything but the pipeline)
@@ -98,6 +99,7 @@ struct agh_query {
     dev_buf seg_copy;                   // aligned copy of a segment whose cut is not 16-byte aligned
     dev_buf seg_dbm;                    // ... and its own delimiter bitmap (q->dbm holds the whole text's)
     bool seg_dbm_active = false;
+    dev_buf giveups;                    // lean scans: matches whose record start the verifier did not reach (k_resolve_giveups)
     dev_buf tickets;                    // fused lean kernel: one work counter (own 256-byte line) per segment
     std::vector<hipEvent_t> dep_events, time_events;
     uint64_t *h_cuts = nullptr;         // pinned: bounds, lower limits, cuts

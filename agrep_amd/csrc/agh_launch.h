@@ -24,6 +24,8 @@ struct agh_tuning {
     unsigned readers = 0;           // AGH_READERS (0: unset)
     long fused_range_kb = -1, fused_tail_kb = -1, fused_tail_mb = -1, fused_blocks = -1;   // AGH_FUSED_* (-1: unset)
     long verify_blocks = -1;        // AGH_VERIFY_BLOCKS (-1: unset)
+    long giveup_cap = -1;           // AGH_GIVEUP_CAP: entries of the lean scans' give-up list (-1: 4096; 0: none -- a record
+                                    // start further back than the verifier looks reruns the segment, as in round 3)
 };
 
 struct agh_marks {
@@ -35,6 +37,11 @@ struct agh_marks {
     uint32_t match_cap;
     uint64_t *hashset;       // lean scans: open-addressing set of (record start + 1)
     uint32_t hashset_mask;   // slots - 1 (power of two)
+    // lean scans, one-byte delimiters: positions of matches whose record start lies more than
+    // AGH_LEAN_BACK_CAP bytes back; k_resolve_giveups finds those starts after the scan (NULL / 0: such a match
+    // raises AGH_C_LEAN_FALLBACK and the host reruns the segment with record numbers)
+    uint64_t *giveups;
+    uint32_t giveup_cap;
 };
 
 struct agh_sweep_args {
@@ -113,6 +120,9 @@ void agh_launch_bitmap_count(uint32_t *bitmap, uint32_t n_words, uint32_t *count
                              hipStream_t st);
 void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *wave_cand,
                               uint32_t nw, uint32_t *counters, hipStream_t st);
+// the record starts of the matches a lean scan left in mk.giveups (a look-back without a limit, one workgroup
+// per match), entered into the scan's hash set
+void agh_launch_resolve_giveups(const void *text, uint32_t delim, const agh_marks &mk, hipStream_t st);
 void agh_launch_accumulate_counts(const uint32_t *counters, uint64_t *acc, hipStream_t st);
 void agh_launch_verify_lean(const agh_scan_args &a, hipStream_t st);
 void agh_launch_find_cuts(const void *text, const uint64_t *bound, const uint64_t *lo,

@@ -1,12 +1,20 @@
 // agh_scan.hip -- the k-error automaton on candidate windows (k_verify) and the record output
 // kernels.  The automaton over every byte lives in agh_fullscan.hip (its own translation unit:
 // the two kernel families compile in parallel).  See agh_sweep.hip for the data flow of a scan.
+//
+// Compiled ten times: once per number of errors (-DAGH_SCAN_K=0..8: the verify kernels of that k, both
+// word widths -- a code object of its own each, so a process loads the one its query needs and not 7 MB
+// of all of them) and once without the define (record output kernels, the dispatch by k).
 #include <stdlib.h>
 
 #include "agh_verify_inl.h"
 
 #define AGH_VGROUP 8u   // sweep-wave slices verified by one workgroup
 
+#define AGH_SK_CAT2(a, b) a##b
+#define AGH_SK_CAT(a, b) AGH_SK_CAT2(a, b)
+
+#ifdef AGH_SCAN_K
 // ---------------------------------------------------------------------------------------
 // verify: one workgroup per AGH_VGROUP sweep-wave slices, one lane per candidate sample
 // ---------------------------------------------------------------------------------------
@@ -68,6 +76,84 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
         }
     }
 }
+// ---------------------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------------------
+template <typename WT, int K, int NCH, bool LEAN>
+static void launch_verify_n(const agh_scan_args &a, const uint64_t *gtab, uint32_t tspan,
+                            hipStream_t st)
+{
+    // slices [w_begin, w_end) of a lean part (w_begin is a multiple of AGH_VGROUP), else all
+    const uint32_t w_hi = (a.w_end && a.w_end < a.nw) ? a.w_end : a.nw;
+    const uint32_t g_base = a.w_begin;
+    if (w_hi <= g_base) return;
+    uint32_t blocks = (w_hi - g_base + AGH_VGROUP - 1u) / AGH_VGROUP;
+    {   // grid cap (workgroups loop over the groups); AGH_VERIFY_BLOCKS=0: one workgroup per group
+        uint32_t cap = 16384u;                  // A/B on 64 GiB: 0 / 4096 / 8192 / 16384 all within 0.5 %
+        if (a.verify_blocks >= 0) cap = (uint32_t)a.verify_blocks;
+        if (cap && blocks > cap) blocks = cap;
+    }
+    if (a.general)                          // single-byte delimiters only (the host checks)
+        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, true>), dim3(blocks), dim3(256), 0, st,
+                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
+                           a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
+    else if (a.q.mb)
+        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, true, false>), dim3(blocks), dim3(256), 0, st,
+                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
+                           a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
+    else
+        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, false>), dim3(blocks), dim3(256), 0, st,
+                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
+                           a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
+}
+
+template <typename WT, int K, bool LEAN>
+static void launch_verify_t(const agh_scan_args &a, hipStream_t st)
+{
+    // window span = max(m+k+1, 16) + q + m + k bytes, fetched as ceil(span/16) pieces
+    const int lw = a.q.m + a.q.k + 1 > 16 ? a.q.m + a.q.k + 1 : 16;
+    const int nch = (lw + a.q.fq + a.q.m + a.q.k + 15) / 16;
+    if (a.gtab && (LEAN || (int)(((uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread + 15u + 15u) / 16u) < nch)) {
+        // gram offsets known: one warm-up byte + (m + 2k + spread) bytes per candidate; numbered
+        // scans may start up to 15 bytes earlier (at the sample's 16-byte chunk)
+        const uint32_t tspan = (uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread + (LEAN ? 0u : 15u);
+        const int tn = (int)((tspan + 15u) / 16u);
+        // (numbered scans come here only when the window gets shorter by at least one 16-byte
+        // piece: the table costs two dependent loads per candidate)
+        if (sizeof(WT) == 4) {
+            if (tn <= 2 && LEAN) launch_verify_n<WT, K, LEAN ? 2 : 3, LEAN>(a, a.gtab, tspan, st);
+            else if (tn <= 3) launch_verify_n<WT, K, 3, LEAN>(a, a.gtab, tspan, st);
+            else launch_verify_n<WT, K, 6, LEAN>(a, a.gtab, tspan, st);
+        } else {
+            if (tn <= 4 && LEAN) launch_verify_n<WT, K, LEAN ? 4 : 7, LEAN>(a, a.gtab, tspan, st);
+            else if (tn <= 7) launch_verify_n<WT, K, 7, LEAN>(a, a.gtab, tspan, st);
+            else launch_verify_n<WT, K, 10, LEAN>(a, a.gtab, tspan, st);
+        }
+        return;
+    }
+    if (sizeof(WT) == 4) {                  // m <= 32: span <= 85
+        if (nch <= 3) launch_verify_n<WT, K, 3, LEAN>(a, nullptr, 0u, st);
+        else launch_verify_n<WT, K, 6, LEAN>(a, nullptr, 0u, st);
+    } else {                                // m <= 64: span <= 149
+        if (nch <= 7) launch_verify_n<WT, K, 7, LEAN>(a, nullptr, 0u, st);
+        else launch_verify_n<WT, K, 10, LEAN>(a, nullptr, 0u, st);
+    }
+}
+
+// what: 0 numbered, 2 lean (count-only)
+void AGH_SK_CAT(agh_launch_verify_k, AGH_SCAN_K)(const agh_scan_args &a, int what, hipStream_t st)
+{
+    if (a.wide) {
+        if (what == 0) launch_verify_t<uint64_t, AGH_SCAN_K, false>(a, st);
+        else launch_verify_t<uint64_t, AGH_SCAN_K, true>(a, st);
+    } else {
+        if (what == 0) launch_verify_t<uint32_t, AGH_SCAN_K, false>(a, st);
+        else launch_verify_t<uint32_t, AGH_SCAN_K, true>(a, st);
+    }
+}
+
+#else   // ---- the object without a k: record output, dispatch ----------------------------------------
+
 
 // ---------------------------------------------------------------------------------------
 // record output: bounds of matched records and their bytes, straight from the staged text
@@ -153,92 +239,33 @@ void agh_launch_gather_records(const void *text, const uint64_t *start, const ui
 // ---------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------
-template <typename WT, int K, int NCH, bool LEAN>
-static void launch_verify_n(const agh_scan_args &a, const uint64_t *gtab, uint32_t tspan,
-                            hipStream_t st)
-{
-    // slices [w_begin, w_end) of a lean part (w_begin is a multiple of AGH_VGROUP), else all
-    const uint32_t w_hi = (a.w_end && a.w_end < a.nw) ? a.w_end : a.nw;
-    const uint32_t g_base = a.w_begin;
-    if (w_hi <= g_base) return;
-    uint32_t blocks = (w_hi - g_base + AGH_VGROUP - 1u) / AGH_VGROUP;
-    {   // grid cap (workgroups loop over the groups); AGH_VERIFY_BLOCKS=0: one workgroup per group
-        uint32_t cap = 16384u;                  // A/B on 64 GiB: 0 / 4096 / 8192 / 16384 all within 0.5 %
-        if (a.verify_blocks >= 0) cap = (uint32_t)a.verify_blocks;
-        if (cap && blocks > cap) blocks = cap;
-    }
-    if (a.general)                          // single-byte delimiters only (the host checks)
-        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, true>), dim3(blocks), dim3(256), 0, st,
-                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
-                           a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
-    else if (a.q.mb)
-        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, true, false>), dim3(blocks), dim3(256), 0, st,
-                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
-                           a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
-    else
-        hipLaunchKernelGGL((k_verify<WT, K, NCH, LEAN, false, false>), dim3(blocks), dim3(256), 0, st,
-                           (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.cand,
-                           a.wave_cand, a.wave_prefix, w_hi, a.mk, a.dbm, gtab, tspan, g_base);
-}
+void agh_launch_verify_k0(const agh_scan_args &, int, hipStream_t);
+void agh_launch_verify_k1(const agh_scan_args &, int, hipStream_t);
+void agh_launch_verify_k2(const agh_scan_args &, int, hipStream_t);
+void agh_launch_verify_k3(const agh_scan_args &, int, hipStream_t);
+void agh_launch_verify_k4(const agh_scan_args &, int, hipStream_t);
+void agh_launch_verify_k5(const agh_scan_args &, int, hipStream_t);
+void agh_launch_verify_k6(const agh_scan_args &, int, hipStream_t);
+void agh_launch_verify_k7(const agh_scan_args &, int, hipStream_t);
+void agh_launch_verify_k8(const agh_scan_args &, int, hipStream_t);
 
-template <typename WT, int K, bool LEAN>
-static void launch_verify_t(const agh_scan_args &a, hipStream_t st)
-{
-    // window span = max(m+k+1, 16) + q + m + k bytes, fetched as ceil(span/16) pieces
-    const int lw = a.q.m + a.q.k + 1 > 16 ? a.q.m + a.q.k + 1 : 16;
-    const int nch = (lw + a.q.fq + a.q.m + a.q.k + 15) / 16;
-    if (a.gtab && (LEAN || (int)(((uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread + 15u + 15u) / 16u) < nch)) {
-        // gram offsets known: one warm-up byte + (m + 2k + spread) bytes per candidate; numbered
-        // scans may start up to 15 bytes earlier (at the sample's 16-byte chunk)
-        const uint32_t tspan = (uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread + (LEAN ? 0u : 15u);
-        const int tn = (int)((tspan + 15u) / 16u);
-        // (numbered scans come here only when the window gets shorter by at least one 16-byte
-        // piece: the table costs two dependent loads per candidate)
-        if (sizeof(WT) == 4) {
-            if (tn <= 2 && LEAN) launch_verify_n<WT, K, LEAN ? 2 : 3, LEAN>(a, a.gtab, tspan, st);
-            else if (tn <= 3) launch_verify_n<WT, K, 3, LEAN>(a, a.gtab, tspan, st);
-            else launch_verify_n<WT, K, 6, LEAN>(a, a.gtab, tspan, st);
-        } else {
-            if (tn <= 4 && LEAN) launch_verify_n<WT, K, LEAN ? 4 : 7, LEAN>(a, a.gtab, tspan, st);
-            else if (tn <= 7) launch_verify_n<WT, K, 7, LEAN>(a, a.gtab, tspan, st);
-            else launch_verify_n<WT, K, 10, LEAN>(a, a.gtab, tspan, st);
-        }
-        return;
-    }
-    if (sizeof(WT) == 4) {                  // m <= 32: span <= 85
-        if (nch <= 3) launch_verify_n<WT, K, 3, LEAN>(a, nullptr, 0u, st);
-        else launch_verify_n<WT, K, 6, LEAN>(a, nullptr, 0u, st);
-    } else {                                // m <= 64: span <= 149
-        if (nch <= 7) launch_verify_n<WT, K, 7, LEAN>(a, nullptr, 0u, st);
-        else launch_verify_n<WT, K, 10, LEAN>(a, nullptr, 0u, st);
-    }
-}
-
-template <typename WT>
 static void dispatch_k(const agh_scan_args &a, int what, hipStream_t st)
 {
-#define AGH_CASE(KK)                                            \
-    case KK:                                                    \
-        if (what == 0) launch_verify_t<WT, KK, false>(a, st);   \
-        else launch_verify_t<WT, KK, true>(a, st);              \
-        break;
     switch (a.q.k) {
-        AGH_CASE(0) AGH_CASE(1) AGH_CASE(2) AGH_CASE(3) AGH_CASE(4)
-        AGH_CASE(5) AGH_CASE(6) AGH_CASE(7) AGH_CASE(8)
+    case 0: agh_launch_verify_k0(a, what, st); break;
+    case 1: agh_launch_verify_k1(a, what, st); break;
+    case 2: agh_launch_verify_k2(a, what, st); break;
+    case 3: agh_launch_verify_k3(a, what, st); break;
+    case 4: agh_launch_verify_k4(a, what, st); break;
+    case 5: agh_launch_verify_k5(a, what, st); break;
+    case 6: agh_launch_verify_k6(a, what, st); break;
+    case 7: agh_launch_verify_k7(a, what, st); break;
+    case 8: agh_launch_verify_k8(a, what, st); break;
     default: break;
     }
-#undef AGH_CASE
 }
 
-void agh_launch_verify(const agh_scan_args &a, hipStream_t st)
-{
-    if (a.wide) dispatch_k<uint64_t>(a, 0, st);
-    else dispatch_k<uint32_t>(a, 0, st);
-}
+void agh_launch_verify(const agh_scan_args &a, hipStream_t st) { dispatch_k(a, 0, st); }
 
-void agh_launch_verify_lean(const agh_scan_args &a, hipStream_t st)
-{
-    if (a.wide) dispatch_k<uint64_t>(a, 2, st);
-    else dispatch_k<uint32_t>(a, 2, st);
-}
-
+void agh_launch_verify_lean(const agh_scan_args &a, hipStream_t st) { dispatch_k(a, 2, st); }
+#endif

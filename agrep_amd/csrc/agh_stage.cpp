@@ -172,10 +172,24 @@ static int ensure_stage_resources(agh_query *q)
 {
     if (q->stage_stream) return 0;
     HIP_TRY(hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking));
-    for (int b = 0; b < AGH_PIN_RING; ++b) {
-        HIP_TRY(hipHostMalloc((void **)&q->pinned[b], AGH_STAGE_CHUNK));
+    for (int b = 0; b < AGH_PIN_RING; ++b)
         HIP_TRY(hipEventCreateWithFlags(&q->pinned_ev[b], hipEventDisableTiming));
-    }
+    return 0;
+}
+
+// Pinned chunk b of the ring, at least `bytes` large.  Allocated on first use and no larger than the input
+// needs: pinning 4 x 32 MiB costs tens of milliseconds, which a 1 MiB file should not pay.
+static int ensure_pinned(agh_query *q, int b, size_t bytes, uint64_t size_hint)
+{
+    if (q->pinned_cap[b] >= bytes) return 0;
+    size_t want = AGH_STAGE_CHUNK;
+    if (size_hint && size_hint < AGH_STAGE_CHUNK) want = ((size_t)size_hint + 65535) & ~(size_t)65535;
+    if (want < bytes) want = bytes;
+    if (q->pinned[b]) (void)hipHostFree(q->pinned[b]);
+    q->pinned[b] = nullptr;
+    q->pinned_cap[b] = 0;
+    HIP_TRY(hipHostMalloc((void **)&q->pinned[b], want));
+    q->pinned_cap[b] = want;
     return 0;
 }
 
@@ -417,8 +431,10 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
     // the first megabyte has been read and scanned, whatever the engine costs
     uint64_t target = early ? std::min<uint64_t>(seg_cap, (uint64_t)1 << 20) : seg_cap;
     const uint64_t hint = rd.size_hint();
+    // (a file smaller than a chunk is read -- and its pinned buffer sized -- as one piece of its own size)
+    const uint64_t chunk_cap = (hint && hint < AGH_STAGE_CHUNK) ? ((hint + 65535) & ~(uint64_t)65535) : AGH_STAGE_CHUNK;
     dev_buf *seg[2] = {&q->staging, &q->staging_b};
-    const uint64_t want0 = std::min<uint64_t>(seg_cap, hint ? hint : seg_cap) + 2 * AGH_STAGE_CHUNK + 64;
+    const uint64_t want0 = std::min<uint64_t>(seg_cap, hint ? hint : seg_cap) + 2 * chunk_cap + 64;
     if (seg[0]->ensure(want0)) return -1;
     if ((!hint || hint > seg_cap) && seg[1]->ensure(want0)) return -1;      // (a small file needs one segment)
     q->staged_len = 0;                          // what stays in HBM is not the whole input
@@ -453,7 +469,8 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         // (-l reads no further ahead than its current segment target)
         // (chunks no larger than a segment: AGH_STREAM_SEG_MB below 32 exercises the residue carry in tests)
         const size_t ask = early ? (size_t)std::min<uint64_t>(AGH_STAGE_CHUNK, std::max<uint64_t>(target > used ? target - used : 0, 65536))
-                                 : (size_t)std::min<uint64_t>(AGH_STAGE_CHUNK, seg_cap);
+                                 : (size_t)std::min<uint64_t>(chunk_cap, seg_cap);
+        if (ensure_pinned(q, b, ask, hint)) return bail(-1);
         const ssize_t got = rd.fill(q->pinned[b], ask);
         if (got < 0) return bail(-1);
         if (got == 0) eof = true;
@@ -495,7 +512,7 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         if (!eof) {
             // the unfinished record opens the next segment, in the buffer the worker has just left
             const int nxt = cur ^ 1;
-            if (seg[nxt]->ensure(std::max<uint64_t>(want0, tail_len + 2 * AGH_STAGE_CHUNK + 64))) return bail(-1);
+            if (seg[nxt]->ensure(std::max<uint64_t>(want0, tail_len + 2 * chunk_cap + 64))) return bail(-1);
             if (tail_len) {
                 PIPE_TRY(hipMemcpyAsync(seg[nxt]->p, tail_src, (size_t)tail_len, hipMemcpyHostToDevice, q->stage_stream));
                 PIPE_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
@@ -553,6 +570,7 @@ static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, u
     for (;;) {
         if (busy[b]) HIP_TRY(hipEventSynchronize(q->pinned_ev[b]));   // its H2D copy finished
         busy[b] = false;
+        if (ensure_pinned(q, b, AGH_STAGE_CHUNK, 0)) return -1;
         const ssize_t r = rd.fill(q->pinned[b], AGH_STAGE_CHUNK);
         if (r < 0) return -1;
         const size_t got = (size_t)r;

@@ -26,6 +26,7 @@
 
 
 #include "agh_sweep_inl.h"
+#include "agh_verify_inl.h"      // lean_insert (k_resolve_giveups)
 
 // One supertile = 4 consecutive strips (4 KiB) of one wave: census, probes, prefix, emit.
 template <int H, int MODE>
@@ -755,6 +756,58 @@ void agh_launch_hashset_count(uint64_t *tab, uint32_t n_slots, const uint32_t *w
     if (!blocks) blocks = 1u;
     hipLaunchKernelGGL(k_hashset_count, dim3(blocks), dim3(256), 0, st, tab, n_slots, wave_cand,
                        nw, counters);
+}
+
+// Matches of a lean scan whose record starts more than AGH_LEAN_BACK_CAP bytes back (agh_marks.giveups holds the
+// position the verifier's own look-back stopped at): one workgroup per entry walks back 4 KiB per step until a
+// delimiter shows (or the text begins) and enters the record start into the hash set.  Round 3 reran the whole
+// segment -- up to 64 GiB -- on the numbered pipeline for one such record.
+__global__ __launch_bounds__(256) void k_resolve_giveups(const uint8_t *__restrict__ text, uint32_t delim, agh_marks mk)
+{
+    __shared__ unsigned long long best;
+    const uint32_t n = mk.counters[AGH_C_GIVEUPS] < mk.giveup_cap ? mk.counters[AGH_C_GIVEUPS] : mk.giveup_cap;
+    const uint32_t dd = delim * 0x01010101u;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        uint64_t pos = mk.giveups[e];           // no delimiter in [pos, the match)
+        uint64_t start = 0;                     // ... none at all: the record opens the text
+        while (pos > 0) {
+            if (threadIdx.x == 0) best = 0ull;
+            __syncthreads();
+            const uint64_t lo = pos > 4096u ? pos - 4096u : 0;
+            // 16 bytes per thread, highest address first; unaligned 16-byte loads stay inside [lo, pos)
+            const uint64_t hi = pos - (uint64_t)threadIdx.x * 16u;
+            if (hi > lo) {
+                const uint64_t at = hi >= lo + 16u ? hi - 16u : lo;
+                unsigned long long found = 0;
+                if (hi - at == 16u) {
+                    typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+                    const u32x4_a1 v = *reinterpret_cast<const u32x4_a1 *>(text + at);
+#pragma unroll
+                    for (int d = 3; d >= 0 && !found; --d) {
+                        const uint32_t x = v[d] ^ dd;
+                        const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+                        if (z) found = at + 4u * (uint32_t)d + (uint32_t)((31 - __clz((int)z)) >> 3) + 1u;
+                    }
+                } else {
+                    for (uint64_t i = hi; i > at && !found; --i)
+                        if (text[i - 1] == delim) found = i;
+                }
+                if (found) atomicMax(&best, found);
+            }
+            __syncthreads();
+            if (best) { start = best; break; }
+            __syncthreads();
+            pos = lo;
+        }
+        if (threadIdx.x == 0) lean_insert(mk, start);
+        __syncthreads();
+    }
+}
+
+void agh_launch_resolve_giveups(const void *text, uint32_t delim, const agh_marks &mk, hipStream_t st)
+{
+    if (!mk.giveups || !mk.giveup_cap) return;
+    hipLaunchKernelGGL(k_resolve_giveups, dim3(64), dim3(256), 0, st, (const uint8_t *)text, delim, mk);
 }
 
 // A sharded count-only scan leaves its totals on the device for the all-reduce that follows on the same

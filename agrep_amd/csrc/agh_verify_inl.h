@@ -76,6 +76,15 @@ __device__ uint64_t lean_record_start(const uint8_t *__restrict__ text, uint64_t
         --pos;
     }
     if (stop == 0) return 0;
+    // a record of more than AGH_LEAN_BACK_CAP bytes in front of a match: noted for k_resolve_giveups (a look-back
+    // without a limit after the scan) -- only a full list sends the whole segment to the numbered pipeline
+    if (mk.giveups) {
+        const uint32_t idx = atomicAdd(&mk.counters[AGH_C_GIVEUPS], 1u);
+        if (idx < mk.giveup_cap) {
+            mk.giveups[idx] = stop;             // nothing ends a record in [stop, pos): the search goes on from here
+            return ~0ull;
+        }
+    }
     mk.counters[AGH_C_LEAN_FALLBACK] = 1u;
     return ~0ull;
 }

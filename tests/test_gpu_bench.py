@@ -110,7 +110,13 @@ def test_scan_device_reduce_one_rank():
             long = np.concatenate([np.full(3 << 20, ord("x"), dtype=np.uint8), np.frombuffer(b" approximatematch\n", dtype=np.uint8), text])
             tl = torch.from_numpy(long).cuda()
             res2, tot2 = q.scan_device_reduce(comm, tl.data_ptr(), tl.numel())
-            assert res2.lean_reruns == 1 and res2.n_matched == tot2[0] == want + 1
+            assert res2.lean_reruns == 0 and res2.n_matched == tot2[0] == want + 1     # (resolved on the device)
+            os.environ["AGH_GIVEUP_CAP"] = "0"                      # ... without the give-up list: the rerun
+            try:
+                res2b, tot2b = q.scan_device_reduce(comm, tl.data_ptr(), tl.numel())
+            finally:
+                del os.environ["AGH_GIVEUP_CAP"]
+            assert res2b.lean_reruns == 1 and res2b.n_matched == tot2b[0] == want + 1
             res3, tot3 = q.scan_device_reduce(comm, t.data_ptr(), t.numel(), flags=A.COUNT | A.FORCE_NUMBERED)
             assert res3.n_matched == tot3[0] == want and tot3[1] == res3.n_records > 0
         pats = [b"approxim", b"matematch", b"zzzzqqqq"]

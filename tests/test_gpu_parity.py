@@ -1187,3 +1187,39 @@ def test_stress_parity_slice():
     tail = p.stdout.decode(errors="replace").strip().splitlines()[-5:]
     assert p.returncode == 0 and tail and tail[-1].endswith("failures 0"), tail
     assert int(tail[-1].split()[1]) > 300, tail
+
+
+def test_long_records_do_not_rerun_the_segment(agh):
+    """Count-only scans identify a matched record by the offset of its first byte, found by looking back at
+    most 1 MiB from the match.  Records longer than that used to send the whole segment to the numbered
+    pipeline (agh_result.lean_reruns); now the match is noted and k_resolve_giveups finds its record start
+    after the scan: one 3 MiB record, several matches in one 5 MiB record (counted once), a long first
+    record (no delimiter in front of it at all), every count-only engine."""
+    import torch
+    base, _ = O.corpus(4096, seed=11, variants=O.VARIANTS_C2, plant_period=50)       # 16 MiB
+    x = lambda n: np.full(n, ord("x"), dtype=np.uint8)
+    lit = lambda b: np.frombuffer(b, dtype=np.uint8)
+    text = np.concatenate([x(2 << 20), lit(b" approximatematch "), x(1 << 20), lit(b"\n"),          # long FIRST record
+                           base[:8 << 20],
+                           x(3 << 20), lit(b" aproximatematch\n"),                                 # 3 MiB in front of a match
+                           base[8 << 20:],
+                           lit(b"approximatematch "), x(2 << 20), lit(b" approximatematch "), x(3 << 20),
+                           lit(b" approxXmatematch\n")])                                            # three matches, one record
+    want = O.asearch(O.PATTERN_C2, 2, text)[0]
+    t = torch.from_numpy(text).cuda()
+    for flags in (agh.COUNT, agh.COUNT | agh.FORCE_FULLSCAN):
+        with agh.Query(O.PATTERN_C2, 2) as q:
+            r = q.scan_device(t.data_ptr(), t.numel(), flags=flags)
+            rn = q.scan_device(t.data_ptr(), t.numel(), flags=flags | agh.FORCE_NUMBERED)
+        assert r.n_matched == rn.n_matched == want and r.lean_reruns == 0, flags
+    os.environ["AGH_FUSED"] = "0"                       # the two-kernel count-only form
+    try:
+        with agh.Query(O.PATTERN_C2, 2) as q:
+            r = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+    finally:
+        del os.environ["AGH_FUSED"]
+    assert r.n_matched == want and r.lean_reruns == 0
+    with agh.Query.multi([b"approxim", b"matematch"], k=1) as q:         # the one-pass -f kernel
+        r = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
+        rn = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT | agh.FORCE_NUMBERED)
+    assert r.n_matched == rn.n_matched and r.lean_reruns == 0 and r.fused_segments == 1
