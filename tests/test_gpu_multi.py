@@ -392,7 +392,12 @@ def test_one_pass_scan_fuzz(agh):
         alpha = rng.choice([b"ab", b"abc", b"abcdefghijklmnopqrstuvwxyz", b"aA", b"abcd "])
         lo, hi = (8, 14) if k else (4, 15)
         nocase = rng.random() < 0.3
-        pats = _rand_patterns(rng, rng.choice([1, 3, 30, 200]), lo, rng.randint(lo, hi), alphabet=alpha.replace(b" ", b"e"))
+        palpha = alpha.replace(b" ", b"e")
+        hi_len = rng.randint(lo, hi)
+        # (no more patterns than a quarter of what the alphabet has at the shortest length: _rand_patterns
+        # draws until it has that many DISTINCT ones)
+        npat = min(rng.choice([1, 3, 30, 200]), max(1, len(set(palpha)) ** lo // 4))
+        pats = _rand_patterns(rng, npat, lo, hi_len, alphabet=palpha)
         n = rng.choice([0, 1, 9, 100, 1023, 1024, 1025, 4097, 70000, 263000, 600000])
         talpha = alpha + b"\n" if rng.random() < 0.7 else alpha + b"\n\n\n\n"
         text = bytes(rng.choice(talpha) for _ in range(n))
