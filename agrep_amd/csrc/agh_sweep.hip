@@ -775,7 +775,8 @@ __global__ __launch_bounds__(256) void k_resolve_giveups(const uint8_t *__restri
             __syncthreads();
             const uint64_t lo = pos > 4096u ? pos - 4096u : 0;
             // 16 bytes per thread, highest address first; unaligned 16-byte loads stay inside [lo, pos)
-            const uint64_t hi = pos - (uint64_t)threadIdx.x * 16u;
+            const uint64_t back = (uint64_t)threadIdx.x * 16u;      // (pos - lo <= 4096: no thread reaches below lo)
+            const uint64_t hi = back < pos - lo ? pos - back : lo;
             if (hi > lo) {
                 const uint64_t at = hi >= lo + 16u ? hi - 16u : lo;
                 unsigned long long found = 0;
