@@ -28,6 +28,12 @@ class Match(C.Structure):
     _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("index", C.c_uint64)]
 
 
+class PatternTables(C.Structure):
+    _fields_ = [("Mask", C.c_uint32 * 256), ("Init0", C.c_uint32), ("Init1", C.c_uint32),
+                ("NO_ERR_MASK", C.c_uint32), ("endposition", C.c_uint32), ("D_endpos", C.c_uint32),
+                ("wildmask", C.c_uint32), ("M", C.c_int), ("AND", C.c_int), ("simple", C.c_int)]
+
+
 class Result(C.Structure):
     _fields_ = [("n_matched", C.c_uint64), ("n_records", C.c_uint64), ("n_bytes", C.c_uint64),
                 ("n_candidates", C.c_uint64), ("n_stored", C.c_uint64), ("engine", C.c_uint32),
@@ -79,6 +85,10 @@ def lib():
     L.agh_query_multi_approx.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                          C.c_int, u8p, C.c_int]
     L.agh_query_multi_approx.restype = vp
+    L.agh_compile_pattern.argtypes = [u8p, C.c_int, C.c_uint, u8p, C.c_int, C.POINTER(PatternTables)]
+    L.agh_compile_pattern.restype = C.c_int
+    L.agh_query_pattern.argtypes = [u8p, C.c_int, C.c_int, C.c_uint, u8p, C.c_int]
+    L.agh_query_pattern.restype = vp
     L.agh_query_set_costs.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.agh_query_set_costs.restype = C.c_int
     L.agh_query_free.argtypes = [vp]
@@ -183,6 +193,16 @@ class Query:
         old_D_pat = bytes(old_D_pat)
         h = lib().agh_query_from_maskgen(arr, Init0, Init1, NO_ERR_MASK, endposition, D_endpos,
                                          M, old_D_pat, len(old_D_pat), D, AND)
+        if not h:
+            raise AghError(lib().agh_last_error().decode("latin1"))
+        return cls(None, _handle=h)
+
+    @classmethod
+    def pattern(cls, pattern, k=0, nocase=False, delim=b"\n", word=False, wholeline=False):
+        """agh_query_pattern: agrep's non-regex pattern language compiled by the library itself"""
+        qf = (Q_NOCASE if nocase else 0) | (Q_WORD if word else 0) | (Q_WHOLELINE if wholeline else 0)
+        pattern, delim = bytes(pattern), bytes(delim)
+        h = lib().agh_query_pattern(pattern, len(pattern), k, qf, delim, len(delim))
         if not h:
             raise AghError(lib().agh_last_error().decode("latin1"))
         return cls(None, _handle=h)
@@ -343,6 +363,15 @@ class Query:
 
     def __exit__(self, *a):
         self.close()
+
+
+def compile_pattern(pattern, nocase=False, delim=b"\n", word=False, wholeline=False):
+    """agh_compile_pattern (host-only) -> PatternTables in maskgen's layout"""
+    qf = (Q_NOCASE if nocase else 0) | (Q_WORD if word else 0) | (Q_WHOLELINE if wholeline else 0)
+    pattern, delim = bytes(pattern), bytes(delim)
+    t = PatternTables()
+    _check(lib().agh_compile_pattern(pattern, len(pattern), qf, delim, len(delim), C.byref(t)))
+    return t
 
 
 def shard_cuts_fd(fd, nranks, delim=b"\n"):

@@ -1,7 +1,8 @@
 /*
  * agrep_hip.c -- C host side of the MI355X agrep scanner: the command-line surface of the
  * reference for the k-error hot path ( -# -c -l -i -w -x -d -B -y -n -h -s -e -k -f -I -S -D -V0 ), driving the
- * HIP C-ABI of include/agrep_hip.h.  It mirrors, for literal patterns,
+ * HIP C-ABI of include/agrep_hip.h.  It mirrors, for literal patterns and for the non-regex pattern language
+ * (classes, '.', '#', <exact>, ^ $, ';' / ',' lists: agh_query_pattern restates preprocess() + maskgen()),
  *
  *   option parsing      agrep.c:2121-2739  (grouped flags, a digit run ends its group)
  *   engine dispatch     agrep.c:3357-3361 / 3428-3432  -> agh_query_literal + agh_scan_fd
@@ -9,7 +10,7 @@
  *   -B best match       agrep.c:3582-3728
  *   Grand Total, exit   agrep.c:3229-3231, main.c:78-96
  *
- * Everything outside the hot path (regular expressions, boolean patterns, character classes, -r ...)
+ * Everything outside the hot path (regular expressions, -v, -r ...)
  * is rejected with exit status 2: this binary is the hot-path driver, not a re-implementation of
  * agrep's control plane (the reference's own front end linked onto the same engines: ref_shim.c).  There is no CPU scan
  * engine here; without a HIP device the library calls fail and so does this program.
@@ -50,6 +51,7 @@ static struct {
     const char *pattern_file;  /* -f  PAT_FILE */
     int gpus;              /* --gpus N: shard every file over N GPUs (0: the plain one-GPU path) */
     int approx_f;          /* --approx-f: -# applies to -f patterns too (BASELINE config 5; the reference ignores it) */
+    int fancy;             /* the pattern uses the pattern language (classes, . # <> ^ $ ; ,): agh_query_pattern */
 } opt;
 
 static void die_usage(const char *msg)
@@ -91,7 +93,7 @@ static void set_delimiter(const char *arg)
 
 static int parse_options(int argc, char **argv, char **files)
 {
-    int nfiles = 0, i, literal_only = 0;
+    int nfiles = 0, i, literal_only = 0, have_d = 0;
     opt.VERBOSE = 1;
     opt.delim[0] = '\n';
     opt.dlen = 1;
@@ -146,6 +148,7 @@ static int parse_options(int argc, char **argv, char **files)
                 case 'S': opt.S = atoi(p); p = (char *)""; break;
                 case 'D': opt.DD = atoi(p); p = (char *)""; break;
                 case 'd':
+                    have_d = 1;
                     if (*p) set_delimiter(p);
                     else if (i + 1 < argc) set_delimiter(argv[++i]);
                     else die_usage("the -d option must have a delimiter argument");
@@ -179,6 +182,7 @@ static int parse_options(int argc, char **argv, char **files)
     if (opt.pattern == NULL) die_usage("no pattern");
     /* agrep.c:2188-2196 (and :2661-2664): "illegal option combination (-x and -w)" */
     if (opt.WORDBOUND && opt.WHOLELINE) die_usage("illegal option combination (-x and -w)");
+    if (opt.WHOLELINE && have_d) die_usage("-d and -x are not compatible");     /* compat.c:89-96 */
     /* -f with errors checks an occurrence by edit distance, the -w / -x tests need a verbatim one */
     if (opt.pattern_file && opt.approx_f && opt.D > 0 && (opt.WORDBOUND || opt.WHOLELINE))
         die_usage("-w / -x with a pattern file need exact matching (drop --approx-f or -#)");
@@ -199,13 +203,10 @@ static int parse_options(int argc, char **argv, char **files)
         if (opt.COUNT && opt.FILENAMEONLY) opt.FILENAMEONLY = 0;
         return nfiles;
     }
-    if (!literal_only && !pattern_is_literal(opt.pattern)) {
-        fprintf(stderr,
-                "%s: pattern '%s' uses regular-expression / boolean / class syntax, which is "
-                "outside the GPU hot path (use -k for a literal pattern)\n",
-                Progname, opt.pattern);
-        exit(2);
-    }
+    /* classes, '.', '#', <exact>, ^ $ anchors and ';' / ',' lists are compiled by the library
+     * (agh_query_pattern = preprocess() + maskgen() restated); it refuses regular expressions */
+    opt.fancy = !literal_only && !pattern_is_literal(opt.pattern);
+    if (opt.fancy && opt.BESTMATCH) die_usage("-B needs a literal pattern in this build");
     /* compat.c:26-29: -B is ignored together with -c, -l or -# */
     if (opt.BESTMATCH && (opt.COUNT || opt.FILENAMEONLY || opt.APPROX)) opt.BESTMATCH = 0;
     if (opt.COUNT && opt.FILENAMEONLY) opt.FILENAMEONLY = 0;     /* agrep.c:2896-2899 */
@@ -578,8 +579,12 @@ static agh_query *build_cli_query(void)
         return agh_query_multi_approx(g_multi_pats, g_multi_lens, g_multi_n, opt.D, opt.NOUPPER, opt.delim, opt.dlen);
     if (opt.pattern_file)
         return agh_query_multi_ex(g_multi_pats, g_multi_lens, g_multi_n, qf, opt.delim, opt.dlen);
-    q = agh_query_literal_ex((const unsigned char *)opt.pattern, (int)strlen(opt.pattern), opt.D, qf,
-                             opt.delim, opt.dlen);
+    if (opt.fancy)
+        q = agh_query_pattern((const unsigned char *)opt.pattern, (int)strlen(opt.pattern), opt.D, qf, opt.delim,
+                              opt.dlen);
+    else
+        q = agh_query_literal_ex((const unsigned char *)opt.pattern, (int)strlen(opt.pattern), opt.D, qf,
+                                 opt.delim, opt.dlen);
     if (q && (opt.I || opt.S || opt.DD) &&
         agh_query_set_costs(q, opt.I ? opt.I : 1, opt.S ? opt.S : 1, opt.DD ? opt.DD : 1)) {
         agh_query_free(q);

@@ -135,6 +135,27 @@ agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint
                                   uint32_t D_endpos, int M, const unsigned char *old_D_pat,
                                   int D_length, int D, int AND);
 
+/* Replaces preprocess() + maskgen() (preproce.c:137-332, maskgen.c:26-269) for callers that do not link the
+ * reference's front end: agrep's non-regex pattern language -- c  \c  [a-fxyz]  [^...]  .  #  <...>  ^  $  a;b
+ * a,b  and the -w / -x / -i options (qflags: AGH_Q_*) -- compiled by the library itself.
+ * agh_compile_pattern is host-only (no device needed): it fills the tables in maskgen's own layout -- the ones
+ * agh_query_from_maskgen takes, bit for bit what the reference's maskgen() leaves in its globals
+ * (tests/test_pattern_compiler.py compares them with the reference's).  M <= 32 positions: the delimiter, one
+ * separator and the pattern (maskgen.c:201-208).  Regular expressions ( * | ( ) ) and unescaped meta
+ * characters inside [] are refused (-1, errno 123).  simple = 1: a plain literal (nothing but bytes, \c and
+ * the option guards).
+ * agh_query_pattern = compile + the query: a plain literal goes to agh_query_literal_ex (sample filter), the
+ * rest to agh_query_from_maskgen (classes / <> on the byte-parallel engines, # ; , on the table engine). */
+typedef struct {
+    uint32_t Mask[256];
+    uint32_t Init0, Init1, NO_ERR_MASK, endposition, D_endpos, wildmask;
+    int M, AND, simple;
+} agh_pattern_tables;
+int agh_compile_pattern(const unsigned char *pat, int len, unsigned qflags, const unsigned char *delim, int dlen,
+                        agh_pattern_tables *out);
+agh_query *agh_query_pattern(const unsigned char *pat, int len, int D, unsigned qflags,
+                             const unsigned char *delim, int dlen);
+
 /* Replaces prepf() (newmgrep.c:192-375, called from agrep_init for -f / -m): npat literal
  * patterns pats[i][0..lens[i]).  A record matches iff it contains any pattern verbatim --
  * exact matching only, like mgrep() (compat.c:34-37 ignores -# with -f).  nocase = -i. */

@@ -30,8 +30,12 @@ HARNESS = os.path.join(REF, "ref_harness")
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
-def run(cmd, stdin=None):
-    p = subprocess.run(cmd, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+def run(cmd, stdin=None, timeout=None):
+    try:
+        p = subprocess.run(cmd, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout,
+                           stdin=subprocess.DEVNULL if stdin is None else None)
+    except subprocess.TimeoutExpired:
+        return -9, b"", b"(the reference did not return)"
     return p.returncode, p.stdout, p.stderr
 
 
@@ -277,6 +281,80 @@ def gen_quirks():
     with open(os.path.join(OUT, "quirks.json"), "w") as f:
         json.dump({"generator": "oracle/gen_golden.py", "cases": q}, f, indent=0)
     print("quirks.json:", [(c["id"], c["sgrep_count"], c.get("asearch_count")) for c in q])
+def gen_pattern_compiler():
+    """Tables only, for the library's own pattern compiler (agrep_amd/csrc/agh_pattern.cpp): the non-regex pattern
+    language as preprocess() + maskgen() see it -- '.', '#', escapes, <exact> segments, classes with ranges,
+    negation and escaped members, ';' / ',' lists, ^ / $ anchors -- alone and under -i / -w / -x / -d, from a fixed
+    list and from a seeded random walk over the same tokens.  A case the reference turns down carries "ret" != 0
+    or "failed": the compiler has to refuse it too."""
+    import random
+    fixed = [("a.c", []), ("a\\.c", []), ("a\\#c", []), ("ab#cd", []), ("<abc>de", []), ("ab<cd>ef", []), ("<ab>c<de>", []),
+             ("[a-c]xyz", []), ("x[^a-c]yz", []), ("xy[a\\]b]z", []), ("xy[a\\-c]z", []), ("[0-9][0-9]:[0-9][0-9]", []),
+             ("[A-Z]bc", ["-i"]), ("a[b-d]E", ["-i"]), ("x[^A-C]y", ["-i"]), ("Ab.Cd", ["-i"]), ("<Ab>cd", ["-i"]),
+             ("c[ao]r", ["-w"]), ("c.r", ["-w"]), ("c[ao]r", ["-x"]), ("ca#r", ["-x"]), ("<ca>r", ["-w"]),
+             ("a.c", ["-d", "From "]), ("[a-c]#z", ["-d", "$$"]), ("<ab>c.", ["-i", "-d", "XY"]),
+             ("ab;c.d", []), ("a[bc];d#e", []), ("ab,c[de]", []), ("<ab>,cd", []), ("^a.c", []), ("a[bc]$", []), ("^<ab>c$", []),
+             ("a\\<b", []), ("a\\[b", []), ("a\\^b\\$", []), ("a\\;b\\,c", []), ("ab\\*c", []), ("a\\|b", []), ("\\(ab\\)", []),
+             ("a<bc", []), ("ab>c", []), ("ab[cd", []), ("a;b,c", []), ("a" * 29, []), ("a" * 30, []), ("a" * 25, ["-d", "From "]),
+             ("a.b#c[d-f]<gh>ijklmnopqrstuvwxy", []), ("a" * 28, ["-w"]), ("a" * 27 + ".", ["-x"])]
+    rng = random.Random(2026)
+    toks = ["a", "b", "c", "Q", "z", "0", "7", " ", ".", "#", "\\.", "\\#", "\\\\", "[a-c]", "[^x-z]", "[abQ]", "[0-9a-f]", "<ab>", "<Qz0>",
+            "[a\\]]", "[A-C]", "-", "_", "\\-"]
+    walk = []
+    for i in range(110):
+        n = rng.randint(1, 9)
+        body = "".join(rng.choice(toks) for _ in range(n))
+        if body[0] == "-":                       # (the harness would read it as an option)
+            body = "a" + body
+        r = rng.random()
+        if r < 0.12:
+            body += ";" + "".join(rng.choice(toks[:8]) for _ in range(rng.randint(1, 4)))
+        elif r < 0.2:
+            body += "," + "".join(rng.choice(toks[:8]) for _ in range(rng.randint(1, 4)))
+        elif r < 0.26:
+            body = "^" + body
+        elif r < 0.32:
+            body += "$"
+        opts = []
+        if rng.random() < 0.35:
+            opts.append("-i")
+        r = rng.random()
+        if r < 0.15:
+            opts.append("-w")
+        elif r < 0.3:
+            opts.append("-x")
+        if rng.random() < 0.2:
+            opts += ["-d", rng.choice(["$$", ";;", "From ", "@@@"])]
+        walk.append((body, opts))
+    cases = []
+    for pat, opts in fixed + walk:
+        rc, out, err = run([HARNESS, "tables", "-n"] + opts + [pat], timeout=10)
+        if rc == -9:
+            print("  (the reference hangs on", repr(pat), opts, "-- left out)")
+            continue
+        case = {"pattern": pat, "opts": opts}
+        if "-d" in opts:
+            d = opts[opts.index("-d") + 1]
+            d = d.replace("$", "\n").replace("^", "\n")
+            if "-i" in opts:
+                d = d.lower()
+            case["delim_latin1"] = d
+        try:
+            t = json.loads(out)
+        except ValueError:
+            t = None
+        if rc != 0 or t is None or t["ret"] < 0:          # ("ret" >= 0: records the harness's own text matched)
+            case["failed"] = True
+            case["stderr"] = err.decode("latin1")[:200]
+        elif t["SGREP"]:
+            case["sgrep"] = True          # the reference never ran maskgen on it (agrep.c:3181-3193)
+        else:
+            case["tables"] = t
+        cases.append(case)
+    with open(os.path.join(OUT, "pattern_compiler.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "cases": cases}, f, indent=0)
+    print("pattern_compiler.json:", len(cases), "cases,", sum("tables" in c for c in cases), "with tables,",
+          sum("failed" in c for c in cases), "refused by the reference")
 
 
 if __name__ == "__main__":
@@ -289,3 +367,4 @@ if __name__ == "__main__":
     gen_exact_segments()
     gen_pattern_language()
     gen_pattern_language_delims()
+    gen_pattern_compiler()

@@ -139,8 +139,26 @@ def test_cli_multi_byte_delimiter_counts(tmp_path):
         assert (rc_g, out_g) == (rc_r, out_r), (dl, out_g, out_r)
 
 
+@needs_ref
+@pytest.mark.parametrize("args", [
+    ["-V0", "-c", "-1", "appr[ox]ximatematch"], ["-V0", "-2", "approx[a-m]matematch"], ["-V0", "-i", "-2", "[^b-z]PProximatematch"],
+    ["-V0", "-c", "approx#match"], ["-V0", "-1", "-n", "appr#mate#ch"], ["-V0", "-c", "-1", "approxi;matematch"],
+    ["-V0", "-1", "aproxi,matemmat"], ["-V0", "-c", "^appro"], ["-V0", "-1", "-c", "tematch$"],
+    ["-V0", "-2", "-c", "<appro>ximatematch"], ["-V0", "-1", "-c", "appro.imatematch"], ["-V0", "-c", "-w", "m[a-c]tch"],
+    ["-V0", "-1", "-l", "appr[ox]ximatematch"], ["-2", "-c", "a\\.proximatematch"],
+])
+def test_cli_pattern_language_matches_reference(files, args):
+    """classes, '.', '#', <exact>, ^ $, ';' and ',' lists: compiled by the library (agh_query_pattern) and by the
+    reference's preprocess() + maskgen() -- same bytes on stdout, same exit status"""
+    for fl in (files[:1], files):
+        rc_r, out_r, _ = _run(REF, args + fl)
+        rc_g, out_g, err_g = _run(CLI, args + fl)
+        assert (rc_g, out_g) == (rc_r, out_r), (args, out_g[:300], out_r[:300], err_g[:200])
+
+
 def test_cli_rejects_what_is_outside_the_hot_path(files):
-    for a in (["-2", "a|b", files[0]], ["-2", "[ab]cdefgh", files[0]], ["-G", "x", files[0]],
+    for a in (["-2", "a|b", files[0]], ["-2", "ab*cdefgh", files[0]], ["-2", "[ab.]cdefgh", files[0]], ["-G", "x", files[0]],
+              ["-B", "[ab]cdefgh", files[0]], ["-x", "-d", ";;", "abc", files[0]],
               ["-9", "approximatematch", files[0]], ["-2", "ab", files[0]]):
         rc, out, err = _run(CLI, a)
         assert rc == 2 and err

@@ -588,6 +588,34 @@ def test_pattern_language_from_maskgen_tables(agh):
         q.close()
 
 
+def test_query_pattern_compiles_what_the_reference_compiles(agh):
+    """agh_query_pattern: the pattern STRING and the options go in, the library compiles them itself
+    (agh_pattern.cpp) -- the reference's own counts on its golden texts and the oracle's match list on the
+    reference's tables, for classes, -w / -x, '#', ';' / ',' lists and ^ $ anchors, under newline and under
+    delimiters of several bytes."""
+    from test_oracle_golden import lang_delims_text
+    for case in _golden("pattern_language.json"):
+        spec = case["text"]
+        text = O.corpus(spec["pages"], seed=spec["seed"], variants=O.VARIANTS_C2,
+                        plant_period=spec["period"])[0].tobytes() + case["extra_latin1"].encode("latin1")
+        t = case["tables"]
+        M = t["D_endpos"].bit_length()
+        q = agh.Query.pattern(case["pattern"].encode("latin1"), case["k"], word="-w" in case["opts"],
+                              wholeline="-x" in case["opts"])
+        res, ms = q.scan_buffer(text, cap=100000)
+        q.close()
+        assert res.n_matched == case["count"], (case["pattern"], case["opts"])
+        want = O.asearch_tables(O.tables_from_golden(t, M), case["k"], text, cap=100000)
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (case["pattern"], case["opts"])
+    for case in _golden("pattern_language_delims.json"):
+        text, delim = lang_delims_text(case)
+        opt = case["opts"][case["opts"].index("-d") + 1].encode("latin1").replace(b"$", b"\n")
+        q = agh.Query.pattern(case["pattern"].encode("latin1"), case["k"], nocase=case["nocase"], delim=opt)
+        res, _ = q.scan_buffer(text, flags=agh.COUNT)
+        q.close()
+        assert res.n_matched == case["count"], (case["pattern"], case["opts"])
+
+
 def test_table_engine_adversarial_texts(agh):
     """'#' wildcards, ';' AND and ',' OR run by the table engine (agh_table.hip): records from
     empty to 300 KiB, chunk-straddling records, no trailing delimiter -- always the oracle's
