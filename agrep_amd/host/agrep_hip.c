@@ -359,11 +359,15 @@ static long run_pass(agh_query *q, char **files, int nfiles, int print, int coun
  * --gpus N: one process, N devices, one host thread per device.
  *   -c / record output: every file is cut into N record-aligned shards (agh_shard_cuts_fd), GPU r
  *       scans shard r (agh_scan_fd_range); the per-file count exec() prints (agrep.c:3444-3558)
- *       is the RCCL sum of the shard counts (agh_reduce_counts_all); matched records are printed
- *       shard after shard, i.e. in file order, record numbers offset by the shards in front.
+ *       is the sum of the shard counts; matched records are printed shard after shard, i.e. in
+ *       file order, record numbers offset by the shards in front.
  *   -l: the files are dealt out to the GPUs (file f -> GPU f mod N), each scanned whole with the
- *       early exit; the file list is the RCCL max of the per-GPU hit vectors
- *       (agh_reduce_file_hits_all), printed in argument order.
+ *       early exit; the file list is the OR of the per-GPU hit vectors, printed in argument order.
+ * The N threads share this process's memory, so the sums are plain host additions: there is no
+ * exchange step and no communicator (ncclCommInitAll costs ~2-3 s per process, more than most jobs).
+ * RCCL belongs to the one-process-per-GPU form (agh_scan_device_reduce, agh_reduce_counts: bench.py);
+ * AGH_CLI_RCCL=1 runs the same sums through agh_reduce_counts_all / agh_reduce_file_hits_all as
+ * well and compares them (tests).
  * The queries are built per device by the same code as the one-GPU path.
  * --------------------------------------------------------------------------------------- */
 typedef agh_query *(*query_builder)(void);
@@ -460,6 +464,8 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
     struct comm_init ci;
     pthread_t ci_th;
     const int want_records = !opt.COUNT && !opt.FILENAMEONLY && !opt.SILENT;
+    const char *rccl_env = getenv("AGH_CLI_RCCL");
+    const int use_rccl = rccl_env && rccl_env[0] == '1';
     struct gpu_task *tasks = (struct gpu_task *)calloc((size_t)G, sizeof(*tasks));
     pthread_t *th = (pthread_t *)calloc((size_t)G, sizeof(*th));
     agh_comm *comms[64];
@@ -470,13 +476,13 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
         fprintf(stderr, "%s: --gpus %d but only %d HIP device(s) are visible\n", Progname, G, agh_device_count());
         exit(2);
     }
-    /* the communicators are needed only for the reductions at the end: ncclCommInitAll (~2 s) runs on a
-     * thread of its own while the workers read and scan their shards */
+    /* AGH_CLI_RCCL=1: the cross-check through RCCL; ncclCommInitAll runs on a thread of its own while
+     * the workers read and scan their shards */
     ci.comms = comms;
     ci.n = G;
     ci.rc = 0;
     ci.err[0] = 0;
-    pthread_create(&ci_th, NULL, comm_init_thread, &ci);
+    if (use_rccl) pthread_create(&ci_th, NULL, comm_init_thread, &ci);
     for (r = 0; r < G; r++) {
         tasks[r].rank = r;
         tasks[r].ngpus = G;
@@ -489,21 +495,34 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
         pthread_create(&th[r], NULL, gpu_worker, &tasks[r]);
     }
     for (r = 0; r < G; r++) pthread_join(th[r], NULL);
-    pthread_join(ci_th, NULL);
-    if (ci.rc) {
-        fprintf(stderr, "%s: RCCL: %s\n", Progname, ci.err);
-        exit(2);
+    if (use_rccl) {
+        pthread_join(ci_th, NULL);
+        if (ci.rc) {
+            fprintf(stderr, "%s: RCCL: %s\n", Progname, ci.err);
+            exit(2);
+        }
     }
     for (r = 0; r < G; r++)
         if (tasks[r].failed) { fprintf(stderr, "%s: %s\n", Progname, tasks[r].err); exit(2); }
 
-    if (opt.FILENAMEONLY) {                      /* the -l hit vector: RCCL max over the GPUs */
-        unsigned char *vec[64];
-        for (r = 0; r < G; r++) vec[r] = tasks[r].file_hit;
-        if (agh_reduce_file_hits_all(comms, G, vec, (size_t)nfiles)) {
-            fprintf(stderr, "%s: RCCL: %s\n", Progname, agh_last_error());
-            exit(2);
+    if (opt.FILENAMEONLY) {                      /* the -l hit vector: OR over the GPUs, into rank 0's */
+        unsigned char *host_or = (unsigned char *)calloc((size_t)nfiles + 1, 1);
+        for (r = 0; r < G; r++)
+            for (f = 0; f < nfiles; f++) host_or[f] |= tasks[r].file_hit[f];
+        if (use_rccl) {
+            unsigned char *vec[64];
+            for (r = 0; r < G; r++) vec[r] = tasks[r].file_hit;
+            if (agh_reduce_file_hits_all(comms, G, vec, (size_t)nfiles)) {
+                fprintf(stderr, "%s: RCCL: %s\n", Progname, agh_last_error());
+                exit(2);
+            }
+            if (memcmp(tasks[0].file_hit, host_or, (size_t)nfiles)) {
+                fprintf(stderr, "%s: internal error: RCCL max differs from the host OR\n", Progname);
+                exit(2);
+            }
         }
+        memcpy(tasks[0].file_hit, host_or, (size_t)nfiles);
+        free(host_or);
     }
     for (f = 0; f < nfiles; f++) {
         uint64_t counts[64][2], host_sum = 0, rec_off = 0;
@@ -526,15 +545,18 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
             counts[r][1] = tasks[r].hits[f].res.n_records;
             host_sum += counts[r][0];
         }
-        if (agh_reduce_counts_all(comms, G, counts)) {   /* ncclAllReduce(sum) over the shard counts */
-            fprintf(stderr, "%s: RCCL: %s\n", Progname, agh_last_error());
-            exit(2);
+        if (use_rccl) {
+            if (agh_reduce_counts_all(comms, G, counts)) {   /* ncclAllReduce(sum) over the shard counts */
+                fprintf(stderr, "%s: RCCL: %s\n", Progname, agh_last_error());
+                exit(2);
+            }
+            if (counts[0][0] != host_sum) {
+                fprintf(stderr, "%s: internal error: RCCL sum %llu != host sum %llu\n", Progname,
+                        (unsigned long long)counts[0][0], (unsigned long long)host_sum);
+                exit(2);
+            }
         }
-        if (counts[0][0] != host_sum) {
-            fprintf(stderr, "%s: internal error: RCCL sum %llu != host sum %llu\n", Progname,
-                    (unsigned long long)counts[0][0], (unsigned long long)host_sum);
-            exit(2);
-        }
+        counts[0][0] = host_sum;
         if (!opt.SILENT) {
             if (opt.COUNT) {                     /* agrep.c:3501-3556 */
                 if (nfiles > 1 && !opt.NOFILENAME)
@@ -558,7 +580,7 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
         for (f = 0; f < nfiles; f++) { free(tasks[r].hits[f].matches); free(tasks[r].hits[f].bytes); }
         free(tasks[r].hits);
         free(tasks[r].file_hit);
-        agh_comm_free(comms[r]);
+        if (use_rccl) agh_comm_free(comms[r]);
     }
     free(tasks);
     free(th);

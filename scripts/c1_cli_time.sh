@@ -19,6 +19,10 @@ def t(label, cmd, env=None, reps=3):
     print("%-44s %.3f s  -> %s" % (label, best, r.stdout.strip().split("\n")[0][:40]), flush=True)
 t("agrep-hip -c haystack (k=0)", ["agrep_amd/agrep-hip", "-c", "haystack", "/tmp/c1.txt"])
 t("agrep-hip -1 -c haystack", ["agrep_amd/agrep-hip", "-1", "-c", "haystack", "/tmp/c1.txt"])
+t("agrep-hip --gpus 1 -c haystack (host sum)", ["agrep_amd/agrep-hip", "--gpus", "1", "-c", "haystack", "/tmp/c1.txt"])
+t("agrep-hip --gpus 1 -l haystack (host sum)", ["agrep_amd/agrep-hip", "--gpus", "1", "-l", "haystack", "/tmp/c1.txt"])
+t("agrep-hip --gpus 1 -c, AGH_CLI_RCCL=1", ["agrep_amd/agrep-hip", "--gpus", "1", "-c", "haystack", "/tmp/c1.txt"], {"AGH_CLI_RCCL": "1"})
+t("agrep-hip -c 'h[a-c]ystack' (compiled class)", ["agrep_amd/agrep-hip", "-c", "h[a-c]ystack", "/tmp/c1.txt"])
 t("reference -c haystack (k=0)", ["oracle/_ref/agrep", "-V0", "-c", "haystack", "/tmp/c1.txt"])
 t("reference -1 -c haystack", ["oracle/_ref/agrep", "-V0", "-1", "-c", "haystack", "/tmp/c1.txt"])
 t("agrep-hip, HIP_ENABLE_DEFERRED_LOADING=0", ["agrep_amd/agrep-hip", "-c", "haystack", "/tmp/c1.txt"], {"HIP_ENABLE_DEFERRED_LOADING": "0"})

@@ -15,8 +15,9 @@ CLI = os.path.join(ROOT, "agrep_amd", "agrep-hip")
 REF = os.path.join(O.REF_DIR, "agrep")
 
 
-def _run(exe, args, stdin=None):
-    p = subprocess.run([exe] + args, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+def _run(exe, args, stdin=None, env=None):
+    p = subprocess.run([exe] + args, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, **env) if env else None)
     return p.returncode, p.stdout, p.stderr
 
 
@@ -174,18 +175,20 @@ def _n_devices():
                                   ["-V0", "-i", "-v", "-l", "-2"], ["-V0", "-v", "-l"], ["-V0", "-i", "-v", "-c", "-1"]])
 def test_cli_multi_gpu_equals_single(files, args):
     """--gpus N: every file cut into N record-aligned shards, one host thread + one
-    query per device, the -c sum / the -l hit vector reduced with RCCL inside the C-ABI
-    (agh_reduce_counts_all / agh_reduce_file_hits_all).  Output, order and exit status equal the
-    one-GPU run.  On a one-GPU box N = 1 still goes through ncclCommInitAll + ncclAllReduce."""
+    query per device; the -c sum / the -l hit vector are host additions over the threads of the one
+    process (no communicator), and with AGH_CLI_RCCL=1 also reduced with RCCL inside the C-ABI
+    (agh_reduce_counts_all / agh_reduce_file_hits_all: ncclCommInitAll + ncclAllReduce, also with
+    N = 1) and compared.  Output, order and exit status equal the one-GPU run."""
     n_dev = _n_devices()
     for g in sorted({1, min(2, n_dev), n_dev}):
         for fl in (files[:1], files):
             a = args + ["approximatematch"] + fl
             rc_1, out_1, err_1 = _run(CLI, a)
-            rc_g, out_g, err_g = _run(CLI, ["--gpus", str(g)] + a)
-            assert err_g == b"", err_g[:500]
-            assert out_g == out_1, (g, a, out_g[:300], out_1[:300])
-            assert rc_g == rc_1
+            for env in ((None, {"AGH_CLI_RCCL": "1"}) if fl is not files else (None,)):
+                rc_g, out_g, err_g = _run(CLI, ["--gpus", str(g)] + a, env=env)
+                assert err_g == b"", err_g[:500]
+                assert out_g == out_1, (g, a, out_g[:300], out_1[:300])
+                assert rc_g == rc_1
 
 
 def test_cli_multi_gpu_pattern_file(files, tmp_path):

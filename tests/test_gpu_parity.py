@@ -973,7 +973,7 @@ def test_record_aligned_shards_add_up(agh, tmp_path, nranks):
 
 
 @pytest.mark.parametrize("k", [0, 1, 2, 3])
-def test_fused_count_on_candidate_dense_text(agh, k):
+def test_fused_count_on_candidate_dense_text(agh, k, monkeypatch):
     """Every sample is a candidate (the text is made of the pattern's own grams): the verifying
     waves of the fused kernel are the bottleneck, the ring runs full, the hash set overflows into
     the numbered re-run -- and the count still equals the numbered pipeline's and the oracle's."""
@@ -998,6 +998,7 @@ def test_fused_count_on_candidate_dense_text(agh, k):
     # the same text many times over on the device (64 MiB): fused against two kernels
     reps = (64 << 20) // len(text)
     t = torch.frombuffer(bytearray(text * reps), dtype=torch.uint8).cuda()
+    monkeypatch.setenv("AGH_FUSED_MIN_MB", "0")         # (whatever the suite runs under: fused at this size)
     with agh.Query(pat, k) as q:
         r1 = q.scan_device(t.data_ptr(), t.numel(), flags=agh.COUNT)
         os.environ["AGH_FUSED"] = "0"
