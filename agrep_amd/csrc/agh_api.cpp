@@ -963,6 +963,11 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     if (q->cand.ensure((n_tiles + 4) * AGH_FF_SLICE_HOST * sizeof(uint64_t))) return -1;
     if (q->wave_cand.ensure((n_tiles + 8) * sizeof(uint32_t))) return -1;
     va->fs_fast = 1;
+    // table engine, M <= 15: two streams per lane (k_tablescan_fast2) -- the always-one bit M must be there
+    if (q->table && q->tune.tf_pack2) {
+        const unsigned M = (unsigned)q->m + (unsigned)q->dlen + 1u;
+        if (M <= 15u && ((q->tab.Init0 >> M) & (q->tab.Init1 >> M) & 1u)) va->fs_fast = 2;
+    }
     va->fs_replay = (uint64_t *)q->cand.p;
     va->fs_tile_cnt = (uint32_t *)q->wave_cand.p;
     return 0;
@@ -1557,6 +1562,7 @@ void agh_read_tuning(agh_tuning *t)
     t->live = env_on("AGH_ENV_LIVE", false);
     t->tight_verify = env_on("AGH_TIGHT_VERIFY", true);
     t->fs_fast = env_on("AGH_FS_FAST", true);
+    t->tf_pack2 = env_on("AGH_TF_PACK2", true);
     t->fused = env_on("AGH_FUSED", AGH_FUSED_DEFAULT != 0);
     t->debug = getenv("AGH_DEBUG") != nullptr;
     t->aligned_cuts_only = getenv("AGH_ALIGNED_CUTS_ONLY") != nullptr;

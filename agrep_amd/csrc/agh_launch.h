@@ -12,6 +12,7 @@ struct agh_tuning {
     bool live = false;              // AGH_ENV_LIVE
     bool tight_verify = true;       // AGH_TIGHT_VERIFY
     bool fs_fast = true;            // AGH_FS_FAST
+    bool tf_pack2 = true;           // AGH_TF_PACK2: table engine, two streams per lane where M <= 15
     bool fused = true;              // AGH_FUSED
     bool debug = false;             // AGH_DEBUG
     bool aligned_cuts_only = false; // AGH_ALIGNED_CUTS_ONLY

@@ -15,6 +15,8 @@
 // delimiter bitmap the other engines use; a lane that learns of a boundary its own state missed takes
 // the state a boundary leaves (TableAutomaton::force_boundary) and is exact from there.  k_tablescan
 // only; the fast form below keeps to one byte.
+#include <type_traits>
+
 #include "agh_verify_inl.h"
 
 #define AGH_TS_CHUNK 256u       // k_unmatched: bytes per lane
@@ -444,6 +446,214 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// fast form, two streams per lane (tables of M <= 15 positions)
+// ---------------------------------------------------------------------------------------
+// k_tablescan_fast issues ~10 VALU instructions per byte and most of them work on words whose upper half
+// is idle: the recurrence only needs bits 0..M (bit M = the always-one bit above position 1 that Init[0]
+// and Init1 keep set, maskgen.c:224).  With M + 1 <= 16 two chunks share every state word -- chunk c of a
+// 256 KiB tile in the low halves, chunk c of the NEXT tile in the high halves -- and one pass of the
+// recurrence, the reset select and the flag logic serves two text bytes.  The shift brings bit 16 into
+// bit 15: with M = 15 that is the always-one bit (already set), with M < 15 a bit above M, and nothing
+// above M reaches the positions (every constant is cut to bits 0..M; the only term that moves bits down,
+// ">> 1", moves bit M + 1 into bit M, which is one anyway).  What a lane extracts per byte (table index,
+// LDS read) stays per stream; the LDS entry is (mask, kill) in 16 + 16 bits and two v_perm put the two
+// streams' halves together.  Tiles, replay lists and counters are the unpacked kernel's: the low stream
+// writes tile 2t, the high stream tile 2t + 1 -- k_table_replay does not know.
+// ring rows: 64 text bytes + 16 of padding (bank spread for the b128 reads), or AGH_TF2_SWZ: no padding, the
+// 16-byte column XORed with bits 1..2 of the row (8 consecutive rows cover the 32 banks once) -- 33 KiB instead
+// of 41 KiB per workgroup, i.e. four workgroups per CU instead of three
+#ifdef AGH_TF2_SWZ
+#define AGH_TF2_ROW 64u
+#define AGH_TF2_COL(row, col) (((col) ^ (((row) >> 1) & 3u)) * 16u)
+#else
+#define AGH_TF2_ROW AGH_FS_ROW
+#define AGH_TF2_COL(row, col) ((col) * 16u)
+#endif
+#ifdef AGH_TF2_OCC
+#define AGH_TF2_ATTR __attribute__((amdgpu_waves_per_eu(AGH_TF2_OCC, AGH_TF2_OCC)))
+#else
+#define AGH_TF2_ATTR
+#endif
+template <int K>
+__global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2(
+    const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
+    const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
+    uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters, uint32_t M, uint32_t n_tiles1)
+{
+    __shared__ uint32_t tab[256];               // mask (bits 0..M-1) | kill << 16 (0 for the delimiter, else 0xffff)
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * 2 * WAVE * AGH_TF2_ROW];
+    const uint32_t keep = (2u << M) - 1u;       // bits 0..M
+    tab[threadIdx.x] = (mask_g[threadIdx.x] & keep & 0xffffu) | (threadIdx.x == q.delim ? 0u : 0xffff0000u);
+    __syncthreads();
+    auto dup = [&](uint32_t x) -> uint32_t { x &= keep; return x | (x << 16); };
+    agh_dev_tables Tp = T;
+    Tp.Init0 = dup(T.Init0);
+    Tp.Init1 = dup(T.Init1);
+    Tp.NO_ERR = dup(T.NO_ERR);
+    Tp.endposition = dup(T.endposition);
+    uint32_t RF[K + 1];
+    table_reset_state<K>(T, mask_g[q.delim & 0xffu], RF);
+#pragma unroll
+    for (int e = 0; e <= K; ++e) RF[e] = dup(RF[e]);
+    const int lane = lane_id();
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    uint8_t *ring = ring_all + wib * (2 * WAVE * AGH_TF2_ROW);
+    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_TF_CHUNK;        // one stream's tile
+    const uint64_t n_tiles2 = ((uint64_t)n_tiles1 + 1) / 2;
+    const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
+    const uint64_t n16 = (n + 15) & ~(uint64_t)15;
+    const uint32_t seg_lo = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
+    uint8_t *ring_w = ring + seg_lo * AGH_TF2_ROW + AGH_TF2_COL(seg_lo, part);     // (rows seg_lo + 16 i: the same swizzle)
+    const uint8_t *ring_ra = ring + (uint32_t)lane * AGH_TF2_ROW;
+    const uint8_t *ring_rb = ring + (WAVE + (uint32_t)lane) * AGH_TF2_ROW;
+
+    for (uint64_t tile2 = (uint64_t)blockIdx.x * (AGH_FS_THREADS / WAVE) + wib; tile2 < n_tiles2;
+         tile2 += (uint64_t)gridDim.x * (AGH_FS_THREADS / WAVE)) {
+        const uint64_t t0 = tile2 * 2 * tile_bytes;
+        // stream 0 (low halves): chunk `lane` of tile 2 * tile2; stream 1: the same chunk of tile 2 * tile2 + 1
+        uint64_t cs[2], ce[2];
+        uint32_t len[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            cs[s2] = t0 + (uint64_t)s2 * tile_bytes + (uint64_t)lane * AGH_TF_CHUNK;
+            ce[s2] = cs[s2] + AGH_TF_CHUNK;
+            if (ce[s2] > n) ce[s2] = n;
+            len[s2] = cs[s2] < n ? (uint32_t)(ce[s2] - cs[s2]) : 0u;
+        }
+        auto gather = [&](uint32_t r, uint32_t first, uint4 (&g)[4]) {      // rows first .. first + 63, 16 apart
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint64_t a = t0 + (uint64_t)(first + seg_lo + 16u * i) * AGH_TF_CHUNK + r * AGH_FS_ROUND + part * 16u;
+                g[i] = a < n16 ? *reinterpret_cast<const uint4 *>(text + a) : make_uint4(fill4, fill4, fill4, fill4);
+            }
+        };
+        uint4 ga[4], gb[4];
+        gather(0, 0u, ga);
+        gather(0, WAVE, gb);
+        TableFast<K> A;
+#pragma unroll
+        for (int e = 0; e <= K; ++e) A.B[e] = Tp.Init0;
+        // per half: 0xffff once the stream has seen the start of the record it is in
+        uint32_t trusted = 0u, cnt0 = 0, cnt1 = 0;
+        if (cs[0] == 0 && len[0]) {             // the virtual head byte, asearch.c:69-78 (stream 1: not trusted yet)
+            const uint32_t e = tab[q.head_byte & 0xffu];
+            (void)A.feed(__builtin_amdgcn_perm(e, e, 0x05040100u), __builtin_amdgcn_perm(e, e, 0x07060302u), Tp, RF);
+            trusted = 0xffffu;
+        }
+        uint32_t dseen = 0;                     // per half: 0xffff once a delimiter went through piece()
+        // 16 bytes of either stream: -> per half, "some trusted record end in the piece shows an end bit on
+        // the top level".  live: 0xffff per half for the bytes that exist (FULL: all 16 of both)
+        // mode 0: bytes beyond a stream's end are masked (live); 1: all 16 bytes of both streams exist; 2: and
+        // every stream of the wave is trusted already (the common case after a record or two): no bookkeeping
+        auto piece = [&](uint4 va, uint4 vb, uint32_t nba, uint32_t nbb, auto mode) -> uint32_t {
+            constexpr int MODE = decltype(mode)::value;
+            const uint32_t da[4] = {va.x, va.y, va.z, va.w}, db[4] = {vb.x, vb.y, vb.z, vb.w};
+            uint32_t flag = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 16; ++b) {
+                const uint32_t ea = tab[(da[b >> 2] >> (8u * (b & 3u))) & 0xffu];
+                const uint32_t eb = tab[(db[b >> 2] >> (8u * (b & 3u))) & 0xffu];
+                const uint32_t cm = __builtin_amdgcn_perm(eb, ea, 0x05040100u);
+                const uint32_t kb = __builtin_amdgcn_perm(eb, ea, 0x07060302u);
+                const uint32_t top = A.feed(cm, kb, Tp, RF);
+                if (MODE == 2) {
+                    flag |= top & ~kb;
+                } else if (MODE == 1) {
+                    flag |= top & ~kb & trusted;
+                    trusted |= ~kb;
+                    dseen |= ~kb;
+                } else {
+                    const uint32_t live = (b < nba ? 0xffffu : 0u) | (b < nbb ? 0xffff0000u : 0u);
+                    flag |= top & ~kb & trusted & live;
+                    trusted |= ~kb & live;
+                    dseen |= ~kb & live;
+                }
+            }
+            return flag & Tp.endposition;
+        };
+        auto emit = [&](bool f, uint64_t pos, uint64_t tile1, uint32_t &cnt) {   // (uniform call sites)
+            const uint64_t fm = __ballot(f);
+            if (!fm) return;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            if (f) {
+                const uint32_t at = cnt + rank;
+                if (at < AGH_TF_SLICE) replay[tile1 * AGH_TF_SLICE + at] = pos;
+                else counters[AGH_C_OVERFLOW] = 1u;
+            }
+            cnt += (uint32_t)__popcll(fm);
+        };
+        for (uint32_t r = 0; r < AGH_TF_CHUNK / AGH_FS_ROUND; ++r) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                *reinterpret_cast<uint4 *>(ring_w + 16u * i * AGH_TF2_ROW) = ga[i];
+                *reinterpret_cast<uint4 *>(ring_w + (WAVE + 16u * i) * AGH_TF2_ROW) = gb[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (r + 1 < AGH_TF_CHUNK / AGH_FS_ROUND) {
+                gather(r + 1, 0u, ga);
+                gather(r + 1, WAVE, gb);
+            }
+#pragma unroll 1
+            for (uint32_t p = 0; p < 4; ++p) {
+                const uint32_t off = r * AGH_FS_ROUND + 16u * p;
+                const uint4 va = *reinterpret_cast<const uint4 *>(ring_ra + AGH_TF2_COL((uint32_t)lane, p));
+                const uint4 vb = *reinterpret_cast<const uint4 *>(ring_rb + AGH_TF2_COL((uint32_t)lane, p));
+                const uint32_t nba = off + 16u <= len[0] ? 16u : (off < len[0] ? len[0] - off : 0u);
+                const uint32_t nbb = off + 16u <= len[1] ? 16u : (off < len[1] ? len[1] - off : 0u);
+                const bool full = __ballot(nba != 16u || nbb != 16u) == 0ull;
+                const bool settled = full && __ballot(trusted != ~0u) == 0ull;
+                const uint32_t flag = settled ? piece(va, vb, nba, nbb, std::integral_constant<int, 2>{})
+                                      : full  ? piece(va, vb, nba, nbb, std::integral_constant<int, 1>{})
+                                              : piece(va, vb, nba, nbb, std::integral_constant<int, 0>{});
+                // the piece that holds the last byte of the text: the appended delimiter is the replay's
+                bool fa = nba && (flag & 0xffffu), fb = nbb && (flag >> 16);
+                if (nba && cs[0] + off + 16u >= n && (trusted & 0xffffu)) fa = true;
+                if (nbb && cs[1] + off + 16u >= n && (trusted >> 16)) fb = true;
+                emit(fa, cs[0] + off, tile2 * 2, cnt0);
+                emit(fb, cs[1] + off, tile2 * 2 + 1, cnt1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all reads done before the next round's writes
+            __builtin_amdgcn_wave_barrier();
+        }
+        // on alone to the delimiter that closes a stream's last record (k_tablescan_fast: the same walk)
+        bool opa = len[0] == AGH_TF_CHUNK && (trusted & 0xffffu) != 0u && ce[0] < n;
+        bool opb = len[1] == AGH_TF_CHUNK && (trusted >> 16) != 0u && ce[1] < n;
+        dseen = 0;
+        for (uint64_t step = 0; __ballot(opa || opb); step += 16) {
+            const uint64_t pa = ce[0] + step, pb = ce[1] + step;
+            const bool ma = opa, mb = opb;
+            uint4 va = make_uint4(fill4, fill4, fill4, fill4), vb = va;
+            uint32_t nba = 0, nbb = 0;
+            if (opa) {
+                va = *reinterpret_cast<const uint4 *>(text + pa);
+                nba = pa + 16 <= n ? 16u : (uint32_t)(n - pa);
+            }
+            if (opb) {
+                vb = *reinterpret_cast<const uint4 *>(text + pb);
+                nbb = pb + 16 <= n ? 16u : (uint32_t)(n - pb);
+            }
+            const uint32_t flag = piece(va, vb, nba, nbb, std::integral_constant<int, 0>{});
+            bool fa = ma && (flag & 0xffffu), fb = mb && (flag >> 16);
+            if (opa) {
+                if (dseen & 0xffffu) opa = false;
+                else if (pa + 16 >= n) { fa = true; opa = false; }      // the text ends inside my record
+            }
+            if (opb) {
+                if (dseen >> 16) opb = false;
+                else if (pb + 16 >= n) { fb = true; opb = false; }
+            }
+            emit(fa, pa, tile2 * 2, cnt0);
+            emit(fb, pb, tile2 * 2 + 1, cnt1);
+        }
+        if (lane == 0) {
+            tile_cnt[tile2 * 2] = cnt0 < AGH_TF_SLICE ? cnt0 : AGH_TF_SLICE;
+            if (tile2 * 2 + 1 < n_tiles1) tile_cnt[tile2 * 2 + 1] = cnt1 < AGH_TF_SLICE ? cnt1 : AGH_TF_SLICE;
+        }
+    }
+}
+
 // Exact: for every listed piece, every record that ENDS in it (a delimiter inside the piece, or the
 // end of the text) is run through asearch.c's recurrence from its first byte.
 template <int K, bool LEAN>
@@ -518,8 +728,16 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
         const uint32_t nt = (uint32_t)((a.n + tf_tile - 1) / tf_tile);
         const uint32_t fblocks = (nt + 3u) / 4u > 16384u ? 16384u : (nt + 3u) / 4u;
         const uint32_t rblocks = fblocks;
+        const uint32_t nt2 = (nt + 1u) / 2u;
+        const uint32_t fblocks2 = (nt2 + 3u) / 4u > 16384u ? 16384u : (nt2 + 3u) / 4u;
+        const uint32_t M = (uint32_t)a.q.m + a.q.dlen + 1u;                  // maskgen's M (agh_query_from_maskgen)
 #define AGH_TF_CASE(KK)                                                                       \
     case KK:                                                                                  \
+        if (a.fs_fast == 2)                                                                   \
+            hipLaunchKernelGGL((k_tablescan_fast2<KK>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
+                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                               a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt);             \
+        else                                                                                  \
         hipLaunchKernelGGL((k_tablescan_fast<KK>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
                            (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
                            a.fs_replay, a.fs_tile_cnt, a.mk.counters);                        \

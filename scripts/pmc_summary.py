@@ -41,8 +41,9 @@ for k, d in out.items():
             "valu_active_quadcycles_over_simd_quadcycles": round(d["SQ_ACTIVE_INST_VALU"] / simd_quad, 3),
             "wave_time_waiting_on_memory_frac": round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 3),
             "wave_time_waiting_to_issue_frac": round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 3),
-            "lds_insts_per_byte": round(d["SQ_INSTS_LDS"] * 64 / nbytes, 3),
-            "lds_bank_conflict_frac_of_lds_active": round(d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1), 3),
+            "lds_insts_per_byte": round(d["SQ_INSTS_LDS"] * 64 / nbytes, 3) if "SQ_INSTS_LDS" in d else None,
+            "lds_bank_conflict_frac_of_lds_active": (round(d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1), 3)
+                                                     if "SQ_LDS_BANK_CONFLICT" in d else None),
             "FETCH_SIZE_KiB_x1024_x2_over_bytes": round(d.get("FETCH_SIZE", 0) * 1024 * 2 / nbytes, 3),
             "ea_read_requests": d.get("TCC_EA0_RDREQ_sum"), "ea_read_requests_32B": d.get("TCC_EA0_RDREQ_32B_sum"),
             "ea_read_bytes_over_bytes_if_others_are_64B": (round((d["TCC_EA0_RDREQ_32B_sum"] * 32 + (d["TCC_EA0_RDREQ_sum"] - d["TCC_EA0_RDREQ_32B_sum"]) * 64) / nbytes, 3)

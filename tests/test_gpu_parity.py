@@ -616,6 +616,41 @@ def test_query_pattern_compiles_what_the_reference_compiles(agh):
         assert res.n_matched == case["count"], (case["pattern"], case["opts"])
 
 
+def test_table_engine_two_streams_per_lane(agh, monkeypatch):
+    """k_tablescan_fast2 (tables of M <= 15 positions: two chunks share every state word) against the one-stream
+    kernel, the exact one-kernel form and the oracle on the reference's tables: record lengths from 0 to beyond a
+    chunk, texts that end inside a tile pair / exactly on a tile / in the odd tile, matches at the last byte, the
+    whole list and count-only."""
+    rng = np.random.default_rng(2026)
+    words = [b"car", b"cars", b"red", b"fast", b"scar", b"cat", b"approx", b"match", b"approxQmatch", b"mat", b" ", b" ", b"\n"]
+    base = b"".join(words[i] for i in rng.integers(0, len(words), 420000))           # ~1.6 MiB
+    long_rec = bytes(rng.integers(97, 123, 9000, dtype=np.uint8))                   # no newline: beyond a 4 KiB chunk
+    tile = 64 * 4096
+    texts = [base, base[:tile], base[:tile + 1], base[:2 * tile], base[:2 * tile + 17], base[:3 * tile - 5] + b"scar",
+             base[:5000] + long_rec + b"cat\n" + long_rec + b"approx match" + long_rec, b"scar", b"", b"\n\n",
+             base[:tile - 3] + b"cat", (b"x" * 4095 + b"\n") * 70 + b"red car"]
+    for pat, k in ((b"approx#match", 0), (b"approx#match", 1), (b"appr#mat#ch", 2), (b"scar,cat", 0), (b"car;red", 1),
+                   (b"cars;fast", 0), (b"ma#ch,c#t", 1), (b"a#h", 0)):
+        tb = agh.compile_pattern(pat)
+        assert tb.M <= 15
+        ot = O.tables_from_golden({"Mask": list(tb.Mask), "Init0": tb.Init0, "Init1": tb.Init1, "NO_ERR_MASK": tb.NO_ERR_MASK,
+                                   "endposition": tb.endposition, "D_endpos": tb.D_endpos, "wildmask": tb.wildmask, "AND": tb.AND}, tb.M)
+        with agh.Query.pattern(pat, k) as q:
+            for i, text in enumerate(texts):
+                want = O.asearch_tables(ot, k, text, cap=400000)
+                for env in ({}, {"AGH_TF_PACK2": "0"}, {"AGH_FS_FAST": "0"}):
+                    monkeypatch.delenv("AGH_TF_PACK2", raising=False)
+                    monkeypatch.delenv("AGH_FS_FAST", raising=False)
+                    for key, v in env.items():
+                        monkeypatch.setenv(key, v)
+                    res, ms = q.scan_buffer(text, cap=400000)
+                    assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (pat, k, i, env)
+                    res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+                    assert res_c.n_matched == want[0], (pat, k, i, env, "count-only")
+    monkeypatch.delenv("AGH_TF_PACK2", raising=False)
+    monkeypatch.delenv("AGH_FS_FAST", raising=False)
+
+
 def test_table_engine_adversarial_texts(agh):
     """'#' wildcards, ';' AND and ',' OR run by the table engine (agh_table.hip): records from
     empty to 300 KiB, chunk-straddling records, no trailing delimiter -- always the oracle's
