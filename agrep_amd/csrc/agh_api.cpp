@@ -945,6 +945,12 @@ extern "C" int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q,
 // no pattern position accepts.  The replay lists live in the candidate buffers a full scan does not
 // use otherwise.  AGH_FS_FAST=0: the exact kernel (A/B runs).
 #define AGH_FF_SLICE_HOST 256u      // = AGH_FF_SLICE (agh_fullscan.hip)
+// The table engine's fast form walks 4 KiB per lane: a wave needs ~0.28 ms for its tile however small the text,
+// and below ~1 GiB there are not enough waves to hide that.  The exact kernel (1 KiB per lane) has a floor of
+// 0.18 ms and wins up to 256 MiB, loses from 512 MiB on (profiles/r04_perf_table_sizes.log).
+#ifndef AGH_TF_FAST_MIN_MB_DEFAULT
+#define AGH_TF_FAST_MIN_MB_DEFAULT 320
+#endif
 static bool fs_fast_ok(const agh_query *q)
 {
     if (!q->tune.fs_fast || q->fs_fast_off || q->multi) return false;
@@ -958,6 +964,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
 {
     va->fs_fast = 0;
     if (!fs_fast_ok(q)) return 0;
+    if (q->table && n < (q->tune.tf_fast_min_mb << 20)) return 0;
     // (64 KiB tiles with 256 entries each; the table engine's 256 KiB tiles with 1024 entries need the same)
     const uint64_t n_tiles = (n + 65535) / 65536;
     if (q->cand.ensure((n_tiles + 4) * AGH_FF_SLICE_HOST * sizeof(uint64_t))) return -1;
@@ -1563,6 +1570,7 @@ void agh_read_tuning(agh_tuning *t)
     t->tight_verify = env_on("AGH_TIGHT_VERIFY", true);
     t->fs_fast = env_on("AGH_FS_FAST", true);
     t->tf_pack2 = env_on("AGH_TF_PACK2", true);
+    t->tf_fast_min_mb = env_u64("AGH_TF_FAST_MIN_MB", AGH_TF_FAST_MIN_MB_DEFAULT);
     t->fused = env_on("AGH_FUSED", AGH_FUSED_DEFAULT != 0);
     t->debug = getenv("AGH_DEBUG") != nullptr;
     t->aligned_cuts_only = getenv("AGH_ALIGNED_CUTS_ONLY") != nullptr;

@@ -13,6 +13,7 @@ struct agh_tuning {
     bool tight_verify = true;       // AGH_TIGHT_VERIFY
     bool fs_fast = true;            // AGH_FS_FAST
     bool tf_pack2 = true;           // AGH_TF_PACK2: table engine, two streams per lane where M <= 15
+    uint64_t tf_fast_min_mb = 320;  // AGH_TF_FAST_MIN_MB: table engine, fast form from this segment size on
     bool fused = true;              // AGH_FUSED
     bool debug = false;             // AGH_DEBUG
     bool aligned_cuts_only = false; // AGH_ALIGNED_CUTS_ONLY

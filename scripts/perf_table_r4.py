@@ -3,7 +3,8 @@
 form (AGH_FS_FAST=0).  Patterns go through the library's own compiler (agh_query_pattern).
 usage: scripts/perf_table_r4.py [GiB, default 4]"""
 import os, sys
-os.environ.setdefault("AGH_ENV_LIVE", "1")   # switches are flipped between scans of one query
+os.environ.setdefault("AGH_ENV_LIVE", "1")
+os.environ.setdefault("AGH_TF_FAST_MIN_MB", "0")   # switches are flipped between scans of one query
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import torch
