@@ -60,6 +60,10 @@ def test_compiler_refuses_what_it_does_not_compile():
                 b"a" * 31, b""):
         with pytest.raises(A.AghError):
             A.compile_pattern(pat)
+    # '#' alone: the reference builds tables without an end position (they can never match); refused here
+    for pat in (b"#", b"##"):
+        with pytest.raises(A.AghError):
+            A.compile_pattern(pat)
     with pytest.raises(A.AghError):
         A.compile_pattern(b"abc", word=True, wholeline=True)
     # 30 - |delimiter| pattern positions (maskgen.c:201-208)
@@ -69,3 +73,59 @@ def test_compiler_refuses_what_it_does_not_compile():
         A.compile_pattern(b"a" * 26, delim=b"From ")
     assert A.compile_pattern(b"abc").simple == 1 and A.compile_pattern(b"a\\#c").simple == 1
     assert A.compile_pattern(b"a#c").simple == 0 and A.compile_pattern(b"a[bc]").simple == 0
+
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not built")
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_compiler_against_the_live_reference(seed):
+    """A fresh random walk over the pattern tokens on every seed, compiled by the reference's own preprocess() +
+    maskgen() (oracle/_ref/ref_harness tables) and by agh_compile_pattern: the same tables, the same refusals."""
+    import json
+    import random
+    import subprocess
+    rng = random.Random(seed)
+    toks = ["a", "b", "c", "Q", "z", "0", "7", " ", ".", "#", "\\.", "\\#", "\\\\", "[a-c]", "[^x-z]", "[abQ]", "[0-9a-f]",
+            "<ab>", "<Qz0>", "[a\\]]", "[A-C]", "_", "\\-", "\\[", "\\<", "[^a]", "x#y", "<a>", "\\^", "\\$"]
+    checked = refused = 0
+    for _ in range(70):
+        body = "".join(rng.choice(toks) for _ in range(rng.randint(1, 12)))
+        if not body.strip("#"):                 # no position at all: see test_compiler_refuses_...
+            continue
+        r = rng.random()
+        if r < 0.1:
+            body += ";" + "".join(rng.choice(toks[:8]) for _ in range(rng.randint(1, 4)))
+        elif r < 0.2:
+            body += "," + "".join(rng.choice(toks[:8]) for _ in range(rng.randint(1, 4)))
+        elif r < 0.25:
+            body = "^" + body
+        elif r < 0.3:
+            body += "$"
+        opts = (["-i"] if rng.random() < 0.35 else []) + rng.choice([[], [], [], ["-w"], ["-x"]])
+        delim = b"\n"
+        if "-x" not in opts and rng.random() < 0.25:
+            d = rng.choice(["$$", ";;", "From ", "@@@", "ab"])
+            opts += ["-d", d]
+            delim = d.replace("$", "\n").encode("latin1")
+            if "-i" in opts:
+                delim = delim.lower()
+        p = subprocess.run([HARNESS, "tables", "-n"] + opts + [body], stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=20)
+        try:
+            g = json.loads(p.stdout)
+        except ValueError:
+            g = None
+        kw = dict(nocase="-i" in opts, word="-w" in opts, wholeline="-x" in opts, delim=delim)
+        what = {"pattern": body, "opts": opts, "delim": delim}
+        if p.returncode != 0 or g is None or g["ret"] < 0:
+            with pytest.raises(A.AghError):
+                A.compile_pattern(body.encode("latin1"), **kw)
+            refused += 1
+            continue
+        if g["SGREP"]:
+            continue
+        _same_tables(A.compile_pattern(body.encode("latin1"), **kw), g, what)
+        checked += 1
+    assert checked >= 40
