@@ -945,11 +945,15 @@ extern "C" int agh_query_info(const agh_query *q, int *m, int *D, int *filter_q,
 // no pattern position accepts.  The replay lists live in the candidate buffers a full scan does not
 // use otherwise.  AGH_FS_FAST=0: the exact kernel (A/B runs).
 #define AGH_FF_SLICE_HOST 256u      // = AGH_FF_SLICE (agh_fullscan.hip)
-// The table engine's fast form walks 4 KiB per lane: a wave needs ~0.28 ms for its tile however small the text,
-// and below ~1 GiB there are not enough waves to hide that.  The exact kernel (1 KiB per lane) has a floor of
-// 0.18 ms and wins up to 256 MiB, loses from 512 MiB on (profiles/r04_perf_table_sizes.log).
+// The table engine's fast form walks its chunk serially: with 4 KiB per lane a wave needs ~0.28 ms however small
+// the text, and the exact kernel (1 KiB per lane, floor 0.18 ms) won below ~320 MiB.  With the chunk chosen by the
+// size of the text (1 KiB below 512 MiB: floor 0.11 ms) the fast form wins at every size
+// (profiles/r04_perf_table_sizes.log), so there is no switch-over any more; AGH_TF_FAST_MIN_MB brings one back.
 #ifndef AGH_TF_FAST_MIN_MB_DEFAULT
-#define AGH_TF_FAST_MIN_MB_DEFAULT 320
+#define AGH_TF_FAST_MIN_MB_DEFAULT 0
+#endif
+#ifndef AGH_TF_CHUNK_DEFAULT
+#define AGH_TF_CHUNK_DEFAULT 0          // bytes per lane of the fast form (1024 / 2048 / 4096); 0: by the size of the text
 #endif
 static bool fs_fast_ok(const agh_query *q)
 {
@@ -963,6 +967,7 @@ static bool fs_fast_ok(const agh_query *q)
 static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
 {
     va->fs_fast = 0;
+    va->tf_chunk = 0;
     if (!fs_fast_ok(q)) return 0;
     if (q->table && n < (q->tune.tf_fast_min_mb << 20)) return 0;
     // (64 KiB tiles with 256 entries each; the table engine's 256 KiB tiles with 1024 entries need the same)
@@ -970,6 +975,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     if (q->cand.ensure((n_tiles + 4) * AGH_FF_SLICE_HOST * sizeof(uint64_t))) return -1;
     if (q->wave_cand.ensure((n_tiles + 8) * sizeof(uint32_t))) return -1;
     va->fs_fast = 1;
+    va->tf_chunk = q->tune.tf_chunk;
     // table engine, M <= 15: two streams per lane (k_tablescan_fast2) -- the always-one bit M must be there
     if (q->table && q->tune.tf_pack2) {
         const unsigned M = (unsigned)q->m + (unsigned)q->dlen + 1u;
@@ -1571,6 +1577,10 @@ void agh_read_tuning(agh_tuning *t)
     t->fs_fast = env_on("AGH_FS_FAST", true);
     t->tf_pack2 = env_on("AGH_TF_PACK2", true);
     t->tf_fast_min_mb = env_u64("AGH_TF_FAST_MIN_MB", AGH_TF_FAST_MIN_MB_DEFAULT);
+    {
+        const uint64_t c = env_u64("AGH_TF_CHUNK", AGH_TF_CHUNK_DEFAULT);
+        t->tf_chunk = (c == 1024 || c == 2048 || c == 4096) ? (uint32_t)c : 0u;
+    }
     t->fused = env_on("AGH_FUSED", AGH_FUSED_DEFAULT != 0);
     t->debug = getenv("AGH_DEBUG") != nullptr;
     t->aligned_cuts_only = getenv("AGH_ALIGNED_CUTS_ONLY") != nullptr;

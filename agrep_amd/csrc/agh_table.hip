@@ -316,15 +316,19 @@ __device__ __forceinline__ void table_reset_state(const agh_dev_tables &T, uint3
 // LONGEST of its 64 lanes' walks (~300 bytes with 80-byte records), a third of a 1 KiB chunk's work
 // but a twelfth of this one's.  Record numbers do not depend on it (the replay takes them from the
 // census strips).
-#define AGH_TF_CHUNK 4096u
-#define AGH_TF_SLICE 1024u      // replay entries per tile (64 chunks = 256 KiB)
+// Round 4: the chunk is a launch parameter (1, 2 or 4 KiB: agh_launch_tablescan picks it by the size of the
+// text -- a wave walks its chunk serially, 0.28 ms at 4 KiB, so small texts take small chunks); a tile is 64
+// chunks and its replay slice holds one entry per 256 bytes of text whatever the chunk.
+#define AGH_TF_CHUNK_MAX 4096u
+#define AGH_TF_SLICE_OF(chunk) ((chunk) / 4u)      // replay entries per tile (64 chunks)
 
 template <int K>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
-    uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters)
+    uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters, uint32_t tf_chunk)
 {
+    const uint32_t tf_slice = AGH_TF_SLICE_OF(tf_chunk);
     struct MK { uint32_t cm, kb; };
     __shared__ MK tab[256];
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * WAVE * AGH_FS_ROW];
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     uint8_t *ring = ring_all + wib * (WAVE * AGH_FS_ROW);
-    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_TF_CHUNK;
+    const uint64_t tile_bytes = (uint64_t)WAVE * tf_chunk;
     const uint64_t n_tiles = (n + tile_bytes - 1) / tile_bytes;
     const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
     const uint64_t n16 = (n + 15) & ~(uint64_t)15;
@@ -347,14 +351,14 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     for (uint64_t tile = (uint64_t)blockIdx.x * (AGH_FS_THREADS / WAVE) + wib; tile < n_tiles;
          tile += (uint64_t)gridDim.x * (AGH_FS_THREADS / WAVE)) {
         const uint64_t t0 = tile * tile_bytes;
-        const uint64_t cs = t0 + (uint64_t)lane * AGH_TF_CHUNK;
-        uint64_t ce = cs + AGH_TF_CHUNK;
+        const uint64_t cs = t0 + (uint64_t)lane * tf_chunk;
+        uint64_t ce = cs + tf_chunk;
         if (ce > n) ce = n;
         const uint32_t len = cs < n ? (uint32_t)(ce - cs) : 0u;
         auto gather = [&](uint32_t r, uint4 (&g)[4]) {
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
-                const uint64_t a = t0 + (uint64_t)(seg_lo + 16u * i) * AGH_TF_CHUNK + r * AGH_FS_ROUND + part * 16u;
+                const uint64_t a = t0 + (uint64_t)(seg_lo + 16u * i) * tf_chunk + r * AGH_FS_ROUND + part * 16u;
                 g[i] = a < n16 ? *reinterpret_cast<const uint4 *>(text + a) : make_uint4(fill4, fill4, fill4, fill4);
             }
         };
@@ -394,18 +398,18 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
             if (f) {
                 const uint32_t at = cnt + rank;
-                if (at < AGH_TF_SLICE) replay[tile * AGH_TF_SLICE + at] = pos;
+                if (at < tf_slice) replay[tile * tf_slice + at] = pos;
                 else counters[AGH_C_OVERFLOW] = 1u;
             }
             cnt += (uint32_t)__popcll(fm);
         };
-        for (uint32_t r = 0; r < AGH_TF_CHUNK / AGH_FS_ROUND; ++r) {
+        for (uint32_t r = 0; r < tf_chunk / AGH_FS_ROUND; ++r) {
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i)
                 *reinterpret_cast<uint4 *>(ring_w + 16u * i * AGH_FS_ROW) = g[i];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (r + 1 < AGH_TF_CHUNK / AGH_FS_ROUND) gather(r + 1, g);
+            if (r + 1 < tf_chunk / AGH_FS_ROUND) gather(r + 1, g);
 #pragma unroll 1
             for (uint32_t p = 0; p < 4; ++p) {
                 const uint32_t off = r * AGH_FS_ROUND + 16u * p;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
         // on alone to the delimiter that closes my last record (ce is 16-byte aligned unless ce == n)
         // (a record that starts exactly at the chunk's end is mine as well: I saw the delimiter in
         // front of it, the next lane trusts its state only behind the first delimiter IT sees)
-        bool open = len == AGH_TF_CHUNK && trusted != 0u && ce < n;
+        bool open = len == tf_chunk && trusted != 0u && ce < n;
         dseen = 0;
         for (uint64_t p0 = ce; __ballot(open); p0 += 16) {
             // whole 16-byte pieces until one holds a delimiter: what it flags behind that delimiter
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
             // (into MY tile's list, whatever tile the piece lies in: the replay only needs the position)
             emit(mine && flag != 0u, p0);
         }
-        if (lane == 0) tile_cnt[tile] = cnt < AGH_TF_SLICE ? cnt : AGH_TF_SLICE;
+        if (lane == 0) tile_cnt[tile] = cnt < tf_slice ? cnt : tf_slice;
     }
 }
 
@@ -479,8 +483,10 @@ template <int K>
 __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
-    uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters, uint32_t M, uint32_t n_tiles1)
+    uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters, uint32_t M, uint32_t n_tiles1,
+    uint32_t tf_chunk)
 {
+    const uint32_t tf_slice = AGH_TF_SLICE_OF(tf_chunk);
     __shared__ uint32_t tab[256];               // mask (bits 0..M-1) | kill << 16 (0 for the delimiter, else 0xffff)
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * 2 * WAVE * AGH_TF2_ROW];
     const uint32_t keep = (2u << M) - 1u;       // bits 0..M
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     uint8_t *ring = ring_all + wib * (2 * WAVE * AGH_TF2_ROW);
-    const uint64_t tile_bytes = (uint64_t)WAVE * AGH_TF_CHUNK;        // one stream's tile
+    const uint64_t tile_bytes = (uint64_t)WAVE * tf_chunk;        // one stream's tile
     const uint64_t n_tiles2 = ((uint64_t)n_tiles1 + 1) / 2;
     const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
     const uint64_t n16 = (n + 15) & ~(uint64_t)15;
@@ -516,15 +522,15 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
         uint32_t len[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            cs[s2] = t0 + (uint64_t)s2 * tile_bytes + (uint64_t)lane * AGH_TF_CHUNK;
-            ce[s2] = cs[s2] + AGH_TF_CHUNK;
+            cs[s2] = t0 + (uint64_t)s2 * tile_bytes + (uint64_t)lane * tf_chunk;
+            ce[s2] = cs[s2] + tf_chunk;
             if (ce[s2] > n) ce[s2] = n;
             len[s2] = cs[s2] < n ? (uint32_t)(ce[s2] - cs[s2]) : 0u;
         }
         auto gather = [&](uint32_t r, uint32_t first, uint4 (&g)[4]) {      // rows first .. first + 63, 16 apart
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
-                const uint64_t a = t0 + (uint64_t)(first + seg_lo + 16u * i) * AGH_TF_CHUNK + r * AGH_FS_ROUND + part * 16u;
+                const uint64_t a = t0 + (uint64_t)(first + seg_lo + 16u * i) * tf_chunk + r * AGH_FS_ROUND + part * 16u;
                 g[i] = a < n16 ? *reinterpret_cast<const uint4 *>(text + a) : make_uint4(fill4, fill4, fill4, fill4);
             }
         };
@@ -578,12 +584,12 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
             if (f) {
                 const uint32_t at = cnt + rank;
-                if (at < AGH_TF_SLICE) replay[tile1 * AGH_TF_SLICE + at] = pos;
+                if (at < tf_slice) replay[tile1 * tf_slice + at] = pos;
                 else counters[AGH_C_OVERFLOW] = 1u;
             }
             cnt += (uint32_t)__popcll(fm);
         };
-        for (uint32_t r = 0; r < AGH_TF_CHUNK / AGH_FS_ROUND; ++r) {
+        for (uint32_t r = 0; r < tf_chunk / AGH_FS_ROUND; ++r) {
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
                 *reinterpret_cast<uint4 *>(ring_w + 16u * i * AGH_TF2_ROW) = ga[i];
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (r + 1 < AGH_TF_CHUNK / AGH_FS_ROUND) {
+            if (r + 1 < tf_chunk / AGH_FS_ROUND) {
                 gather(r + 1, 0u, ga);
                 gather(r + 1, WAVE, gb);
             }
@@ -618,8 +624,8 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
             __builtin_amdgcn_wave_barrier();
         }
         // on alone to the delimiter that closes a stream's last record (k_tablescan_fast: the same walk)
-        bool opa = len[0] == AGH_TF_CHUNK && (trusted & 0xffffu) != 0u && ce[0] < n;
-        bool opb = len[1] == AGH_TF_CHUNK && (trusted >> 16) != 0u && ce[1] < n;
+        bool opa = len[0] == tf_chunk && (trusted & 0xffffu) != 0u && ce[0] < n;
+        bool opb = len[1] == tf_chunk && (trusted >> 16) != 0u && ce[1] < n;
         dseen = 0;
         for (uint64_t step = 0; __ballot(opa || opb); step += 16) {
             const uint64_t pa = ce[0] + step, pb = ce[1] + step;
@@ -648,8 +654,8 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
             emit(fb, pb, tile2 * 2 + 1, cnt1);
         }
         if (lane == 0) {
-            tile_cnt[tile2 * 2] = cnt0 < AGH_TF_SLICE ? cnt0 : AGH_TF_SLICE;
-            if (tile2 * 2 + 1 < n_tiles1) tile_cnt[tile2 * 2 + 1] = cnt1 < AGH_TF_SLICE ? cnt1 : AGH_TF_SLICE;
+            tile_cnt[tile2 * 2] = cnt0 < tf_slice ? cnt0 : tf_slice;
+            if (tile2 * 2 + 1 < n_tiles1) tile_cnt[tile2 * 2 + 1] = cnt1 < tf_slice ? cnt1 : tf_slice;
         }
     }
 }
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(256) void k_table_replay(
     const uint32_t *__restrict__ mask_g, const uint64_t *__restrict__ replay,
     const uint32_t *__restrict__ tile_cnt, uint32_t n_tiles,
     const uint32_t *__restrict__ strip_prefix, const uint32_t *__restrict__ wave_prefix,
-    uint32_t n_strips, agh_marks mk)
+    uint32_t n_strips, agh_marks mk, uint32_t tf_slice)
 {
     __shared__ uint32_t lmask[256];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(256) void k_table_replay(
     for (uint32_t tile = blockIdx.x * 4u + threadIdx.x / WAVE; tile < n_tiles; tile += gridDim.x * 4u) {
         const uint32_t cnt = tile_cnt[tile];
         for (uint32_t e = (uint32_t)lane_id(); e < cnt; e += WAVE) {
-            const uint64_t P = replay[(uint64_t)tile * AGH_TF_SLICE + e];
+            const uint64_t P = replay[(uint64_t)tile * tf_slice + e];
             uint64_t pend = P + 16;
             if (pend > n) pend = n;
             // records that end in [P, pend): one per delimiter there, plus the open one at the text's end
@@ -724,7 +730,11 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
     const bool lean = a.mk.hashset != nullptr;  // count-only: hash set of record starts, no census
     const bool costs = a.q.ci != 1u || a.q.cs != 1u || a.q.cd != 1u;     // asearch1.c instead of asearch.c
     if (a.fs_fast && !costs) {                  // branch-free hot kernel + exact replay (the host checked)
-        const uint64_t tf_tile = (uint64_t)WAVE * AGH_TF_CHUNK;             // 256 KiB tiles here
+        // chunk per lane: 4 KiB from 1 GiB on, 2 KiB from 512 MiB, else 1 KiB (a.tf_chunk forces one)
+        const uint32_t tf_chunk = a.tf_chunk ? a.tf_chunk
+                                      : (a.n >= ((uint64_t)1 << 30) ? 4096u : (a.n >= ((uint64_t)512 << 20) ? 2048u : 1024u));
+        const uint32_t tf_slice = AGH_TF_SLICE_OF(tf_chunk);
+        const uint64_t tf_tile = (uint64_t)WAVE * tf_chunk;             // 64 / 128 / 256 KiB tiles
         const uint32_t nt = (uint32_t)((a.n + tf_tile - 1) / tf_tile);
         const uint32_t fblocks = (nt + 3u) / 4u > 16384u ? 16384u : (nt + 3u) / 4u;
         const uint32_t rblocks = fblocks;
@@ -736,21 +746,21 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
         if (a.fs_fast == 2)                                                                   \
             hipLaunchKernelGGL((k_tablescan_fast2<KK>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
                                (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                               a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt);             \
+                               a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt, tf_chunk); \
         else                                                                                  \
         hipLaunchKernelGGL((k_tablescan_fast<KK>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
                            (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                           a.fs_replay, a.fs_tile_cnt, a.mk.counters);                        \
+                           a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_chunk);          \
         if (lean)                                                                             \
             hipLaunchKernelGGL((k_table_replay<KK, true>), dim3(rblocks), dim3(256), 0, st,   \
                                (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
                                (const uint64_t *)a.fs_replay, (const uint32_t *)a.fs_tile_cnt, nt, \
-                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);              \
+                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, tf_slice); \
         else                                                                                  \
             hipLaunchKernelGGL((k_table_replay<KK, false>), dim3(rblocks), dim3(256), 0, st,  \
                                (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
                                (const uint64_t *)a.fs_replay, (const uint32_t *)a.fs_tile_cnt, nt, \
-                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk);              \
+                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, tf_slice); \
         break;
         switch (a.q.k) {
             AGH_TF_CASE(0) AGH_TF_CASE(1) AGH_TF_CASE(2) AGH_TF_CASE(3) AGH_TF_CASE(4)

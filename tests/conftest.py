@@ -8,8 +8,9 @@ import pytest
 # kernels below; the test texts are small, so the tests ask for the fused kernel at every
 # size -- _check() in test_gpu_parity.py runs the two-kernel form explicitly beside it.
 os.environ.setdefault("AGH_FUSED_MIN_MB", "0")
-# The same for the table engine: its fast form (k_tablescan_fast2 / k_tablescan_fast + k_table_replay) is the
-# default from 320 MiB on; the tests run it at every size and the exact kernel beside it (AGH_FS_FAST=0).
+# The table engine's fast form (k_tablescan_fast2 / k_tablescan_fast + k_table_replay) at every size, whatever
+# AGH_TF_FAST_MIN_MB the build ships (0 since the chunk is chosen by the size of the text); the tests run the
+# exact kernel beside it (AGH_FS_FAST=0) and every chunk size (test_table_engine_two_streams_per_lane).
 os.environ.setdefault("AGH_TF_FAST_MIN_MB", "0")
 # The library reads its environment switches once per query; the tests flip them between scans of one
 # query (AGH_FUSED, AGH_FS_FAST, ...): AGH_ENV_LIVE=1 makes every scan call read them again.

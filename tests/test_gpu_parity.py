@@ -627,6 +627,7 @@ def test_table_engine_two_streams_per_lane(agh, monkeypatch):
     long_rec = bytes(rng.integers(97, 123, 9000, dtype=np.uint8))                   # no newline: beyond a 4 KiB chunk
     tile = 64 * 4096
     texts = [base, base[:tile], base[:tile + 1], base[:2 * tile], base[:2 * tile + 17], base[:3 * tile - 5] + b"scar",
+             base[:65536], base[:65536 + 1], base[:3 * 65536 - 5] + b"scar", base[:128 * 1024 + 17],
              base[:5000] + long_rec + b"cat\n" + long_rec + b"approx match" + long_rec, b"scar", b"", b"\n\n",
              base[:tile - 3] + b"cat", (b"x" * 4095 + b"\n") * 70 + b"red car"]
     for pat, k in ((b"approx#match", 0), (b"approx#match", 1), (b"appr#mat#ch", 2), (b"scar,cat", 0), (b"car;red", 1),
@@ -638,17 +639,20 @@ def test_table_engine_two_streams_per_lane(agh, monkeypatch):
         with agh.Query.pattern(pat, k) as q:
             for i, text in enumerate(texts):
                 want = O.asearch_tables(ot, k, text, cap=400000)
-                for env in ({}, {"AGH_TF_PACK2": "0"}, {"AGH_FS_FAST": "0"}):
-                    monkeypatch.delenv("AGH_TF_PACK2", raising=False)
-                    monkeypatch.delenv("AGH_FS_FAST", raising=False)
+                # (bytes per lane of the fast form: 4 KiB, 2 KiB, 1 KiB, by the size of the text)
+                for env in ({"AGH_TF_CHUNK": "4096"}, {"AGH_TF_CHUNK": "2048"}, {"AGH_TF_CHUNK": "1024"}, {"AGH_TF_CHUNK": "0"},
+                            {"AGH_TF_PACK2": "0", "AGH_TF_CHUNK": "4096"}, {"AGH_TF_PACK2": "0", "AGH_TF_CHUNK": "1024"},
+                            {"AGH_FS_FAST": "0"}):
+                    for key in ("AGH_TF_PACK2", "AGH_FS_FAST", "AGH_TF_CHUNK"):
+                        monkeypatch.delenv(key, raising=False)
                     for key, v in env.items():
                         monkeypatch.setenv(key, v)
                     res, ms = q.scan_buffer(text, cap=400000)
                     assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (pat, k, i, env)
                     res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
                     assert res_c.n_matched == want[0], (pat, k, i, env, "count-only")
-    monkeypatch.delenv("AGH_TF_PACK2", raising=False)
-    monkeypatch.delenv("AGH_FS_FAST", raising=False)
+    for key in ("AGH_TF_PACK2", "AGH_FS_FAST", "AGH_TF_CHUNK"):
+        monkeypatch.delenv(key, raising=False)
 
 
 def test_table_engine_adversarial_texts(agh):
