@@ -207,6 +207,17 @@ static int parse_options(int argc, char **argv, char **files)
      * (agh_query_pattern = preprocess() + maskgen() restated); it refuses regular expressions */
     opt.fancy = !literal_only && !pattern_is_literal(opt.pattern);
     if (opt.fancy && opt.BESTMATCH) die_usage("-B needs a literal pattern in this build");
+    if (opt.fancy) {                            /* host-only: a pattern the library cannot compile is reported
+                                                 * before any device is touched (maskgen.c / preproce.c messages) */
+        agh_pattern_tables tb;
+        const unsigned qf = (opt.NOUPPER ? AGH_Q_NOCASE : 0u) | (opt.WORDBOUND ? AGH_Q_WORD : 0u) |
+                            (opt.WHOLELINE ? AGH_Q_WHOLELINE : 0u);
+        if (agh_compile_pattern((const unsigned char *)opt.pattern, (int)strlen(opt.pattern), qf, opt.delim,
+                                opt.dlen, &tb)) {
+            fprintf(stderr, "%s: %s\n", Progname, agh_last_error());
+            exit(2);
+        }
+    }
     /* compat.c:26-29: -B is ignored together with -c, -l or -# */
     if (opt.BESTMATCH && (opt.COUNT || opt.FILENAMEONLY || opt.APPROX)) opt.BESTMATCH = 0;
     if (opt.COUNT && opt.FILENAMEONLY) opt.FILENAMEONLY = 0;     /* agrep.c:2896-2899 */
