@@ -96,25 +96,18 @@ int parse_class(compiler &C, const unsigned char *p, int len, int &i)
     byte_class k;
     bool complement = false;
     if (i < len && p[i] == '^') { complement = true; ++i; }
-    int prev = -1;                                       // last single byte: a '-' behind it opens a range
     bool closed = false;
+    const char *const unmatched = "unmatched '[', ']' (use \\[, \\] to search for [, ])";
+    // A '-' that is not between two bytes of its own -- first or last in the class, or behind a finished range
+    // ([a-c-e]) -- is read by the reference in ways nobody would guess ([a-e-c] is a..c, [-a] is empty, [a-] is
+    // "unmatched"): refused here, so that whatever this compiler accepts it compiles like the reference.
+    const char *const stray = "'-' inside [] that is not between two bytes must be written \\-";
     while (i < len) {
         unsigned c = p[i];
         if (c == ']') { closed = true; ++i; break; }
-        if (c == '-' && prev >= 0 && i + 1 < len && p[i + 1] != ']') {
-            unsigned hi = p[i + 1];
-            i += 2;
-            if (hi == '\\') {
-                if (i >= len) return fail("unmatched '[', ']' (use \\[, \\] to search for [, ])");
-                hi = p[i++];
-            }
-            if (C.nocase && is_upper(hi)) hi += 32;
-            k.add_range((unsigned)prev, hi);            // (an empty range adds nothing, as in maskgen.c:246-250)
-            prev = -1;
-            continue;
-        }
+        if (c == '-') return fail(stray);
         if (c == '\\') {
-            if (i + 1 >= len) return fail("unmatched '[', ']' (use \\[, \\] to search for [, ])");
+            if (i + 1 >= len) return fail(unmatched);
             c = p[i + 1];
             i += 2;
         } else {
@@ -123,10 +116,24 @@ int parse_class(compiler &C, const unsigned char *p, int len, int &i)
             ++i;
         }
         if (C.nocase && is_upper(c)) c += 32;
+        // lo-hi: the bytes from lo to hi and nothing else -- a range that runs backwards is empty, its first
+        // byte included (maskgen.c:246-250 tests lo <= c <= hi)
+        if (i < len && p[i] == '-') {
+            if (i + 1 >= len || p[i + 1] == ']' || p[i + 1] == '-') return fail(stray);
+            unsigned hi = p[i + 1];
+            i += 2;
+            if (hi == '\\') {
+                if (i >= len) return fail(unmatched);
+                hi = p[i++];
+            }
+            if (C.nocase && is_upper(hi)) hi += 32;
+            k.add_range(c, hi);
+            if (i < len && p[i] == '-') return fail(stray);
+            continue;
+        }
         k.add(c);
-        prev = (int)c;
     }
-    if (!closed) return fail("unmatched '[', ']' (use \\[, \\] to search for [, ])");
+    if (!closed) return fail(unmatched);
     if (complement) k.invert();                          // over all 256 bytes, the newline included (maskgen.c:252)
     C.fancy = true;
     return C.add(k, C.angle > 0);

@@ -60,6 +60,12 @@ def test_compiler_refuses_what_it_does_not_compile():
                 b"a" * 31, b""):
         with pytest.raises(A.AghError):
             A.compile_pattern(pat)
+    # a '-' inside [] that is not between two bytes of its own: the reference reads [a-e-c] as a..c, [-a] as empty
+    # and [a-] as "unmatched" -- refused, so that what compiles, compiles like the reference
+    for pat in (b"[-a]x", b"[a-]x", b"[a-c-e]x", b"[a--]x", b"[^-a]x"):
+        with pytest.raises(A.AghError):
+            A.compile_pattern(pat)
+    assert A.compile_pattern(b"[a\\-c]x").M == 4 and A.compile_pattern(b"[\\-a]x").M == 4
     # '#' alone: the reference builds tables without an end position (they can never match); refused here
     for pat in (b"#", b"##"):
         with pytest.raises(A.AghError):
@@ -129,3 +135,42 @@ def test_compiler_against_the_live_reference(seed):
         _same_tables(A.compile_pattern(body.encode("latin1"), **kw), g, what)
         checked += 1
     assert checked >= 40
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not built")
+def test_character_classes_against_the_live_reference():
+    """Ranges forwards and backwards ([z-a] is empty, its first byte included), complements, escaped members, -i
+    folding both ends of a range before it is evaluated: the reference's Mask[] for every class that compiles."""
+    import json
+    import random
+    import subprocess
+    rng = random.Random(4)
+
+    def rand_class():
+        s = "[" + ("^" if rng.random() < 0.3 else "")
+        for _ in range(rng.randint(1, 4)):
+            c = rng.choice("aAzZmMbB09_!")
+            s += c + "-" + rng.choice("aAzZmMfF09_~") if rng.random() < 0.5 else c
+            if rng.random() < 0.15:
+                s += "\\]"
+            if rng.random() < 0.1:
+                s += "\\-"
+        return s + "]"
+    checked = 0
+    for _ in range(160):
+        body = "".join(rng.choice(["x", "Y", rand_class(), rand_class(), "q"]) for _ in range(rng.randint(1, 5)))
+        opts = ["-i"] if rng.random() < 0.6 else []
+        try:
+            t = A.compile_pattern(body.encode("latin1"), nocase=bool(opts))
+        except A.AghError as e:
+            assert "not between two bytes" in str(e), (body, str(e))      # [a-c-e] and friends
+            continue
+        p = subprocess.run([HARNESS, "tables", "-n"] + opts + [body], stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=20)
+        g = json.loads(p.stdout)
+        assert g["ret"] >= 0, (body, p.stderr)
+        if g["SGREP"]:
+            continue
+        _same_tables(t, g, {"pattern": body, "opts": opts, "delim": b"\n"})
+        checked += 1
+    assert checked >= 100
