@@ -174,3 +174,25 @@ def test_character_classes_against_the_live_reference():
         _same_tables(t, g, {"pattern": body, "opts": opts, "delim": b"\n"})
         checked += 1
     assert checked >= 100
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not built")
+def test_q13_raw_bytes_130_to_145_are_pattern_bytes_here():
+    """Classified deviation (Q13, found here): preprocess() rewrites the meta characters into the byte codes
+    129..145 (agrep.h) and maskgen() acts on those codes -- so a RAW byte of that value in the pattern (UTF-8
+    continuation bytes: the second byte of U+0103 is 0x83) is taken for a wildcard, a class bracket, a
+    boundary ... by the reference's maskgen path, or refused (136..139).  The product compiles every byte as
+    itself; for all other byte values the tables are the reference's."""
+    import json
+    import subprocess
+    quirky = []
+    for b in list(range(1, 10)) + list(range(11, 32)) + list(range(127, 256)):
+        pat = b"ab" + bytes([b]) + b"cd"
+        t = A.compile_pattern(pat)
+        assert t.simple == 1 and t.M == 7 and t.Mask[b] & (1 << 2), b        # position 5 of 7 (delimiter, separator, a, b, it) holds this byte
+        p = subprocess.run([HARNESS.encode(), b"tables", b"-n", pat], stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=20)
+        g = json.loads(p.stdout)
+        if p.returncode != 0 or g["ret"] < 0 or list(t.Mask) != list(g["Mask"]) or t.Init1 != g["Init1"]:
+            quirky.append(b)
+    assert quirky and set(quirky) <= set(range(129, 146)), quirky
