@@ -176,6 +176,9 @@ AGH_HD uint32_t agh_mp_bucket(uint32_t s)
 // Row of a 3-gram held in the low 24 bits of y (the top byte is ignored by the 24-bit multiply):
 // the middle bits [31:19] of y * C; the device takes them as a byte address with
 // ((v_mul_u32_u24 y, C) >> 16) & ((rows - 1) << 3)  (one v_and_b32_sdwa src0_sel:WORD_1).
+#ifndef AGH_MS_NBF
+#define AGH_MS_NBF 0                        // 1: neighbour-byte filter in front of level 3 (agh_mscan.hip), mdir holds 4 words per slot
+#endif
 #define AGH_MS_C 0xC2B2AEu
 #define AGH_MS_RB_MAX 13u                   // rows <= 2^13 (64 KiB)
 AGH_HD uint32_t agh_ms_row(uint32_t y, uint32_t rb)

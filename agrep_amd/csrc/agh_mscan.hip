@@ -39,12 +39,25 @@
 #define MS_RING_B 128u
 #define MS_QA_DW 6u                 // queue A entry: w0 w1 | w2 w3 | w4 meta (three ds_write_b64)
 
+// AGH_MS_NBF (make VARFLAGS=-DAGH_MS_NBF=1; not in the shipped build until it has been measured): level 2 hands
+// level 3 the four text bytes next to the 4-gram -- two behind it, two in front -- and level 3 tests them against
+// three 32-bit masks of the gram's entries (agh_api.cpp fill_multi_tables) BEFORE it loads the text: a piece of
+// >= 5 bytes needs its fifth byte at p + 4; a 4-byte piece needs one of the two nearest bytes of the other side
+// of its pattern among the two text bytes on that side (what side_within_one_edit can accept at all).  On the
+// config-5 set 7 % of level 2's survivors pass where all four bytes are known (CPU model of the tables on the
+// bench corpus: 2357 survivors per MiB, the kernel counts 2365), ~15 % with the chunk-edge positions let through.
+#if AGH_MS_NBF                      // (agh_device.h: 0 unless the build asks for it)
+typedef uint2 ms_qb_t;              // (position << 12 | slot, neighbour bytes S0 S1 T1 T2)
+#else
+typedef uint32_t ms_qb_t;
+#endif
+
 template <int WAVES, int RB>
 struct ms_shared {
     uint2 ptab[1u << RB];
     uint32_t gtab[AGH_MS_GSLOTS];
     uint2 qa[WAVES][MS_RING * MS_QA_DW / 2];
-    uint32_t qb[WAVES][MS_RING_B];
+    ms_qb_t qb[WAVES][MS_RING_B];
     uint64_t qm[WAVES][MS_RING];
 };
 
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
     const uint8_t *ptab8 = reinterpret_cast<const uint8_t *>(sh.ptab);
     const uint4 *gt4 = reinterpret_cast<const uint4 *>(sh.gtab);
     uint2 *qa = sh.qa[wib];
-    uint32_t *qb = sh.qb[wib];
+    ms_qb_t *qb = sh.qb[wib];
     uint64_t *qm = sh.qm[wib];
     const uint8_t *text8 = reinterpret_cast<const uint8_t *>(text);
     const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT, n_full = n >> AGH_STRIP_SHIFT;
@@ -195,10 +208,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
         bool matched = false;
         uint64_t j = 0;
         if ((uint32_t)lane < take) {
+#if AGH_MS_NBF
+            const uint2 e2 = qb[(hB + (uint32_t)lane) & (MS_RING_B - 1u)];
+            const uint32_t e = e2.x;
+            const uint4 d4 = reinterpret_cast<const uint4 *>(ms.mdir)[e & (AGH_MS_GSLOTS - 1u)];   // dir, MX, ML, MB
+            bool near_ok;
+            {
+                // position 1..16 inside its chunk: bytes p + 4 (p = 16), p + 5 (p >= 15) and p - 2 (p = 1) lie
+                // outside the 20 bytes level 2 had -- a term whose byte is unknown counts as passed if its mask is set
+                const uint32_t pc = ((e >> 12) - 1u) & 15u;            // p - 1 = 0..15
+                const uint32_t s0 = e2.y & 31u, s1 = (e2.y >> 8) & 31u, t1 = (e2.y >> 16) & 31u, t2 = (e2.y >> 24) & 31u;
+                uint32_t ok = (d4.w >> t1) & 1u;
+                ok |= pc >= 1u ? (d4.w >> t2) & 1u : (uint32_t)(d4.w != 0u);
+                ok |= pc <= 14u ? ((d4.y | d4.z) >> s0) & 1u : (uint32_t)((d4.y | d4.z) != 0u);
+                ok |= pc <= 13u ? (d4.z >> s1) & 1u : (uint32_t)(d4.z != 0u);
+                near_ok = ok != 0u;
+            }
+#else
             const uint32_t e = qb[(hB + (uint32_t)lane) & (MS_RING_B - 1u)];
+            const bool near_ok = true;
+#endif
             j = range_base + (e >> 12);
-            if (j >= 8u && j + 24u <= n && !(dbg & 1u)) {
+            if (near_ok && j >= 8u && j + 24u <= n && !(dbg & 1u)) {
+#if AGH_MS_NBF
+                const uint32_t dir = d4.x;
+#else
                 const uint32_t dir = ms.mdir[e & (AGH_MS_GSLOTS - 1u)];
+#endif
                 u32x4_a1 t0 = {0u, 0u, 0u, 0u}, t1 = {0u, 0u, 0u, 0u};
                 if (!(dbg & 2u)) {
                     t0 = *reinterpret_cast<const u32x4_a1 *>(text8 + j - 8);
@@ -316,7 +352,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
                 const uint64_t fb = __ballot(found);
                 if (fb) {
                     const uint32_t slot = h1 >= 0 ? b1 * 4u + (uint32_t)h1 : b2 * 4u + (uint32_t)h2;
+#if AGH_MS_NBF
+                    // bytes p + 4, p + 5 (behind the gram) and p - 1, p - 2 (in front of it); what lies outside
+                    // the chunk's 20 bytes is zero here and marked unknown by its position in level 3
+                    const uint32_t gnx = p16 ? 0u : (p8 ? (p4 ? 0u : e[4]) : (p4 ? e[3] : e[2]));
+                    const uint32_t gpv = p16 ? e[3] : (p8 ? (p4 ? e[2] : e[1]) : (p4 ? e[0] : 0u));
+                    const uint32_t aft = __builtin_amdgcn_alignbyte(gnx, ghi, p & 3u);       // bytes p + 4 ..
+                    const uint32_t bef = __builtin_amdgcn_alignbyte(glo, gpv, p & 3u);       // bytes p - 4 .. p - 1
+                    const uint32_t nbv = (aft & 0xffffu) | ((bef >> 24) << 16) | ((bef >> 16) << 24);
+                    if (found) qb[(hB + qnB + rank_of(fb)) & (MS_RING_B - 1u)] = make_uint2(((pos_rel + p) << 12) | slot, nbv);
+#else
                     if (found) qb[(hB + qnB + rank_of(fb)) & (MS_RING_B - 1u)] = ((pos_rel + p) << 12) | slot;
+#endif
                     qnB = ms_uni(qnB + (uint32_t)__popcll(fb));
                 }
             } while (__ballot(m != 0u));
