@@ -46,7 +46,7 @@
 // of its pattern among the two text bytes on that side (what side_within_one_edit can accept at all).  On the
 // config-5 set 7 % of level 2's survivors pass where all four bytes are known (CPU model of the tables on the
 // bench corpus: 2357 survivors per MiB, the kernel counts 2365), ~15 % with the chunk-edge positions let through.
-#if AGH_MS_NBF                      // (agh_device.h: 0 unless the build asks for it)
+#if AGH_MS_NBF == 1                 // (agh_device.h: 0 unless the build asks for it)
 typedef uint2 ms_qb_t;              // (position << 12 | slot, neighbour bytes S0 S1 T1 T2)
 #else
 typedef uint32_t ms_qb_t;
@@ -56,6 +56,9 @@ template <int WAVES, int RB>
 struct ms_shared {
     uint2 ptab[1u << RB];
     uint32_t gtab[AGH_MS_GSLOTS];
+#if AGH_MS_NBF == 2
+    uint32_t gmask[AGH_MS_GSLOTS];   // per gram slot: the fifth bytes (& 31) of its entries, all ones if one has only four
+#endif
     uint2 qa[WAVES][MS_RING * MS_QA_DW / 2];
     ms_qb_t qb[WAVES][MS_RING_B];
     uint64_t qm[WAVES][MS_RING];
@@ -167,12 +170,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
         const uint4 *gs = reinterpret_cast<const uint4 *>(ms.gtab);
         uint4 *gd = reinterpret_cast<uint4 *>(sh.gtab);
         for (uint32_t i = threadIdx.x; i < AGH_MS_GSLOTS / 4u; i += WAVES * 64) gd[i] = gs[i];
+#if AGH_MS_NBF == 2
+        uint4 *md = reinterpret_cast<uint4 *>(sh.gmask);     // (the masks lie behind the grams in ms.gtab)
+        for (uint32_t i = threadIdx.x; i < AGH_MS_GSLOTS / 4u; i += WAVES * 64) md[i] = gs[AGH_MS_GSLOTS / 4u + i];
+#endif
         __syncthreads();
     }
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const uint8_t *ptab8 = reinterpret_cast<const uint8_t *>(sh.ptab);
     const uint4 *gt4 = reinterpret_cast<const uint4 *>(sh.gtab);
+#if AGH_MS_NBF == 2
+    const uint4 *gm4 = reinterpret_cast<const uint4 *>(sh.gmask);
+#endif
     uint2 *qa = sh.qa[wib];
     ms_qb_t *qb = sh.qb[wib];
     uint64_t *qm = sh.qm[wib];
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
         bool matched = false;
         uint64_t j = 0;
         if ((uint32_t)lane < take) {
-#if AGH_MS_NBF
+#if AGH_MS_NBF == 1
             const uint2 e2 = qb[(hB + (uint32_t)lane) & (MS_RING_B - 1u)];
             const uint32_t e = e2.x;
             const uint4 d4 = reinterpret_cast<const uint4 *>(ms.mdir)[e & (AGH_MS_GSLOTS - 1u)];   // dir, MX, ML, MB
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
 #endif
             j = range_base + (e >> 12);
             if (near_ok && j >= 8u && j + 24u <= n && !(dbg & 1u)) {
-#if AGH_MS_NBF
+#if AGH_MS_NBF == 1
                 const uint32_t dir = d4.x;
 #else
                 const uint32_t dir = ms.mdir[e & (AGH_MS_GSLOTS - 1u)];
@@ -348,11 +358,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
                 const uint4 G1 = gt4[b1], G2 = gt4[b2];
                 const int h1 = G1.x == g ? 0 : (G1.y == g ? 1 : (G1.z == g ? 2 : (G1.w == g ? 3 : -1)));
                 const int h2 = G2.x == g ? 0 : (G2.y == g ? 1 : (G2.z == g ? 2 : (G2.w == g ? 3 : -1)));
+#if AGH_MS_NBF == 2
+                // the gram is an entry's prefix: does the byte behind it (p + 4; unknown for p = 16) fit one of them?
+                const uint4 M1 = gm4[b1], M2 = gm4[b2];
+                const uint32_t mx = h1 >= 0 ? (h1 == 0 ? M1.x : (h1 == 1 ? M1.y : (h1 == 2 ? M1.z : M1.w)))
+                                            : (h2 == 0 ? M2.x : (h2 == 1 ? M2.y : (h2 == 2 ? M2.z : M2.w)));
+                const uint32_t gnx5 = p8 ? (p4 ? 0u : e[4]) : (p4 ? e[3] : e[2]);
+                const uint32_t aft5 = __builtin_amdgcn_alignbyte(gnx5, ghi, p & 3u);         // bytes p + 4 ..
+                const bool fifth_ok = p16 || ((mx >> (aft5 & 31u)) & 1u);
+                const bool found = act && (h1 >= 0 || h2 >= 0) && fifth_ok;
+#else
                 const bool found = act && (h1 >= 0 || h2 >= 0);
+#endif
                 const uint64_t fb = __ballot(found);
                 if (fb) {
                     const uint32_t slot = h1 >= 0 ? b1 * 4u + (uint32_t)h1 : b2 * 4u + (uint32_t)h2;
-#if AGH_MS_NBF
+#if AGH_MS_NBF == 1
                     // bytes p + 4, p + 5 (behind the gram) and p - 1, p - 2 (in front of it); what lies outside
                     // the chunk's 20 bytes is zero here and marked unknown by its position in level 3
                     const uint32_t gnx = p16 ? 0u : (p8 ? (p4 ? 0u : e[4]) : (p4 ? e[3] : e[2]));
@@ -483,8 +504,11 @@ bool agh_launch_mscan(const agh_mscan_args &a, hipStream_t st)
     const uint64_t n_strips = (a.n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint64_t n_ranges = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
     if (n_ranges > 0xffffffffull - 65536ull) return false;
+#if AGH_MS_NBF != 2                 // (with the mask table in LDS 2^13 rows do not fit: the host asks for 2^12)
     if (a.ms.rb == 13u) launch_mscan_cfg<16, 13>(a, (uint32_t)n_ranges, st);
-    else if (a.ms.rb == 12u) launch_mscan_cfg<16, 12>(a, (uint32_t)n_ranges, st);
+    else
+#endif
+    if (a.ms.rb == 12u) launch_mscan_cfg<16, 12>(a, (uint32_t)n_ranges, st);
     else return false;
     return true;
 }

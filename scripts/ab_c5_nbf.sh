@@ -1,7 +1,10 @@
 #!/bin/bash
-# A/B of the neighbour-byte filter in front of level 3 of the one-pass -f kernel (AGH_MS_NBF, agh_mscan.hip) --
-# written at the end of round 4 without GPU time left, NOT measured yet.  Build the variant on the CPU box first:
+# A/B of the neighbour-byte filters of the one-pass -f kernel (AGH_MS_NBF, agh_mscan.hip): 1 = four neighbour bytes
+# tested at the head of level 3, 2 = the fifth byte tested in level 2 against a mask table in LDS.  Written at the
+# end of round 4 with seconds of GPU time left: both are parity-green (profiles/r04_nbf*_quick.log) but were timed
+# on different boxes -- this script is the same-box A/B.  Build the variants on the CPU box first:
 #   make -C agrep_amd/csrc -j10 VARIANT=nbf VARFLAGS="-DAGH_MS_NBF=1"
+#   make -C agrep_amd/csrc -j10 VARIANT=nbf2 VARFLAGS="-DAGH_MS_NBF=2"
 # then, on the GPU box (one gpurun call):
 #   bash scripts/ab_c5_nbf.sh
 # 1. parity of the variant: the one-pass tests and the full-size C5 tests; 2. the -f sets on 4 GiB under both libraries.
@@ -16,3 +19,14 @@ echo "== shipped build (2^12 rows for a like-for-like table size)"
 (AGH_MSCAN_RB=12 timeout 120 python scripts/perf_c5_r4.py 4 5 2>&1 | grep -v amdgpu.ids) < /dev/null
 echo "== AGH_MS_NBF=1"
 (AGH_LIB_PATH=$V timeout 120 python scripts/perf_c5_r4.py 4 5 2>&1 | grep -v amdgpu.ids) < /dev/null
+V2=$GRAFT_REPO_ROOT/agrep_amd/libagrep_hip_nbf2.so
+if [ -f $V2 ]; then
+  echo "== AGH_MS_NBF=2"
+  (AGH_LIB_PATH=$V2 timeout 200 python -m pytest tests/test_gpu_multi.py -q -x -k "one_pass" -o timeout=150 2>&1 | tail -4) < /dev/null
+  (AGH_LIB_PATH=$V2 timeout 120 python scripts/perf_c5_r4.py 4 5 2>&1 | grep -v amdgpu.ids) < /dev/null
+  for i in 1 2 3; do
+    (AGH_MSCAN_RB=12 timeout 30 python scripts/perf_c5_quick.py 2>&1 | grep "^c5") < /dev/null
+    (AGH_LIB_PATH=$V timeout 30 python scripts/perf_c5_quick.py 2>&1 | grep "^c5") < /dev/null
+    (AGH_LIB_PATH=$V2 timeout 30 python scripts/perf_c5_quick.py 2>&1 | grep "^c5") < /dev/null
+  done
+fi
