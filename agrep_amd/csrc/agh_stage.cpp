@@ -6,7 +6,10 @@
 #include <condition_variable>
 #include <mutex>
 
+#include <memory>
+
 #include "agh_internal.h"
+#include "agh_order.h"
 
 // Matches of the text staged in q->staging: bounds computed on the device, sorted into file
 // order on the host.
@@ -32,9 +35,8 @@ static int collect_matches(agh_query *q, uint64_t len, const agh_result *res, ag
     HIP_TRY(hipMemcpy(st.data(), q->match_start.p, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(en.data(), q->match_end.p, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(rec.data(), q->match_rec.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::vector<size_t> order(ns);
-    for (size_t i = 0; i < ns; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st[a] < st[b]; });
+    std::vector<uint32_t> order;
+    agh_order_matches(rec.data(), st.data(), ns, order);           // file order (agh_order.h)
     for (size_t i = 0; i < ns; ++i) {
         matches[i].start = st[order[i]];
         matches[i].end = en[order[i]];
@@ -238,9 +240,8 @@ static int emit_records(agh_query *q, const void *d_text, uint64_t n, unsigned f
     HIP_TRY(hipMemcpy(st.data(), q->match_start.p, b8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(en.data(), q->match_end.p, b8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(rec.data(), q->match_rec.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::vector<size_t> order(ns);
-    for (size_t i = 0; i < ns; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st[a] < st[b]; });
+    std::vector<uint32_t> order;
+    agh_order_matches(rec.data(), st.data(), ns, order);           // file order (agh_order.h)
     std::vector<agh_match> ms(ns);
     uint64_t total = 0;
     for (size_t i = 0; i < ns; ++i) {
@@ -251,7 +252,8 @@ static int emit_records(agh_query *q, const void *d_text, uint64_t n, unsigned f
         off[i] = total;
         total += en[o] - st[o];
     }
-    std::vector<unsigned char> bytes;
+    // (malloc, not a vector: 8 MB of zero-fill per call for bytes the copy overwrites anyway)
+    std::unique_ptr<unsigned char, void (*)(void *)> bytes(nullptr, free);
     if (sink.want_bytes && total) {
         std::vector<uint64_t> s2(ns), e2(ns);
         for (size_t i = 0; i < ns; ++i) { s2[i] = st[order[i]]; e2[i] = en[order[i]]; }
@@ -262,10 +264,11 @@ static int emit_records(agh_query *q, const void *d_text, uint64_t n, unsigned f
         agh_launch_gather_records(d_text, (const uint64_t *)q->match_start.p, (const uint64_t *)q->match_end.p,
                                   (const uint64_t *)q->match_off.p, (uint32_t)ns, q->gather.p, nullptr);
         HIP_TRY(hipGetLastError());
-        bytes.resize((size_t)total);
-        HIP_TRY(hipMemcpy(bytes.data(), q->gather.p, (size_t)total, hipMemcpyDeviceToHost));
+        bytes.reset((unsigned char *)malloc((size_t)total));
+        if (!bytes) return fail("out of memory (%llu bytes of matched records)", (unsigned long long)total);
+        HIP_TRY(hipMemcpy(bytes.get(), q->gather.p, (size_t)total, hipMemcpyDeviceToHost));
     }
-    if (sink.emit(sink.ctx, ms.data(), ns, sink.want_bytes ? bytes.data() : nullptr, sink.want_bytes ? (size_t)total : 0))
+    if (sink.emit(sink.ctx, ms.data(), ns, sink.want_bytes ? bytes.get() : nullptr, sink.want_bytes ? (size_t)total : 0))
         *stop = true;
     return 0;
 }
