@@ -179,6 +179,9 @@ AGH_HD uint32_t agh_mp_bucket(uint32_t s)
 #ifndef AGH_MS_NBF
 #define AGH_MS_NBF 0                        // 1: neighbour-byte filter in front of level 3 (agh_mscan.hip), mdir holds 4 words per slot
 #endif
+#ifndef AGH_MS_L3PIPE
+#define AGH_MS_L3PIPE 0                     // 1: level 3 of k_mscan in two halves, one batch in flight (agh_mscan.hip)
+#endif
 #define AGH_MS_C 0xC2B2AEu
 #define AGH_MS_RB_MAX 13u                   // rows <= 2^13 (64 KiB)
 AGH_HD uint32_t agh_ms_row(uint32_t y, uint32_t rb)

@@ -272,6 +272,63 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
         }
     };
 
+#if AGH_MS_L3PIPE
+    // Level 3 in two halves (make VARFLAGS=-DAGH_MS_L3PIPE=1; not in the shipped build until measured): a call of
+    // level 3 is two dependent global round trips (directory + text, then the entries) during which its wave has
+    // nothing to do -- ~37 calls per wave and 4 GiB.  Here the first round trip of a batch is issued when the batch
+    // is taken from queue B and its results stay in registers (12 per lane) while the wave goes on with level 1;
+    // the batch is finished one supertile later, when they have long arrived.
+    uint32_t p_take = 0;                        // batch in flight: its size (wave-uniform), 0 = none
+    bool p_live = false;
+    uint64_t p_j = 0;
+    uint32_t p_dir = 0;
+    u32x4_a1 p_t0 = {0u, 0u, 0u, 0u}, p_t1 = {0u, 0u, 0u, 0u};
+    auto stage_b_issue = [&]() {
+        const uint32_t take = ms_uni(qnB < 64u ? qnB : 64u);
+        __builtin_amdgcn_wave_barrier();
+        p_live = false;
+        p_j = 0;
+        if ((uint32_t)lane < take) {
+            const uint32_t e = qb[(hB + (uint32_t)lane) & (MS_RING_B - 1u)];
+            p_j = range_base + (e >> 12);
+            if (p_j >= 8u && p_j + 24u <= n && !(dbg & 1u)) {
+                p_live = true;
+                p_dir = ms.mdir[e & (AGH_MS_GSLOTS - 1u)];
+                if (!(dbg & 2u)) {
+                    p_t0 = *reinterpret_cast<const u32x4_a1 *>(text8 + p_j - 8);
+                    p_t1 = *reinterpret_cast<const u32x4_a1 *>(text8 + p_j + 8);
+                }
+            }
+        }
+        hB = ms_uni((hB + take) & (MS_RING_B - 1u));
+        qnB = ms_uni(qnB - take);
+        ncand = ms_uni(ncand + take);
+        p_take = take;
+    };
+    auto stage_b_finish = [&]() {
+        bool matched = false;
+        if (p_live) {
+            uint32_t T[8] = {p_t0[0], p_t0[1], p_t0[2], p_t0[3], p_t1[0], p_t1[1], p_t1[2], p_t1[3]};
+            if (FOLD) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d) T[d] = swar_lower(T[d]);
+            }
+            const uint32_t first = p_dir >> 8, cnt = p_dir & 0xffu;
+            for (uint32_t i = 0; i < cnt && !matched; ++i) {
+                const uint4 ent = ms.ment[first + i];
+                matched = K == 0 ? ms_match_k0(ent, T) : ms_match_k1(ent, T, delim);
+            }
+        }
+        p_live = false;
+        p_take = 0;
+        const uint64_t mb = __ballot(matched);
+        if (mb) {
+            if (matched) qm[(hM + qnM + rank_of(mb)) & (MS_RING - 1u)] = p_j;
+            qnM = ms_uni(qnM + (uint32_t)__popcll(mb));
+        }
+    };
+#endif
+
     // ---- one supertile = strips s .. s+3, nx3 = the first dword of strip s+4; st_rel = its number
     // inside the wave's range ------------------------------------------------------------------------
     auto supertile = [&](uint4 v0, uint4 v1, uint4 v2, uint4 v3, uint32_t nx3, uint32_t st_rel, bool range_ends) {
@@ -341,7 +398,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
             qnA = ms_uni(qnA - take);
             do {
                 if (qnB > MS_RING_B - 64u) {            // room for the survivors of this round
+#if AGH_MS_L3PIPE
+                    if (p_take) stage_b_finish();
+                    stage_b_issue();
+#else
                     stage_b();
+#endif
                     if (qnM >= 64u) stage_m();
                 }
                 const bool act = m != 0u;
@@ -400,10 +462,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
             }
             while (qnA >= 64u || (u == 3u && range_ends && qnA)) level2();
         }
+#if AGH_MS_L3PIPE
+        while (qnB >= 64u || ((range_ends || (dbg & 8u)) && qnB)) {
+            if (p_take) stage_b_finish();       // (issued a supertile ago)
+            stage_b_issue();
+            if (qnM >= 64u) stage_m();
+        }
+        if (range_ends && p_take) {             // nothing stays in flight across ranges
+            stage_b_finish();
+            if (qnM >= 64u) stage_m();
+        }
+#else
         while (qnB >= 64u || ((range_ends || (dbg & 8u)) && qnB)) {
             stage_b();
             if (qnM >= 64u) stage_m();
         }
+#endif
     };
 
     auto load_strip = [&](uint64_t st) -> uint4 { return ms_load_strip(text, n, st, fill4); };
