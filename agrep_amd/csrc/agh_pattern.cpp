@@ -54,7 +54,8 @@ struct compiler {
     std::vector<position> pos;  // pos[0] unused: positions count from 1 as in maskgen.c
     uint32_t wild = 0, ends = 0, noerr = 0;     // in Bit[] space: position j <-> bit 32 - j
     bool and_seen = false, or_seen = false, fancy = false;
-    int angle = 0;
+    int angle = 0;              // '<' minus '>' so far (maskgen.c's EVEN): has to end at 0, may not go below
+    bool exact = false;         // maskgen.c's No_error: ON behind a '<', OFF behind a '>' -- not a depth: <<ab>c> leaves c free
     bool nocase = false;
 
     static uint32_t bit(int j) { return j >= 1 && j <= 32 ? 1u << (32 - j) : 0u; }
@@ -111,7 +112,7 @@ int parse_class(compiler &C, const unsigned char *p, int len, int &i)
             c = p[i + 1];
             i += 2;
         } else {
-            if (strchr(".#,;*|()<>^$", (int)c))
+            if (strchr(".#,;*|()<>^${}~", (int)c))
                 return fail("'%c' inside [] must be written \\%c", (int)c, (int)c);
             ++i;
         }
@@ -136,7 +137,7 @@ int parse_class(compiler &C, const unsigned char *p, int len, int &i)
     if (!closed) return fail(unmatched);
     if (complement) k.invert();                          // over all 256 bytes, the newline included (maskgen.c:252)
     C.fancy = true;
-    return C.add(k, C.angle > 0);
+    return C.add(k, C.exact);
 }
 
 }   // namespace
@@ -171,7 +172,7 @@ extern "C" int agh_compile_pattern(const unsigned char *pat, int len, unsigned q
         switch (c) {
         case '\\':
             if (i + 1 >= len) return fail("a pattern cannot end in a backslash");
-            if (C.add_byte(pat[i + 1], C.angle > 0)) return -1;
+            if (C.add_byte(pat[i + 1], C.exact)) return -1;
             i += 2;
             break;
         case '#':                                       // maskgen.c:68-78: the position in front becomes sticky
@@ -187,11 +188,13 @@ extern "C" int agh_compile_pattern(const unsigned char *pat, int len, unsigned q
             return fail("unmatched '[', ']' (use \\[, \\] to search for [, ])");
         case '<':
             ++C.angle;
+            C.exact = true;
             C.fancy = true;
             ++i;
             break;
         case '>':
             if (--C.angle < 0) return fail("unmatched '<', '>' (use \\<, \\> to search for <, >)");
+            C.exact = false;
             ++i;
             break;
         case ';':                                       // maskgen.c:150-163
@@ -219,7 +222,7 @@ extern "C" int agh_compile_pattern(const unsigned char *pat, int len, unsigned q
             k.add_range(0, 255);
             k.w['\n' >> 5] &= ~(1u << ('\n' & 31));
             C.fancy = true;
-            if (C.add(k, C.angle > 0)) return -1;
+            if (C.add(k, C.exact)) return -1;
             ++i;
             break;
         }
@@ -229,8 +232,13 @@ extern "C" int agh_compile_pattern(const unsigned char *pat, int len, unsigned q
         case ')':
             return fail("'%c': regular expressions are outside the scan path of this library (escape it as \\%c for "
                         "the byte itself)", (int)c, (int)c);
+        case '{':
+        case '}':
+        case '~':                               // asplit.c:139-262: grouping and NOT of the boolean-pattern parser
+            return fail("'%c': boolean pattern expressions are outside the scan path of this library (escape it as "
+                        "\\%c for the byte itself)", (int)c, (int)c);
         default:
-            if (C.add_byte(c, C.angle > 0)) return -1;
+            if (C.add_byte(c, C.exact)) return -1;
             ++i;
             break;
         }

@@ -141,7 +141,8 @@ agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint
  * agh_compile_pattern is host-only (no device needed): it fills the tables in maskgen's own layout -- the ones
  * agh_query_from_maskgen takes, bit for bit what the reference's maskgen() leaves in its globals
  * (tests/test_pattern_compiler.py compares them with the reference's).  M <= 32 positions: the delimiter, one
- * separator and the pattern (maskgen.c:201-208).  Regular expressions ( * | ( ) ), unescaped meta
+ * separator and the pattern (maskgen.c:201-208).  Regular expressions ( * | ( ) ), the boolean-pattern
+ * syntax ( { } ~ ), unescaped meta
  * characters inside [] and a '-' inside [] that is not between two bytes of its own ([a-c-e], [-a], [a-]:
  * the reference reads these in ways of its own) are refused (-1, errno 123): what compiles, compiles like
  * the reference.  simple = 1: a plain literal (nothing but bytes, \c and

@@ -57,6 +57,7 @@ def test_compiler_reproduces_the_reference_tables(name):
 
 def test_compiler_refuses_what_it_does_not_compile():
     for pat in (b"ab*c", b"a|b", b"(ab)c", b"ab[cd", b"abc]", b"a<bc", b"ab>c", b"a;b,c", b"a,b;c", b"abc\\", b"[a.b]x",
+                b"a{b", b"a}b", b"~ab", b"[a{]x", b"[~a]x",        # asplit.c's boolean syntax: not this library's
                 b"a" * 31, b""):
         with pytest.raises(A.AghError):
             A.compile_pattern(pat)
@@ -66,6 +67,9 @@ def test_compiler_refuses_what_it_does_not_compile():
         with pytest.raises(A.AghError):
             A.compile_pattern(pat)
     assert A.compile_pattern(b"[a\\-c]x").M == 4 and A.compile_pattern(b"[\\-a]x").M == 4
+    # '<' switches "no error here" on, '>' off (maskgen.c:80-95) -- not a depth: the c of <<ab>c> may take an error
+    t = A.compile_pattern(b"<<ab>c>")
+    assert t.M == 5 and not (t.NO_ERR_MASK >> 0) & 0 and A.compile_pattern(b"a\\{b\\}\\~").simple == 1
     # '#' alone: the reference builds tables without an end position (they can never match); refused here
     for pat in (b"#", b"##"):
         with pytest.raises(A.AghError):
