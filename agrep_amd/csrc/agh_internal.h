@@ -1,6 +1,6 @@
 // agh_internal.h -- what the translation units of the host side of libagrep_hip.so share: the error
 // helper, device buffers, the query object and the entry points of the scan orchestration
-// (agh_api.cpp: queries, segments, kernel sequences; agh_stage.cpp: host <-> HBM staging, files, pipes,
+// (agh_query.cpp: queries; agh_api.cpp: segments, kernel sequences; agh_stage.cpp: host <-> HBM staging, files, pipes,
 // record output).  Internal; the public boundary is include/agrep_hip.h.
 #pragma once
 #include <errno.h>

@@ -1,4 +1,4 @@
-// agh_launch.h -- internal C++ interface between the C-ABI layer (agh_api.cpp) and the
+// agh_launch.h -- internal C++ interface between the C-ABI layer (agh_query.cpp, agh_api.cpp) and the
 // kernel translation units (agh_sweep / agh_scan / agh_multi / agh_table / agh_exp .hip).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -41,7 +41,7 @@
 
 // AGH_MS_NBF (make VARFLAGS=-DAGH_MS_NBF=1; not in the shipped build until it has been measured): level 2 hands
 // level 3 the four text bytes next to the 4-gram -- two behind it, two in front -- and level 3 tests them against
-// three 32-bit masks of the gram's entries (agh_api.cpp fill_multi_tables) BEFORE it loads the text: a piece of
+// three 32-bit masks of the gram's entries (agh_query.cpp fill_multi_tables) BEFORE it loads the text: a piece of
 // >= 5 bytes needs its fifth byte at p + 4; a 4-byte piece needs one of the two nearest bytes of the other side
 // of its pattern among the two text bytes on that side (what side_within_one_edit can accept at all).  On the
 // config-5 set 7 % of level 2's survivors pass where all four bytes are known (CPU model of the tables on the

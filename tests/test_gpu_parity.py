@@ -1061,7 +1061,7 @@ def test_fused_count_on_candidate_dense_text(agh, k, monkeypatch):
 
 def test_h2_sample_shape_parity(agh, monkeypatch):
     """The H = 2 / q = 4 sample shape (4-byte samples at every even offset, overlapping; lossless iff
-    floor((m-k-3)/2) >= 2k+1: agh_api.cpp choose_filter): every pipeline against the oracle, the
+    floor((m-k-3)/2) >= 2k+1: agh_query.cpp choose_filter): every pipeline against the oracle, the
     planted occurrences at every alignment, across strip / range / text-end boundaries."""
     monkeypatch.setenv("AGH_SHAPE_H2", "1")
     monkeypatch.setenv("AGH_FUSED_MIN_MB", "0")
