@@ -8,8 +8,8 @@ library is missing or no HIP device is usable, everything here raises.
 from ._ffi import (AghError, Comm, Match, PatternTables, Query, Result, compile_pattern, corpus_fill_device, device_count, lib,  # noqa: F401
                    shard_cuts_fd,
                    probe_read_ms, set_device, ENGINE_FILTER, ENGINE_FULLSCAN, FORCE_FILTER,
-                   FORCE_FULLSCAN, FORCE_NUMBERED, COUNT, FILENAMEONLY, INVERT, NO_BYTES, TIME_SWEEP, TIME_SCAN)
+                   FORCE_FULLSCAN, FORCE_NUMBERED, COUNT, FILENAMEONLY, INVERT, NO_BYTES, EMIT_HEAD_DELIM, EMIT_TAIL_DELIM, TIME_SWEEP, TIME_SCAN)
 
 __all__ = ["AghError", "Comm", "PatternTables", "compile_pattern", "shard_cuts_fd", "Match", "Query", "Result", "corpus_fill_device", "device_count", "lib",
            "probe_read_ms", "set_device", "ENGINE_FILTER", "ENGINE_FULLSCAN", "FORCE_FILTER",
-           "FORCE_FULLSCAN", "FORCE_NUMBERED", "COUNT", "FILENAMEONLY", "INVERT", "NO_BYTES", "TIME_SWEEP", "TIME_SCAN"]
+           "FORCE_FULLSCAN", "FORCE_NUMBERED", "COUNT", "FILENAMEONLY", "INVERT", "NO_BYTES", "EMIT_HEAD_DELIM", "EMIT_TAIL_DELIM", "TIME_SWEEP", "TIME_SCAN"]

@@ -10,6 +10,8 @@ COUNT = 0x01
 FILENAMEONLY = 0x02
 INVERT = 0x04
 NO_BYTES = 0x200
+EMIT_HEAD_DELIM = 0x400
+EMIT_TAIL_DELIM = 0x800
 TIME_SWEEP = 0x80
 TIME_SCAN = 0x100
 FORCE_FULLSCAN = 0x10
@@ -265,14 +267,17 @@ class Query:
                                        ms if cap else None, cap))
         return res, [(ms[i].start, ms[i].end, ms[i].index) for i in range(int(res.n_stored))]
 
-    def _emit_collector(self, on_batch, stop_after, summarize=False):
+    def _emit_collector(self, on_batch, stop_after, summarize=False, hasher=None):
         """-> (callback object, list of batches); a batch = ([(start, end, index)], [record bytes] or None),
-        or with summarize (timing runs: no Python object per record) (records, bytes, first start, last end)"""
+        or with summarize (timing runs: no Python object per record) (records, bytes, first start, last end);
+        hasher (with summarize): a hashlib object fed with the raw bytes of every emit() call"""
         batches = []
 
         def cb(ctx, m, n, bytes_, n_bytes):
             if summarize:
                 batches.append((n, n_bytes, m[0].start if n else 0, m[n - 1].end if n else 0))
+                if hasher is not None and n_bytes:
+                    hasher.update(C.string_at(bytes_, n_bytes))
                 return 0
             ms = [(m[i].start, m[i].end, m[i].index) for i in range(n)]
             recs = None
@@ -288,10 +293,10 @@ class Query:
             return 1 if (stop_after is not None and len(batches) >= stop_after) else 0
         return EMIT_FN(cb), batches
 
-    def scan_fd_emit(self, fd, flags=0, on_batch=None, stop_after=None, byte_range=None, summarize=False):
+    def scan_fd_emit(self, fd, flags=0, on_batch=None, stop_after=None, byte_range=None, summarize=False, hasher=None):
         """agh_scan_fd_emit / agh_scan_fd_range_emit -> (Result, batches): record output while the input
         streams through bounded device segments; one batch per segment, in file order."""
-        cb, batches = self._emit_collector(on_batch, stop_after, summarize)
+        cb, batches = self._emit_collector(on_batch, stop_after, summarize, hasher)
         res = Result()
         if byte_range is None:
             _check(lib().agh_scan_fd_emit(self._h, fd, flags, C.byref(res), cb, None))
@@ -299,9 +304,9 @@ class Query:
             _check(lib().agh_scan_fd_range_emit(self._h, fd, byte_range[0], byte_range[1], flags, C.byref(res), cb, None))
         return res, batches
 
-    def scan_device_emit(self, dev_ptr, n, flags=0, on_batch=None, summarize=False):
+    def scan_device_emit(self, dev_ptr, n, flags=0, on_batch=None, summarize=False, hasher=None):
         """agh_scan_device_emit: matched records (offsets, numbers, bytes) of text resident in HBM"""
-        cb, batches = self._emit_collector(on_batch, None, summarize)
+        cb, batches = self._emit_collector(on_batch, None, summarize, hasher)
         res = Result()
         _check(lib().agh_scan_device_emit(self._h, dev_ptr, n, flags, C.byref(res), cb, None))
         return res, batches

@@ -104,16 +104,19 @@ static int attach_giveups(agh_query *q, agh_marks *mk)
 }
 
 struct seg_result {
-    uint64_t matched = 0, records = 0, candidates = 0, stored = 0;
+    uint64_t matched = 0, records = 0, candidates = 0, stored = 0, rec_bytes = 0;
     uint32_t engine = 0, truncated = 0, lean_rerun = 0;
     float ms = 0.f, sweep_ms = 0.f;
 };
 
 static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_t st,
                         unsigned flags, uint32_t head_byte, int tail_virtual,
-                        uint64_t *d_match_pos, uint32_t *d_match_rec, uint32_t match_cap,
-                        seg_result *out, const uint64_t *pre_dbm)
+                        const agh_list_out *list, seg_result *out, const uint64_t *pre_dbm)
 {
+    // list: this segment's part of the caller's record list (pointers already advanced, cap = what is left)
+    uint64_t *const d_match_pos = list ? list->pos : nullptr;
+    uint32_t *const d_match_rec = list ? list->rec : nullptr;
+    const uint32_t match_cap = list ? (uint32_t)std::min<size_t>(list->cap, 0xffffffffu) : 0u;
     *out = seg_result();
     if (n == 0) return 0;
     uint32_t lean_rerun = 0;
@@ -270,8 +273,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         if (multi && q->h_counters[AGH_C_OVERFLOW] && !q->multi_dense) {
             // dense hit set (many very short patterns): check hits inline from now on
             q->multi_dense = true;
-            return scan_segment(q, d_text, n, st, flags, head_byte, tail_virtual, d_match_pos,
-                                d_match_rec, match_cap, out, pre_dbm);
+            return scan_segment(q, d_text, n, st, flags, head_byte, tail_virtual, list, out, pre_dbm);
         }
         const bool gave_up = q->h_counters[AGH_C_LEAN_FALLBACK] || q->h_counters[AGH_C_OVERFLOW];
         if (!gave_up) {
@@ -341,8 +343,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             // more pieces to replay than the lists hold (a match in every few records): this text
             // belongs to the kernel that does its bookkeeping on the way
             q->fs_fast_off = true;
-            return scan_segment(q, d_text, n, st, flags, head_byte, tail_virtual, d_match_pos, d_match_rec,
-                                match_cap, out, pre_dbm);
+            return scan_segment(q, d_text, n, st, flags, head_byte, tail_virtual, list, out, pre_dbm);
         }
         if (!q->h_counters[AGH_C_LEAN_FALLBACK]) {
             if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventElapsedTime(&out->ms, q->ev0, q->ev1));
@@ -377,6 +378,10 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                 HIP_TRY(hipMemsetAsync(q->bitmap.p, 0, q->bitmap.cap, st));
             }
             q->bitmap_dirty = true;
+            if (d_match_pos) {                  // the list: rec_pos[r] per bitmap bit, the compaction's block counts
+                if (q->rec_pos.ensure(bm_words * 32 * sizeof(uint64_t))) return -1;
+                if (q->bm_blocks.ensure((q->bitmap.cap / 4 / 1024 + 4) * sizeof(uint32_t))) return -1;
+            }
         }
 
         if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev0, st));
@@ -387,6 +392,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_MATCHED, 0, sizeof(uint32_t), st));
             HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_STORED, 0, sizeof(uint32_t), st));
             HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_BM_OVERFLOW, 0, sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(q->d_counters + AGH_C_RECBYTES_LO, 0, 2 * sizeof(uint32_t), st));
         }
         if (!swept) {
             agh_sweep_args sa;
@@ -413,9 +419,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                 mk0.bitmap = (uint32_t *)q->bitmap.p;
                 mk0.bitmap_bits = (uint32_t)std::min<uint64_t>(bm_words * 32, 0xffffffffu);
                 mk0.counters = q->d_counters;
-                mk0.match_pos = d_match_pos;
-                mk0.match_rec = d_match_rec;
-                mk0.match_cap = match_cap;
+                mk0.rec_pos = d_match_pos ? (uint64_t *)q->rec_pos.p : nullptr;
                 sa.ev_begin = sa.ev_end = nullptr;
                 agh_launch_dense_multi(sa, multi_dev(q, d_dbm), mk0, st);
                 sa.tail_only = 1;
@@ -449,9 +453,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.mk.bitmap = (uint32_t *)q->bitmap.p;
         va.mk.bitmap_bits = (uint32_t)std::min<uint64_t>(bm_words * 32, 0xffffffffu);
         va.mk.counters = q->d_counters;
-        va.mk.match_pos = invert_list ? nullptr : d_match_pos;     // -v: bits only, list below
-        va.mk.match_rec = invert_list ? nullptr : d_match_rec;
-        va.mk.match_cap = invert_list ? 0u : match_cap;
+        va.mk.rec_pos = (d_match_pos && !invert_list) ? (uint64_t *)q->rec_pos.p : nullptr;   // -v: bits only, list below
         va.mk.hashset = nullptr;
         va.mk.hashset_mask = 0;
         va.gtab = (q->tune.tight_verify && !multi) ? q->d_gtab : nullptr;
@@ -463,12 +465,21 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         else if (q->table) agh_launch_tablescan(va, st);
         else agh_launch_fullscan(va, st);
         if (invert_list) {                      // the records whose bit stayed clear
-            va.mk.match_pos = d_match_pos;
-            va.mk.match_rec = d_match_rec;
-            va.mk.match_cap = match_cap;
+            va.mk.rec_pos = (uint64_t *)q->rec_pos.p;
             agh_launch_unmatched(va, st);
         }
-        agh_launch_bitmap_count((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), q->d_counters, st);
+        if (d_match_pos) {
+            // the list in file order: ordered compaction of the bitmap (counts and clears it as well), then the
+            // bounds of the listed records -- everything queued, the host reads the counters once below
+            agh_launch_bitmap_list((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), (uint32_t *)q->bm_blocks.p,
+                                   (const uint64_t *)q->rec_pos.p, invert_list ? 1 : 0, d_match_pos, d_match_rec, match_cap,
+                                   q->d_counters, st);
+            if (list->start)
+                agh_launch_match_bounds(d_text, n, dq, d_dbm, d_match_pos, q->d_counters, match_cap,
+                                        (uint32_t)std::min<uint64_t>(match_cap, bm_words * 32), list->start, list->end, st);
+        } else {
+            agh_launch_bitmap_count((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), q->d_counters, st);
+        }
         HIP_TRY(hipGetLastError());
         if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev1, st));
         HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
@@ -522,6 +533,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         if (invert) out->matched = out->records - out->matched;
         out->stored = std::min<uint64_t>(q->h_counters[AGH_C_STORED], match_cap);
         out->truncated = q->h_counters[AGH_C_STORED] > match_cap;
+        out->rec_bytes = (uint64_t)q->h_counters[AGH_C_RECBYTES_LO] | ((uint64_t)q->h_counters[AGH_C_RECBYTES_HI] << 32);
         out->ms = total_ms;
         out->lean_rerun = lean_rerun;
         return 0;
@@ -696,8 +708,7 @@ static bool lean_pipeline_ok(const agh_query *q, unsigned flags, bool want_list)
 
 static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_t st,
                         unsigned flags, uint32_t head_byte, int tail_virtual,
-                        uint64_t *d_match_pos, uint32_t *d_match_rec, uint32_t match_cap,
-                        seg_result *out, const uint64_t *pre_dbm = nullptr);
+                        const agh_list_out *list, seg_result *out, const uint64_t *pre_dbm = nullptr);
 
 
 static int get_events(std::vector<hipEvent_t> &pool, size_t want, unsigned evflags)
@@ -969,7 +980,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         q->hashset_slots_hint = 4ull * max_matched;
         agh_result rr;
         if (agh_scan_device_impl(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED, &rr,
-                             nullptr, nullptr, 0, i == 0 && is_first, i == nseg - 1 && is_last))
+                                 nullptr, i == 0 && is_first, i == nseg - 1 && is_last))
             return -1;
         if (jobs[i].done_early) res->n_bytes = cuts[i + 1];    // the rerun read the whole segment
         res->n_matched += rr.n_matched;
@@ -1092,7 +1103,7 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
         max_matched = std::max<uint64_t>(max_matched, 2ull * (h[AGH_C_MATCHED] + 1024));
         agh_result rr;
         if (agh_scan_device_impl(q, base + cuts[i], cuts[i + 1] - cuts[i], st, flags | AGH_FORCE_NUMBERED, &rr,
-                             nullptr, nullptr, 0, i == 0 && is_first, i == nseg - 1 && is_last))
+                                 nullptr, i == 0 && is_first, i == nseg - 1 && is_last))
             return -1;
         res->n_matched += rr.n_matched;
         res->n_candidates += rr.n_candidates;
@@ -1104,10 +1115,14 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
 }
 
 int agh_scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
-                         unsigned flags, agh_result *res, uint64_t *d_match_pos,
-                         uint32_t *d_match_rec, size_t match_cap, bool is_first, bool is_last)
+                         unsigned flags, agh_result *res, agh_list_out *list, bool is_first, bool is_last)
 {
     if (!q || !res) return fail("null argument");
+    if (list && !list->pos) list = nullptr;
+    uint64_t *const d_match_pos = list ? list->pos : nullptr;
+    uint32_t *const d_match_rec = list ? list->rec : nullptr;
+    const size_t match_cap = list ? list->cap : 0;
+    if (list) list->rec_bytes = 0;
     memset(res, 0, sizeof(*res));
     res->n_bytes = len;
     if (!len) return 0;
@@ -1167,16 +1182,23 @@ int agh_scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipSt
             q->seg_dbm_active = global_dbm != nullptr;
             res->copied_segments += 1;
         }
+        agh_list_out seg_list;
+        if (list) {
+            seg_list.pos = d_match_pos + stored;
+            seg_list.rec = d_match_rec ? d_match_rec + stored : nullptr;
+            seg_list.start = list->start ? list->start + stored : nullptr;
+            seg_list.end = list->end ? list->end + stored : nullptr;
+            seg_list.cap = cap_left;
+        }
         const int seg_rc = scan_segment(q, seg_text, end - off, st, flags,
                                         (i == 0 && is_first) ? '\n' : q->delim[q->dlen - 1], end == len && is_last,
-                                        d_match_pos ? d_match_pos + stored : nullptr,
-                                        d_match_rec ? d_match_rec + stored : nullptr,
-                                        d_match_pos ? cap_left : 0, &sr, seg_dbm);
+                                        list ? &seg_list : nullptr, &sr, seg_dbm);
         q->seg_dbm_active = false;
         if (seg_rc) return -1;
+        if (list) list->rec_bytes += sr.rec_bytes;
         if (d_match_pos && sr.stored && off > 0) {
             // the segment's kernels saw positions / record numbers relative to its own start
-            agh_launch_offset_matches(d_match_pos + stored, d_match_rec ? d_match_rec + stored : nullptr,
+            agh_launch_offset_matches(seg_list.pos, seg_list.rec, seg_list.start, seg_list.end,
                                       (uint32_t)sr.stored, off, (uint32_t)res->n_records, st);
             HIP_TRY(hipGetLastError());
         }
@@ -1200,8 +1222,10 @@ extern "C" int agh_scan_device(agh_query *q, const void *dev_text, size_t len, v
                                size_t match_cap)
 {
     if (q) agh_refresh_tuning(q);
-    return agh_scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res,
-                            (uint64_t *)dev_match_pos, nullptr, dev_match_pos ? match_cap : 0, true, true);
+    agh_list_out list;
+    list.pos = (uint64_t *)dev_match_pos;
+    list.cap = dev_match_pos ? match_cap : 0;
+    return agh_scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res, dev_match_pos ? &list : nullptr, true, true);
 }
 
 // One step of a sharded count-only scan (the only exchange is the -c aggregate): the scan of this
@@ -1222,7 +1246,7 @@ extern "C" int agh_scan_device_reduce(agh_query *q, agh_comm *c, const void *dev
     HIP_TRY(hipMemsetAsync(q->d_acc, 0, 4 * sizeof(uint64_t), (hipStream_t)stream));
     q->reduce_comm = c;
     q->reduce_done = false;
-    const int rc = agh_scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res, nullptr, nullptr, 0, true, true);
+    const int rc = agh_scan_device_impl(q, dev_text, len, (hipStream_t)stream, flags, res, nullptr, true, true);
     q->reduce_comm = nullptr;
     if (rc) return -1;
     uint64_t v[3] = {res->n_matched, res->n_records, 0};

@@ -36,7 +36,7 @@ enum agh_counter {
     AGH_C_OVERFLOW = 1,  // candidate / match buffer overflow flag
     AGH_C_MATCHED = 2,   // distinct matched records
     AGH_C_NDELIM = 3,    // delimiters in the text
-    AGH_C_STORED = 4,    // match positions stored
+    AGH_C_STORED = 4,    // records the ordered compaction of the record bitmap listed (k_bm_offsets)
     AGH_C_LASTBYTE = 5,  // text[n-1]
     AGH_C_CHECK = 6,     // read-probe checksum sink
     AGH_C_BM_OVERFLOW = 7, // a record number did not fit the record bitmap
@@ -44,7 +44,10 @@ enum agh_counter {
     AGH_C_DELIM_CHAIN = 9, // multi-byte delimiter: overlapping occurrences chain > 4 KiB (unsupported) // lean scan gave up (record start too far back / hash set full)
     AGH_C_ANYHIT = 10,   // lean scans: some record matched (what -l needs to stop early)
     AGH_C_GIVEUPS = 11,  // lean scans: matches whose record starts further back than the verifier looks (agh_marks.giveups)
-    AGH_C_COUNT = 12
+    AGH_C_RECBYTES_LO = 12, // record output: bytes of the listed records (one 64-bit sum: k_match_bounds)
+    AGH_C_RECBYTES_HI = 13,
+    AGH_C_NREC = 14,     // -v record lists: records k_unmatched walked over (the compaction inverts below this)
+    AGH_C_COUNT = 16
 };
 
 // The reference's own query tables for the table engine (agh_table.hip), maskgen.c layout.

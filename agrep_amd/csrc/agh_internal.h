@@ -81,6 +81,11 @@ struct agh_query {
     // per-query workspace (grown lazily, reused across scans)
     dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, hashset, dbm, staging, match_pos,
         match_rec, match_start, match_end, match_off, gather;
+    dev_buf rec_pos;                    // record lists: one byte offset per record number (8 B per bitmap bit)
+    dev_buf bm_blocks;                  // ... scratch of the ordered compaction of the bitmap
+    dev_buf match_out;                  // ... agh_match entries of the piece being emitted
+    unsigned char *h_emit = nullptr;    // pinned: the matched records of one emit() call (entries + bytes)
+    size_t h_emit_cap = 0;
     uint64_t staged_len = 0;            // bytes of the text currently held in `staging`
     bool staged_first = true, staged_last = true;   // ... is the head / the tail of its file (agh_scan_fd_range)
     hipStream_t stage_stream = nullptr; // H2D copies of agh_scan_fd
@@ -151,9 +156,18 @@ extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_host(str
 // ---- agh_api.cpp ------------------------------------------------------------------------------
 // at the start of every public scan call: AGH_ENV_LIVE=1 re-reads the switches (tests, A/B scripts)
 static inline void agh_refresh_tuning(agh_query *q) { if (q->tune.live) agh_read_tuning(&q->tune); }
-// one scan of text resident in HBM, cut into segments as the query needs; d_match_pos / d_match_rec
-// (device, match_cap entries) receive one position / the record number per matched record
+// The record list of a scan, on the device, in file order (agh_records.hip): per listed record one byte offset
+// inside it (pos), its number (rec, optional) and -- if start / end are given -- its bounds [start, end).
+// cap entries each; rec_bytes (out) = sum of the lengths of the stored records.
+struct agh_list_out {
+    uint64_t *pos = nullptr;
+    uint32_t *rec = nullptr;
+    uint64_t *start = nullptr, *end = nullptr;
+    size_t cap = 0;
+    uint64_t rec_bytes = 0;
+};
+// one scan of text resident in HBM, cut into segments as the query needs; list (optional): the matched
+// records (-v: the others)
 __attribute__((visibility("hidden"))) int agh_scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipStream_t st,
-                                                               unsigned flags, agh_result *res, uint64_t *d_match_pos,
-                                                               uint32_t *d_match_rec, size_t match_cap, bool is_first,
-                                                               bool is_last);
+                                                               unsigned flags, agh_result *res, agh_list_out *list,
+                                                               bool is_first, bool is_last);

@@ -35,9 +35,10 @@ struct agh_marks {
     uint32_t *bitmap;        // one bit per record
     uint32_t bitmap_bits;    // capacity; larger record numbers raise AGH_C_BM_OVERFLOW
     uint32_t *counters;
-    uint64_t *match_pos;     // optional: one byte offset per newly matched record
-    uint32_t *match_rec;     // optional: its record number
-    uint32_t match_cap;
+    uint64_t *rec_pos;       // optional (record lists): rec_pos[r] = one byte offset inside record r, written by whoever
+                             // sets r's bit first -- no shared counter (one hot L2 atomic takes ~90 updates/us: 104 197
+                             // matches per 4 GiB cost 1.2 ms of a 0.7 ms sweep); the list comes out of the ordered
+                             // compaction of the bitmap afterwards (agh_records.hip), in file order
     uint64_t *hashset;       // lean scans: open-addressing set of (record start + 1)
     uint32_t hashset_mask;   // slots - 1 (power of two)
     // lean scans, one-byte delimiters: positions of matches whose record start lies more than
@@ -139,13 +140,36 @@ void agh_launch_corpus(void *out, uint64_t first_page, uint64_t n_pages, uint64_
                        uint32_t n_variants, uint32_t plant_period, uint32_t upper_permille,
                        unsigned long long *planted_dev, hipStream_t st);
 void agh_launch_exp(int exp, const void *text, uint64_t n, uint32_t *counters, hipStream_t st);
-void agh_launch_match_bounds(const void *text, uint64_t n, const agh_dev_query &q,
-                             const uint64_t *dbm, const uint64_t *pos, uint32_t cnt,
-                             uint64_t *start, uint64_t *end, hipStream_t st);
-void agh_launch_offset_matches(uint64_t *pos, uint32_t *rec, uint32_t cnt, uint64_t pos_off,
+// ---- record output on the device (agh_records.hip) ----
+// ordered compaction of the record bitmap: listed records (set bits; invert: clear bits below AGH_C_NREC) in file
+// order -> out_pos[i] = rec_pos[r], out_rec[i] = r for the first `cap` of them; AGH_C_STORED = records listed,
+// AGH_C_MATCHED = set bits; the bitmap is left zeroed.  blk: n_words / 1024 + 2 scratch words
+void agh_launch_bitmap_list(uint32_t *bitmap, uint32_t n_words, uint32_t *blk, const uint64_t *rec_pos, int invert,
+                            uint64_t *out_pos, uint32_t *out_rec, uint32_t cap, uint32_t *counters, hipStream_t st);
+// [start, end) of the records around pos[0 .. min(AGH_C_STORED, cap)); AGH_C_RECBYTES += the sum of their lengths
+void agh_launch_match_bounds(const void *text, uint64_t n, const agh_dev_query &q, const uint64_t *dbm, const uint64_t *pos,
+                             uint32_t *counters, uint32_t cap, uint32_t grid_entries, uint64_t *start, uint64_t *end,
+                             hipStream_t st);
+void agh_launch_offset_matches(uint64_t *pos, uint32_t *rec, uint64_t *start, uint64_t *end, uint32_t cnt, uint64_t pos_off,
                                uint32_t rec_off, hipStream_t st);
-void agh_launch_gather_records(const void *text, const uint64_t *start, const uint64_t *end,
-                               const uint64_t *off, uint32_t cnt, void *out, hipStream_t st);
+// What a listed record occupies in the output: [start - pre, end) + post_dlen bytes of delimiter behind it, pre =
+// min(pre_dlen, bytes of the input in front of the record) -- pre_dlen / post_dlen are 0 or the delimiter length
+// (AGH_EMIT_HEAD_DELIM / AGH_EMIT_TAIL_DELIM).  base_off: where text[0] lies in the input.
+struct agh_gather_shape {
+    uint64_t base_off;
+    uint32_t pre_dlen, post_dlen;
+    uint8_t dbytes[8];      // the delimiter: appended behind the last record when the input does not end with one
+};
+// blk[b] = output bytes of the records in front of block b (256 records each) of list entries [first, first + cnt),
+// blk[n_blocks] = their total: (cnt + 255) / 256 + 1 words
+void agh_launch_len_offsets(const uint64_t *start, const uint64_t *end, uint32_t first, uint32_t cnt, const agh_gather_shape &g,
+                            uint64_t *blk, hipStream_t st);
+// the bytes of entries [first, first + cnt) back to back at out (NULL: none) and their agh_match triples
+// (start, end, index -- shifted by g.base_off / rec_off) at out_matches (NULL: none); blk as left by
+// agh_launch_len_offsets, pointing at the block of `first`; n: length of the text
+void agh_launch_gather_records(const void *text, uint64_t n, const uint64_t *start, const uint64_t *end, const uint32_t *rec,
+                               const uint64_t *blk, uint32_t first, uint32_t cnt, const agh_gather_shape &g, uint64_t rec_off,
+                               void *out, void *out_matches, hipStream_t st);
 void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &q, uint64_t *dbm,
                              uint64_t n_words, uint32_t *counters, hipStream_t st);
 

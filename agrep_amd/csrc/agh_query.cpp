@@ -967,6 +967,10 @@ extern "C" void agh_query_free(agh_query *q)
     q->match_end.release();
     q->match_off.release();
     q->gather.release();
+    q->rec_pos.release();
+    q->bm_blocks.release();
+    q->match_out.release();
+    if (q->h_emit) (void)hipHostFree(q->h_emit);
     q->staging_b.release();
     for (int b = 0; b < AGH_PIN_RING; ++b) {
         if (q->pinned[b]) (void)hipHostFree(q->pinned[b]);

@@ -1,10 +1,9 @@
-// agh_scan.hip -- the k-error automaton on candidate windows (k_verify) and the record output
-// kernels.  The automaton over every byte lives in agh_fullscan.hip (its own translation unit:
+// agh_scan.hip -- the k-error automaton on candidate windows (k_verify).  The automaton over every byte lives in agh_fullscan.hip (its own translation unit:
 // the two kernel families compile in parallel).  See agh_sweep.hip for the data flow of a scan.
 //
 // Compiled ten times: once per number of errors (-DAGH_SCAN_K=0..8: the verify kernels of that k, both
 // word widths -- a code object of its own each, so a process loads the one its query needs and not 7 MB
-// of all of them) and once without the define (record output kernels, the dispatch by k).
+// of all of them) and once without the define (the dispatch by k).  Record output: agh_records.hip.
 #include <stdlib.h>
 
 #include "agh_verify_inl.h"
@@ -152,89 +151,7 @@ void AGH_SK_CAT(agh_launch_verify_k, AGH_SCAN_K)(const agh_scan_args &a, int wha
     }
 }
 
-#else   // ---- the object without a k: record output, dispatch ----------------------------------------
-
-
-// ---------------------------------------------------------------------------------------
-// record output: bounds of matched records and their bytes, straight from the staged text
-// (what output()/s_output() derive on the CPU: agrep.c:3805-3956, sgrep.c:1274-1333)
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_match_bounds(const uint8_t *__restrict__ text,
-                                                      uint64_t n, agh_dev_query q,
-                                                      const uint64_t *__restrict__ dbm,
-                                                      const uint64_t *__restrict__ pos,
-                                                      uint32_t cnt, uint64_t *__restrict__ start,
-                                                      uint64_t *__restrict__ end)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cnt) return;
-    uint64_t e = pos[i];
-    if (e > n) e = n;
-    uint64_t s = e, en = e;
-    if (q.mb) {
-        // record = (end of the last delimiter in front of e, start of the next delimiter]
-        const int64_t d = dbm_prev(dbm, e, ~0ull);
-        s = d >= 0 ? (uint64_t)d + 1 : 0;
-        while (en < n && !dbm_bit(dbm, en)) ++en;      // en = end byte of the next delimiter
-        if (en < n) en = en + 1 >= q.dlen ? en + 1 - q.dlen : 0;
-        else en = virtual_close_start(text, n, q, dbm);   // closed by the appended delimiter
-        if (en < s) en = s;
-    } else {
-        while (s > 0 && text[s - 1] != q.delim) --s;   // 1 + last delimiter in front of e
-        while (en < n && text[en] != q.delim) ++en;    // first delimiter at or after e
-    }
-    start[i] = s;
-    end[i] = en;
-}
-
-// One wave per record: out[off[i] .. off[i] + len) = text[start[i] .. end[i]).
-__global__ __launch_bounds__(256) void k_gather_records(const uint8_t *__restrict__ text,
-                                                        const uint64_t *__restrict__ start,
-                                                        const uint64_t *__restrict__ end,
-                                                        const uint64_t *__restrict__ off,
-                                                        uint32_t cnt, uint8_t *__restrict__ out)
-{
-    const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    if (r >= cnt) return;
-    const uint64_t s = start[r], len = end[r] - s, o = off[r];
-    for (uint64_t b = (uint64_t)lane_id(); b < len; b += WAVE) out[o + b] = text[s + b];
-}
-
-// Matches of a later segment: positions and record numbers become absolute.
-__global__ __launch_bounds__(256) void k_offset_matches(uint64_t *__restrict__ pos,
-                                                        uint32_t *__restrict__ rec, uint32_t cnt,
-                                                        uint64_t pos_off, uint32_t rec_off)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cnt) return;
-    pos[i] += pos_off;
-    if (rec) rec[i] += rec_off;
-}
-
-void agh_launch_offset_matches(uint64_t *pos, uint32_t *rec, uint32_t cnt, uint64_t pos_off,
-                               uint32_t rec_off, hipStream_t st)
-{
-    if (!cnt || (!pos_off && !rec_off)) return;
-    hipLaunchKernelGGL(k_offset_matches, dim3((cnt + 255u) / 256u), dim3(256), 0, st, pos, rec, cnt,
-                       pos_off, rec_off);
-}
-
-void agh_launch_match_bounds(const void *text, uint64_t n, const agh_dev_query &q,
-                             const uint64_t *dbm, const uint64_t *pos, uint32_t cnt,
-                             uint64_t *start, uint64_t *end, hipStream_t st)
-{
-    if (!cnt) return;
-    hipLaunchKernelGGL(k_match_bounds, dim3((cnt + 255u) / 256u), dim3(256), 0, st,
-                       (const uint8_t *)text, n, q, dbm, pos, cnt, start, end);
-}
-
-void agh_launch_gather_records(const void *text, const uint64_t *start, const uint64_t *end,
-                               const uint64_t *off, uint32_t cnt, void *out, hipStream_t st)
-{
-    if (!cnt) return;
-    hipLaunchKernelGGL(k_gather_records, dim3((cnt + 3u) / 4u), dim3(256), 0, st,
-                       (const uint8_t *)text, start, end, off, cnt, (uint8_t *)out);
-}
+#else   // ---- the object without a k: dispatch ----------------------------------------
 
 // ---------------------------------------------------------------------------------------
 // host-callable launchers

@@ -9,16 +9,22 @@
 #include <memory>
 
 #include "agh_internal.h"
-#include "agh_order.h"
 
-// Matches of the text staged in q->staging: bounds computed on the device, sorted into file
-// order on the host.
-static int collect_matches(agh_query *q, uint64_t len, const agh_result *res, agh_match *matches)
+// Pinned host memory for what a scan hands back (match entries, record bytes): grown, never shrunk.
+static int ensure_emit_pinned(agh_query *q, size_t bytes)
 {
-    const size_t ns = (size_t)res->n_stored;
-    if (!ns) return 0;
-    if (q->match_start.ensure(ns * sizeof(uint64_t))) return -1;
-    if (q->match_end.ensure(ns * sizeof(uint64_t))) return -1;
+    if (q->h_emit_cap >= bytes) return 0;
+    if (q->h_emit) (void)hipHostFree(q->h_emit);
+    q->h_emit = nullptr;
+    q->h_emit_cap = 0;
+    const size_t want = bytes + bytes / 4 + 65536;
+    HIP_TRY(hipHostMalloc((void **)&q->h_emit, want));
+    q->h_emit_cap = want;
+    return 0;
+}
+
+static agh_dev_query list_dev_query(const agh_query *q)
+{
     agh_dev_query dq;
     memset(&dq, 0, sizeof(dq));
     dq.delim = q->delim[q->dlen - 1];
@@ -26,41 +32,55 @@ static int collect_matches(agh_query *q, uint64_t len, const agh_result *res, ag
     memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
     dq.dfold = q->delim_fold ? 1u : 0u;
     dq.mb = q_mb(q) ? 1u : 0u;
-    agh_launch_match_bounds(q->staging.p, len, dq, (const uint64_t *)q->dbm.p,
-                            (const uint64_t *)q->match_pos.p, (uint32_t)ns,
-                            (uint64_t *)q->match_start.p, (uint64_t *)q->match_end.p, nullptr);
+    return dq;
+}
+
+// Device arrays of a record list of `cap` entries (pos, rec, start, end).
+static int ensure_list(agh_query *q, size_t cap, agh_list_out *list)
+{
+    if (q->match_pos.ensure(cap * sizeof(uint64_t)) || q->match_rec.ensure(cap * sizeof(uint32_t)) ||
+        q->match_start.ensure(cap * sizeof(uint64_t)) || q->match_end.ensure(cap * sizeof(uint64_t)))
+        return -1;
+    list->pos = (uint64_t *)q->match_pos.p;
+    list->rec = (uint32_t *)q->match_rec.p;
+    list->start = (uint64_t *)q->match_start.p;
+    list->end = (uint64_t *)q->match_end.p;
+    list->cap = cap;
+    list->rec_bytes = 0;
+    return 0;
+}
+
+// The matches of the text staged in q->staging -> the caller's array: the list is already in file order on
+// the device with its bounds (agh_records.hip); packed into agh_match entries there and copied back in one piece.
+static int collect_matches(agh_query *q, const agh_result *res, agh_match *matches)
+{
+    const size_t ns = (size_t)res->n_stored;
+    if (!ns) return 0;
+    static_assert(sizeof(agh_match) == 3 * sizeof(uint64_t), "agh_match is three 64-bit words");
+    if (q->match_out.ensure(ns * sizeof(agh_match))) return -1;
+    if (q->match_off.ensure(((ns + 255) / 256 + 2) * sizeof(uint64_t))) return -1;
+    HIP_TRY(hipMemsetAsync(q->match_off.p, 0, ((ns + 255) / 256 + 2) * sizeof(uint64_t), nullptr));
+    agh_gather_shape g;
+    memset(&g, 0, sizeof(g));
+    agh_launch_gather_records(q->staging.p, q->staged_len, (const uint64_t *)q->match_start.p, (const uint64_t *)q->match_end.p,
+                              (const uint32_t *)q->match_rec.p, (const uint64_t *)q->match_off.p, 0, (uint32_t)ns, g, 0,
+                              nullptr, q->match_out.p, nullptr);
     HIP_TRY(hipGetLastError());
-    std::vector<uint64_t> st(ns), en(ns);
-    std::vector<uint32_t> rec(ns);
-    HIP_TRY(hipMemcpy(st.data(), q->match_start.p, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(en.data(), q->match_end.p, ns * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(rec.data(), q->match_rec.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::vector<uint32_t> order;
-    agh_order_matches(rec.data(), st.data(), ns, order);           // file order (agh_order.h)
-    for (size_t i = 0; i < ns; ++i) {
-        matches[i].start = st[order[i]];
-        matches[i].end = en[order[i]];
-        matches[i].index = rec[order[i]];
-    }
+    HIP_TRY(hipMemcpy(matches, q->match_out.p, ns * sizeof(agh_match), hipMemcpyDeviceToHost));
     return 0;
 }
 
 static int scan_staged(agh_query *q, uint64_t len, unsigned flags, agh_result *res,
                        agh_match *matches, size_t cap, bool is_first = true, bool is_last = true)
 {
-    uint64_t *d_pos = nullptr;
-    uint32_t *d_rec = nullptr;
-    if (matches && cap) {
-        if (q->match_pos.ensure(cap * sizeof(uint64_t))) return -1;
-        if (q->match_rec.ensure(cap * sizeof(uint32_t))) return -1;
-        d_pos = (uint64_t *)q->match_pos.p;
-        d_rec = (uint32_t *)q->match_rec.p;
-    }
+    agh_list_out list;
+    const bool want = matches && cap;
+    if (want && ensure_list(q, cap, &list)) return -1;
     q->staged_len = len;
     q->staged_first = is_first;                 // (agh_rescan_staged scans the same shard again)
     q->staged_last = is_last;
-    if (agh_scan_device_impl(q, q->staging.p, len, nullptr, flags, res, d_pos, d_rec, cap, is_first, is_last)) return -1;
-    return d_pos ? collect_matches(q, len, res, matches) : 0;
+    if (agh_scan_device_impl(q, q->staging.p, len, nullptr, flags, res, want ? &list : nullptr, is_first, is_last)) return -1;
+    return want ? collect_matches(q, res, matches) : 0;
 }
 
 extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t len,
@@ -78,6 +98,7 @@ extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t l
 // chunks are being read (a ring of AGH_PIN_RING chunks) -- the staging role of fill_buf
 // (bitap.c:450-477), without an intermediate pageable copy.
 static const size_t AGH_STAGE_CHUNK = (size_t)32 << 20;
+static const size_t AGH_SEG_PFX = 64;       // bytes in front of the text of a device segment of the stream (pipe_scan)
 
 struct fd_reader {
     int fd = -1;
@@ -202,74 +223,88 @@ struct rec_sink {
     agh_emit_fn emit;
     void *ctx;
     bool want_bytes;
+    bool head_delim, tail_delim;    // AGH_EMIT_HEAD_DELIM / AGH_EMIT_TAIL_DELIM
 };
 
-// Numbered scan of text[0, n) (any length: cut into kernel segments by agh_scan_device_impl), match
-// bounds and the gather of the record bytes on the device, one copy back, one emit() call.  Offsets
-// and record numbers are shifted by base_off / rec_off (the segment's place in its file).
+static rec_sink make_sink(agh_emit_fn emit, void *ctx, unsigned flags)
+{
+    rec_sink s = {emit, ctx, !(flags & AGH_NO_BYTES), (flags & AGH_EMIT_HEAD_DELIM) != 0, (flags & AGH_EMIT_TAIL_DELIM) != 0};
+    return s;
+}
+
+// Numbered scan of text[0, n) (any length: cut into kernel segments by agh_scan_device_impl) with the list of
+// matched records left on the device IN FILE ORDER together with their bounds (agh_records.hip); then, per piece
+// of the list, the record bytes are gathered back to back on the device, bytes and agh_match entries come back
+// in ONE copy into pinned memory, and emit() is called.  Two host synchronisations for a list that fits one
+// piece: the scan's counters, the copy.  Offsets and record numbers are shifted by base_off / rec_off (the
+// segment's place in its file).
+#define AGH_EMIT_PIECE_BYTES ((uint64_t)64 << 20)   // record bytes per emit() call (whole blocks of 256 records)
+#define AGH_EMIT_PIECE_RECS ((size_t)1 << 20)
+
 static int emit_records(agh_query *q, const void *d_text, uint64_t n, unsigned flags, bool first, bool last,
                         uint64_t base_off, uint64_t rec_off, const rec_sink &sink, agh_result *r, bool *stop)
 {
-    flags &= ~(AGH_COUNT | AGH_FILENAMEONLY | AGH_NO_BYTES);
+    flags &= ~(AGH_COUNT | AGH_FILENAMEONLY | AGH_NO_BYTES | AGH_EMIT_HEAD_DELIM | AGH_EMIT_TAIL_DELIM);
     size_t mcap = std::max<size_t>(q->match_cap_hint, (size_t)1 << 16);
+    agh_list_out list;
     for (;;) {
-        if (q->match_pos.ensure(mcap * sizeof(uint64_t)) || q->match_rec.ensure(mcap * sizeof(uint32_t))) return -1;
-        if (agh_scan_device_impl(q, d_text, n, nullptr, flags, r, (uint64_t *)q->match_pos.p,
-                                 (uint32_t *)q->match_rec.p, mcap, first, last))
-            return -1;
+        if (ensure_list(q, mcap, &list)) return -1;
+        if (agh_scan_device_impl(q, d_text, n, nullptr, flags, r, &list, first, last)) return -1;
         if (!r->truncated) break;
         mcap = std::max<size_t>(mcap * 4, (size_t)r->n_matched + 1024);     // the text is still resident: again
     }
     q->match_cap_hint = std::max<size_t>(q->match_cap_hint, (size_t)r->n_stored + (size_t)r->n_stored / 4);
     const size_t ns = (size_t)r->n_stored;
     if (!ns) return 0;
-    const size_t b8 = ns * sizeof(uint64_t);
-    if (q->match_start.ensure(b8) || q->match_end.ensure(b8) || q->match_off.ensure(b8)) return -1;
-    agh_dev_query dq;
-    memset(&dq, 0, sizeof(dq));
-    dq.delim = q->delim[q->dlen - 1];
-    dq.dlen = (uint32_t)q->dlen;
-    memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
-    dq.dfold = q->delim_fold ? 1u : 0u;
-    dq.mb = q_mb(q) ? 1u : 0u;
-    agh_launch_match_bounds(d_text, n, dq, (const uint64_t *)q->dbm.p, (const uint64_t *)q->match_pos.p,
-                            (uint32_t)ns, (uint64_t *)q->match_start.p, (uint64_t *)q->match_end.p, nullptr);
+    // what a record occupies in the output (agh_gather_shape): with the delimiter in front of it / behind it on request
+    agh_gather_shape g;
+    memset(&g, 0, sizeof(g));
+    g.base_off = base_off;
+    g.pre_dlen = (sink.want_bytes && sink.head_delim) ? (uint32_t)q->dlen : 0u;
+    g.post_dlen = (sink.want_bytes && sink.tail_delim) ? (uint32_t)q->dlen : 0u;
+    memcpy(g.dbytes, q->delim, (size_t)q->dlen);
+    // (an upper bound for one piece: only the first record of the input can have less than dlen bytes in front of it)
+    const uint64_t total = sink.want_bytes ? list.rec_bytes + (uint64_t)ns * (g.pre_dlen + g.post_dlen) : 0;
+    const size_t n_blocks = (ns + 255) / 256;
+    if (q->match_off.ensure((n_blocks + 2) * sizeof(uint64_t))) return -1;
+    uint64_t *d_blk = (uint64_t *)q->match_off.p;
+    agh_launch_len_offsets(list.start, list.end, 0, (uint32_t)ns, g, d_blk, nullptr);
     HIP_TRY(hipGetLastError());
-    std::vector<uint64_t> st(ns), en(ns), off(ns);
-    std::vector<uint32_t> rec(ns);
-    HIP_TRY(hipMemcpy(st.data(), q->match_start.p, b8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(en.data(), q->match_end.p, b8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(rec.data(), q->match_rec.p, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::vector<uint32_t> order;
-    agh_order_matches(rec.data(), st.data(), ns, order);           // file order (agh_order.h)
-    std::vector<agh_match> ms(ns);
-    uint64_t total = 0;
-    for (size_t i = 0; i < ns; ++i) {
-        const size_t o = order[i];
-        ms[i].start = st[o] + base_off;
-        ms[i].end = en[o] + base_off;
-        ms[i].index = (uint64_t)rec[o] + rec_off;
-        off[i] = total;
-        total += en[o] - st[o];
+    const bool one_piece = ns <= AGH_EMIT_PIECE_RECS && total <= AGH_EMIT_PIECE_BYTES;
+    std::vector<uint64_t> h_blk;
+    if (!one_piece) {                           // the host cuts pieces at block boundaries: it needs the offsets
+        h_blk.resize(n_blocks + 1);
+        HIP_TRY(hipMemcpy(h_blk.data(), d_blk, (n_blocks + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
-    // (malloc, not a vector: 8 MB of zero-fill per call for bytes the copy overwrites anyway)
-    std::unique_ptr<unsigned char, void (*)(void *)> bytes(nullptr, free);
-    if (sink.want_bytes && total) {
-        std::vector<uint64_t> s2(ns), e2(ns);
-        for (size_t i = 0; i < ns; ++i) { s2[i] = st[order[i]]; e2[i] = en[order[i]]; }
-        if (q->gather.ensure((size_t)total)) return -1;
-        HIP_TRY(hipMemcpy(q->match_start.p, s2.data(), b8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(q->match_end.p, e2.data(), b8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(q->match_off.p, off.data(), b8, hipMemcpyHostToDevice));
-        agh_launch_gather_records(d_text, (const uint64_t *)q->match_start.p, (const uint64_t *)q->match_end.p,
-                                  (const uint64_t *)q->match_off.p, (uint32_t)ns, q->gather.p, nullptr);
+    for (size_t b0 = 0; b0 < n_blocks && !*stop;) {
+        size_t b1 = n_blocks;
+        uint64_t piece_bytes = total;
+        if (!one_piece) {
+            b1 = b0 + 1;                        // at least one block, then as many as fit
+            while (b1 < n_blocks && (b1 + 1 - b0) * 256 <= AGH_EMIT_PIECE_RECS &&
+                   (!sink.want_bytes || h_blk[b1 + 1] - h_blk[b0] <= AGH_EMIT_PIECE_BYTES))
+                ++b1;
+            piece_bytes = sink.want_bytes ? h_blk[b1] - h_blk[b0] : 0;
+        }
+        const size_t r0 = b0 * 256, cnt = std::min(ns, b1 * 256) - r0;
+        const size_t m_bytes = cnt * sizeof(agh_match);
+        const size_t m_room = (m_bytes + 63) & ~(size_t)63;
+        if (q->match_out.ensure(m_room + (size_t)piece_bytes + 64)) return -1;
+        if (ensure_emit_pinned(q, m_room + (size_t)piece_bytes)) return -1;
+        unsigned char *d_out = (unsigned char *)q->match_out.p;
+        agh_launch_gather_records(d_text, n, list.start, list.end, list.rec, d_blk + b0, (uint32_t)r0, (uint32_t)cnt, g,
+                                  rec_off, (sink.want_bytes && piece_bytes) ? d_out + m_room : nullptr, d_out, nullptr);
         HIP_TRY(hipGetLastError());
-        bytes.reset((unsigned char *)malloc((size_t)total));
-        if (!bytes) return fail("out of memory (%llu bytes of matched records)", (unsigned long long)total);
-        HIP_TRY(hipMemcpy(bytes.get(), q->gather.p, (size_t)total, hipMemcpyDeviceToHost));
+        // entries and bytes are neighbours on the device: one copy
+        HIP_TRY(hipMemcpyAsync(q->h_emit, d_out, m_room + (size_t)piece_bytes, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        const agh_match *hm = (const agh_match *)q->h_emit;
+        if (one_piece && g.pre_dlen && hm[0].start < g.pre_dlen) piece_bytes -= g.pre_dlen - hm[0].start;   // (the bound above)
+        if (sink.emit(sink.ctx, hm, cnt, sink.want_bytes ? q->h_emit + m_room : nullptr,
+                      sink.want_bytes ? (size_t)piece_bytes : 0))
+            *stop = true;
+        b0 = b1;
     }
-    if (sink.emit(sink.ctx, ms.data(), ns, sink.want_bytes ? bytes.get() : nullptr, sink.want_bytes ? (size_t)total : 0))
-        *stop = true;
     return 0;
 }
 
@@ -300,7 +335,7 @@ extern "C" int agh_scan_device_emit(agh_query *q, const void *dev_text, size_t l
     if (!len) return 0;
     // one emit() per piece of at most AGH_EMIT_SEG_MB (the match arrays and the gathered bytes of a piece
     // are what the call holds at a time); pieces end where a record ends
-    rec_sink sink = {emit, ctx, !(flags & AGH_NO_BYTES)};
+    rec_sink sink = make_sink(emit, ctx, flags);
     bool stop = false;
     agh_result r;
     if (emit_records(q, dev_text, len, flags, true, true, 0, 0, sink, &r, &stop)) return -1;
@@ -352,7 +387,7 @@ struct pipe_worker {
             int rc1;
             bool stop1 = false;
             if (sink) rc1 = emit_records(q, text, len, flags, first, last, base_off, rec_off, *sink, &r, &stop1);
-            else rc1 = agh_scan_device_impl(q, text, len, nullptr, flags, &r, nullptr, nullptr, 0, first, last);
+            else rc1 = agh_scan_device_impl(q, text, len, nullptr, flags, &r, nullptr, first, last);
             if (rc1) {
                 rc = rc1;
                 snprintf(err, sizeof(err), "%s", agh_last_error());
@@ -437,7 +472,9 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
     // (a file smaller than a chunk is read -- and its pinned buffer sized -- as one piece of its own size)
     const uint64_t chunk_cap = (hint && hint < AGH_STAGE_CHUNK) ? ((hint + 65535) & ~(uint64_t)65535) : AGH_STAGE_CHUNK;
     dev_buf *seg[2] = {&q->staging, &q->staging_b};
-    const uint64_t want0 = std::min<uint64_t>(seg_cap, hint ? hint : seg_cap) + 2 * chunk_cap + 64;
+    // every device segment keeps AGH_SEG_PFX bytes in front of its text: the last bytes of the segment before it,
+    // i.e. the delimiter in front of its first record (AGH_EMIT_HEAD_DELIM reads it from there)
+    const uint64_t want0 = std::min<uint64_t>(seg_cap, hint ? hint : seg_cap) + 2 * chunk_cap + 64 + AGH_SEG_PFX;
     if (seg[0]->ensure(want0)) return -1;
     if ((!hint || hint > seg_cap) && seg[1]->ensure(want0)) return -1;      // (a small file needs one segment)
     q->staged_len = 0;                          // what stays in HBM is not the whole input
@@ -478,15 +515,15 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         if (got < 0) return bail(-1);
         if (got == 0) eof = true;
         if (got > 0) {
-            if (used + (uint64_t)got + 64 > seg[cur]->cap) {    // a record longer than the segment: grow
+            if (AGH_SEG_PFX + used + (uint64_t)got + 64 > seg[cur]->cap) {    // a record longer than the segment: grow
                 dev_buf bigger;
-                if (bigger.ensure((used + (uint64_t)got) * 2 + 64)) return bail(-1);
+                if (bigger.ensure((AGH_SEG_PFX + used + (uint64_t)got) * 2 + 64)) return bail(-1);
                 PIPE_TRY(hipStreamSynchronize(q->stage_stream));
-                if (used) PIPE_TRY(hipMemcpy(bigger.p, seg[cur]->p, used, hipMemcpyDeviceToDevice));
+                PIPE_TRY(hipMemcpy(bigger.p, seg[cur]->p, AGH_SEG_PFX + used, hipMemcpyDeviceToDevice));
                 seg[cur]->release();
                 *seg[cur] = bigger;
             }
-            PIPE_TRY(hipMemcpyAsync((unsigned char *)seg[cur]->p + used, q->pinned[b], (size_t)got,
+            PIPE_TRY(hipMemcpyAsync((unsigned char *)seg[cur]->p + AGH_SEG_PFX + used, q->pinned[b], (size_t)got,
                                     hipMemcpyHostToDevice, q->stage_stream));
             PIPE_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
             busy[b] = true;
@@ -508,16 +545,19 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         w.wait_idle();                          // the scan of the segment before this one (the other buffer)
         if (w.rc || w.stop) break;
         if (cut) {
-            w.submit(seg[cur]->p, cut, base_off, first, eof && is_last);
+            w.submit((unsigned char *)seg[cur]->p + AGH_SEG_PFX, cut, base_off, first, eof && is_last);
             first = false;
         }
         base_off += cut;
         if (!eof) {
             // the unfinished record opens the next segment, in the buffer the worker has just left
             const int nxt = cur ^ 1;
-            if (seg[nxt]->ensure(std::max<uint64_t>(want0, tail_len + 2 * chunk_cap + 64))) return bail(-1);
+            if (seg[nxt]->ensure(std::max<uint64_t>(want0, tail_len + 2 * chunk_cap + 64 + AGH_SEG_PFX))) return bail(-1);
+            // ... behind the bytes that end this segment (its own prefix included when the segment is shorter)
+            PIPE_TRY(hipMemcpyAsync(seg[nxt]->p, (unsigned char *)seg[cur]->p + cut, AGH_SEG_PFX, hipMemcpyDeviceToDevice,
+                                    q->stage_stream));
             if (tail_len) {
-                PIPE_TRY(hipMemcpyAsync(seg[nxt]->p, tail_src, (size_t)tail_len, hipMemcpyHostToDevice, q->stage_stream));
+                PIPE_TRY(hipMemcpyAsync((unsigned char *)seg[nxt]->p + AGH_SEG_PFX, tail_src, (size_t)tail_len, hipMemcpyHostToDevice, q->stage_stream));
                 PIPE_TRY(hipEventRecord(q->pinned_ev[b], q->stage_stream));
                 busy[b] = true;
             }
@@ -620,7 +660,7 @@ extern "C" int agh_scan_fd_range(agh_query *q, int fd, uint64_t begin, uint64_t 
 extern "C" int agh_scan_fd_emit(agh_query *q, int fd, unsigned flags, agh_result *res, agh_emit_fn emit, void *ctx)
 {
     if (!emit) return fail("null argument");
-    rec_sink sink = {emit, ctx, !(flags & AGH_NO_BYTES)};
+    rec_sink sink = make_sink(emit, ctx, flags);
     return scan_fd_impl(q, fd, false, 0, 0, flags, res, nullptr, 0, &sink);
 }
 
@@ -628,7 +668,7 @@ extern "C" int agh_scan_fd_range_emit(agh_query *q, int fd, uint64_t begin, uint
                                       agh_result *res, agh_emit_fn emit, void *ctx)
 {
     if (!emit) return fail("null argument");
-    rec_sink sink = {emit, ctx, !(flags & AGH_NO_BYTES)};
+    rec_sink sink = make_sink(emit, ctx, flags);
     return scan_fd_impl(q, fd, true, begin, end, flags, res, nullptr, 0, &sink);
 }
 
@@ -696,14 +736,13 @@ extern "C" int agh_fetch_records(agh_query *q, const agh_match *m, size_t n_matc
                                  unsigned char *out, size_t out_cap, size_t *out_len)
 {
     if (!q || (!m && n_matches) || (!out && out_cap)) return fail("null argument");
-    std::vector<uint64_t> st(n_matches), en(n_matches), off(n_matches);
+    std::vector<uint64_t> st(n_matches), en(n_matches);
     uint64_t total = 0;
     for (size_t i = 0; i < n_matches; ++i) {
         if (m[i].end < m[i].start || m[i].end > q->staged_len)
             return fail("match %zu lies outside the staged text", i);
         st[i] = m[i].start;
         en[i] = m[i].end;
-        off[i] = total;
         total += m[i].end - m[i].start;
     }
     if (out_len) *out_len = (size_t)total;
@@ -711,15 +750,18 @@ extern "C" int agh_fetch_records(agh_query *q, const agh_match *m, size_t n_matc
                                      (unsigned long long)total);
     if (!n_matches || !total) return 0;
     const size_t bytes = n_matches * sizeof(uint64_t);
-    if (q->match_start.ensure(bytes) || q->match_end.ensure(bytes) || q->match_off.ensure(bytes) ||
-        q->gather.ensure((size_t)total))
+    if (q->match_start.ensure(bytes) || q->match_end.ensure(bytes) ||
+        q->match_off.ensure(((n_matches + 255) / 256 + 2) * sizeof(uint64_t)) || q->gather.ensure((size_t)total))
         return -1;
     HIP_TRY(hipMemcpy(q->match_start.p, st.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(q->match_end.p, en.data(), bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(q->match_off.p, off.data(), bytes, hipMemcpyHostToDevice));
-    agh_launch_gather_records(q->staging.p, (const uint64_t *)q->match_start.p,
-                              (const uint64_t *)q->match_end.p, (const uint64_t *)q->match_off.p,
-                              (uint32_t)n_matches, q->gather.p, nullptr);
+    agh_gather_shape g;
+    memset(&g, 0, sizeof(g));
+    agh_launch_len_offsets((const uint64_t *)q->match_start.p, (const uint64_t *)q->match_end.p, 0, (uint32_t)n_matches, g,
+                           (uint64_t *)q->match_off.p, nullptr);
+    agh_launch_gather_records(q->staging.p, q->staged_len, (const uint64_t *)q->match_start.p, (const uint64_t *)q->match_end.p,
+                              nullptr, (const uint64_t *)q->match_off.p, 0, (uint32_t)n_matches, g, 0, q->gather.p, nullptr,
+                              nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, q->gather.p, (size_t)total, hipMemcpyDeviceToHost));
     return 0;

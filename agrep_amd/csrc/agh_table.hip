@@ -796,8 +796,9 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
 // ---------------------------------------------------------------------------------------
 // -v (INVERSE, asearch.c:128): the records whose bit is NOT set in the record bitmap.  Text-
 // parallel like k_tablescan: a lane looks at the delimiters of its 256-byte chunk; the record
-// a delimiter closes has the number "delimiters in front of it".  Emits (position of the
-// closing delimiter, record number) for k_match_bounds; one atomic per wave.
+// a delimiter closes has the number "delimiters in front of it".  Leaves rec_pos[r] = position of the
+// closing delimiter for every unmatched record r and the record count in AGH_C_NREC; the list itself is
+// the ordered compaction of the inverted bitmap (agh_records.hip).
 // ---------------------------------------------------------------------------------------
 // Delimiters of several bytes (or a folded letter): the delimiter ends come from the bitmap.
 __global__ __launch_bounds__(256) void k_unmatched(const uint8_t *__restrict__ text, uint64_t n,
@@ -845,45 +846,17 @@ __global__ __launch_bounds__(256) void k_unmatched(const uint8_t *__restrict__ t
                            : 0u;
         // the last, unterminated record is closed by the delimiter appended at EOF
         const bool open_tail = cs < n && ce == n && q.tail_virtual && !is_delim_end(n - 1);
-        // pass 1: how many of my records are unmatched
-        uint32_t mine = 0;
+        // every record of mine whose bit stayed clear: rec_pos[r] = where it ends (the ordered compaction of the
+        // inverted bitmap turns these into the list, agh_records.hip)
         if (cs < n) {
             uint32_t r = rec;
             for (uint64_t p = cs; p < ce; ++p)
                 if (is_delim_end(p)) {
-                    if (r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) ++mine;
+                    if (r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) mk.rec_pos[r] = p;
                     ++r;
                 }
-            if (open_tail && r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) ++mine;
-        }
-        // one reservation per wave
-        const uint32_t incl = wave_sum_to_lane63(mine);
-        uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        uint32_t wave_base = 0;
-        if (wave_total) {
-            if (lane_id() == 63) wave_base = atomicAdd(&mk.counters[AGH_C_STORED], wave_total);
-            wave_base = (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 63);
-        }
-        uint32_t at = wave_base + incl - mine;
-        if (mine) {
-            uint32_t r = rec;
-            for (uint64_t p = cs; p < ce; ++p)
-                if (is_delim_end(p)) {
-                    if (r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) {
-                        if (at < mk.match_cap) {
-                            mk.match_pos[at] = p;
-                            if (mk.match_rec) mk.match_rec[at] = r;
-                        }
-                        ++at;
-                    }
-                    ++r;
-                }
-            if (open_tail && r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) {
-                if (at < mk.match_cap) {
-                    mk.match_pos[at] = n;
-                    if (mk.match_rec) mk.match_rec[at] = r;
-                }
-            }
+            if (open_tail && r < mk.bitmap_bits && !((mk.bitmap[r >> 5] >> (r & 31u)) & 1u)) mk.rec_pos[r] = n;
+            if (ce == n) mk.counters[AGH_C_NREC] = r + (open_tail ? 1u : 0u);   // records of the text
         }
     }
 }

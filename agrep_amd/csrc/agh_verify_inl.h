@@ -20,13 +20,7 @@ __device__ __forceinline__ void mark_record(const agh_marks &mk, uint32_t r, uin
     // (dense hit sets mark the same record again and again: a plain load settles those)
     if (__atomic_load_n(&mk.bitmap[r >> 5], __ATOMIC_RELAXED) & bit) return;
     uint32_t old = atomicOr(&mk.bitmap[r >> 5], bit);
-    if (mk.match_pos && !(old & bit)) {
-        uint32_t idx = atomicAdd(&mk.counters[AGH_C_STORED], 1u);
-        if (idx < mk.match_cap) {
-            mk.match_pos[idx] = e;
-            if (mk.match_rec) mk.match_rec[idx] = r;
-        }
-    }
+    if (mk.rec_pos && !(old & bit)) mk.rec_pos[r] = e;
 }
 
 // ---- lean scans: a record is identified by the offset of its first byte ---------------------

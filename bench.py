@@ -54,10 +54,12 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 12345
 
 
-def ref_all_cores(ref, host, k, tmpdir, procs):
+def ref_all_cores(ref, host, k, tmpdir, procs, records=False):
     """The reference is single-threaded: 'all host cores' = `procs` independent agrep processes on
     `procs` record-aligned pieces of `host` (pages end with a newline), started together.
-    -> (sum of the counts, seconds from the first start to the last exit)"""
+    -> (sum of the counts, seconds from the first start to the last exit, processes[, sha256 of the lines]);
+    records: run WITHOUT -c -- the reference prints the matched records (s_output(), sgrep.c:1274-1333); the
+    count is then the number of printed lines and the digest covers the pieces' outputs in file order"""
     from concurrent.futures import ThreadPoolExecutor
     n = host.size
     pages = n // 4096
@@ -67,8 +69,28 @@ def ref_all_cores(ref, host, k, tmpdir, procs):
     try:
         with ThreadPoolExecutor(max_workers=8) as ex:             # (tofile releases the GIL)
             list(ex.map(lambda a: host[a[0][0]:a[0][1]].tofile(a[1]), zip(spans, paths)))
-        cmd = [ref, "-V0", "-%d" % k, "-c", PATTERN.decode()]
+        cmd = [ref, "-V0", "-%d" % k] + ([] if records else ["-c"]) + [PATTERN.decode()]
         t0 = time.time()
+        if records:
+            # (stdout to files: 32 pipes read one after the other would stall the writers)
+            outs_p = [pth + ".out" for pth in paths]
+            fhs = [open(o, "wb") for o in outs_p]
+            ps = [subprocess.Popen(cmd + [pth], stdout=fh) for pth, fh in zip(paths, fhs)]
+            for p_ in ps:
+                p_.wait()
+            dt = time.time() - t0
+            for fh in fhs:
+                fh.close()
+            import hashlib
+            h = hashlib.sha256()
+            lines = 0
+            for o in outs_p:
+                with open(o, "rb") as fh:
+                    data = fh.read()
+                h.update(data)
+                lines += data.count(b"\n")
+                os.unlink(o)
+            return lines, dt, len(paths), h.hexdigest()
         ps = [subprocess.Popen(cmd + [pth], stdout=subprocess.PIPE) for pth in paths]
         outs = [p_.communicate()[0] for p_ in ps]
         dt = time.time() - t0
@@ -76,6 +98,8 @@ def ref_all_cores(ref, host, k, tmpdir, procs):
         for pth in paths:
             if os.path.exists(pth):
                 os.unlink(pth)
+            if os.path.exists(pth + ".out"):
+                os.unlink(pth + ".out")
     return sum(int(o.split()[0]) for o in outs if o.strip()), dt, len(paths)
 
 
@@ -100,35 +124,49 @@ def cpu_baseline_extras(ref, host, sample_bytes, k, tmpdir):
 
 
 def reference_all_shards(text_dev, n_bytes, k, q, shard_bytes, first_shard_host):
-    """Parity of the WHOLE corpus against the reference CPU agrep: shard by shard (4 GiB each: the
-    SURVEY 8d shards) through /dev/shm, every shard cut into one file per core, one reference
-    process per file; the GPU count of the same shard beside it.  Not a timing leg."""
+    """Parity of the WHOLE corpus against the reference CPU agrep -- the match SET, not only its size: shard by
+    shard (4 GiB each: the SURVEY 8d shards) through /dev/shm, every shard cut into one file per core, one
+    reference process per file printing the matched records; beside it the GPU's count of the same shard
+    (count-only scan) and the sha256 of the records the GPU returns for it (agh_scan_device_emit with the
+    delimiter behind every record: byte for byte what the reference prints).  Not a timing leg."""
+    import hashlib
     import agrep_amd as A
     ref = os.path.join(ROOT, "oracle", "_ref", "agrep")
     d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     procs = min(os.cpu_count() or 1, 32)
     n_shards = n_bytes // shard_bytes
     t0 = time.time()
-    ref_counts, gpu_counts = [], []
+    ref_counts, gpu_counts, ref_sha, gpu_sha, gpu_recs = [], [], [], [], []
     ref_seconds = 0.0
     for sh in range(n_shards):
         lo = sh * shard_bytes
         host = first_shard_host if (sh == 0 and first_shard_host is not None and first_shard_host.size == shard_bytes) \
             else text_dev[lo:lo + shard_bytes].cpu().numpy()
-        cnt, dt, _ = ref_all_cores(ref, host, k, d, procs)
+        cnt, dt, _, digest = ref_all_cores(ref, host, k, d, procs, records=True)
         del host
         ref_counts.append(int(cnt))
+        ref_sha.append(digest)
         ref_seconds += dt
         gpu_counts.append(int(q.scan_device(text_dev.data_ptr() + lo, shard_bytes, flags=A.COUNT,
                                             time_sweep=False, time_scan=False).n_matched))
+        h = hashlib.sha256()
+        _, batches = q.scan_device_emit(text_dev.data_ptr() + lo, shard_bytes, flags=A.EMIT_TAIL_DELIM,
+                                        summarize=True, hasher=h)
+        gpu_sha.append(h.hexdigest())
+        gpu_recs.append(sum(b[0] for b in batches))
+    all_ref, all_gpu = hashlib.sha256("".join(ref_sha).encode()), hashlib.sha256("".join(gpu_sha).encode())
     return {"shards": n_shards, "shard_bytes": shard_bytes, "processes_per_shard": procs,
-            "reference_count": sum(ref_counts), "gpu_count": sum(gpu_counts),
+            "reference_count": sum(ref_counts), "gpu_count": sum(gpu_counts), "gpu_records_returned": sum(gpu_recs),
             "shards_equal": sum(1 for a, b in zip(ref_counts, gpu_counts) if a == b),
+            "records_sha256_shards_equal": sum(1 for a, b in zip(ref_sha, gpu_sha) if a == b),
+            "records_sha256_equal": ref_sha == gpu_sha and gpu_recs == ref_counts,
+            "records_sha256_of_shard_digests": {"reference": all_ref.hexdigest(), "gpu": all_gpu.hexdigest()},
             "equal": ref_counts == gpu_counts, "reference_seconds": round(ref_seconds, 2),
             "reference_GBps_all_cores": round(n_shards * shard_bytes / 1e9 / max(ref_seconds, 1e-9), 2),
             "wall_seconds": round(time.time() - t0, 1),
-            "what": "`agrep -V0 -%d -c %s` (unmodified reference, sgrep.c path) over every byte of the corpus, "
-                    "per-shard counts compared with the GPU's" % (k, PATTERN.decode())}
+            "what": "`agrep -V0 -%d %s` (unmodified reference, sgrep.c path, printing the matched records) over every "
+                    "byte of the corpus; per shard: its line count against the GPU's -c count, the sha256 of its "
+                    "lines against the sha256 of the records agh_scan_device_emit returns" % (k, PATTERN.decode())}
 
 
 def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes, q=None, all_shards=False):
@@ -160,6 +198,7 @@ def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes, q=None
             try:
                 extra["all_shards"] = reference_all_shards(text_dev, n_bytes, k, q, sample_bytes, host)
                 extra["all_shards_count_equals_gpu"] = bool(extra["all_shards"]["equal"])
+                extra["all_shards_records_sha256_equal"] = bool(extra["all_shards"]["records_sha256_equal"])
             except Exception as e:
                 extra["all_shards_error"] = str(e)[:200]
         return {"value": round(sample_bytes / 1e9 / dt, 4), "unit": "GB/s", "cores": 1,

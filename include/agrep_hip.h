@@ -54,6 +54,12 @@ extern "C" {
                                      events as well */
 #define AGH_FORCE_NUMBERED 0x40u  /* diagnostics: compute record numbers even for -c / -l scans */
 #define AGH_NO_BYTES       0x200u /* agh_scan_*_emit: offsets and record numbers only, no record bytes */
+#define AGH_EMIT_HEAD_DELIM 0x400u /* agh_scan_*_emit: bytes of record i = text[start - pre, end) with pre = min(dlen, start):
+                                      the delimiter in front of the record, as far as the input has one there */
+#define AGH_EMIT_TAIL_DELIM 0x800u /* agh_scan_*_emit: ... followed by the dlen bytes behind the record: the delimiter from
+                                      the text, or -- behind a last, unterminated record -- the one the reference appends
+                                      (asearch.c:87-91).  Both together: the buffer asearch.c:162-170 hands to output();
+                                      tail alone with the default delimiter: byte for byte the lines the reference prints */
 
 /* engine that produced a result */
 #define AGH_ENGINE_FULLSCAN 1u    /* k-error automaton over every byte (asearch.c:94-116) */
@@ -207,15 +213,19 @@ int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res, agh_match
  * size (the scan of one overlaps the read + H2D copy of the next); after every segment emit() receives that
  * segment's matched records in file order: m[0..n) (offsets relative to the start of the input, index = the
  * record number), and bytes[0..n_bytes) = the records themselves back to back (record i has m[i].end -
- * m[i].start bytes; NULL / 0 with AGH_NO_BYTES).  emit() is called from a worker thread of the library, never
- * concurrently; a non-zero return stops the scan (the call returns 0 with res->truncated = 1).  HBM use does
- * not grow with the input, pipes work, records of any number come out.  flags: AGH_INVERT, AGH_NO_BYTES. */
+ * m[i].start bytes, plus its delimiters with AGH_EMIT_HEAD_DELIM / AGH_EMIT_TAIL_DELIM; NULL / 0 with
+ * AGH_NO_BYTES).  A segment with many or long matched records comes in several emit() calls (at most 2^20
+ * records / 64 MiB of record bytes each, file order kept).  emit() is called from a worker thread of the
+ * library, never concurrently; a non-zero return stops the scan (the call returns 0 with res->truncated = 1).
+ * HBM use does not grow with the input, pipes work, records of any number come out.  The list is produced in
+ * file order on the device (ordered compaction of the record bitmap: no sort) and comes back in one copy per
+ * emit().  flags: AGH_INVERT, AGH_NO_BYTES, AGH_EMIT_HEAD_DELIM, AGH_EMIT_TAIL_DELIM. */
 typedef int (*agh_emit_fn)(void *ctx, const agh_match *m, size_t n, const unsigned char *bytes, size_t n_bytes);
 int agh_scan_fd_emit(agh_query *q, int fd, unsigned flags, agh_result *res, agh_emit_fn emit, void *ctx);
 int agh_scan_fd_range_emit(agh_query *q, int fd, uint64_t begin, uint64_t end, unsigned flags,
                            agh_result *res, agh_emit_fn emit, void *ctx);
 /* The same for text already resident in HBM (dev_text as for agh_scan_device): numbered scan, record bounds
- * and the gather of the record bytes on the device, one emit() call. */
+ * and the gather of the record bytes on the device. */
 int agh_scan_device_emit(agh_query *q, const void *dev_text, size_t len, unsigned flags, agh_result *res,
                          agh_emit_fn emit, void *ctx);
 
@@ -234,7 +244,7 @@ int agh_fetch_records(agh_query *q, const agh_match *m, size_t n_matches, unsign
 /* Text already resident in HBM (the measured configuration): dev_text is a device pointer,
  * 16-byte aligned, readable up to the next multiple of 16 bytes after len.  stream is a
  * hipStream_t (NULL = default stream).  dev_match_pos (optional device pointer to
- * match_cap uint64) receives, unordered, one byte offset inside each matched record. */
+ * match_cap uint64) receives, in file order, one byte offset inside each matched record. */
 int agh_scan_device(agh_query *q, const void *dev_text, size_t len, void *stream,
                     unsigned flags, agh_result *res, void *dev_match_pos, size_t match_cap);
 
