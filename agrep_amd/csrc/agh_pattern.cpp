@@ -19,7 +19,7 @@
 //
 // Layout of the result (maskgen.c:218-257, kept so that the tables are interchangeable with the reference's):
 // positions 1..M = delimiter bytes, one separator, the pattern; position p lives at bit M - p of a 32-bit
-// word; M <= 32 (maskgen.c:201-208), i.e. 30 - |delimiter| pattern positions.
+// word; M <= 31 (maskgen.c:201-208), i.e. 29 - |delimiter| pattern positions.
 #include <errno.h>
 #include <string.h>
 
@@ -63,7 +63,8 @@ struct compiler {
 
     int add(const byte_class &c, bool no_error, bool sep = false)
     {
-        if (next() > 32) return fail("pattern too long (has > 32 positions with its delimiter)");    // maskgen.c:201-208
+        // M <= 31 positions (delimiter + separator + pattern): maskgen.c:201-208 tests j > WORD after its j++
+        if (next() > 31) return fail("pattern too long (has > 31 positions with its delimiter)");
         position p;
         p.cls = c;
         p.no_error = no_error;
@@ -172,6 +173,7 @@ extern "C" int agh_compile_pattern(const unsigned char *pat, int len, unsigned q
         switch (c) {
         case '\\':
             if (i + 1 >= len) return fail("a pattern cannot end in a backslash");
+            if (pat[i + 1] == '\n') C.fancy = true;     // (not a plain literal: the literal builder would let an error touch it)
             if (C.add_byte(pat[i + 1], C.exact)) return -1;
             i += 2;
             break;
@@ -212,6 +214,10 @@ extern "C" int agh_compile_pattern(const unsigned char *pat, int len, unsigned q
             ++i;
             break;
         case '^':
+            // preproce.c:282 takes a '^' behind ANY '[' for the class complement, an escaped \[ included: what the
+            // reference makes of "\[^x" is not a '[' followed by an anchor -- refused like its other surprises
+            if (i > 0 && pat[i - 1] == '[') return fail("'^' directly behind \\[ is read as a class complement by the reference: write \\[\\^ or move it");
+            /* fall through */
         case '$':                                       // preproce.c:284-293: an anchor is a newline position
             C.fancy = true;
             if (C.add_byte('\n', true)) return -1;
@@ -238,6 +244,7 @@ extern "C" int agh_compile_pattern(const unsigned char *pat, int len, unsigned q
             return fail("'%c': boolean pattern expressions are outside the scan path of this library (escape it as "
                         "\\%c for the byte itself)", (int)c, (int)c);
         default:
+            if (c == '\n') C.fancy = true;              // a newline byte in the pattern: a no-error position, like ^ and $
             if (C.add_byte(c, C.exact)) return -1;
             ++i;
             break;
@@ -251,8 +258,6 @@ extern "C" int agh_compile_pattern(const unsigned char *pat, int len, unsigned q
     } else if ((qflags & AGH_Q_WORD) && C.add_word_boundary()) {
         return -1;
     }
-    if (C.next() > 32) return fail("pattern too long (has > 32 positions with its delimiter)");
-
     // ---- the tables, in maskgen's layout (maskgen.c:218-266) -----------------------------------------
     const int M = C.next() - 1, base = 32 - M, D_length = dlen + 1;
     memset(out, 0, sizeof(*out));
@@ -288,9 +293,16 @@ extern "C" agh_query *agh_query_pattern(const unsigned char *pat, int len, int D
 {
     agh_pattern_tables t;
     if (agh_compile_pattern(pat, len, qflags, delim, dlen, &t)) return nullptr;
-    if (t.simple) {
-        // a plain literal (with its -w / -x guards): the literal builder knows the sample filter's engines;
-        // the record set is the same (its tables ARE these, agh_query_literal_ex)
+    // A plain literal goes to the literal builder (sample filter).  With a -w / -x guard only where the reference
+    // itself takes its simple-pattern engines -- no errors and nothing checksg() calls non-simple ('\\', '-':
+    // checksg.c:42-139): bm()'s word test is !isalnum() over all 256 bytes (sgrep.c:750-756), what
+    // agh_query_literal_ex implements.  With errors, an escape or a '-' the reference goes through maskgen(),
+    // whose word-boundary class is 1..47, 58..64, 91..96, 123..127 (maskgen.c:176-187: 0x00 and 0x80..0xFF are
+    // NOT boundaries) -- those queries take the compiled tables, which are maskgen's bit for bit.
+    bool sgrep_simple = true;
+    for (int i = 0; i < len; ++i) sgrep_simple = sgrep_simple && pat[i] != '\\' && pat[i] != '-';
+    const bool guarded = (qflags & (AGH_Q_WORD | AGH_Q_WHOLELINE)) != 0;
+    if (t.simple && (!guarded || (D == 0 && sgrep_simple))) {
         std::vector<unsigned char> lit;
         for (int i = 0; i < len; ++i) {
             if (pat[i] == '\\' && i + 1 < len) ++i;

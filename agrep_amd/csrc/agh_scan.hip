@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void k_verify(const uint8_t *__restrict__ text
             win.j = win.ws = 0;
             win.span = win.mode = 0;
             if (valid) win = verify_locate<WT, K, NCH, LEAN>(c, ent);
-            if (LEAN && verify_same_window_as_prev_lane(win)) win.mode = 0u;
+            // (the same window finds the same records, numbered or not)
+            if (verify_same_window_as_prev_lane(win)) win.mode = 0u;
             if (win.mode) verify_walk<WT, K, NCH, LEAN, MB, GEN>(c, ent, LEAN ? 0u : wave_prefix[w], win);
         }
     }
@@ -112,19 +113,18 @@ static void launch_verify_t(const agh_scan_args &a, hipStream_t st)
     // window span = max(m+k+1, 16) + q + m + k bytes, fetched as ceil(span/16) pieces
     const int lw = a.q.m + a.q.k + 1 > 16 ? a.q.m + a.q.k + 1 : 16;
     const int nch = (lw + a.q.fq + a.q.m + a.q.k + 15) / 16;
-    if (a.gtab && (LEAN || (int)(((uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread + 15u + 15u) / 16u) < nch)) {
-        // gram offsets known: one warm-up byte + (m + 2k + spread) bytes per candidate; numbered
-        // scans may start up to 15 bytes earlier (at the sample's 16-byte chunk)
-        const uint32_t tspan = (uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread + (LEAN ? 0u : 15u);
+    if (a.gtab) {
+        // gram offsets known: one warm-up byte + (m + 2k + spread) bytes per candidate, for count-only and
+        // numbered scans alike (round 4 let a numbered window start at the sample's 16-byte chunk: 15 bytes
+        // more, and no two samples of an occurrence shared a window -- 204 us per 8 GiB of config C3)
+        const uint32_t tspan = (uint32_t)(a.q.m + 2 * a.q.k + 1) + a.gram_spread;
         const int tn = (int)((tspan + 15u) / 16u);
-        // (numbered scans come here only when the window gets shorter by at least one 16-byte
-        // piece: the table costs two dependent loads per candidate)
         if (sizeof(WT) == 4) {
-            if (tn <= 2 && LEAN) launch_verify_n<WT, K, LEAN ? 2 : 3, LEAN>(a, a.gtab, tspan, st);
+            if (tn <= 2) launch_verify_n<WT, K, 2, LEAN>(a, a.gtab, tspan, st);
             else if (tn <= 3) launch_verify_n<WT, K, 3, LEAN>(a, a.gtab, tspan, st);
             else launch_verify_n<WT, K, 6, LEAN>(a, a.gtab, tspan, st);
         } else {
-            if (tn <= 4 && LEAN) launch_verify_n<WT, K, LEAN ? 4 : 7, LEAN>(a, a.gtab, tspan, st);
+            if (tn <= 4) launch_verify_n<WT, K, 4, LEAN>(a, a.gtab, tspan, st);
             else if (tn <= 7) launch_verify_n<WT, K, 7, LEAN>(a, a.gtab, tspan, st);
             else launch_verify_n<WT, K, 10, LEAN>(a, a.gtab, tspan, st);
         }

@@ -366,9 +366,8 @@ __device__ __forceinline__ VerifyWin verify_locate(const VerifyCtx<WT, K> &c, ui
             if ((uint32_t)e != g) return w;
             lw = (uint32_t)((e >> 40) & 0xffu) + (uint32_t)c.q->k + 1u;   // + one warm-up byte
             span = c.tspan;
-            // numbered scans count delimiters from the window start to the sample's chunk
-            // (anchor): start no later than that; tspan has 15 bytes of slack for it
-            if (!LEAN && lw < (uint32_t)(j - anchor)) lw = (uint32_t)(j - anchor);
+            // (numbered scans: the window may start behind the start of the sample's chunk, whose record number
+            // the candidate carries -- verify_walk counts the delimiters in between only if something matched)
         }
     }
     fast = fast && j >= lw && (j - lw) + span < c.n && (j - lw) + 16u * NCH <= c.n16;
@@ -510,7 +509,18 @@ __device__ __forceinline__ void verify_walk(const VerifyCtx<WT, K> &c, uint64_t 
             }
             return c;
         };
-        const uint32_t r0 = rc_anchor - delims_before((uint32_t)(anchor - ws));
+        // record number at the window start: the candidate carries the one at the start of its sample's chunk
+        // (anchor); the window starts in front of it, or -- tight windows -- up to 15 bytes behind it
+        uint32_t r0;
+        if (ws <= anchor) {
+            r0 = rc_anchor - delims_before((uint32_t)(anchor - ws));
+        } else if (MB) {
+            r0 = rc_anchor + dbm_count(c.dbm, anchor, ws);
+        } else {
+            const uint4 av = *reinterpret_cast<const uint4 *>(c.text + anchor);
+            r0 = rc_anchor + delims_in(mask_tail(av, (int)(ws - anchor), (~c.q->delim & 0xffu) * 0x01010101u),
+                                       c.q->delim * 0x01010101u);
+        }
 #pragma unroll
         for (int i = 0; i < NMW; ++i) {
             uint64_t hm = hitm[i];

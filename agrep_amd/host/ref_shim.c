@@ -156,6 +156,46 @@ struct text_src {
     size_t mem_len;
 };
 
+/* File mode prints while the file is still being read, as asearch.c:66-324 does from inside its block loop:
+ * agh_scan_fd_emit streams the input through two bounded device segments and hands every segment's matched
+ * records to this callback in file order -- each with the delimiter in front of it and behind it
+ * (AGH_EMIT_HEAD_DELIM | AGH_EMIT_TAIL_DELIM: the buffer shape of asearch.c:162-170), so output() is called
+ * exactly as before, only earlier and without the whole file in HBM. */
+struct stream_ctx {
+    const unsigned char *delim;
+    int dlen, lead_delim, rc;
+};
+
+static int stream_emit(void *vctx, const agh_match *m, size_t n, const unsigned char *bytes, size_t n_bytes)
+{
+    struct stream_ctx *c = (struct stream_ctx *)vctx;
+    size_t off = 0, i;
+    for (i = 0; i < n; i++) {
+        const size_t pre = m[i].start < (uint64_t)c->dlen ? (size_t)m[i].start : (size_t)c->dlen;
+        const size_t body = (size_t)(m[i].end - m[i].start);
+        const size_t wlen = pre + body + (size_t)c->dlen;
+        int rc;
+        if (off + wlen > n_bytes) { c->rc = shim_fail("internal error: short record buffer"); return 1; }
+        rc = emit_one(bytes + off, wlen, pre, body, m[i].index, m[i].end, c->delim, c->dlen, c->lead_delim);
+        off += wlen;
+        if (rc == 1) return 1;                          /* -L limits reached: stop reading */
+        if (rc) { c->rc = rc; return 1; }
+    }
+    return 0;
+}
+
+/* -d: does the input open with the delimiter (asearch.c:79-84 starts counting at -1)?  Known up front for
+ * seekable files only; 0 otherwise (the caller does not stream then) */
+static int peek_lead_delim(int fd, const unsigned char *delim, int dlen, int *known)
+{
+    unsigned char first[AGH_MAX_DELIM];
+    const off_t cur = lseek(fd, 0, SEEK_CUR);
+    *known = 0;
+    if (cur < 0) return 0;
+    *known = 1;
+    return pread(fd, first, (size_t)dlen, cur) == (ssize_t)dlen && memcmp(first, delim, (size_t)dlen) == 0;
+}
+
 static int run_scan(agh_query *q, const struct text_src *src, const unsigned char *delim, int dlen)
 {
     agh_result res;
@@ -176,6 +216,20 @@ static int run_scan(agh_query *q, const struct text_src *src, const unsigned cha
             return 0;
         }
         return res.n_matched ? print_filename() : 0;
+    }
+
+    if (src->fd >= 0) {
+        struct stream_ctx c;
+        int known = 1;
+        c.delim = delim;
+        c.dlen = dlen;
+        c.rc = 0;
+        c.lead_delim = DELIMITER ? peek_lead_delim(src->fd, delim, dlen, &known) : 0;
+        if (known) {                            /* (-d on a pipe: the staged path below) */
+            rc = agh_scan_fd_emit(q, src->fd, flags | AGH_EMIT_HEAD_DELIM | AGH_EMIT_TAIL_DELIM, &res, stream_emit, &c);
+            if (rc) return shim_fail(agh_last_error());
+            return c.rc;
+        }
     }
 
     ms = (agh_match *)malloc(cap * sizeof(*ms));

@@ -146,8 +146,8 @@ agh_query *agh_query_from_maskgen(const uint32_t Mask[256], uint32_t Init0, uint
  * a,b  and the -w / -x / -i options (qflags: AGH_Q_*) -- compiled by the library itself.
  * agh_compile_pattern is host-only (no device needed): it fills the tables in maskgen's own layout -- the ones
  * agh_query_from_maskgen takes, bit for bit what the reference's maskgen() leaves in its globals
- * (tests/test_pattern_compiler.py compares them with the reference's).  M <= 32 positions: the delimiter, one
- * separator and the pattern (maskgen.c:201-208).  Regular expressions ( * | ( ) ), the boolean-pattern
+ * (tests/test_pattern_compiler.py compares them with the reference's).  M <= 31 positions: the delimiter, one
+ * separator and the pattern (maskgen.c:201-208: 29 - |delimiter| pattern positions).  Regular expressions ( * | ( ) ), the boolean-pattern
  * syntax ( { } ~ ), unescaped meta
  * characters inside [] and a '-' inside [] that is not between two bytes of its own ([a-c-e], [-a], [a-]:
  * the reference reads these in ways of its own) are refused (-1, errno 123): what compiles, compiles like
@@ -222,6 +222,9 @@ int agh_scan_fd(agh_query *q, int fd, unsigned flags, agh_result *res, agh_match
  * emit().  flags: AGH_INVERT, AGH_NO_BYTES, AGH_EMIT_HEAD_DELIM, AGH_EMIT_TAIL_DELIM. */
 typedef int (*agh_emit_fn)(void *ctx, const agh_match *m, size_t n, const unsigned char *bytes, size_t n_bytes);
 int agh_scan_fd_emit(agh_query *q, int fd, unsigned flags, agh_result *res, agh_emit_fn emit, void *ctx);
+/* ... restricted to the byte range [begin, end) of a seekable file (one rank's shard): offsets and record numbers
+ * are relative to `begin` (the shard is scanned as an input of its own: add begin / the record count of the
+ * shards in front); AGH_EMIT_HEAD_DELIM gives the first record of the shard no delimiter in front. */
 int agh_scan_fd_range_emit(agh_query *q, int fd, uint64_t begin, uint64_t end, unsigned flags,
                            agh_result *res, agh_emit_fn emit, void *ctx);
 /* The same for text already resident in HBM (dev_text as for agh_scan_device): numbered scan, record bounds
