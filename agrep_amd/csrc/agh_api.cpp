@@ -68,6 +68,9 @@ static agh_multi_dev multi_dev(const agh_query *q, const uint64_t *dbm)
 // one segment (<= AGH_SEG_MAX bytes) resident in HBM
 // ---------------------------------------------------------------------------------------
 static const uint64_t AGH_SEG_MAX_DEFAULT = (uint64_t)8 << 30;   // nominal segment (plan_segments)
+// what one numbered kernel sequence takes: 64 chunks of 1024 wave ranges in the census scan (agh_sweep.hip), 40-bit
+// sample indices in the candidate entries, 32-bit record numbers
+static const uint64_t AGH_SEG_HARD_MAX = (uint64_t)16 << 30;
 static const uint64_t AGH_LEAN_SEG_MAX = (uint64_t)64 << 30;     // lean scans: one launch per 64 GiB
 // lean pipeline defaults (lean_run): part size in MiB (0: one launch per segment) and whether the
 // verifier runs on a second stream; AGH_PART_MB / AGH_OVERLAP override (A/B runs)
@@ -131,8 +134,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     const uint64_t n_strips = (n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint64_t nw = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
     if (multi && n > ((uint64_t)4 << 30)) return fail("multi-pattern segments are limited to 4 GiB");
-    if (n > ((uint64_t)16 << 30) - 4096) return fail("segments are limited to 16 GiB");
-    if (q->fh == 2 && !multi && n > ((uint64_t)8 << 30) - 4096) return fail("segments of this query are limited to 8 GiB");
+    if (n > AGH_SEG_HARD_MAX) return fail("segments are limited to 16 GiB");
     if (multi && (flags & AGH_FORCE_FULLSCAN))
         return fail("multi-pattern queries have no full-scan engine");
     const bool want_filter = (q->fq > 0 || pe) && !(flags & AGH_FORCE_FULLSCAN) && !q->table && !invert_list &&
@@ -493,6 +495,9 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         swept = true;
 
         const uint32_t n_delims = q->h_counters[AGH_C_NDELIM];
+        if (q->h_counters[AGH_C_BM_OVERFLOW] == 2u)
+            return fail("more than 2^32 records in one segment of %llu bytes (record numbers are 32-bit): set AGH_SEG_MAX_MB",
+                        (unsigned long long)n);
         if (q->tune.debug)
             fprintf(stderr, "[agh] attempt %d multi %d dense %d filter %d: ndelim %u cand %u overflow %u "
                             "bm_overflow %u matched %u bm_bits %llu\n", attempt, (int)multi,
@@ -550,15 +555,9 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
 // ---------------------------------------------------------------------------------------
 static uint64_t seg_nominal(const agh_query *q)
 {
-    if (q->tune.seg_max_mb) {                                       // AGH_SEG_MAX_MB (tests: tiny segments)
-        // (H = 2 candidates are 32-bit halfword indices: 8 GiB reach, so 4 GiB nominal at most)
-        const uint64_t mb = (q->fh == 2 && !q->multi && !q->piece_single) ? std::min<uint64_t>(q->tune.seg_max_mb, 4096)
-                                                                         : q->tune.seg_max_mb;
-        return mb << 20;
-    }
+    if (q->tune.seg_max_mb) return q->tune.seg_max_mb << 20;        // AGH_SEG_MAX_MB (tests: tiny segments)
     if (q->multi || q->piece_single) return (uint64_t)2 << 30;
-    // H == 2 candidates are 32-bit HALFWORD indices in numbered scans: 8 GiB reach, 4 GiB nominal
-    return q->fh == 2 ? ((uint64_t)4 << 30) : AGH_SEG_MAX_DEFAULT;
+    return AGH_SEG_MAX_DEFAULT;
 }
 
 static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, hipStream_t st,
@@ -571,7 +570,10 @@ static int plan_segments(agh_query *q, const unsigned char *base, uint64_t len, 
     // the candidate slices: 1/8 of the text); everything else is limited by 32-bit indices.
     uint64_t nominal = seg_nominal(q);
     if (lean && !q->tune.seg_max_mb) nominal = AGH_LEAN_SEG_MAX;
-    if (len > nominal) {
+    // a text one kernel sequence can take is not cut at all (16 GiB: config C3 in one piece -- every segment pays
+    // its launches, its census scan and a host synchronisation, ~80 us)
+    const bool single = !q->tune.seg_max_mb && !q->multi && !q->piece_single && len <= AGH_SEG_HARD_MAX;
+    if (len > nominal && !single) {
         const uint64_t nb = (len - 1) / nominal;        // boundaries strictly inside the text
         if (nb + 1 > AGH_MAX_SEGS) return fail("input too large: more than %d segments", AGH_MAX_SEGS);
         if (q->cuts.ensure(3 * AGH_MAX_SEGS * sizeof(uint64_t))) return -1;

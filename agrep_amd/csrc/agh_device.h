@@ -13,6 +13,12 @@
 // Candidate slots owned by one sweep wave (one per 64 text bytes; more means the filter is
 // not selective on this text and the scan falls back to the full automaton).
 #define AGH_SLICE_CAP (AGH_WAVE_STRIPS * 16u)
+// Candidate entry of a numbered single-pattern sweep: (delimiters in front of the sample's 16-byte chunk inside its
+// wave's range) << 40 | index of the sample (dwords; halfwords for H == 2 samples).  The count is below 2^19 (a
+// range is 256 KiB), the index below 2^34 in a 16 GiB segment.  (Round 4 packed 32 + 32 bits: H == 2 queries were
+// limited to 8 GiB per segment, every other one just below 16.)  Lean entries are the bare 64-bit index.
+#define AGH_CAND_IDX_BITS 40
+#define AGH_CAND_IDX_MASK ((1ull << AGH_CAND_IDX_BITS) - 1ull)
 // multi-pattern scans probe every byte position: room for one hit per 16 bytes
 #define AGH_MP_SLICE_CAP (AGH_WAVE_STRIPS * 64u)
 // Lean scans: how far back the verifier looks for the start of a matched record before the
@@ -179,12 +185,6 @@ AGH_HD uint32_t agh_mp_bucket(uint32_t s)
 // Row of a 3-gram held in the low 24 bits of y (the top byte is ignored by the 24-bit multiply):
 // the middle bits [31:19] of y * C; the device takes them as a byte address with
 // ((v_mul_u32_u24 y, C) >> 16) & ((rows - 1) << 3)  (one v_and_b32_sdwa src0_sel:WORD_1).
-#ifndef AGH_MS_NBF
-#define AGH_MS_NBF 0                        // 1: neighbour-byte filter in front of level 3 (agh_mscan.hip), mdir holds 4 words per slot
-#endif
-#ifndef AGH_MS_L3PIPE
-#define AGH_MS_L3PIPE 0                     // 1: level 3 of k_mscan in two halves, one batch in flight (agh_mscan.hip)
-#endif
 #define AGH_MS_C 0xC2B2AEu
 #define AGH_MS_RB_MAX 13u                   // rows <= 2^13 (64 KiB)
 AGH_HD uint32_t agh_ms_row(uint32_t y, uint32_t rb)

@@ -39,26 +39,15 @@
 #define MS_RING_B 128u
 #define MS_QA_DW 6u                 // queue A entry: w0 w1 | w2 w3 | w4 meta (three ds_write_b64)
 
-// AGH_MS_NBF (make VARFLAGS=-DAGH_MS_NBF=1; not in the shipped build until it has been measured): level 2 hands
-// level 3 the four text bytes next to the 4-gram -- two behind it, two in front -- and level 3 tests them against
-// three 32-bit masks of the gram's entries (agh_query.cpp fill_multi_tables) BEFORE it loads the text: a piece of
-// >= 5 bytes needs its fifth byte at p + 4; a 4-byte piece needs one of the two nearest bytes of the other side
-// of its pattern among the two text bytes on that side (what side_within_one_edit can accept at all).  On the
-// config-5 set 7 % of level 2's survivors pass where all four bytes are known (CPU model of the tables on the
-// bench corpus: 2357 survivors per MiB, the kernel counts 2365), ~15 % with the chunk-edge positions let through.
-#if AGH_MS_NBF == 1                 // (agh_device.h: 0 unless the build asks for it)
-typedef uint2 ms_qb_t;              // (position << 12 | slot, neighbour bytes S0 S1 T1 T2)
-#else
+// Measured and removed (round 5, one box, profiles/r05_ab_c5_variants.log; 4 GiB, config 5: shipped 1.27-1.30 ms):
+// a neighbour-byte filter in front of level 3 (1.39-1.48), a fifth-byte mask in level 2 with 2^12 rows (1.50-1.53),
+// level 3 in two halves with one batch in flight (1.29-1.31), 2^12 rows alone (1.44-1.48).
 typedef uint32_t ms_qb_t;
-#endif
 
 template <int WAVES, int RB>
 struct ms_shared {
     uint2 ptab[1u << RB];
     uint32_t gtab[AGH_MS_GSLOTS];
-#if AGH_MS_NBF == 2
-    uint32_t gmask[AGH_MS_GSLOTS];   // per gram slot: the fifth bytes (& 31) of its entries, all ones if one has only four
-#endif
     uint2 qa[WAVES][MS_RING * MS_QA_DW / 2];
     ms_qb_t qb[WAVES][MS_RING_B];
     uint64_t qm[WAVES][MS_RING];
@@ -170,19 +159,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
         const uint4 *gs = reinterpret_cast<const uint4 *>(ms.gtab);
         uint4 *gd = reinterpret_cast<uint4 *>(sh.gtab);
         for (uint32_t i = threadIdx.x; i < AGH_MS_GSLOTS / 4u; i += WAVES * 64) gd[i] = gs[i];
-#if AGH_MS_NBF == 2
-        uint4 *md = reinterpret_cast<uint4 *>(sh.gmask);     // (the masks lie behind the grams in ms.gtab)
-        for (uint32_t i = threadIdx.x; i < AGH_MS_GSLOTS / 4u; i += WAVES * 64) md[i] = gs[AGH_MS_GSLOTS / 4u + i];
-#endif
         __syncthreads();
     }
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const uint8_t *ptab8 = reinterpret_cast<const uint8_t *>(sh.ptab);
     const uint4 *gt4 = reinterpret_cast<const uint4 *>(sh.gtab);
-#if AGH_MS_NBF == 2
-    const uint4 *gm4 = reinterpret_cast<const uint4 *>(sh.gmask);
-#endif
     uint2 *qa = sh.qa[wib];
     ms_qb_t *qb = sh.qb[wib];
     uint64_t *qm = sh.qm[wib];
@@ -218,33 +200,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
         bool matched = false;
         uint64_t j = 0;
         if ((uint32_t)lane < take) {
-#if AGH_MS_NBF == 1
-            const uint2 e2 = qb[(hB + (uint32_t)lane) & (MS_RING_B - 1u)];
-            const uint32_t e = e2.x;
-            const uint4 d4 = reinterpret_cast<const uint4 *>(ms.mdir)[e & (AGH_MS_GSLOTS - 1u)];   // dir, MX, ML, MB
-            bool near_ok;
-            {
-                // position 1..16 inside its chunk: bytes p + 4 (p = 16), p + 5 (p >= 15) and p - 2 (p = 1) lie
-                // outside the 20 bytes level 2 had -- a term whose byte is unknown counts as passed if its mask is set
-                const uint32_t pc = ((e >> 12) - 1u) & 15u;            // p - 1 = 0..15
-                const uint32_t s0 = e2.y & 31u, s1 = (e2.y >> 8) & 31u, t1 = (e2.y >> 16) & 31u, t2 = (e2.y >> 24) & 31u;
-                uint32_t ok = (d4.w >> t1) & 1u;
-                ok |= pc >= 1u ? (d4.w >> t2) & 1u : (uint32_t)(d4.w != 0u);
-                ok |= pc <= 14u ? ((d4.y | d4.z) >> s0) & 1u : (uint32_t)((d4.y | d4.z) != 0u);
-                ok |= pc <= 13u ? (d4.z >> s1) & 1u : (uint32_t)(d4.z != 0u);
-                near_ok = ok != 0u;
-            }
-#else
             const uint32_t e = qb[(hB + (uint32_t)lane) & (MS_RING_B - 1u)];
-            const bool near_ok = true;
-#endif
             j = range_base + (e >> 12);
-            if (near_ok && j >= 8u && j + 24u <= n && !(dbg & 1u)) {
-#if AGH_MS_NBF == 1
-                const uint32_t dir = d4.x;
-#else
+            if (j >= 8u && j + 24u <= n && !(dbg & 1u)) {
                 const uint32_t dir = ms.mdir[e & (AGH_MS_GSLOTS - 1u)];
-#endif
                 u32x4_a1 t0 = {0u, 0u, 0u, 0u}, t1 = {0u, 0u, 0u, 0u};
                 if (!(dbg & 2u)) {
                     t0 = *reinterpret_cast<const u32x4_a1 *>(text8 + j - 8);
@@ -271,63 +230,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
             qnM = ms_uni(qnM + (uint32_t)__popcll(mb));
         }
     };
-
-#if AGH_MS_L3PIPE
-    // Level 3 in two halves (make VARFLAGS=-DAGH_MS_L3PIPE=1; not in the shipped build until measured): a call of
-    // level 3 is two dependent global round trips (directory + text, then the entries) during which its wave has
-    // nothing to do -- ~37 calls per wave and 4 GiB.  Here the first round trip of a batch is issued when the batch
-    // is taken from queue B and its results stay in registers (12 per lane) while the wave goes on with level 1;
-    // the batch is finished one supertile later, when they have long arrived.
-    uint32_t p_take = 0;                        // batch in flight: its size (wave-uniform), 0 = none
-    bool p_live = false;
-    uint64_t p_j = 0;
-    uint32_t p_dir = 0;
-    u32x4_a1 p_t0 = {0u, 0u, 0u, 0u}, p_t1 = {0u, 0u, 0u, 0u};
-    auto stage_b_issue = [&]() {
-        const uint32_t take = ms_uni(qnB < 64u ? qnB : 64u);
-        __builtin_amdgcn_wave_barrier();
-        p_live = false;
-        p_j = 0;
-        if ((uint32_t)lane < take) {
-            const uint32_t e = qb[(hB + (uint32_t)lane) & (MS_RING_B - 1u)];
-            p_j = range_base + (e >> 12);
-            if (p_j >= 8u && p_j + 24u <= n && !(dbg & 1u)) {
-                p_live = true;
-                p_dir = ms.mdir[e & (AGH_MS_GSLOTS - 1u)];
-                if (!(dbg & 2u)) {
-                    p_t0 = *reinterpret_cast<const u32x4_a1 *>(text8 + p_j - 8);
-                    p_t1 = *reinterpret_cast<const u32x4_a1 *>(text8 + p_j + 8);
-                }
-            }
-        }
-        hB = ms_uni((hB + take) & (MS_RING_B - 1u));
-        qnB = ms_uni(qnB - take);
-        ncand = ms_uni(ncand + take);
-        p_take = take;
-    };
-    auto stage_b_finish = [&]() {
-        bool matched = false;
-        if (p_live) {
-            uint32_t T[8] = {p_t0[0], p_t0[1], p_t0[2], p_t0[3], p_t1[0], p_t1[1], p_t1[2], p_t1[3]};
-            if (FOLD) {
-#pragma unroll
-                for (int d = 0; d < 8; ++d) T[d] = swar_lower(T[d]);
-            }
-            const uint32_t first = p_dir >> 8, cnt = p_dir & 0xffu;
-            for (uint32_t i = 0; i < cnt && !matched; ++i) {
-                const uint4 ent = ms.ment[first + i];
-                matched = K == 0 ? ms_match_k0(ent, T) : ms_match_k1(ent, T, delim);
-            }
-        }
-        p_live = false;
-        p_take = 0;
-        const uint64_t mb = __ballot(matched);
-        if (mb) {
-            if (matched) qm[(hM + qnM + rank_of(mb)) & (MS_RING - 1u)] = p_j;
-            qnM = ms_uni(qnM + (uint32_t)__popcll(mb));
-        }
-    };
-#endif
 
     // ---- one supertile = strips s .. s+3, nx3 = the first dword of strip s+4; st_rel = its number
     // inside the wave's range ------------------------------------------------------------------------
@@ -398,12 +300,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
             qnA = ms_uni(qnA - take);
             do {
                 if (qnB > MS_RING_B - 64u) {            // room for the survivors of this round
-#if AGH_MS_L3PIPE
-                    if (p_take) stage_b_finish();
-                    stage_b_issue();
-#else
                     stage_b();
-#endif
                     if (qnM >= 64u) stage_m();
                 }
                 const bool act = m != 0u;
@@ -420,33 +317,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
                 const uint4 G1 = gt4[b1], G2 = gt4[b2];
                 const int h1 = G1.x == g ? 0 : (G1.y == g ? 1 : (G1.z == g ? 2 : (G1.w == g ? 3 : -1)));
                 const int h2 = G2.x == g ? 0 : (G2.y == g ? 1 : (G2.z == g ? 2 : (G2.w == g ? 3 : -1)));
-#if AGH_MS_NBF == 2
-                // the gram is an entry's prefix: does the byte behind it (p + 4; unknown for p = 16) fit one of them?
-                const uint4 M1 = gm4[b1], M2 = gm4[b2];
-                const uint32_t mx = h1 >= 0 ? (h1 == 0 ? M1.x : (h1 == 1 ? M1.y : (h1 == 2 ? M1.z : M1.w)))
-                                            : (h2 == 0 ? M2.x : (h2 == 1 ? M2.y : (h2 == 2 ? M2.z : M2.w)));
-                const uint32_t gnx5 = p8 ? (p4 ? 0u : e[4]) : (p4 ? e[3] : e[2]);
-                const uint32_t aft5 = __builtin_amdgcn_alignbyte(gnx5, ghi, p & 3u);         // bytes p + 4 ..
-                const bool fifth_ok = p16 || ((mx >> (aft5 & 31u)) & 1u);
-                const bool found = act && (h1 >= 0 || h2 >= 0) && fifth_ok;
-#else
                 const bool found = act && (h1 >= 0 || h2 >= 0);
-#endif
                 const uint64_t fb = __ballot(found);
                 if (fb) {
                     const uint32_t slot = h1 >= 0 ? b1 * 4u + (uint32_t)h1 : b2 * 4u + (uint32_t)h2;
-#if AGH_MS_NBF == 1
-                    // bytes p + 4, p + 5 (behind the gram) and p - 1, p - 2 (in front of it); what lies outside
-                    // the chunk's 20 bytes is zero here and marked unknown by its position in level 3
-                    const uint32_t gnx = p16 ? 0u : (p8 ? (p4 ? 0u : e[4]) : (p4 ? e[3] : e[2]));
-                    const uint32_t gpv = p16 ? e[3] : (p8 ? (p4 ? e[2] : e[1]) : (p4 ? e[0] : 0u));
-                    const uint32_t aft = __builtin_amdgcn_alignbyte(gnx, ghi, p & 3u);       // bytes p + 4 ..
-                    const uint32_t bef = __builtin_amdgcn_alignbyte(glo, gpv, p & 3u);       // bytes p - 4 .. p - 1
-                    const uint32_t nbv = (aft & 0xffffu) | ((bef >> 24) << 16) | ((bef >> 16) << 24);
-                    if (found) qb[(hB + qnB + rank_of(fb)) & (MS_RING_B - 1u)] = make_uint2(((pos_rel + p) << 12) | slot, nbv);
-#else
                     if (found) qb[(hB + qnB + rank_of(fb)) & (MS_RING_B - 1u)] = ((pos_rel + p) << 12) | slot;
-#endif
                     qnB = ms_uni(qnB + (uint32_t)__popcll(fb));
                 }
             } while (__ballot(m != 0u));
@@ -462,22 +337,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
             }
             while (qnA >= 64u || (u == 3u && range_ends && qnA)) level2();
         }
-#if AGH_MS_L3PIPE
-        while (qnB >= 64u || ((range_ends || (dbg & 8u)) && qnB)) {
-            if (p_take) stage_b_finish();       // (issued a supertile ago)
-            stage_b_issue();
-            if (qnM >= 64u) stage_m();
-        }
-        if (range_ends && p_take) {             // nothing stays in flight across ranges
-            stage_b_finish();
-            if (qnM >= 64u) stage_m();
-        }
-#else
         while (qnB >= 64u || ((range_ends || (dbg & 8u)) && qnB)) {
             stage_b();
             if (qnM >= 64u) stage_m();
         }
-#endif
     };
 
     auto load_strip = [&](uint64_t st) -> uint4 { return ms_load_strip(text, n, st, fill4); };
@@ -578,10 +441,8 @@ bool agh_launch_mscan(const agh_mscan_args &a, hipStream_t st)
     const uint64_t n_strips = (a.n + AGH_STRIP - 1) >> AGH_STRIP_SHIFT;
     const uint64_t n_ranges = (n_strips + AGH_WAVE_STRIPS - 1) / AGH_WAVE_STRIPS;
     if (n_ranges > 0xffffffffull - 65536ull) return false;
-#if AGH_MS_NBF != 2                 // (with the mask table in LDS 2^13 rows do not fit: the host asks for 2^12)
     if (a.ms.rb == 13u) launch_mscan_cfg<16, 13>(a, (uint32_t)n_ranges, st);
     else
-#endif
     if (a.ms.rb == 12u) launch_mscan_cfg<16, 12>(a, (uint32_t)n_ranges, st);
     else return false;
     return true;

@@ -735,19 +735,7 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
             const char *e = getenv("AGH_MSCAN_RB");
             if (e && e[0] == '1' && e[1] == '2') rb = 12;
         }
-#if AGH_MS_NBF == 2
-        rb = 12;                                    // (16 KiB of masks next to the gram table in LDS)
-        // ms.gtab: AGH_MS_GSLOTS grams, then AGH_MS_GSLOTS masks of fifth bytes (agh_mscan.hip level 2)
-        std::vector<uint32_t> ptab((size_t)2 << rb, 0), gtab((size_t)AGH_MS_GSLOTS * 2, 0), mdir(AGH_MS_GSLOTS, 0);
-#elif AGH_MS_NBF
-        // (queue B entries are 8 bytes in this build: with 2^13 rows the workgroup would sit exactly on the 160 KiB)
-        rb = 12;
-        // per gram slot: dir, MX (fifth byte of the entries of >= 5 bytes), ML / MB (the two nearest bytes of the
-        // other side of the pattern behind / in front of a 4-byte piece); bit = byte & 31 (agh_mscan.hip stage_b)
-        std::vector<uint32_t> ptab((size_t)2 << rb, 0), gtab(AGH_MS_GSLOTS, 0), mdir((size_t)AGH_MS_GSLOTS * 4, 0);
-#else
         std::vector<uint32_t> ptab((size_t)2 << rb, 0), gtab(AGH_MS_GSLOTS, 0), mdir(AGH_MS_GSLOTS, 0);
-#endif
         std::vector<uint32_t> ment(es.size() * 4 + 4, 0);
         size_t n_grams = 0;
         for (size_t a = 0; a < es.size() && ms;) {
@@ -764,41 +752,7 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
             if (l1 >= 4 && l2 >= 4) { ms = false; break; }     // (both buckets full: the set stays on the two-kernel form)
             const uint32_t sl = l1 <= l2 ? 4 * b1 + (uint32_t)l1 : 4 * b2 + (uint32_t)l2;
             gtab[sl] = g;
-#if AGH_MS_NBF == 2
-            {
-                uint32_t mx = 0;
-                for (size_t i = a; i < b; ++i) {
-                    const ms_entry &e = es[i];
-                    if (D == 0) mx |= (e.w[3] >> 24) >= 5 ? 1u << (e.w[1] & 31u) : ~0u;
-                    else mx |= ((e.w[2] >> 27) & 3u) >= 1 ? 1u << (e.w[3] & 31u) : ~0u;     // (meta >> 3) & 3 = len - 4
-                }
-                gtab[AGH_MS_GSLOTS + sl] = mx;
-            }
             mdir[sl] = (uint32_t)a << 8 | (uint32_t)(b - a);
-#elif AGH_MS_NBF
-            {
-                uint32_t mx = 0, ml = 0, mb = 0;
-                for (size_t i = a; i < b; ++i) {
-                    const ms_entry &e = es[i];
-                    if (D == 0) {
-                        const uint32_t len = e.w[3] >> 24;
-                        mx |= len >= 5 ? 1u << (e.w[1] & 31u) : ~0u;           // 4 bytes: nothing more to ask
-                    } else {
-                        const uint32_t meta = e.w[2] >> 24, L = meta & 7u, tl = (meta >> 3) & 3u;
-                        const uint32_t near2 = L >= 2 ? (1u << (e.w[1] & 31u)) | (1u << ((e.w[1] >> 8) & 31u)) : ~0u;
-                        if (tl >= 1) mx |= 1u << (e.w[3] & 31u);
-                        else if (meta & 32u) mb |= near2;
-                        else ml |= near2;
-                    }
-                }
-                mdir[4 * sl] = (uint32_t)a << 8 | (uint32_t)(b - a);
-                mdir[4 * sl + 1] = mx;
-                mdir[4 * sl + 2] = ml;
-                mdir[4 * sl + 3] = mb;
-            }
-#else
-            mdir[sl] = (uint32_t)a << 8 | (uint32_t)(b - a);
-#endif
             a = b;
         }
         if (es.size() >= (1u << 24)) ms = false;

@@ -385,10 +385,12 @@ __global__ __launch_bounds__(256) void k_scan_fixup(uint32_t *__restrict__ wave_
         uint32_t c = i < n_chunks ? chunk_totals[AGH_SCAN_MAXCHUNKS + i] : 0u;
         const uint32_t dpre = wave_sum_to_lane63(i < blockIdx.x ? d : 0u);
         const uint32_t dall = wave_sum_to_lane63(d);
+        const uint32_t dhi = wave_sum_to_lane63(d >> 16);   // (record numbers are 32-bit: a segment with more records is refused)
         const uint32_t call = wave_sum_to_lane63(c);
         if (i == 63) {
             sh_before = dpre;
             if (blockIdx.x == 0) {
+                if (dhi >= 65000u) counters[AGH_C_BM_OVERFLOW] = 2u;
                 counters[AGH_C_NDELIM] = dall;
                 counters[AGH_C_CAND] = call;
                 // does the text end with a delimiter?  (multi-byte: a selected occurrence)

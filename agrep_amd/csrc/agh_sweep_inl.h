@@ -100,7 +100,7 @@ __device__ __forceinline__ void sweep_chunk(uint4 v, uint32_t dd, const agh_dev_
 // stored with the candidate so that the verifier can number records without re-reading text.
 // qn (queued) and cnt (already in the slice) are wave-uniform.
 // H == 2: hit bit 8u + i = the sample at byte 2i of the lane's chunk in strip s+u, and the entry
-// is a HALFWORD index (j = entry * 2; numbered segments of such queries are limited to 8 GiB).
+// is a HALFWORD index (j = entry * 2).
 template <int H, typename OnFull>
 __device__ __forceinline__ void emit_candidates_to(uint32_t hits, uint64_t s,
                                                    const uint32_t rc[4], uint64_t *cq,
@@ -122,13 +122,13 @@ __device__ __forceinline__ void emit_candidates_to(uint32_t hits, uint64_t s,
             for (int j = 0; j < lane; ++j) t &= t - 1;
             int b = __ffs((int)t) - 1;
             int u = H == 2 ? b >> 3 : b >> 2;
-            // dword index of the sample: < 2^32 inside a numbered segment (<= 16 GiB), where the
-            // upper half carries the record count; lean sweeps (r == 0) use all 64 bits, so one
-            // launch can cover any text length
+            // dword index of the sample: 40 bits inside a numbered segment (<= 16 GiB), the record count in
+            // the 24 bits above (agh_device.h); lean sweeps (r == 0) use all 64 bits, so one launch can
+            // cover any text length
             const uint64_t dw = H == 2 ? ((s + (uint64_t)u) * 64u + (uint64_t)l) * 8u + (uint64_t)(b & 7)
                                        : ((s + (uint64_t)u) * 64u + (uint64_t)l) * 4u + (uint64_t)(b & 3);
             uint32_t r = u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3));
-            cq[qn + (uint32_t)lane] = ((uint64_t)r << 32) | dw;
+            cq[qn + (uint32_t)lane] = ((uint64_t)r << AGH_CAND_IDX_BITS) | dw;
         }
         qn += (uint32_t)c;
         if (qn >= 64u) on_full();

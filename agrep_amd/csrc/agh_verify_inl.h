@@ -13,7 +13,7 @@
 __device__ __forceinline__ void mark_record(const agh_marks &mk, uint32_t r, uint64_t e)
 {
     if (r >= mk.bitmap_bits) {                  // the host retries with a larger bitmap
-        mk.counters[AGH_C_BM_OVERFLOW] = 1u;
+        atomicMax(&mk.counters[AGH_C_BM_OVERFLOW], 1u);     // (2: more than 2^32 records, k_scan_fixup)
         return;
     }
     const uint32_t bit = 1u << (r & 31u);
@@ -342,7 +342,7 @@ __device__ __forceinline__ VerifyWin verify_locate(const VerifyCtx<WT, K> &c, ui
     w.span = 0;
     w.mode = 0;
     // lean entries: 64-bit dword index (halfword index for H == 2 samples: jshift 1)
-    const uint64_t j = (LEAN ? ent : (ent & 0xffffffffull)) << c.jshift;
+    const uint64_t j = (LEAN ? ent : (ent & AGH_CAND_IDX_MASK)) << c.jshift;
     w.j = j;
     if (j >= c.n) return w;
     const uint64_t anchor = j & ~(uint64_t)15;                           // sample's chunk start
@@ -400,7 +400,7 @@ __device__ __forceinline__ void verify_walk(const VerifyCtx<WT, K> &c, uint64_t 
     constexpr int NMW = (NCH * 16 + 63) / 64;           // 64-bit words per position mask
     if (win.mode == 0u) return;
     const uint64_t j = win.j;
-    const uint32_t rc_anchor = LEAN ? 0u : wave_base + (uint32_t)(ent >> 32);  // record no. at anchor
+    const uint32_t rc_anchor = LEAN ? 0u : wave_base + (uint32_t)(ent >> AGH_CAND_IDX_BITS);  // record no. at anchor
     const uint64_t anchor = j & ~(uint64_t)15;                           // sample's chunk start
     const uint32_t span = win.span;
     if (win.mode == 2u) {

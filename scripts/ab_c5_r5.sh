@@ -2,7 +2,7 @@
 # Round 5: the same-box A/B of the experimental variants of the one-pass -f kernel (agh_mscan.hip) the round-4 review
 # asked for: shipped, AGH_MS_NBF=1, AGH_MS_NBF=2 (2^12 rows), AGH_MS_L3PIPE=1; config 5 (1024 x 8..12 B, k = 1) on
 # 4 GiB, device time of the whole count-only scan, median of 5, three interleaved rounds.  Build the variants first:
-#   make -C agrep_amd/csrc -j8 VARIANT=nbf VARFLAGS="-DAGH_MS_NBF=1"; ... nbf2 "-DAGH_MS_NBF=2"; l3pipe "-DAGH_MS_L3PIPE=1"
+# (the variants were built from the round-4 tree with VARFLAGS -DAGH_MS_NBF=1 / =2 / -DAGH_MS_L3PIPE=1; the code is gone: none was faster)
 set -u
 cd $GRAFT_REPO_ROOT
 export AGH_REQUIRE_GPU=1

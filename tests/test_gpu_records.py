@@ -148,20 +148,25 @@ def test_shim_prints_while_the_input_is_still_being_read(tmp_path):
     for args in (["-V0", "-2"], ["-V0", "-2", "-n"]):
         if "-n" in args:
             ref = subprocess.run([REF] + args + [O.PATTERN_C2.decode(), str(p)], stdout=subprocess.PIPE).stdout
-        pr = subprocess.Popen([GPU] + args + [O.PATTERN_C2.decode()], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+        # (the reference's front end wants a file argument: /dev/stdin)
+        pr = subprocess.Popen([GPU] + args + [O.PATTERN_C2.decode(), "/dev/stdin"], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, env=env)
         got = []
         early = {"bytes": 0}
         hold = (len(tb) * 2 // 3) & ~4095
 
         def feed():
-            pr.stdin.write(tb[:hold])
-            pr.stdin.flush()
-            t0 = time.time()
-            while early["bytes"] == 0 and time.time() - t0 < 60:      # wait for the first records
-                time.sleep(0.01)
-            early["seen_before_the_rest"] = early["bytes"]
-            pr.stdin.write(tb[hold:])
-            pr.stdin.close()
+            try:
+                pr.stdin.write(tb[:hold])
+                pr.stdin.flush()
+                t0 = time.time()
+                while early["bytes"] == 0 and time.time() - t0 < 60:      # wait for the first records
+                    time.sleep(0.01)
+                early["seen_before_the_rest"] = early["bytes"]
+                pr.stdin.write(tb[hold:])
+                pr.stdin.close()
+            except BrokenPipeError:
+                pass
         th = threading.Thread(target=feed)
         th.start()
         while True:
