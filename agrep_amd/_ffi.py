@@ -386,13 +386,40 @@ def shard_cuts_fd(fd, nranks, delim=b"\n"):
     return list(cuts)
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+
+
 class Comm:
     """RCCL communicator of the C-ABI (one process per GPU): agh_comm_init_rank."""
 
-    def __init__(self, unique_id, nranks, rank):
-        self._h = lib().agh_comm_init_rank(bytes(unique_id), nranks, rank)
+    def __init__(self, unique_id, nranks, rank, _handle=None, _keep=None):
+        self._keep = _keep
+        self._h = _handle if _handle is not None else lib().agh_comm_init_rank(bytes(unique_id), nranks, rank)
         if not self._h:
             raise AghError(lib().agh_last_error().decode("latin1"))
+
+    @classmethod
+    def custom(cls, allreduce, nranks, rank):
+        """agh_comm_init_custom: allreduce(values: list[int], elem_bytes) -> list[int] over the caller's transport"""
+        def cb(ctx, buf, count, elem):
+            try:
+                arr = (C.c_uint64 * count).from_address(buf) if elem == 8 else (C.c_uint8 * count).from_address(buf)
+                out = allreduce([int(x) for x in arr], elem)
+                for i, v in enumerate(out):
+                    arr[i] = int(v)
+                return 0
+            except Exception:                               # a Python exception must not cross the C frames
+                return 1
+        fn = ALLREDUCE_FN(cb)
+        L = lib()
+        L.agh_comm_init_custom.argtypes = [ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]
+        L.agh_comm_init_custom.restype = C.c_void_p
+        return cls(None, nranks, rank, _handle=L.agh_comm_init_custom(fn, None, nranks, rank), _keep=fn)
+
+    def info(self):
+        r, n, d = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().agh_comm_info(self._h, C.byref(r), C.byref(n), C.byref(d)))
+        return {"rank": r.value, "nranks": n.value, "device": d.value}
 
     @staticmethod
     def unique_id():

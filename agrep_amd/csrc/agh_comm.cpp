@@ -128,6 +128,8 @@ struct stdout_silencer {
     } while (0)
 
 struct agh_comm {
+    agh_allreduce_fn custom = nullptr;      // agh_comm_init_custom: the caller's own transport instead of RCCL
+    void *custom_ctx = nullptr;
     ncclComm_t comm = nullptr;
     int device = 0, rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
@@ -193,6 +195,29 @@ extern "C" agh_comm *agh_comm_init_rank(const unsigned char id[AGH_UNIQUE_ID_BYT
     return c;
 }
 
+// A communicator over the caller's own transport (MPI, gloo, a socket): every reduction of this file calls
+// fn(ctx, buf, count, elem_bytes) on HOST memory -- elem_bytes 8: sum of uint64, 1: max of bytes -- and expects the
+// reduced values back in buf.  For hosts without RCCL between the ranks (several nodes over Ethernet) and for
+// running the N > 1 step of a scan with two ranks on one GPU (tests/test_gpu_records.py).
+extern "C" agh_comm *agh_comm_init_custom(agh_allreduce_fn fn, void *ctx, int nranks, int rank)
+{
+    if (!fn || nranks < 1 || rank < 0 || rank >= nranks) {
+        cfail("agh_comm_init_custom: bad arguments (nranks=%d, rank=%d)", nranks, rank);
+        return nullptr;
+    }
+    agh_comm *c = new agh_comm();
+    if (hipGetDevice(&c->device) != hipSuccess) {
+        cfail("no usable HIP device");
+        delete c;
+        return nullptr;
+    }
+    c->custom = fn;
+    c->custom_ctx = ctx;
+    c->rank = rank;
+    c->nranks = nranks;
+    return c;
+}
+
 extern "C" int agh_comm_init_all(agh_comm **comms, int ndev, const int *devices)
 {
     if (!comms || ndev < 1 || ndev > 64) return cfail("agh_comm_init_all: bad arguments");
@@ -241,6 +266,12 @@ extern "C" int agh_comm_info(const agh_comm *c, int *rank, int *nranks, int *dev
 static int all_reduce_many(agh_comm *const *cs, int n, void *const *host, size_t count,
                            ncclDataType_t dt, ncclRedOp_t op, size_t elem)
 {
+    if (n >= 1 && cs[0] && cs[0]->custom) {     // the caller's transport: one communicator per process
+        if (n != 1 || !host[0]) return cfail("a custom communicator reduces one rank per process");
+        if (cs[0]->custom(cs[0]->custom_ctx, host[0], count, (int)elem)) return cfail("the caller's all-reduce failed");
+        return 0;
+    }
+    if (need_rccl()) return -1;
     for (int i = 0; i < n; ++i) {
         if (!cs[i] || !host[i]) return cfail("null argument");
         if (comm_setup(cs[i], count * elem)) return -1;
@@ -279,6 +310,16 @@ extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_dev(agh_
                                                                             hipStream_t st)
 {
     if (!c || !d_buf) return cfail("null argument");
+    if (c->custom) {                            // host transport: the values come down, are reduced, go back up
+        uint64_t h[8];
+        if (count > 8) return cfail("internal error: %zu values in a device all-reduce", count);
+        HIPC_TRY(hipMemcpyAsync(h, d_buf, count * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPC_TRY(hipStreamSynchronize(st));
+        if (c->custom(c->custom_ctx, h, count, 8)) return cfail("the caller's all-reduce failed");
+        HIPC_TRY(hipMemcpyAsync(d_buf, h, count * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIPC_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
     if (need_rccl()) return -1;
     // RCCL runs on the communicator's own non-blocking stream, never on the caller's (which may be the legacy
     // default stream, with its implicit synchronisation against every blocking stream): the caller's stream
@@ -300,7 +341,6 @@ extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_dev(agh_
 extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_host(agh_comm *c, uint64_t *v, size_t count)
 {
     if (!c || !v) return cfail("null argument");
-    if (need_rccl()) return -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     void *h = v;
@@ -312,7 +352,6 @@ extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_host(agh
 extern "C" int agh_reduce_counts(agh_comm *c, uint64_t counts[2])
 {
     if (!c || !counts) return cfail("null argument");
-    if (need_rccl()) return -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     void *h = counts;
@@ -324,7 +363,6 @@ extern "C" int agh_reduce_counts(agh_comm *c, uint64_t counts[2])
 extern "C" int agh_reduce_counts_all(agh_comm *const *comms, int n, uint64_t (*counts)[2])
 {
     if (!comms || !counts || n < 1 || n > 64) return cfail("bad arguments");
-    if (need_rccl()) return -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     void *h[64];
@@ -338,7 +376,6 @@ extern "C" int agh_reduce_file_hits(agh_comm *c, unsigned char *hits, size_t n_f
 {
     if (!c || (!hits && n_files)) return cfail("null argument");
     if (!n_files) return 0;
-    if (need_rccl()) return -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     void *h = hits;
@@ -352,7 +389,6 @@ extern "C" int agh_reduce_file_hits_all(agh_comm *const *comms, int n, unsigned 
 {
     if (!comms || !hits || n < 1 || n > 64) return cfail("bad arguments");
     if (!n_files) return 0;
-    if (need_rccl()) return -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     void *h[64];

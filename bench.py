@@ -538,21 +538,28 @@ def main():
             launches += res.sweep_launches
         fence()
         elapsed = time.perf_counter() - t0
+        per_rank = None
         if dist_on:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+            # every rank's own numbers travel to rank 0: its time, its sweep launches, and what the C-ABI's RCCL
+            # communicator says about itself (agh_comm_info: a SCALE record can show that RCCL saw N ranks)
+            ci = comm.info() if comm is not None else {"rank": rank, "nranks": 0, "device": local_rank}
+            mine = torch.tensor([elapsed, sweep_ms, launches, n, ci["nranks"], ci["rank"], ci["device"], res.n_matched],
+                                dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [[float(x) for x in t.tolist()] for t in allr]
+            elapsed = max(r[0] for r in per_rank)
             matched_all = int(agg[0])
         else:
             matched_all = int(res.n_matched)
-        return elapsed, res, sweep_ms, launches, matched_all
+        return elapsed, res, sweep_ms, launches, matched_all, per_rank
 
     q = A.Query(PATTERN, args.k)
     info = q.info()
-    elapsed, res, sweep_ms, launches, matched_all = timed_loop(q)
+    elapsed, res, sweep_ms, launches, matched_all, per_rank = timed_loop(q)
     q0 = A.Query(PATTERN, 0)
     info0 = q0.info()
-    elapsed0, res0, sweep_ms0, launches0, matched0 = timed_loop(q0)
+    elapsed0, res0, sweep_ms0, launches0, matched0, per_rank0 = timed_loop(q0)
 
     # planted records of the whole job (all ranks), by number of edits
     pl = torch.tensor([int(x) for x in planted], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
@@ -610,6 +617,25 @@ def main():
                          "avg_launch_ms": round(sweep_avg_ms, 4), "launches_timed": int(launches),
                          "whole_scan_frac": round(value / world / HBM_PEAK_GBPS, 4)},
         }
+        if per_rank is not None:
+            def rank_rows(rows):
+                out_rows = []
+                for r_ in rows:
+                    el, sw, la, nb, cn, cr, cd, mt = r_
+                    avg = sw / max(la, 1)
+                    out_rows.append({"rank": int(cr), "device": int(cd), "rccl_ranks": int(cn), "bytes": int(nb),
+                                     "ms_per_step": round(el / args.steps * 1e3, 4), "matched_records": int(mt),
+                                     "roofline": {"bound": "hbm", "achieved": round(nb * args.steps / max(la, 1) / 1e6 / max(avg, 1e-9), 1),
+                                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                  "frac": round(nb * args.steps / max(la, 1) / 1e6 / max(avg, 1e-9) / HBM_PEAK_GBPS, 4),
+                                                  "avg_launch_ms": round(avg, 4), "launches_timed": int(la)}})
+                return out_rows
+            out["ranks"] = rank_rows(per_rank)
+            out["rank_ms_per_step_max"] = max(r_["ms_per_step"] for r_ in out["ranks"])
+            out["rank_ms_per_step_min"] = min(r_["ms_per_step"] for r_ in out["ranks"])
+            out["rccl_ranks"] = int(per_rank[0][4])
+            out["k0"]["ranks"] = [{"rank": r_["rank"], "ms_per_step": r_["ms_per_step"], "frac": r_["roofline"]["frac"]}
+                                  for r_ in rank_rows(per_rank0)]
         A.probe_read_ms(text.data_ptr(), min(n, 8 << 30))
         rn = min(n, 8 << 30)
         out["read_ceiling_gbps"] = round(rn / 1e6 / min(A.probe_read_ms(text.data_ptr(), rn) for _ in range(3)), 1)

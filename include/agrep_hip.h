@@ -268,6 +268,12 @@ typedef struct agh_comm agh_comm;
 int agh_comm_unique_id(unsigned char id[AGH_UNIQUE_ID_BYTES]);
 agh_comm *agh_comm_init_rank(const unsigned char id[AGH_UNIQUE_ID_BYTES], int nranks, int rank);
 int agh_comm_init_all(agh_comm **comms, int ndev, const int *devices /* NULL: 0..ndev-1 */);
+/* ... or over the caller's own transport (MPI, gloo, a socket -- ranks that RCCL does not connect): every reduction
+ * calls fn(ctx, buf, count, elem_bytes) on host memory (elem_bytes 8: sum of uint64 values; 1: maximum of bytes) and
+ * expects the reduced values in buf; non-zero = failure.  agh_scan_device_reduce then brings its counts to the host
+ * for the exchange (one more synchronisation per step than over RCCL). */
+typedef int (*agh_allreduce_fn)(void *ctx, void *buf, size_t count, int elem_bytes);
+agh_comm *agh_comm_init_custom(agh_allreduce_fn fn, void *ctx, int nranks, int rank);
 int agh_comm_info(const agh_comm *c, int *rank, int *nranks, int *device);
 void agh_comm_free(agh_comm *c);
 

@@ -44,6 +44,10 @@ def test_bench_single_and_two_ranks():
         # the reference over EVERY shard of the corpus (here 4 x 128 MiB), count by count
         assert cb["all_shards_count_equals_gpu"] is True, cb.get("all_shards")
         assert cb["all_shards"]["shards"] == 4 and cb["all_shards"]["gpu_count"] == a["matched_records"]
+        # ... and the match SET: sha256 of the reference's printed lines == sha256 of the records the GPU returns
+        assert cb["all_shards_records_sha256_equal"] is True, cb.get("all_shards")
+        assert cb["all_shards"]["records_sha256_shards_equal"] == 4
+    assert a["c2_records"]["matched_equals_planted"] is True
 
     env.update(AGH_BENCH_BACKEND="gloo", AGH_BENCH_ONE_GPU="1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
@@ -57,6 +61,10 @@ def test_bench_single_and_two_ranks():
     assert b["matched_records"] == a["matched_records"] and b["matched_equals_planted"] is True
     assert b["config"]["bytes_per_gpu"] * 2 == a["config"]["bytes_per_gpu"]
     assert b["config"]["total_bytes"] == a["config"]["total_bytes"] and b["scaling"] == "strong"
+    # every rank's own step time and kernel rate, max / min over the ranks
+    assert [r["rank"] for r in b["ranks"]] == [0, 1] and all(r["bytes"] == b["config"]["bytes_per_gpu"] for r in b["ranks"])
+    assert b["rank_ms_per_step_min"] <= b["rank_ms_per_step_max"] and abs(b["rank_ms_per_step_max"] - b["ms_per_step"]) < 1e-3
+    assert all(0 < r["roofline"]["frac"] < 1 for r in b["ranks"]) and len(b["k0"]["ranks"]) == 2
 
 
 def test_bench_launches_its_own_ranks():
@@ -87,6 +95,7 @@ def test_bench_rccl_code_path_with_one_rank():
     a = _last_json(r.stdout)
     assert a["config"]["count_reduction"].startswith("agh_scan_device_reduce")
     assert a["matched_equals_planted"] is True and a["n_gpus"] == 1
+    assert a["rccl_ranks"] == 1 and a["ranks"][0]["rccl_ranks"] == 1      # what agh_comm_info says about the communicator
 
 
 def test_scan_device_reduce_one_rank():

@@ -42,10 +42,13 @@ def _oracle_union(pats, k, host, threads=32):
 
 
 def _log(rec):
-    d = os.path.join(ROOT, "gpurun_out")
+    """the full-size numbers as JSON lines -- only where AGH_FULLSIZE_LOG names a file (evidence runs): a test run
+    leaves nothing behind in the tree"""
+    path = os.environ.get("AGH_FULLSIZE_LOG")
+    if not path:
+        return
     try:
-        os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "fullsize.jsonl"), "a") as f:
+        with open(path, "a") as f:
             f.write(json.dumps(rec) + "\n")
     except OSError:
         pass
@@ -159,8 +162,8 @@ def test_c3_long_pattern_nocase_16gib():
           "count_only_GBps": round(n / 1e9 / sorted(xs)[1], 1), "fullscan_2gib_matched": int(r_full.n_matched),
           "filter_2gib_matched": int(r_filt.n_matched), "oracle_slice_matched": int(want)})
     # count-only scans carry 64-bit candidate indices (one launch for <= 64 GiB); scans with record
-    # numbers are cut into <= 8 GiB segments at record boundaries
-    assert info["filter_h"] > 0 and rl.engine == A.ENGINE_FILTER and rl.n_segments == 1 and rn.n_segments == 2
+    # numbers take up to 16 GiB in one kernel sequence (40-bit indices), longer texts are cut at record ends
+    assert info["filter_h"] > 0 and rl.engine == A.ENGINE_FILTER and rl.n_segments == 1 and rn.n_segments == 1
     assert rl.n_matched == rn.n_matched == want_all
     assert r_full.engine == A.ENGINE_FULLSCAN and r_full.n_matched == r_filt.n_matched > 0
     assert got == want
