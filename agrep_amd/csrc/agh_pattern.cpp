@@ -293,16 +293,16 @@ extern "C" agh_query *agh_query_pattern(const unsigned char *pat, int len, int D
 {
     agh_pattern_tables t;
     if (agh_compile_pattern(pat, len, qflags, delim, dlen, &t)) return nullptr;
-    // A plain literal goes to the literal builder (sample filter).  With a -w / -x guard only where the reference
-    // itself takes its simple-pattern engines -- no errors and nothing checksg() calls non-simple ('\\', '-':
-    // checksg.c:42-139): bm()'s word test is !isalnum() over all 256 bytes (sgrep.c:750-756), what
-    // agh_query_literal_ex implements.  With errors, an escape or a '-' the reference goes through maskgen(),
-    // whose word-boundary class is 1..47, 58..64, 91..96, 123..127 (maskgen.c:176-187: 0x00 and 0x80..0xFF are
-    // NOT boundaries) -- those queries take the compiled tables, which are maskgen's bit for bit.
-    bool sgrep_simple = true;
-    for (int i = 0; i < len; ++i) sgrep_simple = sgrep_simple && pat[i] != '\\' && pat[i] != '-';
+    // A plain literal goes to the literal builder (sample filter).  With a -w / -x guard only without errors: there
+    // the reference takes its simple-pattern engines (also for patterns with \\c or '-': probed, `agrep -w w-l`
+    // matches "\xc3\xa9w-l"), whose word test is !isalnum() over all 256 bytes (bm(), sgrep.c:750-756) -- what
+    // agh_query_literal_ex implements.  With errors the reference goes through maskgen() (checksg.c:133-134), whose
+    // word-boundary class is 1..47, 58..64, 91..96, 123..127 (maskgen.c:176-187: 0x00 and 0x80..0xFF are NOT
+    // boundaries, "\xc3\xa9car" is no word "car"): those queries take the compiled tables, which are maskgen's bit
+    // for bit.  (-n sends the reference through maskgen() at k = 0 as well; a caller that wants that reading of -w
+    // next to bytes >= 0x80 passes the tables of agh_compile_pattern to agh_query_from_maskgen itself.)
     const bool guarded = (qflags & (AGH_Q_WORD | AGH_Q_WHOLELINE)) != 0;
-    if (t.simple && (!guarded || (D == 0 && sgrep_simple))) {
+    if (t.simple && (!guarded || D == 0)) {
         std::vector<unsigned char> lit;
         for (int i = 0; i < len; ++i) {
             if (pat[i] == '\\' && i + 1 < len) ++i;
