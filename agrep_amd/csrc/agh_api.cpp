@@ -729,6 +729,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     const int nseg = (int)cuts.size() - 1;
     const bool early = (flags & AGH_FILENAMEONLY) != 0;
     const bool timing = (flags & AGH_TIME_SWEEP) != 0;
+    agh_timeline("lean_run: start");
     // part size: a multiple of 8 wave ranges (2 MiB) so verify workgroups never straddle parts
     const uint64_t part_unit = (uint64_t)AGH_WAVE_STRIPS * AGH_STRIP * 8u;
     uint64_t part_bytes = q->tune.part_mb << 20;
@@ -777,6 +778,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     size_t n_dep = 0, n_time = 0;
     if (overlap && get_events(q->dep_events, 4, hipEventDisableTiming)) return -1;
 
+    agh_timeline("lean_run: buffers ready");
     agh_dev_query dq;
     dq.m = q->m;
     dq.k = q->k;
@@ -952,8 +954,10 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
         HIP_TRY(hipMemcpyAsync(q->h_acc, q->d_acc, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         q->reduce_done = true;
     }
+    agh_timeline("lean_run: everything queued");
     HIP_TRY(hipStreamSynchronize(st));
     if (overlap) HIP_TRY(hipStreamSynchronize(aux));
+    agh_timeline("lean_run: synchronised");
     q->hashset_dirty = false;
 
     res->n_bytes = scanned;
@@ -1002,7 +1006,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
 // ---------------------------------------------------------------------------------------
 static bool mscan_applies(const agh_query *q, unsigned flags, bool want_list)
 {
-    return q->multi && q->ms_ok && !want_list && (flags & (AGH_COUNT | AGH_FILENAMEONLY)) &&
+    return q->multi && (q->ms_ok || q->mw_ok) && !want_list && (flags & (AGH_COUNT | AGH_FILENAMEONLY)) &&
            !(flags & (AGH_INVERT | AGH_FORCE_FULLSCAN | AGH_FORCE_NUMBERED));
 }
 
@@ -1013,8 +1017,13 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
     const bool timing = (flags & (AGH_TIME_SWEEP | AGH_TIME_SCAN)) != 0;
     uint64_t max_n = 0;
     for (int i = 0; i < nseg; ++i) max_n = std::max(max_n, cuts[i + 1] - cuts[i]);
+    // the record walk over a dense set (agh_mwalk.hip) counts the records inside a lane's kilobyte in registers; the
+    // set only takes the records that cross a kilobyte boundary -- but on such sets most of those match: one slot
+    // per 256 bytes of text (load <= 1/4)
+    const bool walk = !q->ms_ok;
     uint64_t slots = 1u << 17;
-    if (!q->hashset_slots_hint) while (slots < (max_n >> 13) && slots < (1u << 26)) slots <<= 1;
+    if (walk) while (slots < (max_n >> 8) && slots < (1u << 28)) slots <<= 1;
+    else if (!q->hashset_slots_hint) while (slots < (max_n >> 13) && slots < (1u << 26)) slots <<= 1;
     while (slots < q->hashset_slots_hint) slots <<= 1;
     {
         const size_t cap_before = q->hashset.cap;
@@ -1066,7 +1075,20 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
         a.n_cu = device_cus();
         a.dbg = q->ms_dbg;
         if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i], st));
-        if (!agh_launch_mscan(a, st)) return fail("internal error: no one-pass kernel for this pattern set");
+        if (walk) {
+            agh_mwalk_args w;
+            w.text = a.text;
+            w.n = a.n;
+            w.q = dq;
+            w.mw.ent = (const uint4 *)q->d_mw_ent;
+            w.mw.dir = (const uint32_t *)q->d_mw_dir;
+            w.mw.n_ent = q->mw_nent;
+            w.mt = a.mt;
+            w.mk = a.mk;
+            w.ticket = a.ticket;
+            w.n_cu = a.n_cu;
+            if (!agh_launch_mwalk(w, st)) return fail("internal error: no record walk for this pattern set");
+        } else if (!agh_launch_mscan(a, st)) return fail("internal error: no one-pass kernel for this pattern set");
         if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i + 1], st));
         agh_launch_resolve_giveups(a.text, dq.delim, a.mk, st);
         agh_launch_hashset_count((uint64_t *)q->hashset.p, (uint32_t)(q->hashset.cap / 8), nullptr, 0u, d_cnt, st);
@@ -1112,7 +1134,7 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
         res->lean_reruns += 1;
     }
     res->n_segments = (uint32_t)nseg;
-    q->hashset_slots_hint = 4ull * max_matched;
+    if (!walk) q->hashset_slots_hint = 4ull * max_matched;
     return 0;
 }
 

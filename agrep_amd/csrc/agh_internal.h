@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -24,6 +25,10 @@
 // errors: -1 / NULL + errno = AGH_ERRNO, the text kept per thread (agh_last_error)
 __attribute__((visibility("hidden"))) int agh_fail(const char *fmt, ...);
 #define fail agh_fail
+
+// AGH_TIMELINE=1: time stamps of a call's milestones on stderr (milliseconds since the first stamp of the process;
+// diagnostics of start-up cost, scripts/startup_r5.sh).  One getenv per process, nothing else when it is off.
+__attribute__((visibility("hidden"))) void agh_timeline(const char *what);
 
 #define HIP_TRY(expr)                                                                     \
     do {                                                                                  \
@@ -143,6 +148,10 @@ struct agh_query {
     bool ms_ok = false;
     uint32_t ms_rb = 0, ms_dbg = 0;
     void *d_ms_ptab = nullptr, *d_ms_gtab = nullptr, *d_ms_mdir = nullptr, *d_ms_ment = nullptr;
+    // record walk over dense -f sets with one error (agh_mwalk.hip)
+    bool mw_ok = false;
+    uint32_t mw_nent = 0;
+    void *d_mw_ent = nullptr, *d_mw_dir = nullptr;
 };
 
 // delimiter ends come from the delimiter bitmap: several bytes, or one letter under -i

@@ -217,3 +217,23 @@ struct agh_mscan_args {
     uint32_t dbg;            // AGH_MSCAN_DBG: measurement switches of the kernel (0 in production)
 };
 bool agh_launch_mscan(const agh_mscan_args &a, hipStream_t st);
+
+// record walk over dense -f sets with one error (agh_mwalk.hip): pieces of 2..7 bytes, the other side of the pattern
+// (<= 7 bytes) beside them
+struct agh_mwalk_dev {
+    const uint4 *ent;        // x: piece bytes 0..3; y: bytes 4..6 | piece length << 24; z: side bytes 0..3 (nearest first);
+                             // w: side bytes 4..6 | (side length | 8 if the side lies in front of the piece) << 24
+    const uint32_t *dir;     // AGH_MW_DIR slots by agh_mw_slot(first two piece bytes): (first entry << 16) | entries
+    uint32_t n_ent;
+};
+struct agh_mwalk_args {
+    const void *text;
+    uint64_t n;
+    agh_dev_query q;
+    agh_mwalk_dev mw;
+    agh_multi_dev mt;        // the general tables: positions next to the ends of the text
+    agh_marks mk;            // hash set + counters
+    uint32_t *ticket;
+    uint32_t n_cu;
+};
+bool agh_launch_mwalk(const agh_mwalk_args &a, hipStream_t st);

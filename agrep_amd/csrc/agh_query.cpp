@@ -28,10 +28,28 @@ extern "C" __attribute__((visibility("hidden"))) void agh_set_error(const char *
 }
 extern "C" const char *agh_version(void) { return "agrep-hip 0.1 (gfx950)"; }
 
+void agh_timeline(const char *what)
+{
+    static int on = -1;
+    static double t0 = 0;
+    if (on < 0) {
+        const char *e = getenv("AGH_TIMELINE");
+        on = (e && e[0] == '1') ? 1 : 0;
+    }
+    if (!on) return;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    if (t0 == 0) t0 = t;
+    fprintf(stderr, "[agh %8.2f ms] %s\n", t - t0, what);
+}
+
 extern "C" int agh_device_count(void)
 {
     int n = 0;
+    agh_timeline("hipGetDeviceCount ...");
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    agh_timeline("... runtime is up");
     return n;
 }
 
@@ -207,6 +225,7 @@ static void choose_filter(agh_query *q)
 
 static int upload_common(agh_query *q)
 {
+    agh_timeline("query: device buffers, pinned counters, events ...");
     HIP_TRY(hipMalloc((void **)&q->d_counters, (AGH_LEAN_SLOTS + 1) * AGH_C_COUNT * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&q->d_chunk_totals, 128 * sizeof(uint32_t)));
     HIP_TRY(hipHostMalloc((void **)&q->h_counters, (AGH_MAX_SEGS + 1) * AGH_C_COUNT * sizeof(uint32_t)));
@@ -215,6 +234,7 @@ static int upload_common(agh_query *q)
     HIP_TRY(hipEventCreate(&q->ev1));
     HIP_TRY(hipEventCreate(&q->ev2));
     HIP_TRY(hipEventCreate(&q->ev3));
+    agh_timeline("... query: common resources done");
     return 0;
 }
 
@@ -767,6 +787,55 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
             q->ms_dbg = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u;
         }
     }
+    // ---- tables of the record walk (agh_mwalk.hip): one error, patterns of 4..14 bytes some of which are too short
+    // for the one-pass kernel's 4-byte grams (pieces of 2..3 bytes: every position is a candidate) ---------------
+    q->mw_ok = false;
+    bool mw = D == 1 && q->multi && q->dlen == 1 && !q->delim_fold && !q->guard && !q->ms_ok && minlen >= 2;
+    {
+        const char *e = getenv("AGH_MWALK");
+        if (e && e[0] == '0') mw = false;
+    }
+    for (int p = 0; p < npat && mw; ++p) mw = lens[p] >= 4 && lens[p] <= 14;
+    if (mw) {
+        struct mw_entry { uint32_t slot; uint32_t w[4]; };
+        std::vector<mw_entry> es;
+        for (int i = 0; i < npc; ++i) {
+            if (!usable[i]) continue;
+            const int m = lens[pcs[i].owner], po = pcs[i].po, len = pcs[i].len;
+            const bool before = po > 0;
+            const int L = before ? po : m - len;
+            if (len > 7 || L > 7 || L < 1) { mw = false; break; }
+            auto pb = [&](int t) -> uint32_t { return t < len ? pool[off[i] + t] : 0u; };
+            uint8_t B[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < L; ++t) {           // the other side, nearest byte first, in the case the pool has
+                unsigned char c = before ? pats[pcs[i].owner][po - 1 - t] : pats[pcs[i].owner][len + t];
+                if (nocase && is_upper(c)) c += 32;
+                B[t] = c;
+            }
+            mw_entry e;
+            e.w[0] = pb(0) | pb(1) << 8 | pb(2) << 16 | pb(3) << 24;
+            e.w[1] = pb(4) | pb(5) << 8 | pb(6) << 16 | (uint32_t)len << 24;
+            e.w[2] = B[0] | B[1] << 8 | B[2] << 16 | (uint32_t)B[3] << 24;
+            e.w[3] = B[4] | B[5] << 8 | B[6] << 16 | ((uint32_t)L | (before ? 8u : 0u)) << 24;
+            e.slot = agh_mw_slot(e.w[0] & 0xffffu);
+            es.push_back(e);
+        }
+        if (es.empty() || es.size() > AGH_MW_MAX_ENT) mw = false;
+        if (mw) {
+            std::stable_sort(es.begin(), es.end(), [](const mw_entry &a, const mw_entry &b) { return a.slot < b.slot; });
+            std::vector<uint32_t> dir(AGH_MW_DIR, 0), ent(es.size() * 4);
+            for (size_t a = 0; a < es.size();) {
+                size_t b = a;
+                while (b < es.size() && es[b].slot == es[a].slot) ++b;
+                dir[es[a].slot] = (uint32_t)a << 16 | (uint32_t)(b - a);
+                a = b;
+            }
+            for (size_t i = 0; i < es.size(); ++i) memcpy(&ent[4 * i], es[i].w, 16);
+            if (up(&q->d_mw_ent, ent.data(), ent.size() * 4) || up(&q->d_mw_dir, dir.data(), dir.size() * 4)) return -1;
+            q->mw_nent = (uint32_t)es.size();
+            q->mw_ok = true;
+        }
+    }
     return 0;
 }
 
@@ -883,6 +952,8 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_mp_items) (void)hipFree(q->d_mp_items);
     if (q->d_mp_pool) (void)hipFree(q->d_mp_pool);
     if (q->d_mp_omask) (void)hipFree(q->d_mp_omask);
+    if (q->d_mw_ent) (void)hipFree(q->d_mw_ent);
+    if (q->d_mw_dir) (void)hipFree(q->d_mw_dir);
     if (q->d_ms_ptab) (void)hipFree(q->d_ms_ptab);
     if (q->d_ms_gtab) (void)hipFree(q->d_ms_gtab);
     if (q->d_ms_mdir) (void)hipFree(q->d_ms_mdir);

@@ -100,7 +100,80 @@ extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t l
 static const size_t AGH_STAGE_CHUNK = (size_t)32 << 20;
 static const size_t AGH_SEG_PFX = 64;       // bytes in front of the text of a device segment of the stream (pipe_scan)
 
+// Reader threads that live as long as their fd_reader: a chunk of the ring is 32 MiB, read in ~1 ms -- sixteen
+// std::thread creations and joins per chunk were a third of that (4 GiB: 33 ms per GiB, 30 GB/s).
+struct read_pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    uint64_t gen = 0;
+    unsigned pending = 0;
+    bool quit = false;
+    // the job: thread t reads [lo(t), hi(t)) of `take` bytes at file offset pos into dst
+    int fd = -1;
+    unsigned char *dst = nullptr;
+    off_t pos = 0;
+    size_t take = 0, piece = 0;
+    std::vector<ssize_t> done;
+    std::vector<int> err;
+
+    void work(unsigned t)
+    {
+        const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
+        size_t at = lo;
+        while (at < hi) {
+            ssize_t r = pread(fd, dst + at, hi - at, pos + (off_t)at);
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0) { err[t] = errno; break; }       // EIO, ESTALE ...: not a truncation
+            if (r == 0) break;                          // the file got shorter meanwhile
+            at += (size_t)r;
+        }
+        done[t] = (ssize_t)(at - lo);
+    }
+    void run(unsigned t)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return gen != seen || quit; });
+                if (quit) return;
+                seen = gen;
+            }
+            work(t);
+            std::unique_lock<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_one();
+        }
+    }
+    void start(unsigned n)
+    {
+        done.assign(n, 0);
+        err.assign(n, 0);
+        for (unsigned t = 0; t < n; ++t) th.emplace_back([this, t] { run(t); });
+    }
+    void dispatch()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        std::fill(done.begin(), done.end(), 0);
+        std::fill(err.begin(), err.end(), 0);
+        pending = (unsigned)th.size();
+        ++gen;
+        cv_job.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~read_pool()
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            quit = true;
+            cv_job.notify_all();
+        }
+        for (auto &x : th) x.join();
+    }
+};
+
 struct fd_reader {
+    std::unique_ptr<read_pool> pool;
     int fd = -1;
     bool regular = false;
     off_t pos = 0;                  // regular files: next byte to read
@@ -138,32 +211,23 @@ struct fd_reader {
         if (regular && left >= want / 2 && n_readers > 1) {
             const size_t take = (size_t)std::min<uint64_t>(want, left);
             const size_t piece = ((take + n_readers - 1) / n_readers + 4095) & ~(size_t)4095;
-            std::vector<std::thread> th;
-            std::vector<ssize_t> done(n_readers, 0);
-            std::vector<int> rd_errno(n_readers, 0);
+            if (!pool) {
+                pool.reset(new read_pool());
+                pool->start(n_readers);
+            }
+            pool->fd = fd;
+            pool->dst = dst;
+            pool->pos = pos;
+            pool->take = take;
+            pool->piece = piece;
+            pool->dispatch();
+            for (unsigned t = 0; t < n_readers; ++t)
+                if (pool->err[t]) return fail("read failed: %s", strerror(pool->err[t]));
+            // contiguous prefix that really arrived (a file truncated meanwhile ends the scan)
             for (unsigned t = 0; t < n_readers; ++t) {
                 const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
-                if (lo >= hi) break;
-                th.emplace_back([&, t, lo, hi]() {
-                    size_t at = lo;
-                    while (at < hi) {
-                        ssize_t r = pread(fd, dst + at, hi - at, pos + (off_t)at);
-                        if (r < 0 && errno == EINTR) continue;
-                        if (r < 0) { rd_errno[t] = errno; break; }   // EIO, ESTALE ...: not a truncation
-                        if (r == 0) break;                           // the file got shorter meanwhile
-                        at += (size_t)r;
-                    }
-                    done[t] = (ssize_t)(at - lo);
-                });
-            }
-            for (auto &x : th) x.join();
-            for (unsigned t = 0; t < th.size(); ++t)
-                if (rd_errno[t]) return fail("read failed: %s", strerror(rd_errno[t]));
-            // contiguous prefix that really arrived (a file truncated meanwhile ends the scan)
-            for (unsigned t = 0; t < th.size(); ++t) {
-                const size_t lo = std::min(take, (size_t)t * piece), hi = std::min(take, lo + piece);
-                got += (size_t)done[t];
-                if ((size_t)done[t] < hi - lo) break;
+                got += (size_t)pool->done[t];
+                if ((size_t)pool->done[t] < hi - lo) break;
             }
             pos += (off_t)got;
             left -= std::min<uint64_t>(left, got);
@@ -191,12 +255,15 @@ struct fd_reader {
     }
 };
 
-static int ensure_stage_resources(agh_query *q)
+// The copy stream (H2D of chunk i under the read of chunk i + 1) and the ring's events.  An input that fits one
+// chunk has nothing to overlap: its copy goes to the default stream, and the 9 ms a stream costs to create (an HSA
+// queue; profiles/r05_startup.log) are not spent on a 1 MiB file.
+static int ensure_stage_resources(agh_query *q, bool need_stream)
 {
-    if (q->stage_stream) return 0;
-    HIP_TRY(hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking));
-    for (int b = 0; b < AGH_PIN_RING; ++b)
-        HIP_TRY(hipEventCreateWithFlags(&q->pinned_ev[b], hipEventDisableTiming));
+    if (!q->pinned_ev[0])
+        for (int b = 0; b < AGH_PIN_RING; ++b)
+            HIP_TRY(hipEventCreateWithFlags(&q->pinned_ev[b], hipEventDisableTiming));
+    if (need_stream && !q->stage_stream) HIP_TRY(hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking));
     return 0;
 }
 
@@ -386,6 +453,7 @@ struct pipe_worker {
             memset(&r, 0, sizeof(r));
             int rc1;
             bool stop1 = false;
+            agh_timeline("worker: scan of a segment starts");
             if (sink) rc1 = emit_records(q, text, len, flags, first, last, base_off, rec_off, *sink, &r, &stop1);
             else rc1 = agh_scan_device_impl(q, text, len, nullptr, flags, &r, nullptr, first, last);
             if (rc1) {
@@ -396,6 +464,7 @@ struct pipe_worker {
                 rec_off += r.n_records;
                 if (stop1 || (!sink && (flags & AGH_FILENAMEONLY) && total.n_matched)) stop = true;
             }
+            agh_timeline("worker: scan of the segment done");
             lk.lock();
             busy = false;
             cv.notify_all();
@@ -477,6 +546,7 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
     const uint64_t want0 = std::min<uint64_t>(seg_cap, hint ? hint : seg_cap) + 2 * chunk_cap + 64 + AGH_SEG_PFX;
     if (seg[0]->ensure(want0)) return -1;
     if ((!hint || hint > seg_cap) && seg[1]->ensure(want0)) return -1;      // (a small file needs one segment)
+    agh_timeline("pipe_scan: device segments allocated");
     q->staged_len = 0;                          // what stays in HBM is not the whole input
 
     pipe_worker w;
@@ -511,7 +581,9 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         const size_t ask = early ? (size_t)std::min<uint64_t>(AGH_STAGE_CHUNK, std::max<uint64_t>(target > used ? target - used : 0, 65536))
                                  : (size_t)std::min<uint64_t>(chunk_cap, seg_cap);
         if (ensure_pinned(q, b, ask, hint)) return bail(-1);
+        if (!base_off && !used) agh_timeline("pipe_scan: first pinned chunk ready");
         const ssize_t got = rd.fill(q->pinned[b], ask);
+        if (!base_off && used == 0) agh_timeline("pipe_scan: first chunk read");
         if (got < 0) return bail(-1);
         if (got == 0) eof = true;
         if (got > 0) {
@@ -568,8 +640,10 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         b = (b + 1) % AGH_PIN_RING;
     }
 #undef PIPE_TRY
+    agh_timeline("pipe_scan: input read, waiting for the last scan");
     w.finish();
     (void)hipStreamSynchronize(q->stage_stream);
+    agh_timeline("pipe_scan: done");
     if (w.rc) {
         agh_fail("%s", w.err);
         rc = -1;
@@ -585,10 +659,12 @@ static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, u
     if (!q || !res) return fail("null argument");
     if (fd < 0) return fail("agh_scan_fd needs fd >= 0 (memory mode is agh_scan_buffer)");
     if (with_range && end < begin) return fail("empty byte range");
-    if (ensure_stage_resources(q)) return -1;
+    agh_timeline("scan_fd: start");
     fd_reader rd;
     agh_refresh_tuning(q);
     if (rd.open_fd(fd, with_range, begin, end, q->tune.readers)) return -1;
+    if (ensure_stage_resources(q, !(rd.regular && rd.left <= AGH_STAGE_CHUNK))) return -1;
+    agh_timeline("scan_fd: stage stream + events");
     const bool count_only = (flags & (AGH_COUNT | AGH_FILENAMEONLY)) && !(matches && cap) && !sink;
     // one rank's shard of a file: the virtual head byte / the appended delimiter (asearch.c:69-91)
     // belong to the shards that hold the file's first / last byte

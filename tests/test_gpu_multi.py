@@ -409,3 +409,95 @@ def test_one_pass_scan_fuzz(agh):
         if n <= 70000 and len(pats) <= 30:
             want = len(_approx_want(pats, k, text, nocase)) if k else O.multi_exact_count(pats, text, nocase=nocase)[0]
             assert got == want, (it, k, alpha, n)
+
+
+# ---- record walk over dense sets with one error (agh_mwalk.hip: BASELINE config 5 as SURVEY 8d words it) ----------
+def test_record_walk_takes_dense_one_error_sets(agh):
+    """1024 patterns of 4..12 bytes, k = 1: pieces of two bytes, every position a candidate, most records match.
+    Count-only scans walk the records lane by lane and stop at a record's first hit; the count equals the numbered
+    multi-pattern pipeline and, on a slice, the union of 1024 single-pattern oracle scans."""
+    rng = random.Random(1024)
+    pats = _rand_patterns(rng, 1024, 4, 12)
+    base, _ = O.corpus(2048, seed=5, variants=tuple(pats[:7]), plant_period=500)       # 8 MiB
+    text = base.tobytes()
+    got = _one_pass_count(agh, pats, 1, text)
+    nrec = text.count(b"\n")
+    assert 0.5 * nrec < got <= nrec                       # (four records in five match on this alphabet)
+    small = text[:200000]
+    assert _one_pass_count(agh, pats, 1, small) == len(_approx_want(pats[:1024], 1, small))
+    # the same set without errors, and sets the walk does not take (patterns above 14 bytes / below 4, two errors)
+    with agh.Query.multi(pats, k=1) as q:
+        assert q.scan_buffer(small, flags=agh.COUNT)[0].fused_segments == 1
+    for ps, k in (([b"abc", b"needle"], 1), ([b"needlework", b"a" * 15], 1), ([b"needle", b"haystack"], 2)):
+        with agh.Query.multi(ps, k=k) as q:
+            c = q.scan_buffer(small, flags=agh.COUNT)[0]
+            assert c.fused_segments == 0 and c.n_matched == q.scan_buffer(small, flags=agh.COUNT | agh.FORCE_NUMBERED)[0].n_matched
+
+
+def test_record_walk_boundaries(agh):
+    """Records and occurrences around the seams of the walk: a lane's kilobyte, a wave's 64 KiB tile, the first 8
+    and last 24 positions (k_mwalk_edges), records that cross several kilobytes with hits in each of them (counted
+    once: the set of record starts), empty records, no trailing delimiter, a 2 MiB record in front of a hit (the
+    give-up list), texts below 32 bytes."""
+    pats = [b"needle", b"haystack", b"wxyz", b"abcdefghijklmn"]
+    near = [b"needle", b"nedle", b"neeedle", b"haystak", b"hbystack", b"wxz", b"wxyyz", b"abcdefghijklm", b"abcdefgXijklmn"]
+    for t in (b"", b"n", b"wxyz", b"wxyz\n", b"\nwxyz", b"xwxz", b"needle" * 3, b"needl", b"x" * 7 + b"needle" + b"y" * 23,
+              b"x" * 8 + b"needle" + b"y" * 24, b"\n" * 100, b"wxz\n" * 10 + b"wx"):
+        got = _one_pass_count(agh, pats, 1, t)
+        assert got == len(_approx_want(pats, 1, t)), t[:40]
+    for boundary in (1024, 2048, 65536, 65536 + 1024, 131072):
+        for tail in (0, 7, 24, 900):
+            base = bytearray(b"q" * (boundary + 64 + tail))
+            for i in range(53, len(base), 131):
+                base[i] = 10
+            for j, shift in enumerate(range(-16, 8)):
+                at = boundary + shift
+                w = near[j % len(near)]
+                if at < 0 or at + len(w) > len(base):
+                    continue
+                s = bytearray(base)
+                s[at:at + len(w)] = w
+                for p in range(max(0, at - 2), min(len(s), at + len(w) + 2)):
+                    if s[p] == 10 and not (at <= p < at + len(w)):
+                        s[p] = ord("q")
+                got = _one_pass_count(agh, pats, 1, bytes(s))
+                assert got == len(_approx_want(pats, 1, bytes(s))) == 1, (boundary, tail, shift, w)
+    # one record across five kilobytes with a hit in every one of them; its neighbours match too
+    rec = (b"r" * 500 + b"needle" + b"r" * 518) * 5
+    t = b"wxyz one\n" + rec + b"\n" + b"haystack two\n" + rec[:3000] + b"\n" + b"s" * 3000 + b"\nwxz"
+    assert _one_pass_count(agh, pats, 1, t) == len(_approx_want(pats, 1, t)) == 5
+    # hits in every record of a long run of short records; empty records in between
+    dense = (b"a needl b\n\n" + b"xx haystac yy\n") * 30000
+    assert _one_pass_count(agh, pats, 1, dense) == 60000
+    # a record of 2 MiB in front of a hit: its start is found after the scan (k_resolve_giveups)
+    long = b"v" * (2 << 20) + b" nedle\n" + b"wxyz\n" + b"u" * 5000
+    assert _one_pass_count(agh, pats, 1, long) == 2
+
+
+def test_record_walk_fuzz(agh):
+    """Random sets of 4..14-byte patterns over small and large alphabets (everything is a near miss, several
+    entries per two-byte key, -i), random record lengths: count-only == numbered, and == the oracle's union on the
+    smaller cases."""
+    rng = random.Random(4242)
+    ran = 0
+    for it in range(60):
+        alpha = rng.choice([b"ab", b"abc", b"abcdefghijklmnopqrstuvwxyz", b"aA", b"abcd ", b"etaoin shr"])
+        nocase = rng.random() < 0.3
+        palpha = alpha.replace(b" ", b"e")
+        lo = rng.randint(4, 7)
+        hi = rng.randint(lo, 14)
+        npat = min(rng.choice([1, 3, 30, 300]), max(1, len(set(palpha)) ** lo // 4))
+        pats = _rand_patterns(rng, npat, lo, hi, alphabet=palpha)
+        n = rng.choice([0, 1, 9, 31, 32, 33, 100, 1023, 1024, 1025, 4097, 65535, 65536, 70000, 263000])
+        talpha = alpha + b"\n" if rng.random() < 0.6 else alpha * 3 + b"\n"
+        text = bytes(rng.choice(talpha) for _ in range(n))
+        with agh.Query.multi(pats, nocase=nocase, k=1) as q:
+            took = q.scan_buffer(b"x" * 64, flags=agh.COUNT)[0].fused_segments == 1
+        if min(len(p) for p in pats) >= 8:
+            continue                            # (the one-pass filter kernel's sets: tested above)
+        assert took, (it, lo, hi, npat)
+        ran += 1
+        got = _one_pass_count(agh, pats, 1, text, nocase=nocase)
+        if n <= 70000 and len(pats) <= 30:
+            assert got == len(_approx_want(pats, 1, text, nocase)), (it, alpha, n, lo, hi)
+    assert ran >= 30
