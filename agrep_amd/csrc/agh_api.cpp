@@ -1082,6 +1082,7 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
             w.q = dq;
             w.mw.ent = (const uint4 *)q->d_mw_ent;
             w.mw.dir = (const uint32_t *)q->d_mw_dir;
+            w.mw.fmask = (const uint4 *)q->d_mw_fmask;
             w.mw.n_ent = q->mw_nent;
             w.mt = a.mt;
             w.mk = a.mk;

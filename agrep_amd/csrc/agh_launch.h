@@ -224,6 +224,8 @@ struct agh_mwalk_dev {
     const uint4 *ent;        // x: piece bytes 0..3; y: bytes 4..6 | piece length << 24; z: side bytes 0..3 (nearest first);
                              // w: side bytes 4..6 | (side length | 8 if the side lies in front of the piece) << 24
     const uint32_t *dir;     // AGH_MW_DIR slots by agh_mw_slot(first two piece bytes): (first entry << 16) | entries
+    const uint4 *fmask;      // per slot, bit (byte & 31): x the byte behind the pair (t[j+2]), y t[j+3], z t[j-1], w t[j-2] that
+                             // some entry of the slot can accept at all
     uint32_t n_ent;
 };
 struct agh_mwalk_args {

@@ -5,12 +5,20 @@
 // (newmgrep.c:858-905: monkey1() returns to the record loop after the first verified entry; sgrep.c:1186-1204 jumps
 // to the record end).
 //
-// One LANE per 1 KiB of text, walking it position by position:
-//   examine   the entries whose piece starts with the two bytes at j (directory + entries in LDS): piece verbatim at
-//             j, then the other side of its pattern within one edit of the <= 8 text bytes next to it
-//             (side_within_one_edit: two 64-bit words, no automaton) -- the predicate of the round-3 verifier
-//             (agh_multi_inl.h mp_verify_at<K = 1>), the union over the patterns of the k-error predicate
+// One LANE per 1 KiB of text, walking it position by position, in three kinds of steps:
+//   advance   (cheap, up to eight positions in a row per lane) one 8-byte load around j; the two bytes at j select a
+//             directory slot whose four 32-bit masks say which bytes next to them some entry could accept at all --
+//             the byte behind the pair (the third byte of a longer piece, or one of the two nearest bytes of the other
+//             side of a two-byte piece's pattern), the byte after that, and the two bytes in front (what
+//             side_within_one_edit can accept: the first mismatch is the missing, the replaced or the extra byte).
+//             Lossless; ~1 position in 5 stays a candidate.  Lanes stop at their candidate and wait for the others.
+//   examine   (most lanes at a candidate now) the entries of the slot: piece verbatim at j and the same necessary
+//             condition on the entry's own bytes inside the loop; the full test of the side -- two 64-bit words, the
+//             round-3 verifier's predicate (agh_multi_inl.h mp_verify_at<K = 1>: the union over the patterns of the
+//             k-error predicate) -- once per lane behind the loop
 //   skip      after a hit: 16 bytes per step to the delimiter that ends the record
+// (First version: every position walked its slot's entries with the full test inside the loop -- a wave pays the
+// longest list and the test for every entry some lane passes: 4 GiB in 42.8 ms; profiles/r05_perf_c5_worded.log.)
 // Records that lie inside one lane's kilobyte are counted by that lane alone (a register); a record that crosses
 // into the next lane's text goes into the scan's hash set of record starts like in every other count-only engine,
 // whoever finds the hit -- one record in ~13, not four in five of 53 M.
@@ -18,19 +26,38 @@
 #include "agh_multi_inl.h"
 
 #define MW_CH 1024u                 // text bytes per lane
-#define MW_WAVES 8u                 // waves per workgroup (one copy of the tables: 64 KiB of LDS, two workgroups per CU)
+#define MW_WAVES 16u                // waves per workgroup: one copy of the tables (80 KiB of masks and directory + 16 bytes per
+                                    // entry: 112 KiB for config 5's 2048 pieces) per CU
 
 typedef uint64_t u64_a1 __attribute__((aligned(1)));
+
+#define MW_ADVANCE 8                // positions a lane may advance before the wave examines the candidates it has
+
+__device__ __forceinline__ uint32_t mw_delim_offset16(uint64_t F0, uint64_t F1, uint32_t dd)
+{
+    // offset of the first delimiter byte among 16, or 16
+    auto nz = [&](uint32_t w) -> uint32_t { const uint32_t x = w ^ dd; return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu); };
+    const uint32_t z0 = nz((uint32_t)F0), z1 = nz((uint32_t)(F0 >> 32)), z2 = nz((uint32_t)F1), z3 = nz((uint32_t)(F1 >> 32));
+    if (z0) return (uint32_t)(__ffs((int)z0) - 1) >> 3;
+    if (z1) return 4u + ((uint32_t)(__ffs((int)z1) - 1) >> 3);
+    if (z2) return 8u + ((uint32_t)(__ffs((int)z2) - 1) >> 3);
+    if (z3) return 12u + ((uint32_t)(__ffs((int)z3) - 1) >> 3);
+    return 16u;
+}
 
 template <bool FOLD>
 __global__ __launch_bounds__(MW_WAVES * 64) void k_mwalk(const uint8_t *__restrict__ text, uint64_t n, uint32_t delim,
                                                          agh_mwalk_dev mw, agh_marks mk, uint32_t *__restrict__ ticket,
                                                          uint32_t n_tiles)
 {
-    __shared__ uint4 ent[AGH_MW_MAX_ENT];
-    __shared__ uint32_t dir[AGH_MW_DIR];
+    __shared__ uint4 fmask[AGH_MW_DIR];                   // 64 KiB
+    __shared__ uint32_t dir[AGH_MW_DIR];                  // 16 KiB
+    __shared__ uint4 ent[AGH_MW_MAX_ENT];                 // 48 KiB
+    for (uint32_t i = threadIdx.x; i < AGH_MW_DIR; i += MW_WAVES * 64) {
+        fmask[i] = mw.fmask[i];
+        dir[i] = mw.dir[i];
+    }
     for (uint32_t i = threadIdx.x; i < mw.n_ent; i += MW_WAVES * 64) ent[i] = mw.ent[i];
-    for (uint32_t i = threadIdx.x; i < AGH_MW_DIR; i += MW_WAVES * 64) dir[i] = mw.dir[i];
     __syncthreads();
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
@@ -47,24 +74,38 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_mwalk(const uint8_t *__restri
         // the start of the record at j: known if a delimiter stands right in front of my text
         uint64_t rstart = (active && text[j - 1] == delim) ? j : ~0ull;
         bool own = rstart != ~0ull;                       // the record at j starts inside my text
-        bool skipping = false;
+        bool skipping = false, cand = false;
+        uint32_t cslot = 0;                               // directory slot of the candidate at j
         while (__ballot(active)) {
-            if (active) {
-                uint64_t P = *reinterpret_cast<const u64_a1 *>(text + j - 8);
-                uint64_t F0 = *reinterpret_cast<const u64_a1 *>(text + j);
-                uint64_t F1 = *reinterpret_cast<const u64_a1 *>(text + j + 8);
-                if (skipping) {
-                    // the delimiter that ends the matched record, 16 bytes per step (on the raw bytes)
-                    const uint32_t z0 = (uint32_t)(((((uint32_t)F0 ^ dd) & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ((uint32_t)F0 ^ dd) | 0x7f7f7f7fu);
-                    const uint32_t z1 = (uint32_t)((((((uint32_t)(F0 >> 32)) ^ dd) & 0x7f7f7f7fu) + 0x7f7f7f7fu) | (((uint32_t)(F0 >> 32)) ^ dd) | 0x7f7f7f7fu);
-                    const uint32_t z2 = (uint32_t)(((((uint32_t)F1 ^ dd) & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ((uint32_t)F1 ^ dd) | 0x7f7f7f7fu);
-                    const uint32_t z3 = (uint32_t)((((((uint32_t)(F1 >> 32)) ^ dd) & 0x7f7f7f7fu) + 0x7f7f7f7fu) | (((uint32_t)(F1 >> 32)) ^ dd) | 0x7f7f7f7fu);
-                    // bit 7 of a byte of ~z: that byte is the delimiter
-                    uint32_t d = 16u;
-                    if (~z0) d = (uint32_t)(__ffs((int)~z0) - 1) >> 3;
-                    else if (~z1) d = 4u + ((uint32_t)(__ffs((int)~z1) - 1) >> 3);
-                    else if (~z2) d = 8u + ((uint32_t)(__ffs((int)~z2) - 1) >> 3);
-                    else if (~z3) d = 12u + ((uint32_t)(__ffs((int)~z3) - 1) >> 3);
+            // ---- advance / skip: cheap steps, every lane for itself ----------------------------------
+#pragma clang loop unroll(disable)
+            for (int step = 0; step < MW_ADVANCE; ++step) {
+                const bool adv = active && !skipping && !cand;
+                const bool skp = active && skipping;
+                if (!__ballot(adv || skp)) break;
+                if (adv) {
+                    const uint64_t W = *reinterpret_cast<const u64_a1 *>(text + j - 2);      // t[j-2 .. j+6)
+                    uint32_t pair = (uint32_t)(W >> 16) & 0xffffu;
+                    if ((pair & 0xffu) == delim) {        // (no entry holds the delimiter byte)
+                        ++j;
+                        rstart = j;
+                        own = true;
+                    } else {
+                        if (FOLD) pair = swar_lower(pair);
+                        const uint32_t slot = agh_mw_slot(pair);
+                        const uint4 fm = fmask[slot];     // (all zero where no entry starts with this pair)
+                        const uint32_t hit = (fm.x >> ((uint32_t)(W >> 32) & 31u)) | (fm.y >> ((uint32_t)(W >> 40) & 31u)) |
+                                             (fm.z >> ((uint32_t)(W >> 8) & 31u)) | (fm.w >> ((uint32_t)W & 31u));
+                        if (hit & 1u) { cand = true; cslot = slot; }
+                        else ++j;
+                    }
+                    if (j >= end) active = false;
+                }
+                if (skp) {
+                    // the delimiter that ends the matched record, 16 bytes per step
+                    const uint64_t F0 = *reinterpret_cast<const u64_a1 *>(text + j);
+                    const uint64_t F1 = *reinterpret_cast<const u64_a1 *>(text + j + 8);
+                    const uint32_t d = mw_delim_offset16(F0, F1, dd);
                     if (d < 16u && j + d < end) {         // the record ends inside my text
                         if (own) ++local;                 // ... and began there: mine alone
                         else if (rstart != ~0ull) lean_insert(mk, rstart);
@@ -72,54 +113,74 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_mwalk(const uint8_t *__restri
                         rstart = j;
                         own = true;
                         skipping = false;
+                        if (j >= end) active = false;
                     } else if (d < 16u || j + 16u >= end) {
                         // it crosses into the next lane's text: the set of record starts sorts out who counts it
                         if (rstart != ~0ull) lean_insert(mk, rstart);
-                        j = end;
+                        active = false;
                     } else {
                         j += 16u;
                     }
-                } else {
+                }
+            }
+            // ---- examine: the candidates -------------------------------------------------------------
+            if (__ballot(cand)) {
+                bool matched = false;
+                uint64_t P = 0, F0 = 0, F1 = 0;
+                uint32_t first = 0, cnt = 0;
+                if (cand) {
+                    P = *reinterpret_cast<const u64_a1 *>(text + j - 8);
+                    F0 = *reinterpret_cast<const u64_a1 *>(text + j);
+                    F1 = *reinterpret_cast<const u64_a1 *>(text + j + 8);
                     if (FOLD) {
                         P = (uint64_t)swar_lower((uint32_t)P) | ((uint64_t)swar_lower((uint32_t)(P >> 32)) << 32);
                         F0 = (uint64_t)swar_lower((uint32_t)F0) | ((uint64_t)swar_lower((uint32_t)(F0 >> 32)) << 32);
                         F1 = (uint64_t)swar_lower((uint32_t)F1) | ((uint64_t)swar_lower((uint32_t)(F1 >> 32)) << 32);
                     }
-                    const uint32_t lo = (uint32_t)F0, hi = (uint32_t)(F0 >> 32);
-                    if ((lo & 0xffu) == delim) {          // (no entry holds the delimiter byte)
-                        ++j;
-                        rstart = j;
-                        own = true;
-                    } else {
-                        const uint32_t dr = dir[agh_mw_slot(lo & 0xffffu)];
-                        const uint32_t first = dr >> 16, cnt = dr & 0xffffu;
-                        bool matched = false;
-                        for (uint32_t i = 0; i < cnt && !matched; ++i) {
-                            const uint4 e = ent[first + i];
-                            const uint32_t pl = e.y >> 24;                      // piece length 2..7
-                            uint32_t diff = (lo ^ e.x) & (pl >= 4u ? 0xffffffffu : ((1u << (8u * pl)) - 1u));
-                            if (pl > 4u) diff |= (hi ^ e.y) & ((1u << (8u * (pl - 4u))) - 1u);
-                            if (diff) continue;
-                            const uint32_t meta = e.w >> 24, L = meta & 7u;
-                            const uint64_t B = (uint64_t)e.z | ((uint64_t)(e.w & 0xffffffu) << 32);
-                            uint64_t S;
-                            if (meta & 8u) S = __builtin_bswap64(P);           // the head of the pattern in front of the piece
-                            else S = (F0 >> (8u * pl)) | (F1 << (64u - 8u * pl));   // the rest behind it
-                            matched = side_within_one_edit(S, B, L, delim);
-                        }
-                        if (matched) {
-                            if (rstart == ~0ull) rstart = lean_record_start(text, j, delim, mk);   // (~0: noted as a give-up)
-                            mk.counters[AGH_C_ANYHIT] = 1u;
-                            skipping = true;              // (from j: the delimiter search starts here)
-                        } else {
-                            ++j;
-                        }
+                    const uint32_t dr = dir[cslot];
+                    first = dr >> 16;
+                    cnt = dr & 0xffffu;
+                }
+                const uint32_t lo = (uint32_t)F0, hi = (uint32_t)(F0 >> 32);
+                const uint64_t Ph = __builtin_bswap64(P);               // the bytes in front of j, nearest first
+                uint32_t i = 0;
+                while (__ballot(i < cnt)) {
+                    // the next entry whose piece stands at j and whose side passes the necessary condition ...
+                    bool pend = false;
+                    uint64_t S = 0, B = 0;
+                    uint32_t L = 0;
+                    while (i < cnt && !pend) {
+                        const uint4 e = ent[first + i];
+                        ++i;
+                        const uint32_t pl = e.y >> 24;                  // piece length 2..7
+                        uint32_t diff = (lo ^ e.x) & (pl >= 4u ? 0xffffffffu : ((1u << (8u * pl)) - 1u));
+                        if (pl > 4u) diff |= (hi ^ e.y) & ((1u << (8u * (pl - 4u))) - 1u);
+                        if (diff) continue;
+                        const uint32_t meta = e.w >> 24;
+                        L = meta & 7u;
+                        B = (uint64_t)e.z | ((uint64_t)(e.w & 0xffffffu) << 32);
+                        S = (meta & 8u) ? Ph : ((F0 >> (8u * pl)) | (F1 << (64u - 8u * pl)));
+                        // S0 in {B0, B1} or S1 in {B0, B1} (L == 1: anything goes -- the one byte may be the missing one)
+                        const uint32_t s0 = (uint32_t)S & 0xffu, s1 = (uint32_t)(S >> 8) & 0xffu;
+                        const uint32_t b0 = (uint32_t)B & 0xffu, b1 = (uint32_t)(B >> 8) & 0xffu;
+                        pend = L < 2u || s0 == b0 || s0 == b1 || s1 == b0 || s1 == b1;
+                    }
+                    // ... gets the full test, once per lane and round
+                    if (pend && side_within_one_edit(S, B, L, delim)) {
+                        matched = true;
+                        i = cnt;
                     }
                 }
-                if (j >= end) {
-                    // a matched record still open at the end of my text belongs to the set as well
-                    if (skipping && rstart != ~0ull) lean_insert(mk, rstart);
-                    active = false;
+                if (cand) {
+                    cand = false;
+                    if (matched) {
+                        if (rstart == ~0ull) rstart = lean_record_start(text, j, delim, mk);   // (~0: noted as a give-up)
+                        mk.counters[AGH_C_ANYHIT] = 1u;
+                        skipping = true;                  // (from j: the delimiter search starts here)
+                    } else {
+                        ++j;
+                        if (j >= end) active = false;
+                    }
                 }
             }
         }
@@ -151,7 +212,8 @@ bool agh_launch_mwalk(const agh_mwalk_args &a, hipStream_t st)
     if (a.n >= 32u) {
         const uint64_t n_tiles = (a.n + 64u * MW_CH - 1u) / (64u * MW_CH);
         if (n_tiles > 0xffffffffull - 65536ull) return false;
-        uint32_t blocks = (a.n_cu ? a.n_cu : 256u) * 2u;
+        // masks, directory and up to 3072 entries: 128 KiB of LDS -- one workgroup of 16 waves per CU
+        uint32_t blocks = a.n_cu ? a.n_cu : 256u;
         const uint32_t need = (uint32_t)((n_tiles + MW_WAVES - 1u) / MW_WAVES);
         if (blocks > need) blocks = need;
         if (a.q.fold)

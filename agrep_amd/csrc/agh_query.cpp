@@ -790,7 +790,8 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
     // ---- tables of the record walk (agh_mwalk.hip): one error, patterns of 4..14 bytes some of which are too short
     // for the one-pass kernel's 4-byte grams (pieces of 2..3 bytes: every position is a candidate) ---------------
     q->mw_ok = false;
-    bool mw = D == 1 && q->multi && q->dlen == 1 && !q->delim_fold && !q->guard && !q->ms_ok && minlen >= 2;
+    // (sets whose pieces all have >= 4 bytes are selective: the filter kernels are several times faster there)
+    bool mw = D == 1 && q->multi && q->dlen == 1 && !q->delim_fold && !q->guard && !q->ms_ok && minlen >= 2 && minlen < 4;
     {
         const char *e = getenv("AGH_MWALK");
         if (e && e[0] == '0') mw = false;
@@ -823,15 +824,33 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
         if (es.empty() || es.size() > AGH_MW_MAX_ENT) mw = false;
         if (mw) {
             std::stable_sort(es.begin(), es.end(), [](const mw_entry &a, const mw_entry &b) { return a.slot < b.slot; });
-            std::vector<uint32_t> dir(AGH_MW_DIR, 0), ent(es.size() * 4);
+            std::vector<uint32_t> dir(AGH_MW_DIR, 0), ent(es.size() * 4), fmask((size_t)AGH_MW_DIR * 4, 0);
             for (size_t a = 0; a < es.size();) {
                 size_t b = a;
                 while (b < es.size() && es[b].slot == es[a].slot) ++b;
                 dir[es[a].slot] = (uint32_t)a << 16 | (uint32_t)(b - a);
                 a = b;
             }
-            for (size_t i = 0; i < es.size(); ++i) memcpy(&ent[4 * i], es[i].w, 16);
-            if (up(&q->d_mw_ent, ent.data(), ent.size() * 4) || up(&q->d_mw_dir, dir.data(), dir.size() * 4)) return -1;
+            for (size_t i = 0; i < es.size(); ++i) {
+                memcpy(&ent[4 * i], es[i].w, 16);
+                // which bytes next to the pair this entry can accept at all (bit = byte & 31: the same for both cases
+                // of a letter): a piece of >= 3 bytes its own third byte; a piece of two bytes, whose side stands
+                // right behind (in front of) the pair, one of the side's two nearest bytes as the first or the second
+                // byte there -- side_within_one_edit: the first mismatch is the missing, the replaced or the extra byte
+                const uint32_t *w = es[i].w;
+                const uint32_t pl = w[1] >> 24, meta = w[3] >> 24, L = meta & 7u;
+                uint32_t *fm = &fmask[(size_t)es[i].slot * 4];
+                if (pl >= 3u) {
+                    fm[0] |= 1u << ((w[0] >> 16) & 31u);
+                } else {
+                    const uint32_t near2 = L >= 2u ? (1u << (w[2] & 31u)) | (1u << ((w[2] >> 8) & 31u)) : ~0u;
+                    if (meta & 8u) { fm[2] |= near2; fm[3] |= near2; }
+                    else { fm[0] |= near2; fm[1] |= near2; }
+                }
+            }
+            if (up(&q->d_mw_ent, ent.data(), ent.size() * 4) || up(&q->d_mw_dir, dir.data(), dir.size() * 4) ||
+                up(&q->d_mw_fmask, fmask.data(), fmask.size() * 4))
+                return -1;
             q->mw_nent = (uint32_t)es.size();
             q->mw_ok = true;
         }
@@ -954,6 +973,7 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_mp_omask) (void)hipFree(q->d_mp_omask);
     if (q->d_mw_ent) (void)hipFree(q->d_mw_ent);
     if (q->d_mw_dir) (void)hipFree(q->d_mw_dir);
+    if (q->d_mw_fmask) (void)hipFree(q->d_mw_fmask);
     if (q->d_ms_ptab) (void)hipFree(q->d_ms_ptab);
     if (q->d_ms_gtab) (void)hipFree(q->d_ms_gtab);
     if (q->d_ms_mdir) (void)hipFree(q->d_ms_mdir);

@@ -494,7 +494,7 @@ def test_record_walk_fuzz(agh):
         with agh.Query.multi(pats, nocase=nocase, k=1) as q:
             took = q.scan_buffer(b"x" * 64, flags=agh.COUNT)[0].fused_segments == 1
         if min(len(p) for p in pats) >= 8:
-            continue                            # (the one-pass filter kernel's sets: tested above)
+            continue                            # (pieces of >= 4 bytes: the filter kernels' sets, tested above)
         assert took, (it, lo, hi, npat)
         ran += 1
         got = _one_pass_count(agh, pats, 1, text, nocase=nocase)
