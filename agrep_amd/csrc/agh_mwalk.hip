@@ -77,41 +77,13 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_mwalk(const uint8_t *__restri
         bool skipping = false, cand = false;
         uint32_t cslot = 0;                               // directory slot of the candidate at j
         while (__ballot(active)) {
-            // ---- advance / skip: cheap steps, every lane for itself ----------------------------------
+            // ---- skip, then advance: cheap steps, every lane for itself -------------------------------
             // (a lane's advance steps of one round read t[j0 - 2 .. j0 + 14) once: the window of step p is that
             // 128-bit word shifted by p bytes -- one pair of loads per round instead of one load per position)
-            const uint64_t j0 = j;
-            const bool may_adv = active && !skipping && !cand;        // (a lane that leaves a record's tail examines from the next round on)
-            uint64_t W0 = 0, W1 = 0;
-            if (may_adv) {
-                W0 = *reinterpret_cast<const u64_a1 *>(text + j - 2);
-                W1 = *reinterpret_cast<const u64_a1 *>(text + j + 6);
-            }
-#pragma clang loop unroll(disable)
-            for (int step = 0; step < MW_ADVANCE; ++step) {
-                const bool adv = may_adv && active && !cand;
-                const bool skp = active && skipping;
-                if (!__ballot(adv || skp)) break;
-                if (adv) {
-                    const uint32_t p8 = (uint32_t)(j - j0) * 8u;            // 0, 8, .. 56
-                    const uint64_t W = p8 ? ((W0 >> p8) | (W1 << (64u - p8))) : W0;      // t[j-2 .. j+6)
-                    uint32_t pair = (uint32_t)(W >> 16) & 0xffffu;
-                    if ((pair & 0xffu) == delim) {        // (no entry holds the delimiter byte)
-                        ++j;
-                        rstart = j;
-                        own = true;
-                    } else {
-                        if (FOLD) pair = swar_lower(pair);
-                        const uint32_t slot = agh_mw_slot(pair);
-                        const uint4 fm = fmask[slot];     // (all zero where no entry starts with this pair)
-                        const uint32_t hit = (fm.x >> ((uint32_t)(W >> 32) & 31u)) | (fm.y >> ((uint32_t)(W >> 40) & 31u)) |
-                                             (fm.z >> ((uint32_t)(W >> 8) & 31u)) | (fm.w >> ((uint32_t)W & 31u));
-                        if (hit & 1u) { cand = true; cslot = slot; }
-                        else ++j;
-                    }
-                    if (j >= end) active = false;
-                }
-                if (skp) {
+            // skip first, in a loop of its own (a record's tail is three or four steps; inside the advance loop every
+            // one of its eight steps paid for this path as well)
+            while (__ballot(active && skipping)) {
+                if (active && skipping) {
                     // the delimiter that ends the matched record, 16 bytes per step
                     const uint64_t F0 = *reinterpret_cast<const u64_a1 *>(text + j);
                     const uint64_t F1 = *reinterpret_cast<const u64_a1 *>(text + j + 8);
@@ -131,6 +103,37 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_mwalk(const uint8_t *__restri
                     } else {
                         j += 16u;
                     }
+                }
+            }
+            const uint64_t j0 = j;
+            const bool may_adv = active && !cand;
+            uint64_t W0 = 0, W1 = 0;
+            if (may_adv) {
+                W0 = *reinterpret_cast<const u64_a1 *>(text + j - 2);
+                W1 = *reinterpret_cast<const u64_a1 *>(text + j + 6);
+            }
+#pragma clang loop unroll(disable)
+            for (int step = 0; step < MW_ADVANCE; ++step) {
+                const bool adv = may_adv && active && !cand;
+                if (!__ballot(adv)) break;
+                if (adv) {
+                    const uint32_t p8 = (uint32_t)(j - j0) * 8u;            // 0, 8, .. 56
+                    const uint64_t W = p8 ? ((W0 >> p8) | (W1 << (64u - p8))) : W0;      // t[j-2 .. j+6)
+                    uint32_t pair = (uint32_t)(W >> 16) & 0xffffu;
+                    if ((pair & 0xffu) == delim) {        // (no entry holds the delimiter byte)
+                        ++j;
+                        rstart = j;
+                        own = true;
+                    } else {
+                        if (FOLD) pair = swar_lower(pair);
+                        const uint32_t slot = agh_mw_slot(pair);
+                        const uint4 fm = fmask[slot];     // (all zero where no entry starts with this pair)
+                        const uint32_t hit = (fm.x >> ((uint32_t)(W >> 32) & 31u)) | (fm.y >> ((uint32_t)(W >> 40) & 31u)) |
+                                             (fm.z >> ((uint32_t)(W >> 8) & 31u)) | (fm.w >> ((uint32_t)W & 31u));
+                        if (hit & 1u) { cand = true; cslot = slot; }
+                        else ++j;
+                    }
+                    if (j >= end) active = false;
                 }
             }
             // ---- examine: the candidates -------------------------------------------------------------
