@@ -204,12 +204,13 @@ AGH_HD uint32_t agh_ms_ghash(uint32_t g)
 #define AGH_MS_GB1(h) ((h) >> 22)                    // 10 bits each
 #define AGH_MS_GB2(h) (((h) >> 12) & (AGH_MS_GBUCKETS - 1u))
 // ---- record walk over dense -f sets with one error (agh_mwalk.hip): entries by the first two bytes of their piece --
-#define AGH_MW_DIR 2048u                    // directory slots: (first entry << 16) | number of entries
-#define AGH_MW_MAX_ENT 2304u                // entries (16 bytes each) next to the directory and its masks: 76 KiB of LDS, two
-                                            // workgroups of 16 waves per CU (128 KiB for one: 183 -> GB/s, profiles/r05_perf_c5_worded.log)
+#define AGH_MW_DIR 4096u                    // directory slots: (first entry << 16) | number of entries
+#define AGH_MW_MAX_ENT 3072u                // entries (16 bytes each) next to the directory and its masks: 128 KiB of LDS, one
+                                            // workgroup per CU (2048 slots / 2304 entries, two workgroups of 16 waves per CU:
+                                            // 163 GB/s against 183 -- more waves only evict each other's text lines from the L2)
 AGH_HD uint32_t agh_mw_slot(uint32_t bigram)
 {
-    return ((bigram & 0xffffu) * 40503u >> 5) & (AGH_MW_DIR - 1u);
+    return ((bigram & 0xffffu) * 40503u >> 4) & (AGH_MW_DIR - 1u);
 }
 // q <= 3: the sample already fits 24 bits.
 AGH_HD uint32_t agh_sample_prod_q3(uint32_t s)

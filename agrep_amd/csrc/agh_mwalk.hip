@@ -26,7 +26,9 @@
 #include "agh_multi_inl.h"
 
 #define MW_CH 1024u                 // text bytes per lane
-#define MW_WAVES 16u                // waves per workgroup (one copy of the tables each)
+#ifndef MW_WAVES
+#define MW_WAVES 16u                // waves per workgroup = per CU (one copy of the tables)
+#endif
 
 typedef uint64_t u64_a1 __attribute__((aligned(1)));
 
@@ -49,9 +51,9 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_mwalk(const uint8_t *__restri
                                                          agh_mwalk_dev mw, agh_marks mk, uint32_t *__restrict__ ticket,
                                                          uint32_t n_tiles)
 {
-    __shared__ uint4 fmask[AGH_MW_DIR];                   // 32 KiB
-    __shared__ uint32_t dir[AGH_MW_DIR];                  // 8 KiB
-    __shared__ uint4 ent[AGH_MW_MAX_ENT];                 // 36 KiB
+    __shared__ uint4 fmask[AGH_MW_DIR];                   // 64 KiB
+    __shared__ uint32_t dir[AGH_MW_DIR];                  // 16 KiB
+    __shared__ uint4 ent[AGH_MW_MAX_ENT];                 // 48 KiB
     for (uint32_t i = threadIdx.x; i < AGH_MW_DIR; i += MW_WAVES * 64) {
         fmask[i] = mw.fmask[i];
         dir[i] = mw.dir[i];
@@ -224,8 +226,8 @@ bool agh_launch_mwalk(const agh_mwalk_args &a, hipStream_t st)
     if (a.n >= 32u) {
         const uint64_t n_tiles = (a.n + 64u * MW_CH - 1u) / (64u * MW_CH);
         if (n_tiles > 0xffffffffull - 65536ull) return false;
-        // masks, directory and up to 2304 entries: 76 KiB of LDS -- two workgroups of 16 waves per CU
-        uint32_t blocks = (a.n_cu ? a.n_cu : 256u) * 2u;
+        // masks, directory and up to 3072 entries: 128 KiB of LDS -- one workgroup per CU
+        uint32_t blocks = a.n_cu ? a.n_cu : 256u;
         const uint32_t need = (uint32_t)((n_tiles + MW_WAVES - 1u) / MW_WAVES);
         if (blocks > need) blocks = need;
         if (a.q.fold)
