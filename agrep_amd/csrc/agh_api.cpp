@@ -141,6 +141,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                              !(q->general && (q_mb(q) || pe));   // general verify: 1-byte delimiters
     if (!want_filter && (flags & AGH_FORCE_FILTER))
         return fail("the q-gram filter does not apply to this query (m=%d, k=%d)", q->m, q->k);
+    // the automaton over every byte, the table engine, the multi-pattern kernels, k >= 5 and -v lists: the second library
+    if ((multi || !want_filter || q->k >= 5 || invert_list) && agh_need_engines()) return -1;
     if (q->strip_prefix.ensure((n_strips + 8) * sizeof(uint32_t))) return -1;
     if (q->wave_totals.ensure((nw + 8) * sizeof(uint32_t))) return -1;
     if (want_filter) {
@@ -524,6 +526,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                 return fail("candidate slices overflowed (%u candidates)", q->h_counters[AGH_C_CAND]);
             use_filter = false;                 // not selective on this text: automaton everywhere
             swept = false;                      // the full scan needs the H=0 sweep's strip prefix
+            if (agh_need_engines()) return -1;
         }
         if (slice_overflow || bm_overflow) {
             bits_hint = (uint64_t)n_delims + 1024;
@@ -730,6 +733,7 @@ static int lean_run(agh_query *q, const unsigned char *base, const std::vector<u
     const bool early = (flags & AGH_FILENAMEONLY) != 0;
     const bool timing = (flags & AGH_TIME_SWEEP) != 0;
     agh_timeline("lean_run: start");
+    if (q->k >= 5 && agh_need_engines()) return -1;       // (the verify kernels for k = 5..8 live in the second library)
     // part size: a multiple of 8 wave ranges (2 MiB) so verify workgroups never straddle parts
     const uint64_t part_unit = (uint64_t)AGH_WAVE_STRIPS * AGH_STRIP * 8u;
     uint64_t part_bytes = q->tune.part_mb << 20;

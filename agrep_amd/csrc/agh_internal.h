@@ -162,6 +162,9 @@ extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_dev(stru
                                                                             hipStream_t st);
 extern "C" __attribute__((visibility("hidden"))) int agh_comm_allreduce_host(struct agh_comm *c, uint64_t *v, size_t count);
 
+// ---- agh_ext.cpp: the engines behind the filter live in libagrep_hip_engines.so ------------------------------------
+__attribute__((visibility("hidden"))) int agh_need_engines();
+
 // ---- agh_api.cpp ------------------------------------------------------------------------------
 // at the start of every public scan call: AGH_ENV_LIVE=1 re-reads the switches (tests, A/B scripts)
 static inline void agh_refresh_tuning(agh_query *q) { if (q->tune.live) agh_read_tuning(&q->tune); }
