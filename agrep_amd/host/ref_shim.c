@@ -129,9 +129,15 @@ static int emit_one(const unsigned char *wide, size_t wlen, size_t pre, size_t b
     const int virt = dlen == 1 && delim[0] == '\n';
     const size_t post = wlen - pre - body;
     const size_t vpre = (pre == 0 && virt) ? 1 : 0;     /* the virtual '\n' */
-    unsigned char *rec = (unsigned char *)malloc(wlen + (size_t)dlen + 4);
+    static unsigned char *rec;                          /* (one buffer for all records: grown, never shrunk) */
+    static size_t rec_cap;
     int i2, j, rc = 0;
-    if (!rec) return shim_fail("out of memory");
+    if (wlen + (size_t)dlen + 4 > rec_cap) {
+        free(rec);
+        rec_cap = (wlen + (size_t)dlen + 4) * 2 + 256;
+        rec = (unsigned char *)malloc(rec_cap);
+        if (!rec) { rec_cap = 0; return shim_fail("out of memory"); }
+    }
     if (vpre) rec[0] = '\n';
     memcpy(rec + vpre, wide, wlen);
     /* the delimiter the reference appends at end of input (asearch.c:87-91) */
@@ -142,7 +148,6 @@ static int emit_one(const unsigned char *wide, size_t wlen, size_t pre, size_t b
     CurrentByteOffset = (int)(end_off + 1);
     TRUNCATE = 0;
     if (-1 == output(rec, 0, i2, j)) rc = -1;
-    free(rec);
     if (rc == 0 && ((LIMITOUTPUT > 0 && LIMITOUTPUT <= num_of_matched) ||
                     (LIMITPERFILE > 0 && LIMITPERFILE <= num_of_matched - prev_num_of_matched)))
         rc = 1;
@@ -196,6 +201,27 @@ static int peek_lead_delim(int fd, const unsigned char *delim, int dlen, int *kn
     return pread(fd, first, (size_t)dlen, cur) == (ssize_t)dlen && memcmp(first, delim, (size_t)dlen) == 0;
 }
 
+/* The reference's main() ends in exit(ret) (main.c:79,96).  A process that has scanned on the GPU would then tear
+ * down two device segments, the pinned ring and the HIP runtime itself: 50-80 ms of a 0.3 s run on a 4 GiB file
+ * (profiles/r05_startup.log).  Registered at the first scan, this handler runs before the runtime's own (handlers
+ * run in reverse order of registration): it flushes what the front end has printed and leaves with the same
+ * status -- the kernel reclaims the rest.  AGH_CLI_TEARDOWN=1 keeps the orderly teardown. */
+static void fast_exit(int status, void *unused)
+{
+    (void)unused;
+    fflush(NULL);
+    _exit(status);
+}
+
+static void arm_fast_exit(void)
+{
+    static int armed;
+    const char *e = getenv("AGH_CLI_TEARDOWN");
+    if (armed || (e && e[0] == '1')) return;
+    armed = 1;
+    on_exit(fast_exit, NULL);
+}
+
 static int run_scan(agh_query *q, const struct text_src *src, const unsigned char *delim, int dlen)
 {
     agh_result res;
@@ -206,6 +232,7 @@ static int run_scan(agh_query *q, const struct text_src *src, const unsigned cha
     uint64_t i, text_len;
     int rc = 0, lead_delim = 0;
 
+    if (src->fd >= 0) arm_fast_exit();          /* (memory mode: the caller's process, not ours to end) */
     if (COUNT || (FILENAMEONLY && (NEW_FILE || !POST_FILTER))) {
         flags |= FILENAMEONLY && !COUNT ? AGH_FILENAMEONLY : AGH_COUNT;
         rc = src->fd >= 0 ? agh_scan_fd(q, src->fd, flags, &res, NULL, 0)
