@@ -29,11 +29,11 @@ agrep_amd/agrep-hip -V0 -2 -c approximatematch /dev/shm/agh_r5_4g.txt > /dev/nul
 AGH_TIMELINE=1 agrep_amd/agrep-hip -V0 -2 -c approximatematch /dev/shm/agh_r5_4g.txt
 echo "== wall times (best of 5)"
 python - <<'PY'
-import subprocess, time
-def t(label, cmd, reps=5):
+import os, subprocess, time
+def t(label, cmd, reps=5, env=None):
     best = 1e9
     for _ in range(reps):
-        t0 = time.time(); r = subprocess.run(cmd, capture_output=True, text=True); best = min(best, time.time() - t0)
+        t0 = time.time(); r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **(env or {}))); best = min(best, time.time() - t0)
     print("%-52s %.3f s  -> %s" % (label, best, r.stdout.strip().split("\n")[0][:40]), flush=True)
 t("agrep-hip -c haystack, 1 MiB", ["agrep_amd/agrep-hip", "-c", "haystack", "/tmp/c1.txt"])
 t("agrep-hip -1 -c haystack, 1 MiB", ["agrep_amd/agrep-hip", "-1", "-c", "haystack", "/tmp/c1.txt"])
@@ -41,6 +41,10 @@ t("agrep-hip -V0 -2 -c approximatematch, 4 GiB", ["agrep_amd/agrep-hip", "-V0", 
 t("agrep-hip -V0 -2 approximatematch, 4 GiB (records)", ["agrep_amd/agrep-hip", "-V0", "-2", "approximatematch", "/dev/shm/agh_r5_4g.txt"])
 t("agrep_gpu (reference front end) -V0 -2, 4 GiB", ["oracle/_ref/agrep_gpu", "-V0", "-2", "approximatematch", "/dev/shm/agh_r5_4g.txt"], 3)
 t("agrep_gpu -V0 -2 -c, 4 GiB", ["oracle/_ref/agrep_gpu", "-V0", "-2", "-c", "approximatematch", "/dev/shm/agh_r5_4g.txt"], 3)
+t("agrep_gpu -V0 -2, 4 GiB, AGH_CLI_TEARDOWN=1", ["oracle/_ref/agrep_gpu", "-V0", "-2", "approximatematch", "/dev/shm/agh_r5_4g.txt"], 3, {"AGH_CLI_TEARDOWN": "1"})
+t("agrep-hip -V0 -2 -c, 4 GiB, AGH_CLI_TEARDOWN=1", ["agrep_amd/agrep-hip", "-V0", "-2", "-c", "approximatematch", "/dev/shm/agh_r5_4g.txt"], 3, {"AGH_CLI_TEARDOWN": "1"})
+t("agrep_gpu -V0 -2 > /dev/null, 4 GiB", ["sh", "-c", "oracle/_ref/agrep_gpu -V0 -2 approximatematch /dev/shm/agh_r5_4g.txt > /dev/null"], 3)
+t("agrep-hip -V0 -2 > /dev/null, 4 GiB", ["sh", "-c", "agrep_amd/agrep-hip -V0 -2 approximatematch /dev/shm/agh_r5_4g.txt > /dev/null"], 3)
 t("reference -c haystack, 1 MiB", ["oracle/_ref/agrep", "-V0", "-c", "haystack", "/tmp/c1.txt"])
 PY
 ls -la agrep_amd/libagrep_hip*.so
