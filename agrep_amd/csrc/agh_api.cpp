@@ -24,8 +24,8 @@
 static bool fs_fast_ok(const agh_query *q)
 {
     if (!q->tune.fs_fast || q->fs_fast_off || q->multi) return false;
-    // table engine (k_tablescan_fast + k_table_replay): unit costs, one-byte delimiter
-    if (q->table) return q->ci == 1 && q->cs == 1 && q->cd == 1 && !(q->dlen > 1 || q->delim_fold);
+    // table engine (k_tablescan_fast + k_table_replay): one-byte delimiter; edit costs since round 5 (one stream per lane)
+    if (q->table) return !(q->dlen > 1 || q->delim_fold);
     // k = 0: one level, nothing to pack -- the one-kernel form is faster there (3.8 vs 3.2 TB/s)
     return q->k >= 1 && !q->general && !(q->dlen > 1 || q->delim_fold) && q->mask[q->delim[0]] == 0;
 }
@@ -43,7 +43,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     va->fs_fast = 1;
     va->tf_chunk = q->tune.tf_chunk;
     // table engine, M <= 15: two streams per lane (k_tablescan_fast2) -- the always-one bit M must be there
-    if (q->table && q->tune.tf_pack2) {
+    if (q->table && q->tune.tf_pack2 && q->ci == 1 && q->cs == 1 && q->cd == 1) {
         const unsigned M = (unsigned)q->m + (unsigned)q->dlen + 1u;
         if (M <= 15u && ((q->tab.Init0 >> M) & (q->tab.Init1 >> M) & 1u)) va->fs_fast = 2;
     }

@@ -285,15 +285,32 @@ template <int K>
 struct TableFast {
     uint32_t B[K + 1];
     // one byte: (CM, kb) = (mask of the byte, 0 for the delimiter else ~0) -> A[K] BEFORE the reset
+    // COSTS (round 5): asearch1.c's levels by accumulated cost (TableAutomaton::feed_costs) in the same branch-free
+    // form -- the sources of a level are selected by the three costs, the reset stays a select
+    template <bool COSTS = false>
     __device__ __forceinline__ uint32_t feed(uint32_t CM, uint32_t kb, const agh_dev_tables &T,
-                                             const uint32_t (&RF)[K + 1])
+                                             const uint32_t (&RF)[K + 1], uint32_t ci = 1u, uint32_t cs = 1u,
+                                             uint32_t cd = 1u)
     {
         uint32_t A[K + 1];
         A[0] = ((B[0] >> 1) & CM) | (T.Init1 & B[0]);
 #pragma unroll
-        for (int e = 1; e <= K; ++e)
-            A[e] = ((B[e] >> 1) & CM) | (T.Init1 & B[e]) | B[e - 1] |
-                   (((A[e - 1] | B[e - 1]) >> 1) & T.NO_ERR);
+        for (int e = 1; e <= K; ++e) {
+            if (COSTS) {
+                uint32_t ins = 0, via = 0;
+#pragma unroll
+                for (int s = 0; s < e; ++s) {
+                    const uint32_t d = (uint32_t)(e - s);
+                    if (d == ci) ins = B[s];
+                    if (d == cs) via |= B[s];
+                    if (d == cd) via |= A[s];
+                }
+                A[e] = ((B[e] >> 1) & CM) | (T.Init1 & B[e]) | ins | ((via >> 1) & T.NO_ERR);
+            } else {
+                A[e] = ((B[e] >> 1) & CM) | (T.Init1 & B[e]) | B[e - 1] |
+                       (((A[e - 1] | B[e - 1]) >> 1) & T.NO_ERR);
+            }
+        }
         const uint32_t top = A[K];
 #pragma unroll
         for (int e = 0; e <= K; ++e) B[e] = (A[e] & kb) | (RF[e] & ~kb);     // v_bfi: the reset is a select
@@ -303,13 +320,27 @@ struct TableFast {
 
 // the state asearch.c:175-186 leaves behind a delimiter (all levels Init[0], the delimiter consumed
 // again, level 0 masked)
-template <int K>
-__device__ __forceinline__ void table_reset_state(const agh_dev_tables &T, uint32_t CMd, uint32_t (&RF)[K + 1])
+template <int K, bool COSTS = false>
+__device__ __forceinline__ void table_reset_state(const agh_dev_tables &T, uint32_t CMd, uint32_t (&RF)[K + 1],
+                                                  uint32_t ci = 1u, uint32_t cs = 1u, uint32_t cd = 1u)
 {
     RF[0] = (((T.Init0 >> 1) & CMd) | (T.Init0 & T.Init1)) & T.D_Mask;
 #pragma unroll
-    for (int e = 1; e <= K; ++e)
-        RF[e] = ((T.Init0 >> 1) & CMd) | (T.Init1 & T.Init0) | T.Init0 | (((RF[e - 1] | T.Init0) >> 1) & T.NO_ERR);
+    for (int e = 1; e <= K; ++e) {
+        if (COSTS) {                            // asearch1.c:150-159 (TableAutomaton::feed_costs' reset branch)
+            uint32_t ins = 0, via = 0;
+#pragma unroll
+            for (int s = 0; s < e; ++s) {
+                const uint32_t d = (uint32_t)(e - s);
+                if (d == ci) ins = T.Init0;
+                if (d == cs) via |= T.Init0;
+                if (d == cd) via |= RF[s];
+            }
+            RF[e] = ((T.Init0 >> 1) & CMd) | (T.Init1 & T.Init0) | ins | ((via >> 1) & T.NO_ERR);
+        } else {
+            RF[e] = ((T.Init0 >> 1) & CMd) | (T.Init1 & T.Init0) | T.Init0 | (((RF[e - 1] | T.Init0) >> 1) & T.NO_ERR);
+        }
+    }
 }
 
 // A lane's chunk is 4 KiB here (k_tablescan: 1 KiB): the walk past the chunk's end costs a wave the
@@ -322,7 +353,7 @@ __device__ __forceinline__ void table_reset_state(const agh_dev_tables &T, uint3
 #define AGH_TF_CHUNK_MAX 4096u
 #define AGH_TF_SLICE_OF(chunk) ((chunk) / 4u)      // replay entries per tile (64 chunks)
 
-template <int K>
+template <int K, bool COSTS>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
@@ -336,7 +367,8 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     tab[threadIdx.x].kb = threadIdx.x == q.delim ? 0u : ~0u;
     __syncthreads();
     uint32_t RF[K + 1];
-    table_reset_state<K>(T, mask_g[q.delim & 0xffu], RF);
+    const uint32_t ci = q.ci, cs_ = q.cs, cd = q.cd;
+    table_reset_state<K, COSTS>(T, mask_g[q.delim & 0xffu], RF, ci, cs_, cd);
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     uint8_t *ring = ring_all + wib * (WAVE * AGH_FS_ROW);
@@ -372,7 +404,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
         uint32_t trusted = 0u, cnt = 0;
         if (cs == 0 && len) {                   // the virtual head byte, asearch.c:69-78
             const MK e = tab[q.head_byte & 0xffu];
-            (void)A.feed(e.cm, e.kb, T, RF);
+            (void)A.template feed<COSTS>(e.cm, e.kb, T, RF, ci, cs_, cd);
             trusted = ~0u;
         }
         // 16 bytes: -> "some trusted record end in the piece shows an end bit on the top level"
@@ -384,7 +416,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
             for (uint32_t b = 0; b < 16; ++b) {
                 if (b < nbytes) {
                     const MK e = tab[(dws[b >> 2] >> (8u * (b & 3u))) & 0xffu];
-                    const uint32_t top = A.feed(e.cm, e.kb, T, RF);
+                    const uint32_t top = A.template feed<COSTS>(e.cm, e.kb, T, RF, ci, cs_, cd);
                     flag |= top & ~e.kb & trusted;
                     trusted |= ~e.kb;
                     dseen |= ~e.kb;
@@ -662,7 +694,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
 
 // Exact: for every listed piece, every record that ENDS in it (a delimiter inside the piece, or the
 // end of the text) is run through asearch.c's recurrence from its first byte.
-template <int K, bool LEAN>
+template <int K, bool LEAN, bool COSTS>
 __global__ __launch_bounds__(256) void k_table_replay(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, const uint64_t *__restrict__ replay,
@@ -698,10 +730,10 @@ __global__ __launch_bounds__(256) void k_table_replay(
             A.reset(T);
             // the state at the record's start: what the delimiter (or the virtual head byte) in front
             // of it left behind
-            if (rs == 0) (void)A.feed(lmask[q.head_byte], T);
-            else (void)A.feed(lmask[q.delim], T);
+            if (rs == 0) (void)A.template feed_q<COSTS>(lmask[q.head_byte], T, q);
+            else (void)A.template feed_q<COSTS>(lmask[q.delim], T, q);
             for (uint64_t i = rs; i < pend; ++i) {
-                const uint32_t r = A.feed(lmask[text[i]], T);
+                const uint32_t r = A.template feed_q<COSTS>(lmask[text[i]], T, q);
                 if (r & 1u) {                   // a record closes at i
                     if ((r & 2u) && i >= P) {
                         if (LEAN) lean_insert(mk, rs); else mark_record(mk, rec, i);
@@ -711,7 +743,7 @@ __global__ __launch_bounds__(256) void k_table_replay(
                 }
             }
             if (pend == n && q.tail_virtual && rs < n) {    // asearch.c:87-91: the open record at the end
-                const uint32_t r = A.feed(lmask[q.delim], T);
+                const uint32_t r = A.template feed_q<COSTS>(lmask[q.delim], T, q);
                 if ((r & 3u) == 3u) {
                     if (LEAN) lean_insert(mk, rs); else mark_record(mk, rec, n);
                 }
@@ -729,7 +761,7 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
     const uint32_t blocks = want > 16384 ? 16384u : (uint32_t)want;
     const bool lean = a.mk.hashset != nullptr;  // count-only: hash set of record starts, no census
     const bool costs = a.q.ci != 1u || a.q.cs != 1u || a.q.cd != 1u;     // asearch1.c instead of asearch.c
-    if (a.fs_fast && !costs) {                  // branch-free hot kernel + exact replay (the host checked)
+    if (a.fs_fast) {                            // branch-free hot kernel + exact replay (the host checked)
         // chunk per lane: 4 KiB from 1 GiB on, 2 KiB from 512 MiB, else 1 KiB (a.tf_chunk forces one)
         const uint32_t tf_chunk = a.tf_chunk ? a.tf_chunk
                                       : (a.n >= ((uint64_t)1 << 30) ? 4096u : (a.n >= ((uint64_t)512 << 20) ? 2048u : 1024u));
@@ -741,26 +773,29 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
         const uint32_t nt2 = (nt + 1u) / 2u;
         const uint32_t fblocks2 = (nt2 + 3u) / 4u > 16384u ? 16384u : (nt2 + 3u) / 4u;
         const uint32_t M = (uint32_t)a.q.m + a.q.dlen + 1u;                  // maskgen's M (agh_query_from_maskgen)
+#define AGH_TF_REPLAY(KK, LEANV, COSTV)                                                       \
+            hipLaunchKernelGGL((k_table_replay<KK, LEANV, COSTV>), dim3(rblocks), dim3(256), 0, st, \
+                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                               (const uint64_t *)a.fs_replay, (const uint32_t *)a.fs_tile_cnt, nt, \
+                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, tf_slice)
 #define AGH_TF_CASE(KK)                                                                       \
     case KK:                                                                                  \
+        if (costs) {            /* (asearch1.c's levels: one stream per lane) */              \
+            hipLaunchKernelGGL((k_tablescan_fast<KK, true>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
+                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                               a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_chunk);          \
+            if (lean) AGH_TF_REPLAY(KK, true, true); else AGH_TF_REPLAY(KK, false, true);     \
+            break;                                                                            \
+        }                                                                                     \
         if (a.fs_fast == 2)                                                                   \
             hipLaunchKernelGGL((k_tablescan_fast2<KK>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
                                (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
                                a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt, tf_chunk); \
         else                                                                                  \
-        hipLaunchKernelGGL((k_tablescan_fast<KK>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
+        hipLaunchKernelGGL((k_tablescan_fast<KK, false>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
                            (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
                            a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_chunk);          \
-        if (lean)                                                                             \
-            hipLaunchKernelGGL((k_table_replay<KK, true>), dim3(rblocks), dim3(256), 0, st,   \
-                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                               (const uint64_t *)a.fs_replay, (const uint32_t *)a.fs_tile_cnt, nt, \
-                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, tf_slice); \
-        else                                                                                  \
-            hipLaunchKernelGGL((k_table_replay<KK, false>), dim3(rblocks), dim3(256), 0, st,  \
-                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                               (const uint64_t *)a.fs_replay, (const uint32_t *)a.fs_tile_cnt, nt, \
-                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, tf_slice); \
+        if (lean) AGH_TF_REPLAY(KK, true, false); else AGH_TF_REPLAY(KK, false, false);       \
         break;
         switch (a.q.k) {
             AGH_TF_CASE(0) AGH_TF_CASE(1) AGH_TF_CASE(2) AGH_TF_CASE(3) AGH_TF_CASE(4)
@@ -768,6 +803,7 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
         default: break;
         }
 #undef AGH_TF_CASE
+#undef AGH_TF_REPLAY
         return;
     }
 #define AGH_TS_LAUNCH(KK, LEANV, COSTV, MBV)                                                  \

@@ -1167,9 +1167,17 @@ def test_table_engine_with_edit_costs(agh):
             want = O.asearch_tables_costs(ot, case["k"], costs, text, cap=200000)
             res, ms = q.scan_buffer(text, cap=200000)
             res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+            # (round 5: costs take the fast form -- branch-free kernel + exact replay -- as well; the one-kernel form beside it)
+            os.environ["AGH_FS_FAST"] = "0"
+            try:
+                res_x, ms_x = q.scan_buffer(text, cap=200000)
+                res_xc, _ = q.scan_buffer(text, flags=agh.COUNT)
+            finally:
+                del os.environ["AGH_FS_FAST"]
             q.close()
             assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (case["pattern"], case["k"], costs)
-            assert res_c.n_matched == want[0]
+            assert (res_x.n_matched, [(s, e) for s, e, _ in ms_x]) == want, ("exact kernel", case["pattern"], case["k"], costs)
+            assert res_c.n_matched == want[0] == res_xc.n_matched
             n += 1
     assert n >= 5
 
