@@ -25,7 +25,9 @@ static bool fs_fast_ok(const agh_query *q)
 {
     if (!q->tune.fs_fast || q->fs_fast_off || q->multi) return false;
     // table engine (k_tablescan_fast + k_table_replay): one-byte delimiter; edit costs since round 5 (one stream per lane)
-    if (q->table) return !(q->dlen > 1 || q->delim_fold);
+    // (';' AND patterns flag a piece for every record end with ANY of their end bits: with costs -- one stream per lane --
+    // the replays outweigh the fast kernel: 'match;approx' k = 2 0.71 against 0.80 TB/s, profiles/r05_perf_table_costs.log)
+    if (q->table) return !(q->dlen > 1 || q->delim_fold) && !((q->ci != 1 || q->cs != 1 || q->cd != 1) && q->tab.AND);
     // k = 0: one level, nothing to pack -- the one-kernel form is faster there (3.8 vs 3.2 TB/s)
     return q->k >= 1 && !q->general && !(q->dlen > 1 || q->delim_fold) && q->mask[q->delim[0]] == 0;
 }
