@@ -45,7 +45,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     va->fs_fast = 1;
     va->tf_chunk = q->tune.tf_chunk;
     // table engine, M <= 15: two streams per lane (k_tablescan_fast2) -- the always-one bit M must be there
-    if (q->table && q->tune.tf_pack2 && q->ci == 1 && q->cs == 1 && q->cd == 1) {
+    if (q->table && q->tune.tf_pack2) {
         const unsigned M = (unsigned)q->m + (unsigned)q->dlen + 1u;
         if (M <= 15u && ((q->tab.Init0 >> M) & (q->tab.Init1 >> M) & 1u)) va->fs_fast = 2;
     }

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
 #else
 #define AGH_TF2_ATTR
 #endif
-template <int K>
+template <int K, bool COSTS>
 __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
@@ -531,7 +531,8 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
     Tp.NO_ERR = dup(T.NO_ERR);
     Tp.endposition = dup(T.endposition);
     uint32_t RF[K + 1];
-    table_reset_state<K>(T, mask_g[q.delim & 0xffu], RF);
+    const uint32_t ci = q.ci, cs_ = q.cs, cd = q.cd;        // (COSTS: asearch1.c's levels -- the same bitwise recurrence shape,
+    table_reset_state<K, COSTS>(T, mask_g[q.delim & 0xffu], RF, ci, cs_, cd);   //  so the two halves keep out of each other's way)
 #pragma unroll
     for (int e = 0; e <= K; ++e) RF[e] = dup(RF[e]);
     const int lane = lane_id();
@@ -576,7 +577,8 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
         uint32_t trusted = 0u, cnt0 = 0, cnt1 = 0;
         if (cs[0] == 0 && len[0]) {             // the virtual head byte, asearch.c:69-78 (stream 1: not trusted yet)
             const uint32_t e = tab[q.head_byte & 0xffu];
-            (void)A.feed(__builtin_amdgcn_perm(e, e, 0x05040100u), __builtin_amdgcn_perm(e, e, 0x07060302u), Tp, RF);
+            (void)A.template feed<COSTS>(__builtin_amdgcn_perm(e, e, 0x05040100u), __builtin_amdgcn_perm(e, e, 0x07060302u), Tp, RF,
+                                         ci, cs_, cd);
             trusted = 0xffffu;
         }
         uint32_t dseen = 0;                     // per half: 0xffff once a delimiter went through piece()
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
                 const uint32_t eb = tab[(db[b >> 2] >> (8u * (b & 3u))) & 0xffu];
                 const uint32_t cm = __builtin_amdgcn_perm(eb, ea, 0x05040100u);
                 const uint32_t kb = __builtin_amdgcn_perm(eb, ea, 0x07060302u);
-                const uint32_t top = A.feed(cm, kb, Tp, RF);
+                const uint32_t top = A.template feed<COSTS>(cm, kb, Tp, RF, ci, cs_, cd);
                 if (MODE == 2) {
                     flag |= top & ~kb;
                 } else if (MODE == 1) {
@@ -780,7 +782,12 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
                                a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, tf_slice)
 #define AGH_TF_CASE(KK)                                                                       \
     case KK:                                                                                  \
-        if (costs) {            /* (asearch1.c's levels: one stream per lane) */              \
+        if (costs) {            /* (asearch1.c's levels) */                                   \
+            if (a.fs_fast == 2)                                                               \
+                hipLaunchKernelGGL((k_tablescan_fast2<KK, true>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
+                                   (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                                   a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt, tf_chunk); \
+            else                                                                              \
             hipLaunchKernelGGL((k_tablescan_fast<KK, true>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
                                (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
                                a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_chunk);          \
@@ -788,7 +795,7 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
             break;                                                                            \
         }                                                                                     \
         if (a.fs_fast == 2)                                                                   \
-            hipLaunchKernelGGL((k_tablescan_fast2<KK>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
+            hipLaunchKernelGGL((k_tablescan_fast2<KK, false>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
                                (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
                                a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt, tf_chunk); \
         else                                                                                  \
