@@ -24,10 +24,11 @@
 static bool fs_fast_ok(const agh_query *q)
 {
     if (!q->tune.fs_fast || q->fs_fast_off || q->multi) return false;
-    // table engine (k_tablescan_fast + k_table_replay): one-byte delimiter; edit costs since round 5 (one stream per lane)
+    // table engine (k_tablescan_fast + k_table_replay); edit costs since round 5
     // (';' AND patterns flag a piece for every record end with ANY of their end bits: with costs -- one stream per lane --
     // the replays outweigh the fast kernel: 'match;approx' k = 2 0.71 against 0.80 TB/s, profiles/r05_perf_table_costs.log)
-    if (q->table) return !(q->dlen > 1 || q->delim_fold) && !((q->ci != 1 || q->cs != 1 || q->cd != 1) && q->tab.AND);
+    // delimiters of several bytes / a folded letter (round 5): record ends from the delimiter-end bitmap, k <= 4
+    if (q->table) return !((q->dlen > 1 || q->delim_fold) && q->k > 4) && !((q->ci != 1 || q->cs != 1 || q->cd != 1) && q->tab.AND);
     // k = 0: one level, nothing to pack -- the one-kernel form is faster there (3.8 vs 3.2 TB/s)
     return q->k >= 1 && !q->general && !(q->dlen > 1 || q->delim_fold) && q->mask[q->delim[0]] == 0;
 }
@@ -36,6 +37,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
 {
     va->fs_fast = 0;
     va->tf_chunk = 0;
+    va->tr_group = 0;
     if (!fs_fast_ok(q)) return 0;
     if (q->table && n < (q->tune.tf_fast_min_mb << 20)) return 0;
     // (64 KiB tiles with 256 entries each; the table engine's 256 KiB tiles with 1024 entries need the same)
@@ -44,6 +46,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     if (q->wave_cand.ensure((n_tiles + 8) * sizeof(uint32_t))) return -1;
     va->fs_fast = 1;
     va->tf_chunk = q->tune.tf_chunk;
+    va->tr_group = q->tune.tr_group;
     // table engine, M <= 15: two streams per lane (k_tablescan_fast2) -- the always-one bit M must be there
     if (q->table && q->tune.tf_pack2) {
         const unsigned M = (unsigned)q->m + (unsigned)q->dlen + 1u;
@@ -183,10 +186,17 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         dev_buf &dbm_buf = q->seg_dbm_active ? q->seg_dbm : q->dbm;
         if (dbm_buf.ensure(n_words * sizeof(uint64_t))) return -1;
         HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev2, st));     // (device_ms includes the bitmap since round 5)
         agh_launch_delim_bitmap(d_text, n, dq, (uint64_t *)dbm_buf.p, n_words, q->d_counters, st);
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev3, st));
         HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (flags & AGH_TIME_SCAN) {
+            float bm_ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&bm_ms, q->ev2, q->ev3));
+            q->dbm_ms += bm_ms;
+        }
         if (q->h_counters[AGH_C_DELIM_CHAIN])
             return fail("a run of overlapping delimiter occurrences exceeds 4 KiB (unsupported)");
         d_dbm = (const uint64_t *)dbm_buf.p;
@@ -665,6 +675,8 @@ void agh_read_tuning(agh_tuning *t)
     {
         const uint64_t c = env_u64("AGH_TF_CHUNK", AGH_TF_CHUNK_DEFAULT);
         t->tf_chunk = (c == 1024 || c == 2048 || c == 4096) ? (uint32_t)c : 0u;
+        const uint64_t g = env_u64("AGH_TR_GROUP", 8);
+        t->tr_group = (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ? (uint32_t)g : 8u;
     }
     t->fused = env_on("AGH_FUSED", AGH_FUSED_DEFAULT != 0);
     t->debug = getenv("AGH_DEBUG") != nullptr;
@@ -1177,10 +1189,17 @@ int agh_scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipSt
         dq.mb = 1u;
         dq.head_byte = is_first ? '\n' : q->delim[q->dlen - 1];
         HIP_TRY(hipMemsetAsync(q->d_counters, 0, AGH_C_COUNT * sizeof(uint32_t), st));
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev2, st));
         agh_launch_delim_bitmap(base, len, dq, (uint64_t *)q->dbm.p, n_words, q->d_counters, st);
+        if (flags & AGH_TIME_SCAN) HIP_TRY(hipEventRecord(q->ev3, st));
         HIP_TRY(hipMemcpyAsync(q->h_counters, q->d_counters, AGH_C_COUNT * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (flags & AGH_TIME_SCAN) {
+            float bm_ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&bm_ms, q->ev2, q->ev3));
+            res->device_ms += bm_ms;
+        }
         if (q->h_counters[AGH_C_DELIM_CHAIN])
             return fail("a run of overlapping delimiter occurrences exceeds 4 KiB (unsupported)");
         global_dbm = (const uint64_t *)q->dbm.p;
@@ -1238,7 +1257,8 @@ int agh_scan_device_impl(agh_query *q, const void *dev_text, uint64_t len, hipSt
         res->n_candidates += sr.candidates;
         res->n_stored += sr.stored;
         res->truncated |= sr.truncated;
-        res->device_ms += sr.ms;
+        res->device_ms += sr.ms + q->dbm_ms;    // (the delimiter-end bitmap of the segment, if it needed one)
+        q->dbm_ms = 0.f;
         res->sweep_ms += sr.sweep_ms;
         if (sr.sweep_ms > 0.f) res->sweep_launches += 1;
         res->lean_reruns += sr.lean_rerun;

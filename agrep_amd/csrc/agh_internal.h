@@ -118,6 +118,7 @@ struct agh_query {
     uint64_t hashset_slots_hint = 0;    // lean scans: slots wanted by the previous scan
     bool hashset_dirty = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    float dbm_ms = 0.f;                         // time of the delimiter-end bitmaps built since the last segment result
     // multi-pattern (-f) queries
     // general automaton (asearch1.c costs, <exact> segments): full scan only
     bool general = false;

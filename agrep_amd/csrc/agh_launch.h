@@ -15,6 +15,7 @@ struct agh_tuning {
     bool tf_pack2 = true;           // AGH_TF_PACK2: table engine, two streams per lane where M <= 15
     uint64_t tf_fast_min_mb = 0;    // AGH_TF_FAST_MIN_MB: table engine, fast form from this segment size on
     uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 / 2048 / 4096), 0 = by size
+    uint32_t tr_group = 8;          // AGH_TR_GROUP: tiles whose replay lists one wave of k_table_replay takes (1, 2, 4, 8, 16)
     bool fused = true;              // AGH_FUSED
     bool debug = false;             // AGH_DEBUG
     bool aligned_cuts_only = false; // AGH_ALIGNED_CUTS_ONLY
@@ -94,6 +95,7 @@ struct agh_scan_args {
     // walk exactly (AGH_FF_SLICE entries per 64 KiB tile) and its per-tile counts
     int fs_fast;
     uint32_t tf_chunk;              // table engine, fast form: bytes per lane (1024 / 2048 / 4096), 0 = by size
+    uint32_t tr_group;              // tiles per wave of k_table_replay (0: 8)
     uint64_t *fs_replay;
     uint32_t *fs_tile_cnt;
     long verify_blocks;      // AGH_VERIFY_BLOCKS: grid cap of k_verify (-1: the default)

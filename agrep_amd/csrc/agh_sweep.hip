@@ -283,16 +283,28 @@ __device__ __forceinline__ bool delim_occurs_at(const uint8_t *__restrict__ text
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_delim_bitmap(const uint8_t *__restrict__ text,
-                                                      uint64_t n, agh_dev_query q,
-                                                      uint64_t *__restrict__ dbm,
-                                                      uint64_t n_words,
-                                                      uint32_t *__restrict__ counters)
+// Round 5: the bitmap was 5 of the 7 ms of a 4 GiB scan under -d 'xy' (a byte at a time through delim_class, one
+// lane per 64 bytes).  Now a lane turns its 64 bytes (+ the 16 in front) into one "this byte equals delimiter byte j"
+// bit mask per j with dword SWAR compares (folded first under -i), ANDs the shifted masks into "an occurrence ends
+// here", and keeps all of them when no two of them overlap -- which is every lane of a text without runs of a
+// delimiter that overlaps itself.  A lane that sees two overlapping occurrences (ends less than dlen apart), and the
+// lane with the virtual head byte in front of it, selects leftmost / non-overlapping with the serial automaton as before.
+__device__ __forceinline__ uint32_t delim_eq4(uint32_t x, uint32_t dd)
 {
-    const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wi >= n_words) return;
-    const uint64_t b = wi * 64;
-    if (b >= n) { dbm[wi] = 0; return; }
+    const uint32_t y = x ^ dd;                  // bit 7 of every byte of x that equals the byte in dd, packed to 4 bits
+    const uint32_t z = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
+    return ((z >> 7) * 0x01020408u) >> 24;      // bytes 0..3 -> bits 0..3 (no carries: all partial products distinct)
+}
+__device__ __forceinline__ uint32_t fold4(uint32_t x)
+{
+    const uint32_t t = x & 0x7f7f7f7fu;         // 'A'..'Z' -> 'a'..'z', four bytes at once
+    const uint32_t up = (t + 0x3f3f3f3fu) & ~(t + 0x25252525u) & ~x & 0x80808080u;
+    return x | (up >> 2);
+}
+
+__device__ uint64_t delim_bitmap_serial(const uint8_t *__restrict__ text, uint64_t n, const agh_dev_query &q,
+                                        uint64_t b, uint32_t *__restrict__ counters)
+{
     // restart point: no occurrence may start before r and end at or after r
     uint64_t r = b >= q.dlen - 1 ? b - (q.dlen - 1) : 0;
     uint32_t steps = 0;
@@ -319,7 +331,74 @@ __global__ __launch_bounds__(256) void k_delim_bitmap(const uint8_t *__restrict_
             ds = 0;
         }
     }
-    dbm[wi] = out;
+    return out;
+}
+
+__global__ __launch_bounds__(256) void k_delim_bitmap(const uint8_t *__restrict__ text,
+                                                      uint64_t n, agh_dev_query q,
+                                                      uint64_t *__restrict__ dbm,
+                                                      uint64_t n_words,
+                                                      uint32_t *__restrict__ counters)
+{
+    const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    const uint64_t b = wi * 64;
+    if (b >= n) { dbm[wi] = 0; return; }
+    if (wi == 0) {                              // (the virtual head byte in front)
+        dbm[0] = delim_bitmap_serial(text, n, q, 0, counters);
+        return;
+    }
+    // bytes b - 16 .. b + 63 as 20 dwords (pieces at or behind the end of the text: none; the piece that holds the
+    // last byte is readable to its end, its bytes behind the text are masked below)
+    uint32_t w[20];
+#pragma unroll
+    for (uint32_t p = 0; p < 5; ++p) {
+        const uint64_t a = b - 16 + 16u * p;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (a < n) v = *reinterpret_cast<const uint4 *>(text + a);
+        w[4 * p] = v.x; w[4 * p + 1] = v.y; w[4 * p + 2] = v.z; w[4 * p + 3] = v.w;
+    }
+    if (q.dfold) {
+#pragma unroll
+        for (uint32_t d = 0; d < 20; ++d) w[d] = fold4(w[d]);
+    }
+    // window bit i = text byte b - 16 + i; 80 bits as (lo: 64, hi: 16)
+    const uint64_t live = n - (b - 16);         // bytes of the window inside the text (> 16)
+    const uint64_t live_lo = live >= 64 ? ~0ull : ((1ull << live) - 1ull);
+    const uint32_t live_hi = live >= 80 ? 0xffffu : (live > 64 ? ((1u << (live - 64)) - 1u) : 0u);
+    uint64_t e_lo = ~0ull;
+    uint32_t e_hi = 0xffffu;
+    const uint32_t dlen = q.dlen;
+    for (uint32_t j = 0; j < dlen; ++j) {
+        const uint32_t dd = (uint32_t)q.dbytes[j] * 0x01010101u;
+        uint64_t m_lo = 0;
+        uint32_t m_hi = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < 16; ++d) m_lo |= (uint64_t)delim_eq4(w[d], dd) << (4u * d);
+#pragma unroll
+        for (uint32_t d = 16; d < 20; ++d) m_hi |= delim_eq4(w[d], dd) << (4u * (d - 16));
+        m_lo &= live_lo;
+        m_hi &= live_hi;
+        const uint32_t sh = dlen - 1u - j;      // an occurrence that ends at i has byte j at i - sh
+        if (sh) {
+            m_hi = ((m_hi << sh) | (uint32_t)(m_lo >> (64u - sh))) & 0xffffu;
+            m_lo <<= sh;
+        }
+        e_lo &= m_lo;
+        e_hi &= m_hi;
+    }
+    // two occurrences whose ends are less than dlen apart overlap: the serial selection decides
+    uint64_t s_lo = e_lo, a_lo = 0;
+    uint32_t s_hi = e_hi, a_hi = 0;
+    for (uint32_t p = 1; p < dlen; ++p) {
+        s_hi = ((s_hi << 1) | (uint32_t)(s_lo >> 63)) & 0xffffu;
+        s_lo <<= 1;
+        a_lo |= s_lo;
+        a_hi |= s_hi;
+    }
+    const uint64_t out = (e_lo >> 16) | ((uint64_t)e_hi << 48);
+    const uint64_t ov = ((e_lo & a_lo) >> 16) | ((uint64_t)(e_hi & a_hi) << 48);
+    dbm[wi] = ov ? delim_bitmap_serial(text, n, q, b, counters) : out;
 }
 
 void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &q, uint64_t *dbm,

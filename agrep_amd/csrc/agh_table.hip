@@ -353,18 +353,24 @@ __device__ __forceinline__ void table_reset_state(const agh_dev_tables &T, uint3
 #define AGH_TF_CHUNK_MAX 4096u
 #define AGH_TF_SLICE_OF(chunk) ((chunk) / 4u)      // replay entries per tile (64 chunks)
 
-template <int K, bool COSTS>
+// MB (round 5): delimiters of several bytes / a folded letter -- WHERE a record ends is read from the delimiter-end
+// bitmap (16 bits per 16-byte piece, one 2-byte load), so the reset select is driven by the bitmap's bit instead of
+// the byte's table entry; what a boundary does to the state (RF: every level Init[0], the delimiter's last byte
+// consumed again, level 0 masked) is the one-byte case's.  A lane that starts inside a delimiter needs no special
+// case here: its state is untrusted until the first bitmap bit anyway.
+template <int K, bool COSTS, bool MB>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
-    uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters, uint32_t tf_chunk)
+    uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters, uint32_t tf_chunk,
+    const uint16_t *__restrict__ dbm16)
 {
     const uint32_t tf_slice = AGH_TF_SLICE_OF(tf_chunk);
     struct MK { uint32_t cm, kb; };
     __shared__ MK tab[256];
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * WAVE * AGH_FS_ROW];
     tab[threadIdx.x].cm = mask_g[threadIdx.x];
-    tab[threadIdx.x].kb = threadIdx.x == q.delim ? 0u : ~0u;
+    tab[threadIdx.x].kb = (!MB && threadIdx.x == q.delim) ? 0u : ~0u;
     __syncthreads();
     uint32_t RF[K + 1];
     const uint32_t ci = q.ci, cs_ = q.cs, cd = q.cd;
@@ -409,17 +415,19 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
         }
         // 16 bytes: -> "some trusted record end in the piece shows an end bit on the top level"
         uint32_t dseen = 0;                     // ~0 once a delimiter went through piece()
-        auto piece = [&](uint4 v, uint32_t nbytes) -> uint32_t {
+        auto piece = [&](uint4 v, uint32_t nbytes, uint32_t d16) -> uint32_t {
             const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t nd16 = ~d16;         // (MB) bit b clear: a delimiter ends at byte b
             uint32_t flag = 0;
 #pragma unroll
             for (uint32_t b = 0; b < 16; ++b) {
                 if (b < nbytes) {
                     const MK e = tab[(dws[b >> 2] >> (8u * (b & 3u))) & 0xffu];
-                    const uint32_t top = A.template feed<COSTS>(e.cm, e.kb, T, RF, ci, cs_, cd);
-                    flag |= top & ~e.kb & trusted;
-                    trusted |= ~e.kb;
-                    dseen |= ~e.kb;
+                    const uint32_t kb = MB ? (uint32_t)__builtin_amdgcn_sbfe((int)nd16, b, 1u) : e.kb;
+                    const uint32_t top = A.template feed<COSTS>(e.cm, kb, T, RF, ci, cs_, cd);
+                    flag |= top & ~kb & trusted;
+                    trusted |= ~kb;
+                    dseen |= ~kb;
                 }
             }
             return flag & T.endposition;
@@ -435,19 +443,32 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
             }
             cnt += (uint32_t)__popcll(fm);
         };
+        // (MB) the delimiter-end bits of two rounds (128 text bytes): one 16-byte load per lane, two rounds ahead.
+        // (8-byte loads per round cost as much L1 time as the text itself -- 64 lanes, 64 cache lines per
+        // instruction: 5.9 ms on 4 GiB; 16 bytes per two rounds: see profiles/r05_perf_table_mb.log)
+        auto dload = [&](uint64_t at) -> uint4 {
+            return (MB && at < n) ? *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(dbm16) + (at >> 3))
+                                  : make_uint4(0, 0, 0, 0);
+        };
+        uint4 dv = make_uint4(0, 0, 0, 0), dnext = dload(cs);
         for (uint32_t r = 0; r < tf_chunk / AGH_FS_ROUND; ++r) {
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i)
                 *reinterpret_cast<uint4 *>(ring_w + 16u * i * AGH_FS_ROW) = g[i];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            if (MB && !(r & 1u)) {
+                dv = dnext;
+                dnext = dload(cs + (uint64_t)(r + 2) * AGH_FS_ROUND);
+            }
+            const uint64_t dcur = (r & 1u) ? ((uint64_t)dv.w << 32 | dv.z) : ((uint64_t)dv.y << 32 | dv.x);
             if (r + 1 < tf_chunk / AGH_FS_ROUND) gather(r + 1, g);
 #pragma unroll 1
             for (uint32_t p = 0; p < 4; ++p) {
                 const uint32_t off = r * AGH_FS_ROUND + 16u * p;
                 const uint4 v = *reinterpret_cast<const uint4 *>(ring_r + 16u * p);
                 const uint32_t nb = off + 16u <= len ? 16u : (off < len ? len - off : 0u);
-                uint32_t flag = nb ? piece(v, nb) : 0u;
+                uint32_t flag = nb ? piece(v, nb, (uint32_t)(dcur >> (16u * p)) & 0xffffu) : 0u;
                 // the piece that holds the last byte of the text: the appended delimiter is the replay's
                 if (nb && cs + off + 16u >= n && trusted) flag = 1u;
                 emit(flag != 0u, cs + off);
@@ -460,15 +481,27 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
         // front of it, the next lane trusts its state only behind the first delimiter IT sees)
         bool open = len == tf_chunk && trusted != 0u && ce < n;
         dseen = 0;
+        // (the next piece is loaded while this one runs: with records of a KiB or two the walk is most of the kernel)
+        uint4 vw = make_uint4(0, 0, 0, 0);
+        uint32_t dw16 = 0;
+        if (open) {
+            vw = *reinterpret_cast<const uint4 *>(text + ce);
+            dw16 = MB ? (uint32_t)dbm16[ce >> 4] : 0u;
+        }
         for (uint64_t p0 = ce; __ballot(open); p0 += 16) {
             // whole 16-byte pieces until one holds a delimiter: what it flags behind that delimiter
             // belongs to the next lane, which flags it as well -- the replay does not mind
             uint32_t flag = 0;
             const bool mine = open;
             if (open) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
+                const uint4 v = vw;
+                const uint32_t d16 = dw16;
+                if (p0 + 16 < n) {
+                    vw = *reinterpret_cast<const uint4 *>(text + p0 + 16);
+                    dw16 = MB ? (uint32_t)dbm16[(p0 + 16) >> 4] : 0u;
+                }
                 const uint32_t nb = p0 + 16 <= n ? 16u : (uint32_t)(n - p0);
-                flag = piece(v, nb);
+                flag = piece(v, nb, d16);
                 if (dseen) open = false;
                 else if (p0 + 16 >= n) {         // the text ends inside my record: the last piece
                     flag = 1u;
@@ -511,18 +544,18 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
 #else
 #define AGH_TF2_ATTR
 #endif
-template <int K, bool COSTS>
+template <int K, bool COSTS, bool MB>
 __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
     uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters, uint32_t M, uint32_t n_tiles1,
-    uint32_t tf_chunk)
+    uint32_t tf_chunk, const uint16_t *__restrict__ dbm16)
 {
     const uint32_t tf_slice = AGH_TF_SLICE_OF(tf_chunk);
     __shared__ uint32_t tab[256];               // mask (bits 0..M-1) | kill << 16 (0 for the delimiter, else 0xffff)
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * 2 * WAVE * AGH_TF2_ROW];
     const uint32_t keep = (2u << M) - 1u;       // bits 0..M
-    tab[threadIdx.x] = (mask_g[threadIdx.x] & keep & 0xffffu) | (threadIdx.x == q.delim ? 0u : 0xffff0000u);
+    tab[threadIdx.x] = (mask_g[threadIdx.x] & keep & 0xffffu) | ((!MB && threadIdx.x == q.delim) ? 0u : 0xffff0000u);
     __syncthreads();
     auto dup = [&](uint32_t x) -> uint32_t { x &= keep; return x | (x << 16); };
     agh_dev_tables Tp = T;
@@ -586,16 +619,20 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
         // the top level".  live: 0xffff per half for the bytes that exist (FULL: all 16 of both)
         // mode 0: bytes beyond a stream's end are masked (live); 1: all 16 bytes of both streams exist; 2: and
         // every stream of the wave is trusted already (the common case after a record or two): no bookkeeping
-        auto piece = [&](uint4 va, uint4 vb, uint32_t nba, uint32_t nbb, auto mode) -> uint32_t {
+        auto piece = [&](uint4 va, uint4 vb, uint32_t nba, uint32_t nbb, uint32_t d16a, uint32_t d16b, auto mode) -> uint32_t {
             constexpr int MODE = decltype(mode)::value;
             const uint32_t da[4] = {va.x, va.y, va.z, va.w}, db[4] = {vb.x, vb.y, vb.z, vb.w};
+            // (MB: the kill halves come from the delimiter-end bitmap of either stream's piece; bits behind the text are clear)
+            const uint32_t nda = ~d16a, ndb = ~d16b;
             uint32_t flag = 0;
 #pragma unroll
             for (uint32_t b = 0; b < 16; ++b) {
                 const uint32_t ea = tab[(da[b >> 2] >> (8u * (b & 3u))) & 0xffu];
                 const uint32_t eb = tab[(db[b >> 2] >> (8u * (b & 3u))) & 0xffu];
                 const uint32_t cm = __builtin_amdgcn_perm(eb, ea, 0x05040100u);
-                const uint32_t kb = __builtin_amdgcn_perm(eb, ea, 0x07060302u);
+                const uint32_t kb = MB ? __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)ndb, b, 1u),
+                                                               (uint32_t)__builtin_amdgcn_sbfe((int)nda, b, 1u), 0x05040100u)
+                                       : __builtin_amdgcn_perm(eb, ea, 0x07060302u);
                 const uint32_t top = A.template feed<COSTS>(cm, kb, Tp, RF, ci, cs_, cd);
                 if (MODE == 2) {
                     flag |= top & ~kb;
@@ -623,6 +660,13 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
             }
             cnt += (uint32_t)__popcll(fm);
         };
+        // (MB) the delimiter-end bits of two rounds and either stream: one 16-byte load each, two rounds ahead
+        // (k_tablescan_fast has the reason)
+        auto dload = [&](uint64_t at) -> uint4 {
+            return (MB && at < n) ? *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(dbm16) + (at >> 3))
+                                  : make_uint4(0, 0, 0, 0);
+        };
+        uint4 dva = make_uint4(0, 0, 0, 0), dvb = dva, dna = dload(cs[0]), dnb = dload(cs[1]);
         for (uint32_t r = 0; r < tf_chunk / AGH_FS_ROUND; ++r) {
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {
@@ -631,6 +675,14 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            if (MB && !(r & 1u)) {
+                dva = dna;
+                dvb = dnb;
+                dna = dload(cs[0] + (uint64_t)(r + 2) * AGH_FS_ROUND);
+                dnb = dload(cs[1] + (uint64_t)(r + 2) * AGH_FS_ROUND);
+            }
+            const uint64_t dca = (r & 1u) ? ((uint64_t)dva.w << 32 | dva.z) : ((uint64_t)dva.y << 32 | dva.x);
+            const uint64_t dcb = (r & 1u) ? ((uint64_t)dvb.w << 32 | dvb.z) : ((uint64_t)dvb.y << 32 | dvb.x);
             if (r + 1 < tf_chunk / AGH_FS_ROUND) {
                 gather(r + 1, 0u, ga);
                 gather(r + 1, WAVE, gb);
@@ -644,9 +696,10 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
                 const uint32_t nbb = off + 16u <= len[1] ? 16u : (off < len[1] ? len[1] - off : 0u);
                 const bool full = __ballot(nba != 16u || nbb != 16u) == 0ull;
                 const bool settled = full && __ballot(trusted != ~0u) == 0ull;
-                const uint32_t flag = settled ? piece(va, vb, nba, nbb, std::integral_constant<int, 2>{})
-                                      : full  ? piece(va, vb, nba, nbb, std::integral_constant<int, 1>{})
-                                              : piece(va, vb, nba, nbb, std::integral_constant<int, 0>{});
+                const uint32_t posa = (uint32_t)(dca >> (16u * p)) & 0xffffu, posb = (uint32_t)(dcb >> (16u * p)) & 0xffffu;
+                const uint32_t flag = settled ? piece(va, vb, nba, nbb, posa, posb, std::integral_constant<int, 2>{})
+                                      : full  ? piece(va, vb, nba, nbb, posa, posb, std::integral_constant<int, 1>{})
+                                              : piece(va, vb, nba, nbb, posa, posb, std::integral_constant<int, 0>{});
                 // the piece that holds the last byte of the text: the appended delimiter is the replay's
                 bool fa = nba && (flag & 0xffffu), fb = nbb && (flag >> 16);
                 if (nba && cs[0] + off + 16u >= n && (trusted & 0xffffu)) fa = true;
@@ -661,20 +714,42 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
         bool opa = len[0] == tf_chunk && (trusted & 0xffffu) != 0u && ce[0] < n;
         bool opb = len[1] == tf_chunk && (trusted >> 16) != 0u && ce[1] < n;
         dseen = 0;
+        // (the next pieces are loaded while these run: with records of a KiB or two the walk is most of the kernel)
+        const uint4 vfill = make_uint4(fill4, fill4, fill4, fill4);
+        uint4 wa = vfill, wb = vfill;
+        uint32_t wda = 0, wdb = 0;
+        if (opa) {
+            wa = *reinterpret_cast<const uint4 *>(text + ce[0]);
+            wda = MB ? (uint32_t)dbm16[ce[0] >> 4] : 0u;
+        }
+        if (opb) {
+            wb = *reinterpret_cast<const uint4 *>(text + ce[1]);
+            wdb = MB ? (uint32_t)dbm16[ce[1] >> 4] : 0u;
+        }
         for (uint64_t step = 0; __ballot(opa || opb); step += 16) {
             const uint64_t pa = ce[0] + step, pb = ce[1] + step;
             const bool ma = opa, mb = opb;
-            uint4 va = make_uint4(fill4, fill4, fill4, fill4), vb = va;
-            uint32_t nba = 0, nbb = 0;
+            uint4 va = vfill, vb = vfill;
+            uint32_t nba = 0, nbb = 0, da16 = 0, db16 = 0;
             if (opa) {
-                va = *reinterpret_cast<const uint4 *>(text + pa);
+                va = wa;
+                da16 = wda;
                 nba = pa + 16 <= n ? 16u : (uint32_t)(n - pa);
+                if (pa + 16 < n) {
+                    wa = *reinterpret_cast<const uint4 *>(text + pa + 16);
+                    wda = MB ? (uint32_t)dbm16[(pa + 16) >> 4] : 0u;
+                }
             }
             if (opb) {
-                vb = *reinterpret_cast<const uint4 *>(text + pb);
+                vb = wb;
+                db16 = wdb;
                 nbb = pb + 16 <= n ? 16u : (uint32_t)(n - pb);
+                if (pb + 16 < n) {
+                    wb = *reinterpret_cast<const uint4 *>(text + pb + 16);
+                    wdb = MB ? (uint32_t)dbm16[(pb + 16) >> 4] : 0u;
+                }
             }
-            const uint32_t flag = piece(va, vb, nba, nbb, std::integral_constant<int, 0>{});
+            const uint32_t flag = piece(va, vb, nba, nbb, da16, db16, std::integral_constant<int, 0>{});
             bool fa = ma && (flag & 0xffffu), fb = mb && (flag >> 16);
             if (opa) {
                 if (dseen & 0xffffu) opa = false;
@@ -702,20 +777,36 @@ __global__ __launch_bounds__(256) void k_table_replay(
     const uint32_t *__restrict__ mask_g, const uint64_t *__restrict__ replay,
     const uint32_t *__restrict__ tile_cnt, uint32_t n_tiles,
     const uint32_t *__restrict__ strip_prefix, const uint32_t *__restrict__ wave_prefix,
-    uint32_t n_strips, agh_marks mk, uint32_t tf_slice)
+    uint32_t n_strips, agh_marks mk, uint32_t tf_slice, const uint64_t *__restrict__ dbm, uint32_t group)
 {
     __shared__ uint32_t lmask[256];
     lmask[threadIdx.x] = mask_g[threadIdx.x];
     __syncthreads();
     const uint32_t dd = q.delim * 0x01010101u;
-    for (uint32_t tile = blockIdx.x * 4u + threadIdx.x / WAVE; tile < n_tiles; tile += gridDim.x * 4u) {
-        const uint32_t cnt = tile_cnt[tile];
+    const bool mb = q.mb != 0;                  // record ends from the delimiter-end bitmap (as in k_tablescan)
+    // A wave takes the lists of `group` consecutive tiles at once (round 5; 8 by default): a tile lists five pieces or
+    // so (a match every 500 lines) and a VALU instruction costs a wave its four cycles whatever the number of busy lanes
+    // -- but a wave per SIMD has nothing to hide its latencies behind, so not the fullest waves either
+    // (profiles/r05_perf_table_mb.log).
+    const uint32_t n_groups = (n_tiles + group - 1u) / group;
+    for (uint32_t grp = blockIdx.x * 4u + threadIdx.x / WAVE; grp < n_groups; grp += gridDim.x * 4u) {
+        const uint32_t tl = grp * group + (uint32_t)lane_id();
+        const uint32_t mine = ((uint32_t)lane_id() < group && tl < n_tiles) ? tile_cnt[tl] : 0u;
+        const uint32_t incl = wave_sum_to_lane63(mine);     // inclusive scan over the lanes
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         for (uint32_t e = (uint32_t)lane_id(); e < cnt; e += WAVE) {
-            const uint64_t P = replay[(uint64_t)tile * tf_slice + e];
+            uint32_t tsel = 0, tbase = 0;
+#pragma unroll
+            for (int t = 0; t < 15; ++t) {
+                const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)incl, t);
+                if (it <= e) { tsel = (uint32_t)t + 1u; tbase = it; }
+            }
+            const uint64_t P = replay[(uint64_t)(grp * group + tsel) * tf_slice + (e - tbase)];
             uint64_t pend = P + 16;
             if (pend > n) pend = n;
             // records that end in [P, pend): one per delimiter there, plus the open one at the text's end
-            uint64_t rs = lean_record_start(text, P, q.delim, mk);      // start of the record that holds byte P
+            uint64_t rs = mb ? lean_record_start_mb(dbm, P, mk)         // start of the record that holds byte P
+                             : lean_record_start(text, P, q.delim, mk);
             if (rs == ~0ull) {                  // more than 1 MiB back: this text belongs to the exact kernel
                 mk.counters[AGH_C_OVERFLOW] = 1u;
                 continue;
@@ -724,28 +815,84 @@ __global__ __launch_bounds__(256) void k_table_replay(
             if (!LEAN) {
                 const uint64_t strip = rs >> AGH_STRIP_SHIFT;
                 rec = strip < n_strips ? wave_prefix[strip / AGH_WAVE_STRIPS] + strip_prefix[strip] : 0u;
-                for (uint64_t i = strip << AGH_STRIP_SHIFT; i + 16 <= rs; i += 16)
-                    rec += delims_in(*reinterpret_cast<const uint4 *>(text + i), dd);
-                for (uint64_t i = rs & ~(uint64_t)15; i < rs; ++i) rec += text[i] == q.delim;
+                if (mb) {
+                    rec += dbm_count(dbm, strip << AGH_STRIP_SHIFT, rs);
+                } else {
+                    for (uint64_t i = strip << AGH_STRIP_SHIFT; i + 16 <= rs; i += 16)
+                        rec += delims_in(*reinterpret_cast<const uint4 *>(text + i), dd);
+                    for (uint64_t i = rs & ~(uint64_t)15; i < rs; ++i) rec += text[i] == q.delim;
+                }
             }
             TableAutomaton<K> A;
             A.reset(T);
             // the state at the record's start: what the delimiter (or the virtual head byte) in front
             // of it left behind
             if (rs == 0) (void)A.template feed_q<COSTS>(lmask[q.head_byte], T, q);
+            else if (mb) A.template force_boundary<COSTS>(lmask[text[rs - 1]], T, q);
             else (void)A.template feed_q<COSTS>(lmask[q.delim], T, q);
-            for (uint64_t i = rs; i < pend; ++i) {
-                const uint32_t r = A.template feed_q<COSTS>(lmask[text[i]], T, q);
-                if (r & 1u) {                   // a record closes at i
-                    if ((r & 2u) && i >= P) {
-                        if (LEAN) lean_insert(mk, rs); else mark_record(mk, rec, i);
+            // 16-byte pieces (aligned; the next one is on its way while this one runs): a byte load and -- under
+            // delimiters from the bitmap -- an 8-byte load per text byte, plus three branches, made this loop ~200
+            // cycles a byte: 1.4 ms of a 4.5 ms scan (15 of 24 ms with 1.7 KB records), five lanes of a wave busy.
+            // No record ends in [rs, P) (rs is the start of the record that holds byte P, P is 16-byte aligned), so the
+            // whole pieces in front of P only advance the recurrence: 16 masks from LDS, 16 steps, nothing else.
+            const uint64_t pb_end = (pend + 15) & ~(uint64_t)15;
+            uint64_t pb = rs & ~(uint64_t)15;
+            uint4 vn = make_uint4(0, 0, 0, 0);
+            uint32_t dn = 0;
+            if (pb < pb_end) {
+                vn = *reinterpret_cast<const uint4 *>(text + pb);
+                dn = mb ? (uint32_t)reinterpret_cast<const uint16_t *>(dbm)[pb >> 4] : 0u;
+            }
+            for (; pb < pb_end; pb += 16) {
+                const uint4 v = vn;
+                const uint32_t d16 = dn;
+                if (pb + 16 < pb_end) {
+                    vn = *reinterpret_cast<const uint4 *>(text + pb + 16);
+                    dn = mb ? (uint32_t)reinterpret_cast<const uint16_t *>(dbm)[(pb + 16) >> 4] : 0u;
+                }
+                const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+                if (pb >= rs && pb + 16 <= P) {             // a whole piece inside the record
+                    uint32_t cm[16];
+#pragma unroll
+                    for (uint32_t bi = 0; bi < 16; ++bi) cm[bi] = lmask[(dws[bi >> 2] >> (8u * (bi & 3u))) & 0xffu];
+#pragma unroll
+                    for (uint32_t bi = 0; bi < 16; ++bi) (void)A.template feed_q<COSTS>(cm[bi], T, q);
+                    continue;
+                }
+                const uint32_t b0 = pb < rs ? (uint32_t)(rs - pb) : 0u;           // (rs only moves forward inside the loop: fixed here)
+                const uint32_t b1 = pb + 16 <= pend ? 16u : (uint32_t)(pend - pb);
+#pragma unroll
+                for (uint32_t bi = 0; bi < 16; ++bi) {
+                    if (bi < b0 || bi >= b1) continue;
+                    const uint64_t i = pb + bi;
+                    const uint32_t c = (dws[bi >> 2] >> (8u * (bi & 3u))) & 0xffu;
+                    uint32_t r = A.template feed_q<COSTS>(lmask[c], T, q);
+                    if (mb) {                   // k_tablescan's step(): the bitmap says where, the automaton what
+                        const uint32_t dbit = (d16 >> bi) & 1u;
+                        if (dbit && !(r & 1u)) {
+                            A.template force_boundary<COSTS>(lmask[c], T, q);
+                            r = 1u;
+                        } else if (!dbit) {
+                            r = 0u;
+                        }
                     }
-                    ++rec;
-                    rs = i + 1;
+                    if (r & 1u) {               // a record closes at i
+                        if ((r & 2u) && i >= P) {
+                            if (LEAN) lean_insert(mk, rs); else mark_record(mk, rec, i);
+                        }
+                        ++rec;
+                        rs = i + 1;
+                    }
                 }
             }
             if (pend == n && q.tail_virtual && rs < n) {    // asearch.c:87-91: the open record at the end
-                const uint32_t r = A.template feed_q<COSTS>(lmask[q.delim], T, q);
+                uint32_t r = 0;
+                if (mb) {
+                    for (uint32_t jd = 0; jd < q.dlen && !(r & 1u); ++jd)
+                        r = A.template feed_q<COSTS>(lmask[q.dbytes[jd]], T, q);
+                } else {
+                    r = A.template feed_q<COSTS>(lmask[q.delim], T, q);
+                }
                 if ((r & 3u) == 3u) {
                     if (LEAN) lean_insert(mk, rs); else mark_record(mk, rec, n);
                 }
@@ -771,7 +918,8 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
         const uint64_t tf_tile = (uint64_t)WAVE * tf_chunk;             // 64 / 128 / 256 KiB tiles
         const uint32_t nt = (uint32_t)((a.n + tf_tile - 1) / tf_tile);
         const uint32_t fblocks = (nt + 3u) / 4u > 16384u ? 16384u : (nt + 3u) / 4u;
-        const uint32_t rblocks = fblocks;
+        const uint32_t group = a.tr_group ? a.tr_group : 8u;
+        const uint32_t rblocks = ((nt + group - 1u) / group + 3u) / 4u;    // (k_table_replay: a wave per `group` tiles)
         const uint32_t nt2 = (nt + 1u) / 2u;
         const uint32_t fblocks2 = (nt2 + 3u) / 4u > 16384u ? 16384u : (nt2 + 3u) / 4u;
         const uint32_t M = (uint32_t)a.q.m + a.q.dlen + 1u;                  // maskgen's M (agh_query_from_maskgen)
@@ -779,36 +927,38 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
             hipLaunchKernelGGL((k_table_replay<KK, LEANV, COSTV>), dim3(rblocks), dim3(256), 0, st, \
                                (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
                                (const uint64_t *)a.fs_replay, (const uint32_t *)a.fs_tile_cnt, nt, \
-                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, tf_slice)
+                               a.strip_prefix, a.wave_prefix, a.n_strips, a.mk, tf_slice, a.dbm, group)
+#define AGH_TF_FAST(KK, COSTV, MBV)                                                           \
+            if (a.fs_fast == 2)                                                               \
+                hipLaunchKernelGGL((k_tablescan_fast2<KK, COSTV, MBV>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
+                                   (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                                   a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt, tf_chunk, (const uint16_t *)a.dbm); \
+            else                                                                              \
+                hipLaunchKernelGGL((k_tablescan_fast<KK, COSTV, MBV>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
+                                   (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                                   a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_chunk, (const uint16_t *)a.dbm)
+#define AGH_TF_TAIL(KK, COSTV)                                                                \
+            if (lean) AGH_TF_REPLAY(KK, true, COSTV); else AGH_TF_REPLAY(KK, false, COSTV);   \
+            break
+// (delimiters of several bytes: fast forms up to k = 4 -- the host keeps more errors on the exact kernel)
+#define AGH_TF_CASE_MB(KK)                                                                    \
+    case KK:                                                                                  \
+        if (costs && a.q.mb) { AGH_TF_FAST(KK, true, true); AGH_TF_TAIL(KK, true); }          \
+        if (costs) { AGH_TF_FAST(KK, true, false); AGH_TF_TAIL(KK, true); }                   \
+        if (a.q.mb) { AGH_TF_FAST(KK, false, true); AGH_TF_TAIL(KK, false); }                 \
+        { AGH_TF_FAST(KK, false, false); AGH_TF_TAIL(KK, false); }
 #define AGH_TF_CASE(KK)                                                                       \
     case KK:                                                                                  \
-        if (costs) {            /* (asearch1.c's levels) */                                   \
-            if (a.fs_fast == 2)                                                               \
-                hipLaunchKernelGGL((k_tablescan_fast2<KK, true>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
-                                   (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                                   a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt, tf_chunk); \
-            else                                                                              \
-            hipLaunchKernelGGL((k_tablescan_fast<KK, true>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
-                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                               a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_chunk);          \
-            if (lean) AGH_TF_REPLAY(KK, true, true); else AGH_TF_REPLAY(KK, false, true);     \
-            break;                                                                            \
-        }                                                                                     \
-        if (a.fs_fast == 2)                                                                   \
-            hipLaunchKernelGGL((k_tablescan_fast2<KK, false>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
-                               (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                               a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt, tf_chunk); \
-        else                                                                                  \
-        hipLaunchKernelGGL((k_tablescan_fast<KK, false>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
-                           (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                           a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_chunk);          \
-        if (lean) AGH_TF_REPLAY(KK, true, false); else AGH_TF_REPLAY(KK, false, false);       \
-        break;
+        if (costs) { AGH_TF_FAST(KK, true, false); AGH_TF_TAIL(KK, true); }                   \
+        { AGH_TF_FAST(KK, false, false); AGH_TF_TAIL(KK, false); }
         switch (a.q.k) {
-            AGH_TF_CASE(0) AGH_TF_CASE(1) AGH_TF_CASE(2) AGH_TF_CASE(3) AGH_TF_CASE(4)
+            AGH_TF_CASE_MB(0) AGH_TF_CASE_MB(1) AGH_TF_CASE_MB(2) AGH_TF_CASE_MB(3) AGH_TF_CASE_MB(4)
             AGH_TF_CASE(5) AGH_TF_CASE(6) AGH_TF_CASE(7) AGH_TF_CASE(8)
         default: break;
         }
+#undef AGH_TF_CASE_MB
+#undef AGH_TF_FAST
+#undef AGH_TF_TAIL
 #undef AGH_TF_CASE
 #undef AGH_TF_REPLAY
         return;

@@ -730,6 +730,16 @@ def test_table_engine_with_multi_byte_delimiters(agh):
             res_c, _ = q.scan_buffer(t, flags=agh.COUNT)
             res_n, _ = q.scan_buffer(t, flags=agh.COUNT | agh.FORCE_NUMBERED)
             assert res_c.n_matched == res_n.n_matched == want[0], (case["pattern"], case["opts"], ti)
+            # the same on the exact one-kernel form (the default above is the fast form + replay since round 5),
+            # and with one stream per lane
+            for sw in ("AGH_FS_FAST", "AGH_TF_PACK2"):
+                os.environ[sw] = "0"
+                try:
+                    res_x, ms_x = q.scan_buffer(t, cap=300000)
+                    res_xc, _ = q.scan_buffer(t, flags=agh.COUNT)
+                finally:
+                    del os.environ[sw]
+                assert (res_x.n_matched, [(s, e) for s, e, _ in ms_x]) == want and res_xc.n_matched == want[0], (sw, case["pattern"], ti)
         q.close()
 
 
