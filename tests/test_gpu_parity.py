@@ -740,6 +740,23 @@ def test_table_engine_with_multi_byte_delimiters(agh):
                 finally:
                     del os.environ[sw]
                 assert (res_x.n_matched, [(s, e) for s, e, _ in ms_x]) == want and res_xc.n_matched == want[0], (sw, case["pattern"], ti)
+            # ... and with edit costs (asearch1.c's levels, fast form and exact kernel)
+            if case["k"] >= 1 and ti <= 1:
+                for costs in ((2, 1, 1), (1, 2, 2)):
+                    want_c = O.asearch_tables_costs(ot, case["k"], costs, t, delim=delim, cap=300000)
+                    q.set_costs(*costs)
+                    try:
+                        res_k, ms_k = q.scan_buffer(t, cap=300000)
+                        res_kc, _ = q.scan_buffer(t, flags=agh.COUNT)
+                        os.environ["AGH_FS_FAST"] = "0"
+                        try:
+                            res_kx, _ = q.scan_buffer(t, flags=agh.COUNT)
+                        finally:
+                            del os.environ["AGH_FS_FAST"]
+                    finally:
+                        q.set_costs(1, 1, 1)
+                    assert (res_k.n_matched, [(s, e) for s, e, _ in ms_k]) == want_c, (costs, case["pattern"], case["opts"], ti)
+                    assert res_kc.n_matched == res_kx.n_matched == want_c[0], (costs, case["pattern"], case["opts"], ti)
         q.close()
 
 
