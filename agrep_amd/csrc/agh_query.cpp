@@ -148,9 +148,24 @@ static void choose_filter(agh_query *q)
         // '\n' in front of a file, the delimiter appended at its end (asearch.c:69-91), the last byte
         // of the previous segment.  Samples are taken from real text only, so such positions end a
         // run: the sampled core of an occurrence then lies inside its record.
+        // Round 5, delimiters of several bytes: WHICH positions a byte outside the text can reach.  The bytes of a real
+        // delimiter occurrence are text like any other (sampled, and the verifier takes the verdict at the
+        // occurrence's last byte as asearch.c does), so `-d 'From '` need not cost every pattern with an r, o or m in
+        // it its filter.  Outside the text stand (a) the byte in front of a segment -- '\n' or the last delimiter byte,
+        // re-fed after the reset (asearch.c:175-186) -- which only the first k + 1 positions can take, and (b) the dlen
+        // bytes appended at the end, which an occurrence that ends inside them takes with its last positions: position
+        // p sits at most (m - 1 - p) + k bytes in front of the occurrence's end, so p < m - dlen - k never gets there.
+        // A one-byte delimiter keeps the old rule (every position).
+        const bool positional = q->dlen > 1;
         for (uint8_t c : raw) {
             bool virt = c == '\n';
-            for (int j = 0; j < q->dlen; ++j) virt = virt || c == q->delim[j] || (q->delim_fold && (c | 0x20) == q->delim[j]);
+            for (int j = 0; j < q->dlen; ++j) {
+                const bool is_d = c == q->delim[j] || (q->delim_fold && (c | 0x20) == q->delim[j]);
+                if (!is_d) continue;
+                if (!positional) virt = true;
+                else if (p >= q->m - q->dlen - q->k) virt = true;                  // (b)
+                else if (j == q->dlen - 1 && p <= q->k) virt = true;               // (a)
+            }
             if (virt) { width[(size_t)p] = 0; break; }
         }
     }

@@ -519,6 +519,73 @@ def test_multi_byte_delimiters(agh, delim):
             assert q.scan_buffer(text, flags=agh.COUNT)[0].n_matched == want[0]
 
 
+def test_filter_with_delimiter_bytes_inside_the_pattern(agh, monkeypatch):
+    """Round 5: under a delimiter of several bytes a pattern position that accepts one of the delimiter's bytes no
+    longer ends the sampled run (`-d 'From '` against any pattern with an r, o or m) -- only the positions a byte
+    OUTSIDE the text can reach do: the last dlen + k ones (the delimiter appended at the end) and the first k + 1 (the
+    byte in front of a segment).  Delimiters cut out of the pattern itself, occurrences that run into a delimiter at a
+    record's end, start on its last byte, or end inside the appended one; default engine (the filter where a shape
+    exists), full scan, count-only and numbered count against asearch.c -- also with 1 MiB segments (the byte in front
+    of a segment is the previous delimiter's last)."""
+    # (AGH_FUZZ_SEED: another walk; profiles/r05_fuzz_delim_bytes.log holds 40 of them)
+    rng = random.Random(int(os.environ.get("AGH_FUZZ_SEED", "2026")))
+    filtered = 0
+    for it in range(120):
+        sigma = rng.choice((4, 6, 8))
+        alpha = bytes(rng.sample(range(97, 123), sigma - 1)) + b" "
+        m = rng.randint(8, 24)
+        k = rng.randint(0, 2)
+        pat = bytes(rng.choice(alpha[:-1]) for _ in range(m))
+        dlen = rng.randint(2, 5)
+        at = rng.randint(0, m - dlen)
+        delim = pat[at:at + dlen] if rng.random() < 0.7 else bytes(rng.choice(alpha) for _ in range(dlen))
+        recs = []
+        for _ in range(rng.randint(1, 80)):
+            L = rng.randint(0, 150)
+            r = bytearray(rng.choice(alpha) for _ in range(L))
+            if rng.random() < 0.5:
+                v = bytearray(pat)
+                for _ in range(rng.randint(0, k + 1)):
+                    op, pos = rng.randint(0, 2), rng.randrange(len(v))
+                    if op == 0:
+                        v[pos] = rng.choice(alpha)
+                    elif op == 1 and len(v) > 1:
+                        del v[pos]
+                    else:
+                        v.insert(pos, rng.choice(alpha))
+                where = rng.random()
+                if where < 0.3:                  # at the record's end: the tail of the copy runs into the delimiter
+                    r += v[:rng.randint(max(1, len(v) - dlen - 1), len(v))]
+                elif where < 0.5:                # at the record's start, minus what the previous delimiter may supply
+                    r = v[rng.randint(0, 2):] + r
+                elif L > len(v):
+                    o = rng.randint(0, L - len(v))
+                    r[o:o + len(v)] = v
+            recs.append(bytes(r))
+        text = delim.join(recs)
+        tail = rng.random()
+        if tail < 0.4:
+            text += delim
+        elif tail < 0.6:
+            text += delim[:rng.randint(1, dlen - 1)]        # a delimiter cut short by the end of the text
+        if it % 9 == 0 and delim in text:
+            text = text * (1 + (3 << 20) // max(1, len(text)))      # > 3 MiB: several segments below
+            monkeypatch.setenv("AGH_SEG_MAX_MB", "1")
+        else:
+            monkeypatch.delenv("AGH_SEG_MAX_MB", raising=False)
+        want = O.asearch(pat, k, text, delim=delim, cap=400000)
+        with agh.Query(pat, k, delim=delim) as q:
+            res, ms = q.scan_buffer(text, cap=400000)
+            res_f, ms_f = q.scan_buffer(text, flags=agh.FORCE_FULLSCAN, cap=400000)
+            res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+            res_n, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
+        assert (res_f.n_matched, [(s, e) for s, e, _ in ms_f]) == want, ("full scan", pat, k, delim, it)
+        assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, ("default", res.engine, pat, k, delim, it)
+        assert res_c.n_matched == res_n.n_matched == want[0], ("counts", pat, k, delim, it)
+        filtered += res.engine == agh.ENGINE_FILTER and any(c in delim for c in pat)
+    assert filtered >= 20       # the filter did take patterns that hold delimiter bytes
+
+
 def _golden(name):
     with open(os.path.join(GOLD, name)) as f:
         return json.load(f)["cases"]
