@@ -674,7 +674,7 @@ void agh_read_tuning(agh_tuning *t)
     t->tf_fast_min_mb = env_u64("AGH_TF_FAST_MIN_MB", AGH_TF_FAST_MIN_MB_DEFAULT);
     {
         const uint64_t c = env_u64("AGH_TF_CHUNK", AGH_TF_CHUNK_DEFAULT);
-        t->tf_chunk = (c == 1024 || c == 2048 || c == 4096) ? (uint32_t)c : 0u;
+        t->tf_chunk = (c == 1024 || c == 2048 || c == 4096 || c == 8192 || c == 16384 || c == 32768) ? (uint32_t)c : 0u;
         const uint64_t g = env_u64("AGH_TR_GROUP", 8);
         t->tr_group = (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ? (uint32_t)g : 8u;
     }

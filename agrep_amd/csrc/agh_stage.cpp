@@ -23,18 +23,6 @@ static int ensure_emit_pinned(agh_query *q, size_t bytes)
     return 0;
 }
 
-static agh_dev_query list_dev_query(const agh_query *q)
-{
-    agh_dev_query dq;
-    memset(&dq, 0, sizeof(dq));
-    dq.delim = q->delim[q->dlen - 1];
-    dq.dlen = (uint32_t)q->dlen;
-    memcpy(dq.dbytes, q->delim, (size_t)q->dlen);
-    dq.dfold = q->delim_fold ? 1u : 0u;
-    dq.mb = q_mb(q) ? 1u : 0u;
-    return dq;
-}
-
 // Device arrays of a record list of `cap` entries (pos, rec, start, end).
 static int ensure_list(agh_query *q, size_t cap, agh_list_out *list)
 {

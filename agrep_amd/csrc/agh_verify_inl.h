@@ -345,7 +345,6 @@ __device__ __forceinline__ VerifyWin verify_locate(const VerifyCtx<WT, K> &c, ui
     const uint64_t j = (LEAN ? ent : (ent & AGH_CAND_IDX_MASK)) << c.jshift;
     w.j = j;
     if (j >= c.n) return w;
-    const uint64_t anchor = j & ~(uint64_t)15;                           // sample's chunk start
 
     // Lean scans with a gram table: the sample's q-gram says where in the pattern it sits.
     // A gram that is not the pattern's (hash false positive) is dropped here; otherwise an
