@@ -63,7 +63,7 @@ struct dev_buf {
     }
 };
 
-#define AGH_PIN_RING 4        // pinned 32 MiB chunks between read() and the H2D copies (agh_stage.cpp)
+#define AGH_PIN_RING 4        // pinned 16 MiB chunks between read() and the H2D copies (agh_stage.cpp)
 #define AGH_LEAN_SLOTS 2      // segments of the lean pipeline in flight (sweep i+1 | verify i)
 #define AGH_MAX_SEGS 256      // segments of one scan (8 GiB each: 2 TiB)
 

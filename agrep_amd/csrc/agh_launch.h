@@ -241,3 +241,5 @@ struct agh_mwalk_args {
     uint32_t n_cu;
 };
 bool agh_launch_mwalk(const agh_mwalk_args &a, hipStream_t st);
+// forces the load of the core library's code object (first launch: ~7 ms) -- for a thread that has time for it
+void agh_warm_core_module();

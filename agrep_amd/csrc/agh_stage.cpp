@@ -85,7 +85,18 @@ extern "C" int agh_scan_buffer(agh_query *q, const unsigned char *text, size_t l
 // File mode: read() lands directly in pinned memory and is copied to HBM asynchronously while the next
 // chunks are being read (a ring of AGH_PIN_RING chunks) -- the staging role of fill_buf
 // (bitap.c:450-477), without an intermediate pageable copy.
-static const size_t AGH_STAGE_CHUNK = (size_t)32 << 20;
+// bytes per pinned chunk of the ring (AGH_STAGE_CHUNK_MB: A/B switch, 1..256)
+static size_t stage_chunk_bytes()
+{
+    static const size_t v = [] {
+        const char *e = getenv("AGH_STAGE_CHUNK_MB");
+        long mb = e && *e ? atol(e) : 16;       // (16: one process on a 4 GiB file 0.188-0.200 s, 32: 0.197-0.201, 64: 0.215-0.235;
+        if (mb < 1 || mb > 256) mb = 16;        //  profiles/r05_startup_ab.log -- pinning costs 5.4 ms per 32 MiB)
+        return (size_t)mb << 20;
+    }();
+    return v;
+}
+#define AGH_STAGE_CHUNK stage_chunk_bytes()
 static const size_t AGH_SEG_PFX = 64;       // bytes in front of the text of a device segment of the stream (pipe_scan)
 
 // Reader threads that live as long as their fd_reader: a chunk of the ring is 32 MiB, read in ~1 ms -- sixteen
@@ -271,6 +282,35 @@ static int ensure_pinned(agh_query *q, int b, size_t bytes, uint64_t size_hint)
     return 0;
 }
 
+// Round 5: the copy stream (its hardware queue: ~8 ms) is created by a helper thread while the main thread pins
+// chunk 0 and reads the first bytes of the file into it.
+struct stage_prep {
+    agh_query *q = nullptr;
+    int device = 0, n_slots = 0;
+    size_t chunk = 0;
+    uint64_t hint = 0;
+    bool want_stream = false;
+    std::atomic<int> stream_ready{0};           // 1: there, -1: failed (the main thread tries itself)
+    std::atomic<int> slot_ready[AGH_PIN_RING];
+    std::thread th;
+    stage_prep() { for (int b = 0; b < AGH_PIN_RING; ++b) slot_ready[b] = 0; }
+    void start()
+    {
+        th = std::thread([this] {
+            (void)hipSetDevice(device);
+            if (want_stream)
+                stream_ready.store((q->stage_stream || hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking) == hipSuccess) ? 1 : -1,
+                                   std::memory_order_release);
+            // (pinning chunks 1..3 here as well was tried: page pinning and the main thread's read() into chunk 0
+            // fight over the address space -- the first read took 14 ms instead of 1, profiles/r05_startup_ab.log)
+            for (int b = 1; b < n_slots; ++b) slot_ready[b].store(1, std::memory_order_release);
+        });
+    }
+    bool active() const { return th.joinable(); }
+    static void wait(std::atomic<int> &f) { while (!f.load(std::memory_order_acquire)) std::this_thread::yield(); }
+    ~stage_prep() { if (th.joinable()) th.join(); }
+};
+
 // ---------------------------------------------------------------------------------------
 // matched records of one resident segment -> the caller's emit function
 // ---------------------------------------------------------------------------------------
@@ -431,6 +471,9 @@ struct pipe_worker {
     void run()
     {
         (void)hipSetDevice(device);
+        // (the code object of the library is loaded at the first launch -- ~7 ms; this thread has nothing to do until
+        // the first segment is in HBM)
+        agh_warm_core_module();
         for (;;) {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return has_job || quit; });
@@ -536,6 +579,18 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
     if ((!hint || hint > seg_cap) && seg[1]->ensure(want0)) return -1;      // (a small file needs one segment)
     agh_timeline("pipe_scan: device segments allocated");
     q->staged_len = 0;                          // what stays in HBM is not the whole input
+    stage_prep prep;                            // (joined on every way out, after the worker)
+    if (!early && hint > 2 * chunk_cap && !q->stage_stream) {
+        prep.q = q;
+        prep.n_slots = AGH_PIN_RING;
+        prep.chunk = (size_t)std::min<uint64_t>(chunk_cap, seg_cap);
+        prep.hint = hint;
+        prep.want_stream = true;
+        if (hipGetDevice(&prep.device) != hipSuccess) prep.device = 0;
+        prep.start();
+    } else if (!q->stage_stream && ensure_stage_resources(q, true)) {
+        return -1;
+    }
 
     pipe_worker w;
     w.q = q;
@@ -568,6 +623,7 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         // (chunks no larger than a segment: AGH_STREAM_SEG_MB below 32 exercises the residue carry in tests)
         const size_t ask = early ? (size_t)std::min<uint64_t>(AGH_STAGE_CHUNK, std::max<uint64_t>(target > used ? target - used : 0, 65536))
                                  : (size_t)std::min<uint64_t>(chunk_cap, seg_cap);
+        if (prep.active() && b > 0) stage_prep::wait(prep.slot_ready[b]);
         if (ensure_pinned(q, b, ask, hint)) return bail(-1);
         if (!base_off && !used) agh_timeline("pipe_scan: first pinned chunk ready");
         const ssize_t got = rd.fill(q->pinned[b], ask);
@@ -575,6 +631,9 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         if (got < 0) return bail(-1);
         if (got == 0) eof = true;
         if (got > 0) {
+            // (the helper thread's stream: there by now, or the main thread makes it)
+            if (prep.active() && prep.want_stream) stage_prep::wait(prep.stream_ready);
+            if (!q->stage_stream && ensure_stage_resources(q, true)) return bail(-1);
             if (AGH_SEG_PFX + used + (uint64_t)got + 64 > seg[cur]->cap) {    // a record longer than the segment: grow
                 dev_buf bigger;
                 if (bigger.ensure((AGH_SEG_PFX + used + (uint64_t)got) * 2 + 64)) return bail(-1);
@@ -629,6 +688,7 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
     }
 #undef PIPE_TRY
     agh_timeline("pipe_scan: input read, waiting for the last scan");
+    if (prep.active()) prep.th.join();
     w.finish();
     (void)hipStreamSynchronize(q->stage_stream);
     agh_timeline("pipe_scan: done");
@@ -651,8 +711,8 @@ static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, u
     fd_reader rd;
     agh_refresh_tuning(q);
     if (rd.open_fd(fd, with_range, begin, end, q->tune.readers)) return -1;
-    if (ensure_stage_resources(q, !(rd.regular && rd.left <= AGH_STAGE_CHUNK))) return -1;
-    agh_timeline("scan_fd: stage stream + events");
+    if (ensure_stage_resources(q, false)) return -1;       // (the copy stream: pipe_scan, next to its first read)
+    agh_timeline("scan_fd: events");
     const bool count_only = (flags & (AGH_COUNT | AGH_FILENAMEONLY)) && !(matches && cap) && !sink;
     // one rank's shard of a file: the virtual head byte / the appended delimiter (asearch.c:69-91)
     // belong to the shards that hold the file's first / last byte

@@ -401,6 +401,12 @@ __global__ __launch_bounds__(256) void k_delim_bitmap(const uint8_t *__restrict_
     dbm[wi] = ov ? delim_bitmap_serial(text, n, q, b, counters) : out;
 }
 
+void agh_warm_core_module()
+{
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_delim_bitmap));
+}
+
 void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &q, uint64_t *dbm,
                              uint64_t n_words, uint32_t *counters, hipStream_t st)
 {
