@@ -728,6 +728,7 @@ static int scan_fd_impl(agh_query *q, int fd, bool with_range, uint64_t begin, u
     // a match ARRAY wanted (agh_scan_fd with matches / cap; or AGH_STREAM=0): the whole input is staged,
     // then scanned -- agh_fetch_records and agh_rescan_staged work on that copy.  Bounded memory and
     // output while reading: agh_scan_fd_emit.
+    if (ensure_stage_resources(q, !(rd.regular && rd.left <= AGH_STAGE_CHUNK))) return -1;
     size_t want = rd.regular ? (size_t)rd.left + 64 : AGH_STAGE_CHUNK * 2;
     if (q->staging.ensure(want + 32)) return -1;
     size_t used = 0;
