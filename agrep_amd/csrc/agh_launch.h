@@ -16,6 +16,7 @@ struct agh_tuning {
     uint64_t tf_fast_min_mb = 0;    // AGH_TF_FAST_MIN_MB: table engine, fast form from this segment size on
     uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 / 2048 / 4096), 0 = by size
     uint32_t tr_group = 8;          // AGH_TR_GROUP: tiles whose replay lists one wave of k_table_replay takes (1, 2, 4, 8, 16)
+    uint32_t mw_ch = 0;             // AGH_MW_CH: text bytes per lane of the record walk (a power of two, 256 .. 65536); 0: by size
     bool fused = true;              // AGH_FUSED
     bool debug = false;             // AGH_DEBUG
     bool aligned_cuts_only = false; // AGH_ALIGNED_CUTS_ONLY
@@ -239,6 +240,7 @@ struct agh_mwalk_args {
     agh_marks mk;            // hash set + counters
     uint32_t *ticket;
     uint32_t n_cu;
+    uint32_t ch;             // text bytes per lane (0: 1024)
 };
 bool agh_launch_mwalk(const agh_mwalk_args &a, hipStream_t st);
 // forces the load of the core library's code object (first launch: ~7 ms) -- for a thread that has time for it

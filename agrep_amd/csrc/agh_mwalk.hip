@@ -5,7 +5,8 @@
 // (newmgrep.c:858-905: monkey1() returns to the record loop after the first verified entry; sgrep.c:1186-1204 jumps
 // to the record end).
 //
-// One LANE per 1 KiB of text, walking it position by position, in three kinds of steps:
+// One LANE per 1 .. 4 KiB of text (by the size of the segment: the launcher's caller picks), walking it position by
+// position, in three kinds of steps:
 //   advance   (cheap, up to eight positions in a row per lane) one 8-byte load around j; the two bytes at j select a
 //             directory slot whose four 32-bit masks say which bytes next to them some entry could accept at all --
 //             the byte behind the pair (the third byte of a longer piece, or one of the two nearest bytes of the other
@@ -49,7 +50,7 @@ __device__ __forceinline__ uint32_t mw_delim_offset16(uint64_t F0, uint64_t F1, 
 template <bool FOLD>
 __global__ __launch_bounds__(MW_WAVES * 64) void k_mwalk(const uint8_t *__restrict__ text, uint64_t n, uint32_t delim,
                                                          agh_mwalk_dev mw, agh_marks mk, uint32_t *__restrict__ ticket,
-                                                         uint32_t n_tiles)
+                                                         uint32_t n_tiles, uint32_t ch)
 {
     __shared__ uint4 fmask[AGH_MW_DIR];                   // 64 KiB
     __shared__ uint32_t dir[AGH_MW_DIR];                  // 16 KiB
@@ -68,9 +69,9 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_mwalk(const uint8_t *__restri
     uint32_t local = 0;                                   // matched records that lie inside my kilobytes
     uint32_t t = blockIdx.x * MW_WAVES + wib;
     while (t < n_tiles) {
-        const uint64_t cs = (uint64_t)t * (64u * MW_CH) + (uint64_t)lane * MW_CH;
+        const uint64_t cs = (uint64_t)t * (64u * ch) + (uint64_t)lane * ch;
         uint64_t j = cs < lo_lim ? lo_lim : cs;
-        const uint64_t end = cs + MW_CH < hi_lim ? cs + MW_CH : hi_lim;
+        const uint64_t end = cs + ch < hi_lim ? cs + ch : hi_lim;
         bool active = j < end;
         // the start of the record at j: known if a delimiter stands right in front of my text
         uint64_t rstart = (active && text[j - 1] == delim) ? j : ~0ull;
@@ -224,7 +225,8 @@ bool agh_launch_mwalk(const agh_mwalk_args &a, hipStream_t st)
 {
     if (a.q.k != 1 || a.q.mb || !a.n || !a.mw.n_ent || a.mw.n_ent > AGH_MW_MAX_ENT) return false;
     if (a.n >= 32u) {
-        const uint64_t n_tiles = (a.n + 64u * MW_CH - 1u) / (64u * MW_CH);
+        const uint32_t ch = a.ch ? a.ch : MW_CH;
+        const uint64_t n_tiles = (a.n + 64u * ch - 1u) / (64u * ch);
         if (n_tiles > 0xffffffffull - 65536ull) return false;
         // masks, directory and up to 3072 entries: 128 KiB of LDS -- one workgroup per CU
         uint32_t blocks = a.n_cu ? a.n_cu : 256u;
@@ -232,10 +234,10 @@ bool agh_launch_mwalk(const agh_mwalk_args &a, hipStream_t st)
         if (blocks > need) blocks = need;
         if (a.q.fold)
             hipLaunchKernelGGL((k_mwalk<true>), dim3(blocks), dim3(MW_WAVES * 64), 0, st, (const uint8_t *)a.text, a.n, a.q.delim,
-                               a.mw, a.mk, a.ticket, (uint32_t)n_tiles);
+                               a.mw, a.mk, a.ticket, (uint32_t)n_tiles, ch);
         else
             hipLaunchKernelGGL((k_mwalk<false>), dim3(blocks), dim3(MW_WAVES * 64), 0, st, (const uint8_t *)a.text, a.n, a.q.delim,
-                               a.mw, a.mk, a.ticket, (uint32_t)n_tiles);
+                               a.mw, a.mk, a.ticket, (uint32_t)n_tiles, ch);
     }
     hipLaunchKernelGGL(k_mwalk_edges, dim3(1), dim3(64), 0, st, (const uint8_t *)a.text, a.n, a.q, a.mt, a.mk);
     return true;
