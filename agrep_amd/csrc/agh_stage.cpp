@@ -580,7 +580,9 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
     agh_timeline("pipe_scan: device segments allocated");
     q->staged_len = 0;                          // what stays in HBM is not the whole input
     stage_prep prep;                            // (joined on every way out, after the worker)
-    if (!early && hint > 2 * chunk_cap && !q->stage_stream) {
+    // (a file of one chunk: its single copy goes through the null stream -- a stream of its own costs ~8 ms)
+    const bool need_stream = !(hint && hint <= AGH_STAGE_CHUNK);
+    if (need_stream && !early && hint > 2 * chunk_cap && !q->stage_stream) {
         prep.q = q;
         prep.n_slots = AGH_PIN_RING;
         prep.chunk = (size_t)std::min<uint64_t>(chunk_cap, seg_cap);
@@ -588,7 +590,7 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         prep.want_stream = true;
         if (hipGetDevice(&prep.device) != hipSuccess) prep.device = 0;
         prep.start();
-    } else if (!q->stage_stream && ensure_stage_resources(q, true)) {
+    } else if (need_stream && !q->stage_stream && ensure_stage_resources(q, true)) {
         return -1;
     }
 
@@ -633,7 +635,7 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         if (got > 0) {
             // (the helper thread's stream: there by now, or the main thread makes it)
             if (prep.active() && prep.want_stream) stage_prep::wait(prep.stream_ready);
-            if (!q->stage_stream && ensure_stage_resources(q, true)) return bail(-1);
+            if (need_stream && !q->stage_stream && ensure_stage_resources(q, true)) return bail(-1);
             if (AGH_SEG_PFX + used + (uint64_t)got + 64 > seg[cur]->cap) {    // a record longer than the segment: grow
                 dev_buf bigger;
                 if (bigger.ensure((AGH_SEG_PFX + used + (uint64_t)got) * 2 + 64)) return bail(-1);
