@@ -827,6 +827,40 @@ def test_table_engine_with_multi_byte_delimiters(agh):
         q.close()
 
 
+def test_table_engine_multi_byte_delimiters_above_one_segment(agh, monkeypatch):
+    """The table engine's fast form under a delimiter of several bytes on a text of several kernel segments
+    (AGH_SEG_MAX_MB=1): the delimiter-end bitmap of the whole text, every segment on its part of it (16-byte loads at
+    8-byte-aligned word offsets), segments whose cut is not aligned on a copy with a bitmap of their own; counts,
+    records and record numbers against asearch.c on the same tables, fast forms and exact kernel."""
+    monkeypatch.setenv("AGH_SEG_MAX_MB", "1")
+    rng = random.Random(77)
+    base, _ = O.corpus(1100, seed=21, variants=O.VARIANTS_C2[:5] + (b"approxXXmatch", b"aprox mat ch"), plant_period=9)
+    for delim, width in ((b"e ", 0), (b"\n\n", 0), (b"ab", 63), (b"xyz", 64)):
+        text = base.tobytes()
+        if width:                               # records of `width` bytes: cuts fall on unaligned / aligned offsets
+            body = text.replace(b"\n", b" ")
+            text = delim.join(body[i:i + width - len(delim)] for i in range(0, 3400000, width - len(delim)))
+        elif delim != b"e ":
+            text = text.replace(b"\n", delim)
+        for pat, k in ((b"approx#match", 1), (b"match,approx", 0), (b"approx;match", 2)):
+            tb = agh.compile_pattern(pat, delim=delim)      # (== the reference's maskgen: tests/test_pattern_compiler.py)
+            ot = O.tables_from_golden({"Mask": list(tb.Mask), "Init0": tb.Init0, "Init1": tb.Init1, "NO_ERR_MASK": tb.NO_ERR_MASK,
+                                       "endposition": tb.endposition, "D_endpos": tb.D_endpos, "wildmask": tb.wildmask,
+                                       "AND": tb.AND}, tb.M, dlen=len(delim))
+            want = O.asearch_tables(ot, k, text, delim=delim, cap=600000)
+            with agh.Query.pattern(pat, k, delim=delim) as q:
+                res, ms = q.scan_buffer(text, cap=600000)
+                res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+                monkeypatch.setenv("AGH_FS_FAST", "0")
+                res_x, _ = q.scan_buffer(text, flags=agh.COUNT)
+                monkeypatch.delenv("AGH_FS_FAST")
+            assert res.n_segments >= 3, (delim, res.n_segments)
+            assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (delim, pat, k, res.copied_segments)
+            assert res_c.n_matched == res_x.n_matched == want[0], (delim, pat, k)
+            assert [i for _, _, i in ms] == sorted(i for _, _, i in ms)
+    del rng
+
+
 def test_piece_engine_for_short_patterns(agh):
     """Patterns the sample lemma cannot filter (m < 5k+6) run through the piece engine: k+1
     verbatim pieces found by the multi-pattern sweep, the pattern's automaton on the window.
