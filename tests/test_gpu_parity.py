@@ -861,6 +861,80 @@ def test_table_engine_multi_byte_delimiters_above_one_segment(agh, monkeypatch):
     del rng
 
 
+def test_table_engine_fuzz_delimiters_and_costs(agh):
+    """Random `#` / `,` / `;` patterns under random delimiters (one byte, several bytes, sharing letters with the pattern,
+    overlapping themselves), unit and edit costs, texts with delimiters across the 1 / 4 / 64 KiB borders of the fast
+    forms: every form of the table engine (fast forms with one and two streams per lane, exact kernel; records, counts,
+    numbered counts) against asearch.c / asearch1.c on the tables agh_compile_pattern makes (== maskgen's,
+    tests/test_pattern_compiler.py).  AGH_FUZZ_SEED: another walk."""
+    rng = random.Random(int(os.environ.get("AGH_FUZZ_SEED", "7")))
+    done = 0
+    for it in range(60):
+        alpha = bytes(rng.sample(range(97, 123), rng.choice((3, 5, 8))))
+        parts = [bytes(rng.choice(alpha) for _ in range(rng.randint(1, 4))) for _ in range(rng.randint(2, 3))]
+        sep = rng.choice((b"#", b",", b";"))
+        pat = sep.join(parts)
+        k = rng.randint(0, 2)
+        if rng.random() < 0.4:
+            delim = b"\n"
+        else:
+            dl = rng.randint(2, 4)
+            delim = bytes(rng.choice(alpha + b" .") for _ in range(dl))
+            if rng.random() < 0.3:
+                delim = delim[:1] * dl                         # overlaps itself
+        try:
+            tb = agh.compile_pattern(pat, delim=delim)
+        except agh.AghError:
+            continue                                            # (a pattern the reference turns down as well)
+        if tb.M + len(delim) > 30:
+            continue
+        ot = O.tables_from_golden({"Mask": list(tb.Mask), "Init0": tb.Init0, "Init1": tb.Init1, "NO_ERR_MASK": tb.NO_ERR_MASK,
+                                   "endposition": tb.endposition, "D_endpos": tb.D_endpos, "wildmask": tb.wildmask,
+                                   "AND": tb.AND}, tb.M, dlen=len(delim))
+        n = rng.choice((3000, 70000, 200000))
+        body = bytearray(rng.choice(alpha + b"  ") for _ in range(n))
+        for _ in range(n // 90):
+            at = rng.randrange(n)
+            body[at:at + len(delim)] = delim
+        for _ in range(n // 400):                               # near matches
+            at = rng.randrange(n)
+            v = bytearray(b"".join(parts) if rng.random() < 0.5 else parts[0] + bytes(rng.choice(alpha) for _ in range(rng.randint(0, 5))) + parts[-1])
+            if v and rng.random() < 0.5:
+                v[rng.randrange(len(v))] = rng.choice(alpha)
+            body[at:at + len(v)] = v
+        for border in (1024, 4096, 65536, 131072):
+            for shift in range(len(delim) + 1):
+                at = border - shift
+                if 0 <= at and at + len(delim) < n:
+                    body[at:at + len(delim)] = delim
+        text = bytes(body[:n]) + (delim if rng.random() < 0.5 else b"")
+        costs = None if rng.random() < 0.6 or k == 0 else (rng.randint(1, 2), rng.randint(1, 2), rng.randint(1, 2))
+        if costs:
+            want = O.asearch_tables_costs(ot, k, costs, text, delim=delim, cap=400000)
+        else:
+            want = O.asearch_tables(ot, k, text, delim=delim, cap=400000)
+        try:
+            q = agh.Query.pattern(pat, k, delim=delim)
+        except agh.AghError:
+            continue                                            # (e.g. a pattern that matches the empty record with k errors)
+        with q:
+            if costs:
+                q.set_costs(*costs)
+            for env in ({}, {"AGH_TF_PACK2": "0"}, {"AGH_FS_FAST": "0"}, {"AGH_TF_CHUNK": "1024"}):
+                os.environ.update(env)
+                try:
+                    res, ms = q.scan_buffer(text, cap=400000)
+                    res_c, _ = q.scan_buffer(text, flags=agh.COUNT)
+                    res_n, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
+                finally:
+                    for key in env:
+                        del os.environ[key]
+                assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (env, pat, k, delim, costs, it)
+                assert res_c.n_matched == res_n.n_matched == want[0], (env, pat, k, delim, costs, it)
+        done += 1
+    assert done >= 20
+
+
 def test_piece_engine_for_short_patterns(agh):
     """Patterns the sample lemma cannot filter (m < 5k+6) run through the piece engine: k+1
     verbatim pieces found by the multi-pattern sweep, the pattern's automaton on the window.
