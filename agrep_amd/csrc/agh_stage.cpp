@@ -286,28 +286,21 @@ static int ensure_pinned(agh_query *q, int b, size_t bytes, uint64_t size_hint)
 // chunk 0 and reads the first bytes of the file into it.
 struct stage_prep {
     agh_query *q = nullptr;
-    int device = 0, n_slots = 0;
-    size_t chunk = 0;
-    uint64_t hint = 0;
-    bool want_stream = false;
+    int device = 0;
     std::atomic<int> stream_ready{0};           // 1: there, -1: failed (the main thread tries itself)
-    std::atomic<int> slot_ready[AGH_PIN_RING];
     std::thread th;
-    stage_prep() { for (int b = 0; b < AGH_PIN_RING; ++b) slot_ready[b] = 0; }
     void start()
     {
         th = std::thread([this] {
             (void)hipSetDevice(device);
-            if (want_stream)
-                stream_ready.store((q->stage_stream || hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking) == hipSuccess) ? 1 : -1,
-                                   std::memory_order_release);
-            // (pinning chunks 1..3 here as well was tried: page pinning and the main thread's read() into chunk 0
-            // fight over the address space -- the first read took 14 ms instead of 1, profiles/r05_startup_ab.log)
-            for (int b = 1; b < n_slots; ++b) slot_ready[b].store(1, std::memory_order_release);
+            // (pinning chunks 1..3 of the ring here as well was tried: page pinning and the main thread's read() into
+            // chunk 0 fight over the address space -- the first read took 14 ms instead of 1, profiles/r05_startup_ab.log)
+            stream_ready.store((q->stage_stream || hipStreamCreateWithFlags(&q->stage_stream, hipStreamNonBlocking) == hipSuccess) ? 1 : -1,
+                               std::memory_order_release);
         });
     }
     bool active() const { return th.joinable(); }
-    static void wait(std::atomic<int> &f) { while (!f.load(std::memory_order_acquire)) std::this_thread::yield(); }
+    void wait_stream() { while (!stream_ready.load(std::memory_order_acquire)) std::this_thread::yield(); }
     ~stage_prep() { if (th.joinable()) th.join(); }
 };
 
@@ -584,10 +577,6 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
     const bool need_stream = !(hint && hint <= AGH_STAGE_CHUNK);
     if (need_stream && !early && hint > 2 * chunk_cap && !q->stage_stream) {
         prep.q = q;
-        prep.n_slots = AGH_PIN_RING;
-        prep.chunk = (size_t)std::min<uint64_t>(chunk_cap, seg_cap);
-        prep.hint = hint;
-        prep.want_stream = true;
         if (hipGetDevice(&prep.device) != hipSuccess) prep.device = 0;
         prep.start();
     } else if (need_stream && !q->stage_stream && ensure_stage_resources(q, true)) {
@@ -625,7 +614,6 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         // (chunks no larger than a segment: AGH_STREAM_SEG_MB below 32 exercises the residue carry in tests)
         const size_t ask = early ? (size_t)std::min<uint64_t>(AGH_STAGE_CHUNK, std::max<uint64_t>(target > used ? target - used : 0, 65536))
                                  : (size_t)std::min<uint64_t>(chunk_cap, seg_cap);
-        if (prep.active() && b > 0) stage_prep::wait(prep.slot_ready[b]);
         if (ensure_pinned(q, b, ask, hint)) return bail(-1);
         if (!base_off && !used) agh_timeline("pipe_scan: first pinned chunk ready");
         const ssize_t got = rd.fill(q->pinned[b], ask);
@@ -634,7 +622,7 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         if (got == 0) eof = true;
         if (got > 0) {
             // (the helper thread's stream: there by now, or the main thread makes it)
-            if (prep.active() && prep.want_stream) stage_prep::wait(prep.stream_ready);
+            if (prep.active()) prep.wait_stream();
             if (need_stream && !q->stage_stream && ensure_stage_resources(q, true)) return bail(-1);
             if (AGH_SEG_PFX + used + (uint64_t)got + 64 > seg[cur]->cap) {    // a record longer than the segment: grow
                 dev_buf bigger;
