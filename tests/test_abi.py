@@ -38,6 +38,18 @@ def test_product_library_is_not_the_diagnostics_build():
     assert extra == [], "exported but not declared in include/agrep_hip.h: %s" % extra
 
 
+def test_core_library_stays_small_and_the_engines_sit_beside_it():
+    """One process = one code-object load: what the headline queries need is `libagrep_hip.so` and stays below 12 MB
+    (round 5: 10.1 MB); the engines behind the sample filter are `libagrep_hip_engines.so` in the same directory,
+    opened on first use (agh_ext.cpp) -- both are built by `make -C agrep_amd/csrc` / __graft_entry__.build()."""
+    import agrep_amd
+    path = agrep_amd._ffi.LIB_PATH
+    assert os.path.getsize(path) < 12 * 1000 * 1000, "libagrep_hip.so grew to %d bytes" % os.path.getsize(path)
+    engines = os.path.join(os.path.dirname(path), "libagrep_hip_engines.so")
+    assert os.path.exists(engines), "libagrep_hip_engines.so is missing next to libagrep_hip.so"
+    ctypes.CDLL(engines)                        # loads without a GPU, like the core library
+
+
 def test_no_silent_fallback_without_gpu():
     """Product path must fail loudly when no HIP device is usable."""
     import agrep_amd
