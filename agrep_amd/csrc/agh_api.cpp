@@ -487,7 +487,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         if (d_match_pos) {
             // the list in file order: ordered compaction of the bitmap (counts and clears it as well), then the
             // bounds of the listed records -- everything queued, the host reads the counters once below
-            agh_launch_bitmap_list((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4), (uint32_t *)q->bm_blocks.p,
+            agh_launch_bitmap_list((uint32_t *)q->bitmap.p, (uint32_t)(q->bitmap.cap / 4),
+                                   (uint32_t)std::min<uint64_t>(bm_words * 32, 0xffffffffu), (uint32_t *)q->bm_blocks.p,
                                    (const uint64_t *)q->rec_pos.p, invert_list ? 1 : 0, d_match_pos, d_match_rec, match_cap,
                                    q->d_counters, st);
             if (list->start)

@@ -19,7 +19,7 @@ char g_err[384] = "";
 
 void open_engines()
 {
-    // AGH_ENGINES_PATH, else the file next to this library
+    // AGH_ENGINES_PATH, else the file next to this library that carries its name
     std::string path;
     const char *e = getenv("AGH_ENGINES_PATH");
     if (e && *e) {
@@ -27,9 +27,12 @@ void open_engines()
     } else {
         Dl_info info;
         if (dladdr((const void *)&open_engines, &info) && info.dli_fname) {
+            // this library's own file name with "_engines" in front of ".so": an A/B build loaded through AGH_LIB_PATH
+            // (libagrep_hip_<variant>.so) opens the engines built with ITS flags, not the default build's
             path = info.dli_fname;
-            const size_t slash = path.rfind('/');
-            path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libagrep_hip_engines.so";
+            const size_t dot = path.rfind(".so");
+            if (dot != std::string::npos && dot + 3 == path.size()) path.insert(dot, "_engines");
+            else path += "_engines.so";
         } else {
             path = "libagrep_hip_engines.so";
         }

@@ -92,6 +92,8 @@ struct agh_query {
     unsigned char *h_emit = nullptr;    // pinned: the matched records of one emit() call (entries + bytes)
     size_t h_emit_cap = 0;
     uint64_t staged_len = 0;            // bytes of the text currently held in `staging`
+    unsigned char input_head[64] = {0}; // streamed scans: the first bytes of the input (agh_input_head)
+    uint32_t input_head_len = 0;
     bool staged_first = true, staged_last = true;   // ... is the head / the tail of its file (agh_scan_fd_range)
     hipStream_t stage_stream = nullptr; // H2D copies of agh_scan_fd
     unsigned char *pinned[AGH_PIN_RING] = {nullptr, nullptr, nullptr, nullptr};

@@ -146,8 +146,9 @@ void agh_launch_exp(int exp, const void *text, uint64_t n, uint32_t *counters, h
 // ---- record output on the device (agh_records.hip) ----
 // ordered compaction of the record bitmap: listed records (set bits; invert: clear bits below AGH_C_NREC) in file
 // order -> out_pos[i] = rec_pos[r], out_rec[i] = r for the first `cap` of them; AGH_C_STORED = records listed,
-// AGH_C_MATCHED = set bits; the bitmap is left zeroed.  blk: n_words / 1024 + 2 scratch words
-void agh_launch_bitmap_list(uint32_t *bitmap, uint32_t n_words, uint32_t *blk, const uint64_t *rec_pos, int invert,
+// AGH_C_MATCHED = set bits; the bitmap is left zeroed.  bits: the bits of this scan (= entries of rec_pos; an inverted
+// list names no record at or above it).  blk: n_words / 1024 + 2 scratch words
+void agh_launch_bitmap_list(uint32_t *bitmap, uint32_t n_words, uint32_t bits, uint32_t *blk, const uint64_t *rec_pos, int invert,
                             uint64_t *out_pos, uint32_t *out_rec, uint32_t cap, uint32_t *counters, hipStream_t st);
 // [start, end) of the records around pos[0 .. min(AGH_C_STORED, cap)); AGH_C_RECBYTES += the sum of their lengths
 void agh_launch_match_bounds(const void *text, uint64_t n, const agh_dev_query &q, const uint64_t *dbm, const uint64_t *pos,

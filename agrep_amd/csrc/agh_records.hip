@@ -48,14 +48,23 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, 
     return before;
 }
 
+// (-v lists) the records a list may name: those below AGH_C_NREC that the scan's bitmap -- and rec_pos, which has
+// one entry per bit of it -- covers.  A first attempt on a text with more records than the hint foresaw has
+// NREC > bits: the host sees AGH_C_BM_OVERFLOW and reruns, but this launch is already queued and must stay inside.
+__device__ __forceinline__ uint64_t listable_records(const uint32_t *__restrict__ counters, uint32_t bits)
+{
+    const uint32_t nrec = counters[AGH_C_NREC];
+    return nrec < bits ? nrec : bits;
+}
+
 __global__ __launch_bounds__(AGH_BM_BLOCK) void k_bm_block_counts(const uint4 *__restrict__ bitmap, uint32_t n_vec,
                                                                   uint32_t *__restrict__ blk, int invert,
-                                                                  const uint32_t *__restrict__ counters)
+                                                                  const uint32_t *__restrict__ counters, uint32_t bits)
 {
     __shared__ uint32_t wsum[4];
     const uint64_t i = (uint64_t)blockIdx.x * AGH_BM_BLOCK + threadIdx.x;
     uint32_t c = i < n_vec ? popc4(bitmap[i]) : 0u;
-    if (invert) c = (i < n_vec ? valid_in_piece(i, counters[AGH_C_NREC]) : 0u) - c;   // (no bit at or above NREC is ever set)
+    if (invert) c = (i < n_vec ? valid_in_piece(i, listable_records(counters, bits)) : 0u) - c;   // (no bit at or above NREC is ever set)
     uint32_t total;
     (void)block_excl_scan(c, wsum, &total);
     if (threadIdx.x == 0) blk[blockIdx.x] = total;
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(AGH_BM_BLOCK) void k_bm_compact(uint4 *__restrict__
                                                              const uint64_t *__restrict__ rec_pos,
                                                              uint64_t *__restrict__ out_pos, uint32_t *__restrict__ out_rec,
                                                              uint32_t cap, int invert,
-                                                             const uint32_t *__restrict__ counters)
+                                                             const uint32_t *__restrict__ counters, uint32_t bits)
 {
     __shared__ uint32_t wsum[4];
     const uint32_t b0 = blk[blockIdx.x], b1 = blk[blockIdx.x + 1];
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(AGH_BM_BLOCK) void k_bm_compact(uint4 *__restrict__
     const bool dirty = (v.x | v.y | v.z | v.w) != 0;
     if (dirty) bitmap[i] = make_uint4(0, 0, 0, 0);      // the next scan finds a clean bitmap
     if (b0 == b1) return;                               // (uniform) nothing to list in this block
-    const uint64_t nrec = invert ? (uint64_t)counters[AGH_C_NREC] : ~0ull;
+    const uint64_t nrec = invert ? listable_records(counters, bits) : ~0ull;
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
     uint32_t c = 0;
     if (invert) {
@@ -136,19 +145,20 @@ __global__ __launch_bounds__(AGH_BM_BLOCK) void k_bm_compact(uint4 *__restrict__
     }
 }
 
-// n_words: 32-bit words of the bitmap (allocated in 16-byte units); blk: n_words / 1024 + 2 scratch words
-void agh_launch_bitmap_list(uint32_t *bitmap, uint32_t n_words, uint32_t *blk, const uint64_t *rec_pos, int invert,
+// n_words: 32-bit words of the bitmap (allocated in 16-byte units; all of them are walked and cleared); bits: the bits
+// this scan may have set = the entries of rec_pos; blk: n_words / 1024 + 2 scratch words
+void agh_launch_bitmap_list(uint32_t *bitmap, uint32_t n_words, uint32_t bits, uint32_t *blk, const uint64_t *rec_pos, int invert,
                             uint64_t *out_pos, uint32_t *out_rec, uint32_t cap, uint32_t *counters, hipStream_t st)
 {
     const uint32_t n_vec = n_words / 4u;
     const uint32_t n_blocks = (n_vec + AGH_BM_BLOCK - 1u) / AGH_BM_BLOCK;
     if (n_blocks)
         hipLaunchKernelGGL(k_bm_block_counts, dim3(n_blocks), dim3(AGH_BM_BLOCK), 0, st, (const uint4 *)bitmap, n_vec, blk,
-                           invert, (const uint32_t *)counters);
+                           invert, (const uint32_t *)counters, bits);
     hipLaunchKernelGGL(k_bm_offsets, dim3(1), dim3(1024), 0, st, blk, n_blocks, counters, invert);
     if (n_blocks)
         hipLaunchKernelGGL(k_bm_compact, dim3(n_blocks), dim3(AGH_BM_BLOCK), 0, st, (uint4 *)bitmap, n_vec,
-                           (const uint32_t *)blk, rec_pos, out_pos, out_rec, cap, invert, (const uint32_t *)counters);
+                           (const uint32_t *)blk, rec_pos, out_pos, out_rec, cap, invert, (const uint32_t *)counters, bits);
 }
 
 // ---------------------------------------------------------------------------------------

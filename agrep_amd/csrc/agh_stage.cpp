@@ -620,10 +620,16 @@ static int pipe_scan(agh_query *q, fd_reader &rd, unsigned flags, agh_result *re
         if (!base_off && used == 0) agh_timeline("pipe_scan: first chunk read");
         if (got < 0) return bail(-1);
         if (got == 0) eof = true;
+        if (!base_off && !used) {               // agh_input_head(): known before the first emit()
+            q->input_head_len = (uint32_t)std::min<size_t>((size_t)got, sizeof(q->input_head));
+            memcpy(q->input_head, q->pinned[b], q->input_head_len);
+        }
+        // (the helper thread's stream: there by now, or the main thread makes it -- also when nothing was read, e.g. a
+        // file truncated after fstat(): q->stage_stream is synchronised below either way and must not be read while
+        // the helper is still writing it)
+        if (prep.active()) prep.wait_stream();
+        if (need_stream && !q->stage_stream && ensure_stage_resources(q, true)) return bail(-1);
         if (got > 0) {
-            // (the helper thread's stream: there by now, or the main thread makes it)
-            if (prep.active()) prep.wait_stream();
-            if (need_stream && !q->stage_stream && ensure_stage_resources(q, true)) return bail(-1);
             if (AGH_SEG_PFX + used + (uint64_t)got + 64 > seg[cur]->cap) {    // a record longer than the segment: grow
                 dev_buf bigger;
                 if (bigger.ensure((AGH_SEG_PFX + used + (uint64_t)got) * 2 + 64)) return bail(-1);
@@ -770,6 +776,14 @@ extern "C" int agh_scan_fd_range(agh_query *q, int fd, uint64_t begin, uint64_t 
                                  unsigned flags, agh_result *res, agh_match *matches, size_t cap)
 {
     return scan_fd_impl(q, fd, true, begin, end, flags, res, matches, cap, nullptr);
+}
+
+extern "C" size_t agh_input_head(const agh_query *q, unsigned char *out, size_t cap)
+{
+    if (!q || !out) return 0;
+    const size_t n = std::min<size_t>(cap, q->input_head_len);
+    memcpy(out, q->input_head, n);
+    return n;
 }
 
 extern "C" int agh_scan_fd_emit(agh_query *q, int fd, unsigned flags, agh_result *res, agh_emit_fn emit, void *ctx)

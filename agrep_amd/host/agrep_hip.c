@@ -369,9 +369,10 @@ static long run_pass(agh_query *q, char **files, int nfiles, int print, int coun
 /* ---------------------------------------------------------------------------------------
  * --gpus N: one process, N devices, one host thread per device.
  *   -c / record output: every file is cut into N record-aligned shards (agh_shard_cuts_fd), GPU r
- *       scans shard r (agh_scan_fd_range); the per-file count exec() prints (agrep.c:3444-3558)
- *       is the sum of the shard counts; matched records are printed shard after shard, i.e. in
- *       file order, record numbers offset by the shards in front.
+ *       scans shard r (-c: agh_scan_fd_range; records: agh_scan_fd_range_emit, streamed); the per-file
+ *       count exec() prints (agrep.c:3444-3558) is the sum of the shard counts; matched records are
+ *       printed shard after shard, i.e. in file order, while the later shards are still being scanned,
+ *       record numbers offset by the shards in front (struct shard_order).
  *   -l: the files are dealt out to the GPUs (file f -> GPU f mod N), each scanned whole with the
  *       early exit; the file list is the OR of the per-GPU hit vectors, printed in argument order.
  * The N threads share this process's memory, so the sums are plain host additions: there is no
@@ -389,6 +390,8 @@ struct gpu_task {
     char **files;
     int nfiles;
     int want_records;
+    struct shard_order *order;  /* record output: whose records go to stdout now */
+    int with_name;
     /* results */
     struct filehit *hits;       /* [nfiles]: this rank's shard of every file (-c / records) */
     unsigned char *file_hit;    /* [nfiles]: -l */
@@ -396,29 +399,128 @@ struct gpu_task {
     char err[512];
 };
 
-static int scan_range(agh_query *q, int fd, uint64_t b, uint64_t e, int want_records,
-                      struct filehit *out)
+/* Record output of the shards, in file order, while the shards are still being scanned (asearch.c:162-170 prints
+ * from inside its block loop): every (file, shard) pair has a number in the order its records belong on stdout --
+ * file after file, shard after shard -- and `turn` says whose records may go out.  The shard whose turn it is prints
+ * straight from its emit() calls; a shard further back keeps what its scan hands over in host memory until the
+ * shards in front are done (and knows only then how many records lie in front of it: `rec_off`, for -n and for
+ * "the first record of a file has no delimiter in front"). */
+struct shard_order {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    long turn;                  /* file * ngpus + rank of the shard that prints */
+    uint64_t rec_off;           /* records of this file's shards in front of it */
+};
+
+struct shard_emit {
+    struct shard_order *ord;
+    long seq;
+    const char *name;
+    int with_name;
+    /* held back while it is another shard's turn */
+    agh_match *m;
+    size_t n, cap_m;
+    unsigned char *bytes;
+    size_t nb, cap_b;
+    int oom;
+};
+
+static void shard_print(const struct shard_emit *c, const agh_match *m, size_t n, const unsigned char *bytes,
+                        uint64_t rec_off)
 {
-    size_t cap = 65536, total = 0;
+    struct filehit h;
+    agh_match *mm;
+    size_t i;
+    if (!n) return;
+    mm = (agh_match *)malloc(n * sizeof(*mm));
+    if (!mm) { fprintf(stderr, "%s: out of memory\n", Progname); exit(2); }
+    for (i = 0; i < n; i++) { mm[i] = m[i]; mm[i].index += rec_off; }
+    memset(&h, 0, sizeof(h));
+    h.res.n_stored = n;
+    h.matches = mm;
+    h.bytes = (unsigned char *)bytes;
+    print_records(&h, c->name, c->with_name);
+    free(mm);
+}
+
+static int shard_my_turn(struct shard_emit *c, int wait, uint64_t *rec_off)
+{
+    int mine;
+    pthread_mutex_lock(&c->ord->mu);
+    while (wait && c->ord->turn != c->seq) pthread_cond_wait(&c->ord->cv, &c->ord->mu);
+    mine = c->ord->turn == c->seq;
+    *rec_off = c->ord->rec_off;
+    pthread_mutex_unlock(&c->ord->mu);
+    return mine;
+}
+
+static void shard_flush_held(struct shard_emit *c, uint64_t rec_off)
+{
+    shard_print(c, c->m, c->n, c->bytes, rec_off);
+    c->n = c->nb = 0;
+}
+
+static int shard_emit_records(void *vctx, const agh_match *m, size_t n, const unsigned char *bytes, size_t n_bytes)
+{
+    struct shard_emit *c = (struct shard_emit *)vctx;
+    uint64_t rec_off;
+    if (shard_my_turn(c, 0, &rec_off)) {         /* (nobody else prints: turn moves on only when this shard is done) */
+        shard_flush_held(c, rec_off);
+        shard_print(c, m, n, bytes, rec_off);
+        return 0;
+    }
+    if (c->n + n > c->cap_m) {
+        size_t cap = (c->n + n) * 2;
+        agh_match *nm = (agh_match *)realloc(c->m, cap * sizeof(*nm));
+        if (!nm) { c->oom = 1; return 1; }
+        c->m = nm;
+        c->cap_m = cap;
+    }
+    if (c->nb + n_bytes > c->cap_b) {
+        size_t cap = (c->nb + n_bytes) * 2;
+        unsigned char *nbuf = (unsigned char *)realloc(c->bytes, cap);
+        if (!nbuf) { c->oom = 1; return 1; }
+        c->bytes = nbuf;
+        c->cap_b = cap;
+    }
+    memcpy(c->m + c->n, m, n * sizeof(*m));
+    if (n_bytes) memcpy(c->bytes + c->nb, bytes, n_bytes);
+    c->n += n;
+    c->nb += n_bytes;
+    return 0;
+}
+
+/* this shard is done (or was never scanned: its file could not be opened): print what is still held back when the
+ * shards in front have finished, then hand the turn on */
+static void shard_done(struct shard_emit *c, uint64_t n_records, int last_of_file)
+{
+    uint64_t rec_off;
+    (void)shard_my_turn(c, 1, &rec_off);
+    shard_flush_held(c, rec_off);
+    pthread_mutex_lock(&c->ord->mu);
+    c->ord->rec_off = last_of_file ? 0 : c->ord->rec_off + n_records;
+    c->ord->turn = c->seq + 1;
+    pthread_cond_broadcast(&c->ord->cv);
+    pthread_mutex_unlock(&c->ord->mu);
+    free(c->m);
+    free(c->bytes);
+    c->m = NULL;
+    c->bytes = NULL;
+    c->cap_m = c->cap_b = 0;
+}
+
+static int scan_range(agh_query *q, int fd, uint64_t b, uint64_t e, struct shard_emit *emit, struct filehit *out)
+{
     unsigned inv = opt.INVERSE ? AGH_INVERT : 0u;
     memset(out, 0, sizeof(*out));
-    if (!want_records)
+    if (!emit)
         return agh_scan_fd_range(q, fd, b, e, AGH_COUNT | inv, &out->res, NULL, 0);
-    out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
-    if (!out->matches) return -1;
-    if (agh_scan_fd_range(q, fd, b, e, inv, &out->res, out->matches, cap)) return -1;
-    if (out->res.truncated) {
-        free(out->matches);
-        cap = (size_t)out->res.n_matched + 16;
-        out->matches = (agh_match *)malloc(cap * sizeof(agh_match));
-        if (!out->matches) return -1;
-        if (agh_rescan_staged(q, inv, &out->res, out->matches, cap)) return -1;
-    }
-    if (agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, NULL, 0, &total) == 0 && total == 0)
-        return 0;
-    out->bytes = (unsigned char *)malloc(total ? total : 1);
-    if (!out->bytes) return -1;
-    return agh_fetch_records(q, out->matches, (size_t)out->res.n_stored, out->bytes, total, &total);
+    /* the shard streams through two bounded device segments like a file of its own (agh_scan_fd_range_emit): HBM
+     * and host memory stay bounded whatever the size of the file (round 5 staged the whole shard and fetched its
+     * records after the scan) */
+    if (agh_scan_fd_range_emit(q, fd, b, e, inv, &out->res, shard_emit_records, emit)) return -1;
+    if (emit->oom) { fprintf(stderr, "%s: out of memory\n", Progname); exit(2); }
+    return 0;
 }
 
 static void *gpu_worker(void *arg)
@@ -426,16 +528,25 @@ static void *gpu_worker(void *arg)
     struct gpu_task *t = (struct gpu_task *)arg;
     agh_query *q;
     int f;
+    q = NULL;
     if (agh_set_device(t->rank) || !(q = t->build())) {
         t->failed = 1;
         snprintf(t->err, sizeof(t->err), "GPU %d: %s", t->rank, agh_last_error());
-        return NULL;
     }
     for (f = 0; f < t->nfiles && !t->failed; f++) {
         int fd;
+        struct shard_emit em;
         if (opt.FILENAMEONLY && f % t->ngpus != t->rank) continue;     /* dealt to another GPU */
+        memset(&em, 0, sizeof(em));
+        em.ord = t->order;
+        em.seq = (long)f * t->ngpus + t->rank;
+        em.name = t->files[f];
+        em.with_name = t->with_name;
         fd = open(t->files[f], O_RDONLY);
-        if (fd < 0) continue;                    /* reported once by the main thread */
+        if (fd < 0) {                            /* reported once by the main thread */
+            if (t->want_records) shard_done(&em, 0, t->rank == t->ngpus - 1);
+            continue;
+        }
         if (opt.FILENAMEONLY) {
             agh_result r;
             /* the same flags as the one-GPU path (scan_one): -l -v lists the files with a record
@@ -445,13 +556,24 @@ static void *gpu_worker(void *arg)
         } else {
             uint64_t cuts[65];
             if (agh_shard_cuts_fd(fd, opt.delim, opt.dlen, t->ngpus, cuts) ||
-                scan_range(q, fd, cuts[t->rank], cuts[t->rank + 1], t->want_records, &t->hits[f]))
+                scan_range(q, fd, cuts[t->rank], cuts[t->rank + 1], t->want_records ? &em : NULL, &t->hits[f]))
                 t->failed = 1;
+            /* (a failed shard still hands the turn on: the other threads must come to their join) */
+            if (t->want_records) shard_done(&em, t->failed ? 0 : t->hits[f].res.n_records, t->rank == t->ngpus - 1);
         }
         if (t->failed) snprintf(t->err, sizeof(t->err), "%s: %s", t->files[f], agh_last_error());
         close(fd);
     }
-    agh_query_free(q);
+    /* a thread that gave up hands on the turns of the shards it will not scan */
+    if (t->failed && t->want_records)
+        for (; f < t->nfiles; f++) {             /* (f: the first file this thread has not handed on) */
+            struct shard_emit em;
+            memset(&em, 0, sizeof(em));
+            em.ord = t->order;
+            em.seq = (long)f * t->ngpus + t->rank;
+            shard_done(&em, 0, t->rank == t->ngpus - 1);
+        }
+    if (q) agh_query_free(q);
     return NULL;
 }
 
@@ -482,7 +604,12 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
     agh_comm *comms[64];
     long total = 0;
     int r, f;
+    struct shard_order order;
     if (nfiles == 0) die_usage("--gpus needs file arguments (stdin cannot be cut into shards)");
+    pthread_mutex_init(&order.mu, NULL);
+    pthread_cond_init(&order.cv, NULL);
+    order.turn = 0;
+    order.rec_off = 0;
     if (agh_device_count() < G) {
         fprintf(stderr, "%s: --gpus %d but only %d HIP device(s) are visible\n", Progname, G, agh_device_count());
         exit(2);
@@ -501,6 +628,8 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
         tasks[r].files = files;
         tasks[r].nfiles = nfiles;
         tasks[r].want_records = want_records;
+        tasks[r].order = &order;
+        tasks[r].with_name = nfiles > 1 && !opt.NOFILENAME;
         tasks[r].hits = (struct filehit *)calloc((size_t)nfiles, sizeof(struct filehit));
         tasks[r].file_hit = (unsigned char *)calloc((size_t)nfiles, 1);
         pthread_create(&th[r], NULL, gpu_worker, &tasks[r]);
@@ -536,7 +665,7 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
         free(host_or);
     }
     for (f = 0; f < nfiles; f++) {
-        uint64_t counts[64][2], host_sum = 0, rec_off = 0;
+        uint64_t counts[64][2], host_sum = 0;
         int fd = open(files[f], O_RDONLY);
         if (fd < 0) {                            /* agrep.c:2952-2958 */
             fprintf(stderr, "%s: '%s' no such file or directory\n", Progname, files[f]);
@@ -574,15 +703,7 @@ static long run_multi_gpu(query_builder build, char **files, int nfiles, long *f
                     printf("%s: %llu\n", files[f], (unsigned long long)counts[0][0]);
                 else
                     printf("%llu\n", (unsigned long long)counts[0][0]);
-            } else if (want_records) {
-                for (r = 0; r < G; r++) {        /* shard after shard = file order */
-                    struct filehit *h = &tasks[r].hits[f];
-                    uint64_t i;
-                    for (i = 0; i < h->res.n_stored; i++) h->matches[i].index += rec_off;
-                    print_records(h, files[f], nfiles > 1 && !opt.NOFILENAME);
-                    rec_off += h->res.n_records;
-                }
-            }
+            }                                    /* (records: printed by the workers, shard after shard) */
         }
         if (counts[0][0]) (*files_matched)++;
         total += (long)counts[0][0];

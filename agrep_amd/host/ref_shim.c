@@ -167,14 +167,23 @@ struct text_src {
  * (AGH_EMIT_HEAD_DELIM | AGH_EMIT_TAIL_DELIM: the buffer shape of asearch.c:162-170), so output() is called
  * exactly as before, only earlier and without the whole file in HBM. */
 struct stream_ctx {
+    const agh_query *q;
     const unsigned char *delim;
-    int dlen, lead_delim, rc;
+    int dlen, lead_delim, lead_known, rc;
 };
 
 static int stream_emit(void *vctx, const agh_match *m, size_t n, const unsigned char *bytes, size_t n_bytes)
 {
     struct stream_ctx *c = (struct stream_ctx *)vctx;
     size_t off = 0, i;
+    if (!c->lead_known) {
+        /* -d: does the input open with the delimiter (asearch.c:79-84 starts counting at -1)?  The library has
+         * kept the first bytes of what it read: no second look at the input, so a pipe streams like a file */
+        unsigned char first[AGH_MAX_DELIM];
+        c->lead_delim = agh_input_head(c->q, first, (size_t)c->dlen) == (size_t)c->dlen &&
+                        memcmp(first, c->delim, (size_t)c->dlen) == 0;
+        c->lead_known = 1;
+    }
     for (i = 0; i < n; i++) {
         const size_t pre = m[i].start < (uint64_t)c->dlen ? (size_t)m[i].start : (size_t)c->dlen;
         const size_t body = (size_t)(m[i].end - m[i].start);
@@ -189,23 +198,19 @@ static int stream_emit(void *vctx, const agh_match *m, size_t n, const unsigned 
     return 0;
 }
 
-/* -d: does the input open with the delimiter (asearch.c:79-84 starts counting at -1)?  Known up front for
- * seekable files only; 0 otherwise (the caller does not stream then) */
-static int peek_lead_delim(int fd, const unsigned char *delim, int dlen, int *known)
-{
-    unsigned char first[AGH_MAX_DELIM];
-    const off_t cur = lseek(fd, 0, SEEK_CUR);
-    *known = 0;
-    if (cur < 0) return 0;
-    *known = 1;
-    return pread(fd, first, (size_t)dlen, cur) == (ssize_t)dlen && memcmp(first, delim, (size_t)dlen) == 0;
-}
-
 /* The reference's main() ends in exit(ret) (main.c:79,96).  A process that has scanned on the GPU would then tear
  * down two device segments, the pinned ring and the HIP runtime itself: 50-80 ms of a 0.3 s run on a 4 GiB file
  * (profiles/r05_startup.log).  Registered at the first scan, this handler runs before the runtime's own (handlers
  * run in reverse order of registration): it flushes what the front end has printed and leaves with the same
- * status -- the kernel reclaims the rest.  AGH_CLI_TEARDOWN=1 keeps the orderly teardown. */
+ * status -- the kernel reclaims the rest.  AGH_CLI_TEARDOWN=1 keeps the orderly teardown.
+ *
+ * Only where the shim OWNS THE PROCESS: -DAGH_SHIM_OWNS_PROCESS=1 is given by the link recipe of the command-line
+ * binary (the reference's main.o is the program: oracle/Makefile agrep_gpu).  A host application
+ * that links the front end as a library and calls fileagrep() / fileagrep_search() (glimpse; SURVEY 8b "higher-level
+ * API") is file mode too, and its own atexit handlers registered earlier must run: without the macro nothing is
+ * armed.  (EXITONERROR cannot tell the two apart at run time: main.c:78 sets it to 1 and the initial_value() of every
+ * agrep_init() puts it back to 0, agrep.c:347, before any engine runs.) */
+#if defined(AGH_SHIM_OWNS_PROCESS) && AGH_SHIM_OWNS_PROCESS
 static void fast_exit(int status, void *unused)
 {
     (void)unused;
@@ -221,6 +226,9 @@ static void arm_fast_exit(void)
     armed = 1;
     on_exit(fast_exit, NULL);
 }
+#else
+static void arm_fast_exit(void) {}
+#endif
 
 static int run_scan(agh_query *q, const struct text_src *src, const unsigned char *delim, int dlen)
 {
@@ -232,7 +240,7 @@ static int run_scan(agh_query *q, const struct text_src *src, const unsigned cha
     uint64_t i, text_len;
     int rc = 0, lead_delim = 0;
 
-    if (src->fd >= 0) arm_fast_exit();          /* (memory mode: the caller's process, not ours to end) */
+    if (src->fd >= 0) arm_fast_exit();          /* (command-line build only; memory mode: never) */
     if (COUNT || (FILENAMEONLY && (NEW_FILE || !POST_FILTER))) {
         flags |= FILENAMEONLY && !COUNT ? AGH_FILENAMEONLY : AGH_COUNT;
         rc = src->fd >= 0 ? agh_scan_fd(q, src->fd, flags, &res, NULL, 0)
@@ -245,24 +253,23 @@ static int run_scan(agh_query *q, const struct text_src *src, const unsigned cha
         return res.n_matched ? print_filename() : 0;
     }
 
-    if (src->fd >= 0) {
+    if (src->fd >= 0) {                         /* files and pipes alike, with or without -d */
         struct stream_ctx c;
-        int known = 1;
+        c.q = q;
         c.delim = delim;
         c.dlen = dlen;
         c.rc = 0;
-        c.lead_delim = DELIMITER ? peek_lead_delim(src->fd, delim, dlen, &known) : 0;
-        if (known) {                            /* (-d on a pipe: the staged path below) */
-            rc = agh_scan_fd_emit(q, src->fd, flags | AGH_EMIT_HEAD_DELIM | AGH_EMIT_TAIL_DELIM, &res, stream_emit, &c);
-            if (rc) return shim_fail(agh_last_error());
-            return c.rc;
-        }
+        c.lead_delim = 0;
+        c.lead_known = !DELIMITER;
+        rc = agh_scan_fd_emit(q, src->fd, flags | AGH_EMIT_HEAD_DELIM | AGH_EMIT_TAIL_DELIM, &res, stream_emit, &c);
+        if (rc) return shim_fail(agh_last_error());
+        return c.rc;
     }
 
     ms = (agh_match *)malloc(cap * sizeof(*ms));
     if (!ms) return shim_fail("out of memory");
-    rc = src->fd >= 0 ? agh_scan_fd(q, src->fd, flags, &res, ms, cap)
-                      : agh_scan_buffer(q, src->mem, src->mem_len, flags, &res, ms, cap);
+    /* memory mode (fd == -1): the caller's buffer is staged whole */
+    rc = agh_scan_buffer(q, src->mem, src->mem_len, flags, &res, ms, cap);
     if (!rc && res.truncated) {                 /* more matches than guessed: the text is staged */
         free(ms);
         cap = (size_t)res.n_matched + 16;

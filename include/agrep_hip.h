@@ -227,6 +227,11 @@ int agh_scan_fd_emit(agh_query *q, int fd, unsigned flags, agh_result *res, agh_
  * shards in front); AGH_EMIT_HEAD_DELIM gives the first record of the shard no delimiter in front. */
 int agh_scan_fd_range_emit(agh_query *q, int fd, uint64_t begin, uint64_t end, unsigned flags,
                            agh_result *res, agh_emit_fn emit, void *ctx);
+/* The first bytes (at most 64) of the input of the streamed scan that is running or ran last on this query
+ * (agh_scan_fd / agh_scan_fd_emit and their ranged forms): known from the first chunk on, i.e. inside every emit()
+ * call.  What asearch.c:79-84 looks at -- "does the input open with the delimiter?" decides where its record
+ * numbers start -- without a second read of the input: a pipe can be streamed too.  Returns the bytes copied. */
+size_t agh_input_head(const agh_query *q, unsigned char *out, size_t cap);
 /* The same for text already resident in HBM (dev_text as for agh_scan_device): numbered scan, record bounds
  * and the gather of the record bytes on the device. */
 int agh_scan_device_emit(agh_query *q, const void *dev_text, size_t len, unsigned flags, agh_result *res,

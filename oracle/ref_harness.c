@@ -17,6 +17,10 @@
  *   ref_harness membuf:N FILE [agrep options] PATTERN
  *       -> memory mode on BOTH sides: output into a caller buffer of N bytes (agrep_outbuffer,
  *          agrep.h:130 OUTPUT_OVERFLOW); prints "ret=<r> matched=<n> outlen=<bytes>\n" and the bytes
+ *   ref_harness fileapi FILE [agrep options] PATTERN
+ *       -> FILE mode as a host application (glimpse) uses it: registers an atexit() handler of its own, calls
+ *          fileagrep() (agrep.c:3300) on FILE with output to stdout and leaves through exit(): the handler's line
+ *          "host-atexit-ran" must follow the records -- a drop-in engine may not end the caller's process its own way
  *
  * The same source linked with agrep_amd/host/ref_shim.c instead of the reference's engine objects
  * (oracle/Makefile, _ref/ref_harness_gpu) exercises the shim's memory mode.
@@ -35,6 +39,9 @@ extern unsigned wildmask, endposition, D_endpos;
 extern int num_of_matched, D_length, AND, SGREP, DELIMITER, NOUPPER;
 extern int memagrep(int argc, char *argv[], int input_len, char *input_buffer,
                     int output_len, void *output);
+extern int fileagrep(int argc, char *argv[], int output_len, void *output);
+
+static void host_atexit(void) { fputs("host-atexit-ran\n", stdout); fflush(stdout); }
 
 static char *slurp(const char *path, long *len_out)
 {
@@ -67,6 +74,16 @@ int main(int argc, char **argv)
     }
     mode = argv[1];
     av[ac++] = "agrep";
+    if (strcmp(mode, "fileapi") == 0) {
+        atexit(host_atexit);
+        av[ac++] = "-V0";
+        for (i = 3; i < argc && ac < 62; i++) av[ac++] = argv[i];
+        av[ac++] = argv[2];
+        av[ac] = NULL;
+        ret = fileagrep(ac, av, 0, stdout);
+        fflush(stdout);
+        exit(ret < 0 ? 1 : 0);
+    }
     if (strcmp(mode, "tables") == 0) {
         first_opt = 2;
         buf = (char *)calloc(8192, 1);
