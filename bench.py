@@ -55,12 +55,15 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 12345
 
 
-def ref_all_cores(ref, host, k, tmpdir, procs, records=False):
+def ref_all_cores(ref, host, k, tmpdir, procs, records=False, opts=(), pattern=None):
     """The reference is single-threaded: 'all host cores' = `procs` independent agrep processes on
     `procs` record-aligned pieces of `host` (pages end with a newline), started together.
     -> (sum of the counts, seconds from the first start to the last exit, processes[, sha256 of the lines]);
     records: run WITHOUT -c -- the reference prints the matched records (s_output(), sgrep.c:1274-1333); the
-    count is then the number of printed lines and the digest covers the pieces' outputs in file order"""
+    count is then the number of printed lines and the digest covers the pieces' outputs in file order.
+    opts / pattern: further options (-i: checksg.c:129 sends every -i query with errors to asearch(), asearch.c:32-572)
+    and another pattern.  The pieces start at page boundaries and no record crosses a page, so no occurrence
+    straddles byte 49152 of a piece (quirk Q1 of the asearch path's file mode)"""
     from concurrent.futures import ThreadPoolExecutor
     n = host.size
     pages = n // 4096
@@ -70,7 +73,7 @@ def ref_all_cores(ref, host, k, tmpdir, procs, records=False):
     try:
         with ThreadPoolExecutor(max_workers=8) as ex:             # (tofile releases the GIL)
             list(ex.map(lambda a: host[a[0][0]:a[0][1]].tofile(a[1]), zip(spans, paths)))
-        cmd = [ref, "-V0", "-%d" % k] + ([] if records else ["-c"]) + [PATTERN.decode()]
+        cmd = [ref, "-V0"] + list(opts) + ["-%d" % k] + ([] if records else ["-c"]) + [(pattern or PATTERN).decode()]
         t0 = time.time()
         if records:
             # (stdout to files: 32 pipes read one after the other would stall the writers)
@@ -124,7 +127,8 @@ def cpu_baseline_extras(ref, host, sample_bytes, k, tmpdir):
     return out
 
 
-def reference_all_shards(text_dev, n_bytes, k, q, shard_bytes, first_shard_host):
+def reference_all_shards(text_dev, n_bytes, k, q, shard_bytes, first_shard_host, opts=(), pattern=None, make_shard=None,
+                         what=None):
     """Parity of the WHOLE corpus against the reference CPU agrep -- the match SET, not only its size: shard by
     shard (4 GiB each: the SURVEY 8d shards) through /dev/shm, every shard cut into one file per core, one
     reference process per file printing the matched records; beside it the GPU's count of the same shard
@@ -141,9 +145,12 @@ def reference_all_shards(text_dev, n_bytes, k, q, shard_bytes, first_shard_host)
     ref_seconds = 0.0
     for sh in range(n_shards):
         lo = sh * shard_bytes
+        if make_shard is not None:              # the shard is generated into text_dev[0:shard_bytes) now
+            make_shard(sh)
+            lo = 0
         host = first_shard_host if (sh == 0 and first_shard_host is not None and first_shard_host.size == shard_bytes) \
             else text_dev[lo:lo + shard_bytes].cpu().numpy()
-        cnt, dt, _, digest = ref_all_cores(ref, host, k, d, procs, records=True)
+        cnt, dt, _, digest = ref_all_cores(ref, host, k, d, procs, records=True, opts=opts, pattern=pattern)
         del host
         ref_counts.append(int(cnt))
         ref_sha.append(digest)
@@ -165,9 +172,39 @@ def reference_all_shards(text_dev, n_bytes, k, q, shard_bytes, first_shard_host)
             "equal": ref_counts == gpu_counts, "reference_seconds": round(ref_seconds, 2),
             "reference_GBps_all_cores": round(n_shards * shard_bytes / 1e9 / max(ref_seconds, 1e-9), 2),
             "wall_seconds": round(time.time() - t0, 1),
-            "what": "`agrep -V0 -%d %s` (unmodified reference, sgrep.c path, printing the matched records) over every "
-                    "byte of the corpus; per shard: its line count against the GPU's -c count, the sha256 of its "
-                    "lines against the sha256 of the records agh_scan_device_emit returns" % (k, PATTERN.decode())}
+            "what": what or ("`agrep -V0 -%d %s` (unmodified reference, sgrep.c path, printing the matched records) over every "
+                             "byte of the corpus; per shard: its line count against the GPU's -c count, the sha256 of its "
+                             "lines against the sha256 of the records agh_scan_device_emit returns" % (k, PATTERN.decode()))}
+
+
+def reference_all_shards_nocase(n_bytes, k, shard_bytes):
+    """The asearch() path at full size (asearch.c:32-572: what EVERY -i query with errors runs, checksg.c:129): the
+    same 16 shards of SURVEY 8d's generator with half of the letters upper-cased, `agrep -V0 -i -k pattern` (all
+    cores, printing) against agh_scan_device_emit of a nocase query, sha256 per shard.  The shards are generated
+    one after the other into a scratch buffer (the lower-case corpus stays resident next to it)."""
+    import torch
+    import agrep_amd as A
+    buf = torch.empty(shard_bytes, dtype=torch.uint8, device="cuda")
+    pages = shard_bytes // 4096
+
+    def make_shard(sh):
+        A.corpus_fill_device(buf.data_ptr(), pages, first_page=sh * pages, seed=SEED, variants=VARIANTS, plant_period=500,
+                             upper_permille=500)
+        torch.cuda.synchronize()
+    try:
+        with A.Query(PATTERN, k, nocase=True) as q:
+            out = reference_all_shards(
+                buf, n_bytes, k, q, shard_bytes, None, opts=("-i",), make_shard=make_shard,
+                what="`agrep -V0 -i -%d %s` (unmodified reference: -i with errors = asearch(), asearch.c:32-572) over "
+                     "every shard of the corpus with 50 %% of its letters upper-cased; per shard: its line count "
+                     "against the GPU's -c count of the nocase query, the sha256 of its lines against the sha256 of "
+                     "the records agh_scan_device_emit returns" % (k, PATTERN.decode()))
+            out["engine"] = {1: "fullscan", 2: "q-gram sample filter + verify"}.get(
+                int(q.scan_device(buf.data_ptr(), shard_bytes, flags=A.COUNT, time_sweep=False, time_scan=False).engine), "?")
+    finally:
+        del buf
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes, q=None, all_shards=False):
@@ -202,6 +239,11 @@ def cpu_baseline(text_dev, n_bytes, k, gpu_count_on_sample, sample_bytes, q=None
                 extra["all_shards_records_sha256_equal"] = bool(extra["all_shards"]["records_sha256_equal"])
             except Exception as e:
                 extra["all_shards_error"] = str(e)[:200]
+            try:
+                extra["all_shards_nocase"] = reference_all_shards_nocase(n_bytes, k, sample_bytes)
+                extra["all_shards_nocase_records_sha256_equal"] = bool(extra["all_shards_nocase"]["records_sha256_equal"])
+            except Exception as e:
+                extra["all_shards_nocase_error"] = str(e)[:200]
         return {"value": round(sample_bytes / 1e9 / dt, 4), "unit": "GB/s", "cores": 1,
                 **extra,
                 "kind": "reference",
@@ -303,6 +345,61 @@ def c5_patterns_and_variants():
     return pats, variants
 
 
+def c3_pinned_m29(A, torch, buf, n):
+    import hashlib
+    ref = os.path.join(ROOT, "oracle", "_ref", "agrep")
+    if not os.path.exists(ref):
+        return {"skipped": "oracle/_ref/agrep not built"}
+    rng = random.Random(29)
+    pat = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(29))
+    vs = [pat]
+    for edits in (1, 2, 3, 4):
+        v = bytearray(pat)
+        for _ in range(edits):
+            op, pos = rng.randint(0, 2), rng.randrange(3, len(v) - 3)
+            if op == 0:
+                v[pos] = ord("Q")
+            elif op == 1:
+                del v[pos]
+            else:
+                v.insert(pos, ord("Z"))
+        vs.append(bytes(v))
+    planted = A.corpus_fill_device(buf.data_ptr(), n // 4096, seed=29, variants=tuple(vs), plant_period=500, upper_permille=500)
+    want = int(sum(planted[:4]))
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    procs = min(os.cpu_count() or 1, 32)
+    piece = min(n, 4 << 30)
+    t0 = time.time()
+    ref_sha, gpu_sha, ref_lines, gpu_recs, ref_s = [], [], 0, 0, 0.0
+    with A.Query(pat, 3, nocase=True) as q:
+        info = q.info()
+        sec, r, sweep, launches, dev = timed_steps(torch, lambda: q.scan_device(buf.data_ptr(), n, flags=A.COUNT | A.TIME_SWEEP | A.TIME_SCAN), 5)
+        for lo in range(0, n, piece):
+            host = buf[lo:lo + piece].cpu().numpy()
+            cnt, dt, _, digest = ref_all_cores(ref, host, 3, d, procs, records=True, opts=("-i",), pattern=pat)
+            del host
+            ref_lines += int(cnt)
+            ref_s += dt
+            ref_sha.append(digest)
+            h = hashlib.sha256()
+            _, batches = q.scan_device_emit(buf.data_ptr() + lo, piece, flags=A.EMIT_TAIL_DELIM, summarize=True, hasher=h)
+            gpu_sha.append(h.hexdigest())
+            gpu_recs += sum(b[0] for b in batches)
+    return {"workload": "m=29 (the longest pattern maskgen.c:201-208 accepts) k=3 -i, %d GiB resident, 50 %% of the letters "
+                        "upper-cased: `agrep -V0 -i -3 <pattern>` (asearch(), asearch.c:32-572; %d processes per %d GiB "
+                        "piece, printing) against agh_scan_device_emit" % (n >> 30, procs, piece >> 30),
+            "pattern": pat.decode(), "value": round(n / 1e9 / sec, 2), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4),
+            "filter_sample": "q=%d bytes every h=%d bytes" % (info["filter_q"], info["filter_h"]),
+            "matched_records": int(r.n_matched), "planted_records_0_3_edits": want,
+            "reference_lines": ref_lines, "gpu_records_returned": gpu_recs,
+            "records_sha256_pieces_equal": sum(1 for a, b in zip(ref_sha, gpu_sha) if a == b), "pieces": len(ref_sha),
+            "records_sha256_equal": bool(ref_sha == gpu_sha and ref_lines == gpu_recs == int(r.n_matched)),
+            "reference_seconds": round(ref_s, 2), "reference_GBps_all_cores": round(n / 1e9 / max(ref_s, 1e-9), 2),
+            "wall_seconds": round(time.time() - t0, 1),
+            "roofline": roofline_block("k_sweep_fused<H=%d>" % info["filter_h"] if r.fused_segments else "k_sweep<H=%d>" % info["filter_h"],
+                                       n, 5, sweep, launches)}
+
+
 def timed_steps(torch, fn, steps, warmup=2):
     """-> (seconds per step, last result, sum of sweep_ms, sweep launches, sum of device_ms)"""
     for _ in range(warmup):
@@ -383,6 +480,14 @@ def config_blocks(A, torch, steps):
                      "matched_equals_planted": bool(rn.n_matched == want),
                      "roofline": roofline_block("k_sweep<H=%d, census>" % info["filter_h"], n, nsteps, sweepn, launchesn)}}
 
+    # C3's pinned neighbour: m = 29 is the longest pattern the reference's maskgen accepts with a newline delimiter
+    # (maskgen.c:201-208) -- k = 3, -i, the same 16 GiB recipe; the reference runs it (asearch(), 0.23 GB/s per core),
+    # so the match SET is compared: sha256 of its lines against the records the device returns, 4 GiB at a time
+    try:
+        out["c3"]["pinned_m29"] = c3_pinned_m29(A, torch, buf, n)
+    except Exception as e:                                      # never lose the line over this
+        out["c3"]["pinned_m29"] = {"error": str(e)[:300]}
+
     # C5: -f, 1024 patterns of 8..12 bytes, k = 1, 8 GiB (one GPU's share of 32 GiB over 4), count-only
     n = 8 << 30
     pats, variants = c5_patterns_and_variants()
@@ -438,6 +543,159 @@ def config_blocks(A, torch, steps):
     return out
 
 
+def c5_file_hits_job(A, torch, dist, comm, rank, world, backend, fence, args, n_files=32, steps=5):
+    """BASELINE configs[4] at N > 1: 32 files x 1 GiB of the C5 corpus, 1024 patterns of 8..12 bytes, k = 1, dealt in
+    blocks to G = min(N, 4) GPUs (rank r < G holds files [r * 32 / G, (r + 1) * 32 / G) resident in HBM).  A step = the
+    rank's files scanned one by one + ONE agh_reduce_file_hits over all ranks of the C-ABI's communicator.  Timed twice:
+    `every_byte` -- count-only scans (hit = count > 0; the throughput figure: every byte is read) -- and `dash_l` -- the
+    -l flag itself (asearch.c:130-161 stops at a file's first match).  The vector is cross-checked against
+    torch.distributed's own MAX all-reduce of the same local flags."""
+    G = min(world, 4)
+    per = n_files // G
+    fbytes = (args.c5_file_mib << 20) // 4096 * 4096
+    pats, variants = c5_patterns_and_variants()
+    mine = list(range(rank * per, (rank + 1) * per)) if rank < G else []
+    buf = torch.empty(max(len(mine), 1) * fbytes, dtype=torch.uint8, device="cuda")
+    pages = fbytes // 4096
+    planted_files = []
+    for i, f in enumerate(mine):
+        # (SURVEY 8d: one file in four holds planted patterns; with one error allowed the other files have chance
+        # matches of their own -- about 4 per MiB -- so on this corpus -l lists every file of a GiB)
+        pl = A.corpus_fill_device(buf.data_ptr() + i * fbytes, pages, first_page=f * pages, seed=55, variants=variants,
+                                  plant_period=500 if f % 4 == 0 else 1 << 30)
+        planted_files.append(int(sum(pl[:5])))
+    torch.cuda.synchronize()
+    q = A.Query.multi(pats, k=1)
+    res = {}
+    try:
+        for name, fl in (("every_byte", A.COUNT), ("dash_l", A.FILENAMEONLY)):
+            def step():
+                hits = [0] * n_files
+                cnt = 0
+                for i, f in enumerate(mine):
+                    r = q.scan_device(buf.data_ptr() + i * fbytes, fbytes, flags=fl, time_sweep=False, time_scan=False)
+                    hits[f] = 1 if r.n_matched else 0
+                    cnt += int(r.n_matched)
+                if comm is not None:
+                    return comm.reduce_file_hits(hits), hits, cnt
+                from agrep_amd import shard
+                return shard.reduce_file_hits(hits, device="cpu"), hits, cnt
+            step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                vec, local, cnt = step()
+            fence()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el, float(cnt)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            allr = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allr, t)
+            chk = torch.tensor(local, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+            res[name] = {"ms_per_step": round(max(float(a[0]) for a in allr) / steps * 1e3, 4),
+                         "rank_ms_per_step": [round(float(a[0]) / steps * 1e3, 4) for a in allr],
+                         "files_listed": int(sum(1 for v in vec if v)),
+                         "vector_equals_torch_all_reduce": bool([bool(v) for v in vec] == [bool(x) for x in chk.tolist()]),
+                         "matched_records_all_ranks": int(sum(float(a[1]) for a in allr)) if name == "every_byte" else None}
+    finally:
+        q.close()
+        del buf
+        torch.cuda.empty_cache()
+    ci = comm.info() if comm is not None else {"nranks": 0}
+    tot = n_files * fbytes
+    return {"workload": "BASELINE configs[4]: -f 1024 patterns (8..12 B) k=1, %d files x %d MiB resident on %d of %d GPU(s), "
+                        "per step every file scanned + one agh_reduce_file_hits (ncclAllReduce max) over all %d ranks"
+                        % (n_files, fbytes >> 20, G, world, world),
+            "value": round(tot / 1e9 / (res["every_byte"]["ms_per_step"] / 1e3), 2), "unit": "GB/s", "files": n_files,
+            "gpus_with_files": G, "rccl_ranks": int(ci["nranks"]), "steps": steps,
+            "hit_reduction": ("agh_reduce_file_hits (RCCL inside the C-ABI)" if backend == "nccl" else
+                              "agh_reduce_file_hits over agh_comm_init_custom (torch.distributed/%s: test hook)" % backend)
+                             if comm is not None else "torch.distributed/" + backend,
+            "planted_files_of_rank0": int(sum(1 for c in planted_files if c)) if rank == 0 else None,
+            **res}
+
+
+def engine_blocks(A, torch, steps=5):
+    """The engines BEHIND the sample filter, 4 GiB resident each, count-only, every one with a roofline sub-block
+    (algorithmic bytes = the text, time = the scan's device time between HIP events on its stream: the engine's
+    kernel, its replay kernel and the count) and its count on the first 64 MiB against the oracle's
+    (oracle/agrep_oracle.c: orc_asearch on the tables agh_compile_pattern makes, orc_asearch_costs, orc_wm_count
+    for m > 29).  `matching` is the word of the reference's own timing table (agrep.ps.2 table 3: BASELINE.md)."""
+    import _oracle as O
+    n = 4 << 30
+    sl = 64 << 20
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+    F = A.TIME_SWEEP | A.TIME_SCAN
+    ENG = {1: "fullscan / table engine", 2: "q-gram sample filter + verify"}
+    rng = random.Random(40)
+    pat40 = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(40))
+
+    def tables(pat, delim):
+        tb = A.compile_pattern(pat, delim=delim)
+        return O.tables_from_golden({"Mask": list(tb.Mask), "Init0": tb.Init0, "Init1": tb.Init1, "NO_ERR_MASK": tb.NO_ERR_MASK,
+                                     "endposition": tb.endposition, "D_endpos": tb.D_endpos, "wildmask": tb.wildmask,
+                                     "AND": tb.AND}, tb.M, dlen=len(delim))
+
+    cases = []      # (name, corpus, query factory, oracle(slice bytes) -> count, flags, slice bytes)
+    for k in (1, 2, 3):
+        cases.append(("matching_k%d" % k, "nl", lambda k=k: A.Query(b"matching", k),
+                      lambda t, k=k: O.asearch(b"matching", k, t)[0], 0, sl))
+    for k in (0, 1, 2):
+        cases.append(("approx#match_k%d" % k, "nl", lambda k=k: A.Query.pattern(b"approx#match", k),
+                      lambda t, k=k: O.asearch_tables(tables(b"approx#match", b"\n"), k, t)[0], 0, sl))
+    for k in (1, 2):
+        cases.append(("approx#match_I2_k%d" % k, "nl", lambda k=k: A.Query.pattern(b"approx#match", k).set_costs(2, 1, 1),
+                      lambda t, k=k: O.asearch_tables_costs(tables(b"approx#match", b"\n"), k, (2, 1, 1), t)[0], 0, sl))
+    for k in (0, 1, 2):
+        cases.append(("approx#match_d_e_space_k%d" % k, "nl", lambda k=k: A.Query.pattern(b"approx#match", k, delim=b"e "),
+                      lambda t, k=k: O.asearch_tables(tables(b"approx#match", b"e "), k, t, delim=b"e ")[0], 0, sl))
+    for k in (0, 1):
+        cases.append(("approx#match_1700B_records_k%d" % k, "nl", lambda k=k: A.Query.pattern(b"approx#match", k, delim=b"s\n"),
+                      lambda t, k=k: O.asearch_tables(tables(b"approx#match", b"s\n"), k, t, delim=b"s\n")[0], 0, sl))
+    cases.append(("m40_nocase_k6_filter", "upper", lambda: A.Query(pat40, 6, nocase=True),
+                  lambda t: O.wm_count(pat40, 6, t, nocase=True)[0], 0, 16 << 20))
+    cases.append(("m40_nocase_k6_fullscan_64bit_words", "upper", lambda: A.Query(pat40, 6, nocase=True),
+                  lambda t: O.wm_count(pat40, 6, t, nocase=True)[0], A.FORCE_FULLSCAN, 16 << 20))
+
+    out = {"workload": "engines behind the sample filter: 4 GiB of the SURVEY 8d corpus resident, count-only (-c), %d timed "
+                       "steps each; slice = the first 64 MiB (16 MiB for m = 40) against the oracle" % steps}
+    have = None
+    host_cache = {}
+    for name, corpus, make, oracle, flags, slb in cases:
+        try:
+            if have != corpus:
+                A.corpus_fill_device(buf.data_ptr(), n // 4096, seed=SEED, variants=VARIANTS + (pat40,), plant_period=500,
+                                     upper_permille=500 if corpus == "upper" else 0)
+                torch.cuda.synchronize()
+                have = corpus
+                host_cache.clear()
+            q = make()
+            try:
+                sec, r, sweep, launches, dev = timed_steps(torch, lambda: q.scan_device(buf.data_ptr(), n, flags=A.COUNT | F | flags), steps, warmup=1)
+                got = int(q.scan_device(buf.data_ptr(), slb, flags=A.COUNT | flags, time_sweep=False, time_scan=False).n_matched)
+            finally:
+                q.close()
+            if slb not in host_cache:
+                host_cache[slb] = buf[:slb].cpu().numpy()
+            t0 = time.time()
+            want = int(oracle(host_cache[slb]))
+            # (count-only scans on the sample filter report their one fused kernel as sweep_ms, not device_ms)
+            dev_ms = (dev if dev > 0 else sweep) / steps
+            ach = n / 1e6 / max(dev_ms, 1e-9)
+            out[name] = {"value": round(n / 1e9 / sec, 1), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4),
+                         "engine": ENG.get(int(r.engine), str(int(r.engine))), "matched_records": int(r.n_matched),
+                         "slice_count": got, "slice_oracle_count": want, "slice_equals_oracle": bool(got == want),
+                         "oracle_seconds": round(time.time() - t0, 2),
+                         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                      "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "device_ms": round(dev_ms, 4),
+                                      "algorithmic_bytes_per_launch": n}}
+        except Exception as e:                                  # never lose the line over this
+            out[name] = {"error": str(e)[:200]}
+    del buf
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -455,6 +713,9 @@ def main():
     ap.add_argument("--pmc-config", default="headline", help=argparse.SUPPRESS)
     ap.add_argument("--no-configs", action="store_true", help="skip the c2_records / c3 / c5 blocks (N = 1 only, ~30 s)")
     ap.add_argument("--config-steps", type=int, default=20)
+    ap.add_argument("--no-engines", action="store_true", help="skip the engines block (N = 1 only, ~20 s)")
+    ap.add_argument("--no-c5-files", action="store_true", help="skip the configs[4] file job with the -l hit vector (N > 1 only)")
+    ap.add_argument("--c5-file-mib", type=int, default=1024, help="size of one of the 32 files of the configs[4] job")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -503,7 +764,16 @@ def main():
             dist.broadcast(uid, src=0)
             comm = A.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank)
         else:
+            # (test hook, one-GPU boxes: RCCL refuses two ranks on one device) the SAME C-ABI calls --
+            # agh_scan_device_reduce, agh_reduce_file_hits -- on a communicator over the caller's transport
+            # (agh_comm_init_custom), here torch.distributed/gloo
             dist.init_process_group(backend)
+
+            def _allreduce(vals, elem):
+                t = torch.tensor(vals, dtype=torch.int64)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM if elem == 8 else dist.ReduceOp.MAX)
+                return t.tolist()
+            comm = A.Comm.custom(_allreduce, world, rank)
 
     if args.pmc_child and args.pmc_config == "c5":       # under rocprofv3 --pmc: the C5 scan, nothing else
         n5 = int(args.total_gib * (1 << 30)) // 4096 * 4096
@@ -588,6 +858,16 @@ def main():
     info0 = q0.info()
     elapsed0, res0, sweep_ms0, launches0, matched0, per_rank0 = timed_loop(q0)
 
+    # N > 1: BASELINE configs[4] as a job of its own -- 32 "files" of 1 GiB dealt to min(N, 4) GPUs, -f 1024 patterns
+    # k = 1, and the -l hit vector through agh_reduce_file_hits (ncclAllReduce(max) inside the C-ABI; every rank of the
+    # communicator takes part, the ones without files contribute zeros)
+    c5_files = None
+    if dist_on and not args.no_c5_files:
+        try:
+            c5_files = c5_file_hits_job(A, torch, dist, comm, rank, world, backend, fence, args)
+        except Exception as e:                                  # never lose the headline over this
+            c5_files = {"error": str(e)[:300]}
+
     # planted records of the whole job (all ranks), by number of edits
     pl = torch.tensor([int(x) for x in planted], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
     if dist_on:
@@ -616,9 +896,10 @@ def main():
                        "segments_per_gpu": int(res.n_segments),
                        "sharding": "contiguous page range per rank; the only exchange is the RCCL all-reduce of "
                                    "the counts (agh_reduce_counts)" if world > 1 else "one GPU holds the whole corpus",
-                       "count_reduction": ("agh_scan_device_reduce (RCCL ncclAllReduce inside the C-ABI, enqueued on the scan's "
-                                           "stream with the counts in device memory: one host sync per step)" if comm is not None
-                                           else ("torch.distributed/" + backend if dist_on else "none (one rank)")),
+                       "count_reduction": (("agh_scan_device_reduce (RCCL ncclAllReduce inside the C-ABI, enqueued on the scan's "
+                                            "stream with the counts in device memory: one host sync per step)" if backend == "nccl"
+                                            else "agh_scan_device_reduce over agh_comm_init_custom (torch.distributed/%s: test hook)" % backend)
+                                           if comm is not None else "none (one rank)"),
                        "engine": {1: "fullscan", 2: "q-gram sample filter + verify"}[res.engine],
                        "filter_sample": "q=%d bytes every h=%d bytes" % (info["filter_q"], info["filter_h"]),
                        "seed": SEED},
@@ -644,6 +925,8 @@ def main():
                          "avg_launch_ms": round(sweep_avg_ms, 4), "launches_timed": int(launches),
                          "whole_scan_frac": round(value / world / HBM_PEAK_GBPS, 4)},
         }
+        if c5_files is not None:
+            out["c5_files"] = c5_files
         if per_rank is not None:
             def rank_rows(rows):
                 out_rows = []
@@ -682,6 +965,11 @@ def main():
                 out.update(config_blocks(A, torch, args.config_steps))
             except Exception as e:                              # never lose the headline over this
                 out["configs_error"] = str(e)[:300]
+        if world == 1 and not args.no_engines:
+            try:
+                out["engines"] = engine_blocks(A, torch)
+            except Exception as e:                              # never lose the headline over this
+                out["engines_error"] = str(e)[:300]
         if world == 1 and not args.no_traffic:
             del text
             torch.cuda.empty_cache()

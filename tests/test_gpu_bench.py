@@ -48,14 +48,35 @@ def test_bench_single_and_two_ranks():
         assert cb["all_shards_records_sha256_equal"] is True, cb.get("all_shards")
         assert cb["all_shards"]["records_sha256_shards_equal"] == 4
     assert a["c2_records"]["matched_equals_planted"] is True
+    if cb["kind"] == "reference":
+        # the asearch() path at full size: -i on mixed-case shards, and the longest pattern the reference accepts
+        assert cb["all_shards_nocase_records_sha256_equal"] is True, cb.get("all_shards_nocase", cb.get("all_shards_nocase_error"))
+        assert cb["all_shards_nocase"]["shards"] == 4 and cb["all_shards_nocase"]["reference_count"] > 0
+        m29 = a["c3"]["pinned_m29"]
+        assert m29.get("records_sha256_equal") is True, m29
+        assert m29["matched_records"] >= m29["planted_records_0_3_edits"] > 0
+    # the engines behind the filter: every case measured, its slice count equal to the oracle's
+    eng = a["engines"]
+    cases = [k for k in eng if k != "workload"]
+    assert len(cases) >= 15, cases
+    for k in cases:
+        assert eng[k].get("slice_equals_oracle") is True, (k, eng[k])
+        assert 0 < eng[k]["roofline"]["frac"] < 1
+    assert eng["m40_nocase_k6_fullscan_64bit_words"]["engine"].startswith("fullscan")
 
     env.update(AGH_BENCH_BACKEND="gloo", AGH_BENCH_ONE_GPU="1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--total-gib", "0.5", "--steps", "3", "--warmup", "1"],
+                          "--gpus", "2", "--total-gib", "0.5", "--steps", "3", "--warmup", "1", "--c5-file-mib", "64"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT)
     assert two.returncode == 0, two.stderr[-2000:]
     b = _last_json(two.stdout)
+    # configs[4] as a file job over the ranks: the -l hit vector reduced over both ranks (here: gloo)
+    cf = b["c5_files"]
+    assert cf.get("files") == 32 and cf["gpus_with_files"] == 2, cf
+    for leg in ("every_byte", "dash_l"):
+        assert cf[leg]["vector_equals_torch_all_reduce"] is True and len(cf[leg]["rank_ms_per_step"]) == 2
+    assert cf["every_byte"]["files_listed"] == cf["dash_l"]["files_listed"] >= 8
     assert b["n_gpus"] == 2 and b["cpu_baseline"] is None
     # strong scaling: the same 0.5 GiB job, half of it per rank
     assert b["matched_records"] == a["matched_records"] and b["matched_equals_planted"] is True
@@ -89,10 +110,14 @@ def test_bench_rccl_code_path_with_one_rank():
     with a world of one rank."""
     env = dict(os.environ, AGH_BENCH_FORCE_DIST="1", MASTER_PORT="29541")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--total-gib", "0.5", "--steps", "3",
-                        "--warmup", "1", "--no-cpu-baseline", "--no-traffic"], stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, env=env, cwd=ROOT)
+                        "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--no-engines", "--no-configs", "--c5-file-mib", "64"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     a = _last_json(r.stdout)
+    # the file job's hit vector through agh_reduce_file_hits on RCCL (a communicator of one rank)
+    cf = a["c5_files"]
+    assert cf.get("hit_reduction", "").startswith("agh_reduce_file_hits") and cf["rccl_ranks"] == 1, cf
+    assert cf["every_byte"]["vector_equals_torch_all_reduce"] is True and cf["dash_l"]["files_listed"] == cf["every_byte"]["files_listed"]
     assert a["config"]["count_reduction"].startswith("agh_scan_device_reduce")
     assert a["matched_equals_planted"] is True and a["n_gpus"] == 1
     assert a["rccl_ranks"] == 1 and a["ranks"][0]["rccl_ranks"] == 1      # what agh_comm_info says about the communicator

@@ -191,6 +191,23 @@ def test_cli_multi_gpu_equals_single(files, args):
                 assert rc_g == rc_1
 
 
+@pytest.mark.parametrize("args", [["-V0", "-2"], ["-V0", "-n", "-i", "-2"], ["-V0", "-2", "-c"], ["-V0", "-v", "-n", "-2"],
+                                  ["-V0", "-d", "e ", "-n", "-i", "-1"], ["-V0", "-h", "-1"]])
+def test_cli_shards_print_in_file_order_while_scanning(files, args, tmp_path):
+    """--gpus N record output: every shard streams through agh_scan_fd_range_emit on a thread of its own; the shard
+    whose turn it is prints straight from its emit() calls, the ones behind it hold their records back until the
+    shards in front are done (file order, -n numbers offset by the records in front).  AGH_CLI_SHARE_DEVICES=1 puts
+    the N threads on the box's one GPU, so N = 2, 3, 5 run here; AGH_STREAM_SEG_MB=1 gives every shard several
+    emit() calls."""
+    for fl in (files[:1], files, files + ["/nonexistent/x"] + files[:1]):
+        a = args + ["approximatematch"] + fl
+        rc_1, out_1, err_1 = _run(CLI, a)
+        for g in (2, 3, 5):
+            rc_g, out_g, err_g = _run(CLI, ["--gpus", str(g)] + a, env={"AGH_CLI_SHARE_DEVICES": "1", "AGH_STREAM_SEG_MB": "1"})
+            assert out_g == out_1, (g, a, out_g[:300], out_1[:300], err_g[:300])
+            assert rc_g == rc_1 and err_g == err_1
+
+
 def test_cli_multi_gpu_pattern_file(files, tmp_path):
     pf = tmp_path / "pats.txt"
     pf.write_bytes(b"approximatematch\naproximatematch\nzzzzqqqq\n")

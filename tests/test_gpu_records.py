@@ -134,6 +134,39 @@ def test_inverse_list_above_one_emit_piece(agh, tmp_path):
     assert firsts == sorted(firsts) and firsts[0] == (0 if 0 not in matched_starts else firsts[0])
 
 
+def test_inverse_list_of_a_fresh_query_over_short_lines(agh):
+    """-v with a record list on a query that has not scanned before, over 8-byte lines: the first attempt sizes the
+    record bitmap (and rec_pos, one entry per bit) from a hint of one record per 64 bytes, the text has eight times
+    as many -- the queued compaction must stay inside what was allocated (it clamps the record count to the bitmap's
+    bits) and the rerun with the right size lists every non-matching record once, in file order."""
+    n_lines = 1 << 20
+    rows = np.full((n_lines, 8), ord("x"), dtype=np.uint8)
+    rows[:, 7] = 10
+    hit = np.arange(5, n_lines, 997)
+    rows[hit, :7] = np.frombuffer(b"matchme", dtype=np.uint8)
+    text = rows.reshape(-1)
+    for delim_flags in (0, agh.EMIT_TAIL_DELIM):
+        with agh.Query(b"matchme", 0) as q:                       # fresh: no bitmap hint from an earlier scan
+            import torch
+            dev = torch.from_numpy(text).cuda()
+            res, batches = q.scan_device_emit(dev.data_ptr(), text.size, flags=agh.INVERT | delim_flags, summarize=True)
+            assert res.n_matched == n_lines - hit.size
+            assert sum(b[0] for b in batches) == n_lines - hit.size
+            assert sum(b[1] for b in batches) == (n_lines - hit.size) * (8 if delim_flags else 7)
+            # ... and the plain list afterwards (the hint is right now), then -v again on the grown buffers
+            res2, b2 = q.scan_device_emit(dev.data_ptr(), text.size, flags=delim_flags, summarize=True)
+            assert res2.n_matched == hit.size == sum(b[0] for b in b2)
+            res3, b3 = q.scan_device_emit(dev.data_ptr(), text.size, flags=agh.INVERT | delim_flags, summarize=True)
+            assert sum(b[0] for b in b3) == n_lines - hit.size
+            # starts ascend over the pieces
+            firsts = [b[2] for b in batches]
+            assert firsts == sorted(firsts)
+    with agh.Query(b"matchme", 0) as q:
+        res, ms = q.scan_buffer(text[: 8 * 4096], flags=agh.INVERT, cap=8192)
+        want = [i * 8 for i in range(4096) if i not in set(hit.tolist())]
+        assert [m[0] for m in ms] == want
+
+
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(GPU)), reason="oracle/_ref/agrep and agrep_gpu not built")
 def test_shim_prints_while_the_input_is_still_being_read(tmp_path):
     """The reference's front end on the GPU engines (agrep_gpu) prints the matched records of the first stream

@@ -149,6 +149,30 @@ def test_stdin_and_missing_file(files):
     _same(["-V0", "-2", "-c", "approximatematch", "/nonexistent/file"], files[:1])
 
 
+@needs
+@pytest.mark.parametrize("delim", [";", "e ", "$$"])
+def test_delimiter_on_a_pipe_streams_like_a_file(files, tmp_path, delim):
+    """-d on a pipe: "does the input open with the delimiter" (asearch.c:79-84: where -n starts counting) comes from
+    agh_input_head() inside the first emit(), so the pipe streams through the same two segments as a file -- with
+    and without a leading delimiter, -n numbers included."""
+    text = open(files[1], "rb").read()[:60000]
+    raw = {";": b";", "e ": b"e ", "$$": b"\n\n"}[delim]
+    if delim != "e ":
+        text = text.replace(b"\n", raw)
+    for lead in (b"", raw):
+        data = lead + text
+        f = tmp_path / "p.txt"
+        f.write_bytes(data)
+        for args in (["-V0", "-d", delim, "-i", "-n", "-1"], ["-V0", "-d", delim, "-i", "-2"], ["-V0", "-d", delim, "-n", "-1", "-c"]):
+            a = args + ["approximatematch"]
+            rc_r, out_r, _ = _run(REF, a + [str(f)])
+            rc_g, out_g, err_g = _run(GPU, a + ["/dev/stdin"], stdin=data)
+            assert (rc_g, out_g) == (rc_r, out_r), (a, bool(lead), out_g[:200], out_r[:200], err_g[:200])
+            env = dict(os.environ, AGH_STREAM_SEG_MB="1")           # several segments
+            p = subprocess.run([GPU] + a + ["/dev/stdin"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert (p.returncode, p.stdout) == (rc_r, out_r), (a, bool(lead), "1 MiB segments")
+
+
 HARNESS = os.path.join(O.REF_DIR, "ref_harness")
 HARNESS_GPU = os.path.join(O.REF_DIR, "ref_harness_gpu")
 
@@ -330,3 +354,17 @@ def test_long_simple_patterns_reference_records_are_a_subset(tmp_path, m, k):
     assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want            # the device set is the exact one
     assert sum(ref_lines.values()) > 20, (rc, err[:200])
     assert not (ref_lines - gpu_lines), "the reference printed a record the device does not have"
+
+
+@pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(HARNESS_GPU)),
+                    reason="oracle/_ref/ref_harness(_gpu) not built (make -C oracle ref ref_gpu)")
+@pytest.mark.parametrize("opts", [["-i", "-2"], ["-2"], ["-2", "-c"], ["-i", "-1", "-l"]])
+def test_library_host_keeps_its_atexit_handlers(files, opts):
+    """fileagrep() called by a host application (glimpse's use): FILE mode, but not the shim's process.
+    The host registers an atexit() handler before the search and leaves through exit(); its handler must run behind
+    the records -- the shim's fast _exit() is compiled into the command-line binary only (AGH_SHIM_OWNS_PROCESS)."""
+    a = ["fileapi", files[0]] + opts + ["approximatematch"]
+    rc_r, out_r, _ = _run(HARNESS, a)
+    rc_g, out_g, err_g = _run(HARNESS_GPU, a)
+    assert out_r.endswith(b"host-atexit-ran\n")
+    assert (rc_g, out_g) == (rc_r, out_r), (opts, out_g[-200:], out_r[-200:], err_g[:300])
