@@ -680,6 +680,8 @@ void agh_read_tuning(agh_tuning *t)
         t->tr_group = (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ? (uint32_t)g : 8u;
         const uint64_t mc = env_u64("AGH_MW_CH", 0);
         t->mw_ch = (mc >= 256 && mc <= 65536 && !(mc & (mc - 1))) ? (uint32_t)mc : 0u;     // 0: by the size of the segment
+        const uint64_t mtl = env_u64("AGH_MTILE", 2);
+        t->mtile = (mtl == 0 || mtl == 1 || mtl == 2 || mtl == 4) ? (uint32_t)mtl : 2u;
     }
     t->fused = env_on("AGH_FUSED", AGH_FUSED_DEFAULT != 0);
     t->debug = getenv("AGH_DEBUG") != nullptr;
@@ -1113,7 +1115,10 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
             // text -- those go through the hash set; 4 GiB: 183 / 199 / 207 / 192 GB/s at 1 / 2 / 4 / 8 KiB,
             // profiles/r05_ab_mw_ch.log)
             w.ch = q->tune.mw_ch ? q->tune.mw_ch : (a.n >= ((uint64_t)2 << 30) ? 4096u : (a.n >= ((uint64_t)512 << 20) ? 2048u : 1024u));
-            if (!agh_launch_mwalk(w, st)) return fail("internal error: no record walk for this pattern set");
+            if (q->tune.mtile) {
+                w.ch = q->tune.mtile | (uint32_t)(env_u64("AGH_MTILE_DBG", 0) << 8);
+                if (!agh_launch_mtile(w, st)) return fail("internal error: no tile walk for this pattern set");
+            } else if (!agh_launch_mwalk(w, st)) return fail("internal error: no record walk for this pattern set");
         } else if (!agh_launch_mscan(a, st)) return fail("internal error: no one-pass kernel for this pattern set");
         if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i + 1], st));
         agh_launch_resolve_giveups(a.text, dq.delim, a.mk, st);

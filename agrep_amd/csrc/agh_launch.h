@@ -17,6 +17,8 @@ struct agh_tuning {
     uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 / 2048 / 4096), 0 = by size
     uint32_t tr_group = 8;          // AGH_TR_GROUP: tiles whose replay lists one wave of k_table_replay takes (1, 2, 4, 8, 16)
     uint32_t mw_ch = 0;             // AGH_MW_CH: text bytes per lane of the record walk (a power of two, 256 .. 65536); 0: by size
+    uint32_t mtile = 2;             // AGH_MTILE: dense -f sets with one error: tiles a wave of k_mtile holds at a time (1, 2, 4);
+                                    // 0: the round-5 record walk k_mwalk (A/B)
     bool fused = true;              // AGH_FUSED
     bool debug = false;             // AGH_DEBUG
     bool aligned_cuts_only = false; // AGH_ALIGNED_CUTS_ONLY
@@ -244,5 +246,8 @@ struct agh_mwalk_args {
     uint32_t ch;             // text bytes per lane (0: 1024)
 };
 bool agh_launch_mwalk(const agh_mwalk_args &a, hipStream_t st);
+// ... the same scan as candidate / delimiter bits per tile and a walk over the candidate bits (agh_mtile.hip); a.ch: tiles
+// a wave holds at a time (1, 2, 4)
+bool agh_launch_mtile(const agh_mwalk_args &a, hipStream_t st);
 // forces the load of the core library's code object (first launch: ~7 ms) -- for a thread that has time for it
 void agh_warm_core_module();

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Round 6, second GPU call: the dense-set tile kernel -- parity (every form), then the A/B against round 5's walk.
+set -u
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests/test_gpu_multi.py -m gpu -x -q -k "record_walk" 2>&1 | tail -15 > gpurun_out/r06_b_pytest_walk.log
+cat gpurun_out/r06_b_pytest_walk.log
+timeout 600 python scripts/perf_c5_worded_r6.py 4 2>&1 | grep "^c5" > gpurun_out/r06_ab_mtile.log
+cat gpurun_out/r06_ab_mtile.log

@@ -434,18 +434,21 @@ def test_record_walk_takes_dense_one_error_sets(agh):
             assert c.fused_segments == 0 and c.n_matched == q.scan_buffer(small, flags=agh.COUNT | agh.FORCE_NUMBERED)[0].n_matched
 
 
-def test_record_walk_boundaries(agh):
-    """Records and occurrences around the seams of the walk: a lane's kilobyte, a wave's 64 KiB tile, the first 8
-    and last 24 positions (k_mwalk_edges), records that cross several kilobytes with hits in each of them (counted
-    once: the set of record starts), empty records, no trailing delimiter, a 2 MiB record in front of a hit (the
-    give-up list), texts below 32 bytes."""
+@pytest.mark.parametrize("mtile", ["2", "1", "4", "0"])
+def test_record_walk_boundaries(agh, monkeypatch, mtile):
+    """Records and occurrences around the seams of the dense-set kernels (AGH_MTILE: k_mtile with 1 / 2 / 4 tiles per
+    wave; 0: the round-5 record walk): a lane's 64-position word and kilobyte, a 4 KiB tile, a wave's 256 KiB range,
+    the first 8 and last 24 positions (the edges kernel), records that cross several tiles with hits in each of them
+    (counted once: the set of record starts), empty records, no trailing delimiter, a 2 MiB record in front of a hit
+    (the give-up list), texts below 32 bytes."""
+    monkeypatch.setenv("AGH_MTILE", mtile)
     pats = [b"needle", b"haystack", b"wxyz", b"abcdefghijklmn"]
     near = [b"needle", b"nedle", b"neeedle", b"haystak", b"hbystack", b"wxz", b"wxyyz", b"abcdefghijklm", b"abcdefgXijklmn"]
     for t in (b"", b"n", b"wxyz", b"wxyz\n", b"\nwxyz", b"xwxz", b"needle" * 3, b"needl", b"x" * 7 + b"needle" + b"y" * 23,
               b"x" * 8 + b"needle" + b"y" * 24, b"\n" * 100, b"wxz\n" * 10 + b"wx"):
         got = _one_pass_count(agh, pats, 1, t)
         assert got == len(_approx_want(pats, 1, t)), t[:40]
-    for boundary in (1024, 2048, 65536, 65536 + 1024, 131072):
+    for boundary in (64, 1024, 2048, 4096, 8192, 16384, 65536, 65536 + 1024, 131072, 262144):
         for tail in (0, 7, 24, 900):
             base = bytearray(b"q" * (boundary + 64 + tail))
             for i in range(53, len(base), 131):
@@ -474,10 +477,12 @@ def test_record_walk_boundaries(agh):
     assert _one_pass_count(agh, pats, 1, long) == 2
 
 
-def test_record_walk_fuzz(agh):
+@pytest.mark.parametrize("mtile", ["2", "1", "4", "0"])
+def test_record_walk_fuzz(agh, monkeypatch, mtile):
     """Random sets of 4..14-byte patterns over small and large alphabets (everything is a near miss, several
     entries per two-byte key, -i), random record lengths: count-only == numbered, and == the oracle's union on the
-    smaller cases."""
+    smaller cases.  Every form of the dense-set kernel (AGH_MTILE)."""
+    monkeypatch.setenv("AGH_MTILE", mtile)
     rng = random.Random(4242)
     ran = 0
     for it in range(60):
@@ -488,7 +493,7 @@ def test_record_walk_fuzz(agh):
         hi = rng.randint(lo, 14)
         npat = min(rng.choice([1, 3, 30, 300]), max(1, len(set(palpha)) ** lo // 4))
         pats = _rand_patterns(rng, npat, lo, hi, alphabet=palpha)
-        n = rng.choice([0, 1, 9, 31, 32, 33, 100, 1023, 1024, 1025, 4097, 65535, 65536, 70000, 263000])
+        n = rng.choice([0, 1, 9, 31, 32, 33, 100, 1023, 1024, 1025, 4095, 4096, 4097, 8200, 65535, 65536, 70000, 263000, 530000])
         talpha = alpha + b"\n" if rng.random() < 0.6 else alpha * 3 + b"\n"
         text = bytes(rng.choice(talpha) for _ in range(n))
         with agh.Query.multi(pats, nocase=nocase, k=1) as q:
