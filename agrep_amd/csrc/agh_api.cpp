@@ -678,10 +678,11 @@ void agh_read_tuning(agh_tuning *t)
         t->tf_chunk = (c == 1024 || c == 2048 || c == 4096 || c == 8192 || c == 16384 || c == 32768) ? (uint32_t)c : 0u;
         const uint64_t g = env_u64("AGH_TR_GROUP", 8);
         t->tr_group = (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ? (uint32_t)g : 8u;
-        const uint64_t mc = env_u64("AGH_MW_CH", 0);
-        t->mw_ch = (mc >= 256 && mc <= 65536 && !(mc & (mc - 1))) ? (uint32_t)mc : 0u;     // 0: by the size of the segment
-        const uint64_t mtl = env_u64("AGH_MTILE", 2);
-        t->mtile = (mtl == 0 || mtl == 1 || mtl == 2 || mtl == 4) ? (uint32_t)mtl : 2u;
+        const uint64_t mtl = env_u64("AGH_MTILE", 4);
+        t->mtile = (mtl == 1 || mtl == 2 || mtl == 4) ? (uint32_t)mtl : 4u;
+        // (measurements: AGH_MTILE_DBG bits, AGH_MTILE_SHARE = lanes with candidates at which the rest is shared out)
+        t->mtile_dbg = (uint32_t)(env_u64("AGH_MTILE_DBG", 0) & 0xff);
+        if (getenv("AGH_MTILE_SHARE")) t->mtile_dbg |= (uint32_t)((env_u64("AGH_MTILE_SHARE", 32) & 0x7f) + 1) << 8;
     }
     t->fused = env_on("AGH_FUSED", AGH_FUSED_DEFAULT != 0);
     t->debug = getenv("AGH_DEBUG") != nullptr;
@@ -1040,12 +1041,12 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
     const bool timing = (flags & (AGH_TIME_SWEEP | AGH_TIME_SCAN)) != 0;
     uint64_t max_n = 0;
     for (int i = 0; i < nseg; ++i) max_n = std::max(max_n, cuts[i + 1] - cuts[i]);
-    // the record walk over a dense set (agh_mwalk.hip) counts the records inside a lane's kilobyte in registers; the
-    // set only takes the records that cross a kilobyte boundary -- but on such sets most of those match: one slot
-    // per 256 bytes of text (load <= 1/4)
+    // the tile kernel over a dense set (agh_mtile.hip) counts the records inside a 4 KiB tile in registers; the set only
+    // takes the records that cross a tile's bounds (two per tile at most) -- but on such sets most of those match: one
+    // slot per 512 bytes of text (load <= 1/4)
     const bool walk = !q->ms_ok;
     uint64_t slots = 1u << 17;
-    if (walk) while (slots < (max_n >> 8) * (1024u / std::min(q->tune.mw_ch ? q->tune.mw_ch : 1024u, 1024u)) && slots < (1u << 28)) slots <<= 1;
+    if (walk) while (slots < (max_n >> 9) && slots < (1u << 28)) slots <<= 1;
     else if (!q->hashset_slots_hint) while (slots < (max_n >> 13) && slots < (1u << 26)) slots <<= 1;
     while (slots < q->hashset_slots_hint) slots <<= 1;
     {
@@ -1111,14 +1112,8 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
             w.mk = a.mk;
             w.ticket = a.ticket;
             w.n_cu = a.n_cu;
-            // bytes per lane: 4 KiB from 2 GiB on, 2 KiB from 512 MiB, else 1 KiB (fewer records cross into the next lane's
-            // text -- those go through the hash set; 4 GiB: 183 / 199 / 207 / 192 GB/s at 1 / 2 / 4 / 8 KiB,
-            // profiles/r05_ab_mw_ch.log)
-            w.ch = q->tune.mw_ch ? q->tune.mw_ch : (a.n >= ((uint64_t)2 << 30) ? 4096u : (a.n >= ((uint64_t)512 << 20) ? 2048u : 1024u));
-            if (q->tune.mtile) {
-                w.ch = q->tune.mtile | (uint32_t)(env_u64("AGH_MTILE_DBG", 0) << 8);
-                if (!agh_launch_mtile(w, st)) return fail("internal error: no tile walk for this pattern set");
-            } else if (!agh_launch_mwalk(w, st)) return fail("internal error: no record walk for this pattern set");
+            w.ch = q->tune.mtile | q->tune.mtile_dbg << 8;
+            if (!agh_launch_mtile(w, st)) return fail("internal error: no tile walk for this pattern set");
         } else if (!agh_launch_mscan(a, st)) return fail("internal error: no one-pass kernel for this pattern set");
         if (timing) HIP_TRY(hipEventRecord(q->time_events[3 * i + 1], st));
         agh_launch_resolve_giveups(a.text, dq.delim, a.mk, st);

@@ -203,14 +203,22 @@ AGH_HD uint32_t agh_ms_ghash(uint32_t g)
 }
 #define AGH_MS_GB1(h) ((h) >> 22)                    // 10 bits each
 #define AGH_MS_GB2(h) (((h) >> 12) & (AGH_MS_GBUCKETS - 1u))
-// ---- record walk over dense -f sets with one error (agh_mwalk.hip): entries by the first two bytes of their piece --
-#define AGH_MW_DIR 4096u                    // directory slots: (first entry << 16) | number of entries
-#define AGH_MW_MAX_ENT 3072u                // entries (16 bytes each) next to the directory and its masks: 128 KiB of LDS, one
-                                            // workgroup per CU (2048 slots / 2304 entries, two workgroups of 16 waves per CU:
-                                            // 163 GB/s against 183 -- more waves only evict each other's text lines from the L2)
+// ---- dense -f sets with one error (agh_mtile.hip): pieces of 2..7 bytes --------------------------------------------
+#define AGH_MW_DIR 4096u                    // slots of the mask table (by the pair) and of the entry directory
+#define AGH_MW_MAX_ENT 3072u                // entries (16 bytes each) next to the directory and the masks: 144 KiB of LDS, one
+                                            // workgroup per CU
+// the mask table's slot: the first two bytes of a piece
 AGH_HD uint32_t agh_mw_slot(uint32_t bigram)
 {
     return ((bigram & 0xffffu) * 40503u >> 4) & (AGH_MW_DIR - 1u);
+}
+// the entry directory's slot of a piece of >= 3 bytes: its first three bytes (pieces of two bytes: agh_mw_slot of the
+// pair).  A text position looks into both slots; with the pair alone a slot of the 4..12-byte set held 2.8 entries on
+// average and a wave waited for the longest of its 64 lists in every round (87 lane-instructions per byte,
+// profiles/r06_pmc_mtile_v1.json)
+AGH_HD uint32_t agh_mw_slot3(uint32_t trigram)
+{
+    return ((trigram & 0xffffffu) * 0x9E3779B1u >> 20) & (AGH_MW_DIR - 1u);
 }
 // q <= 3: the sample already fits 24 bits.
 AGH_HD uint32_t agh_sample_prod_q3(uint32_t s)

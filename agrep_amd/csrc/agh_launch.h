@@ -16,9 +16,8 @@ struct agh_tuning {
     uint64_t tf_fast_min_mb = 0;    // AGH_TF_FAST_MIN_MB: table engine, fast form from this segment size on
     uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 / 2048 / 4096), 0 = by size
     uint32_t tr_group = 8;          // AGH_TR_GROUP: tiles whose replay lists one wave of k_table_replay takes (1, 2, 4, 8, 16)
-    uint32_t mw_ch = 0;             // AGH_MW_CH: text bytes per lane of the record walk (a power of two, 256 .. 65536); 0: by size
-    uint32_t mtile = 2;             // AGH_MTILE: dense -f sets with one error: tiles a wave of k_mtile holds at a time (1, 2, 4);
-                                    // 0: the round-5 record walk k_mwalk (A/B)
+    uint32_t mtile = 4;             // AGH_MTILE: dense -f sets with one error: tiles a wave of k_mtile holds at a time (1, 2, 4)
+    uint32_t mtile_dbg = 0;         // AGH_MTILE_DBG | (AGH_MTILE_SHARE + 1) << 8: measurement switches of k_mtile
     bool fused = true;              // AGH_FUSED
     bool debug = false;             // AGH_DEBUG
     bool aligned_cuts_only = false; // AGH_ALIGNED_CUTS_ONLY
@@ -224,14 +223,14 @@ struct agh_mscan_args {
 };
 bool agh_launch_mscan(const agh_mscan_args &a, hipStream_t st);
 
-// record walk over dense -f sets with one error (agh_mwalk.hip): pieces of 2..7 bytes, the other side of the pattern
-// (<= 7 bytes) beside them
+// dense -f sets with one error (agh_mtile.hip): pieces of 2..7 bytes, the other side of the pattern <= 7 bytes
 struct agh_mwalk_dev {
     const uint4 *ent;        // x: piece bytes 0..3; y: bytes 4..6 | piece length << 24; z: side bytes 0..3 (nearest first);
                              // w: side bytes 4..6 | (side length | 8 if the side lies in front of the piece) << 24
-    const uint32_t *dir;     // AGH_MW_DIR slots by agh_mw_slot(first two piece bytes): (first entry << 16) | entries
-    const uint4 *fmask;      // per slot, bit (byte & 31): x the byte behind the pair (t[j+2]), y t[j+3], z t[j-1], w t[j-2] that
-                             // some entry of the slot can accept at all
+    const uint32_t *dir;     // AGH_MW_DIR slots, (first entry << 16) | entries: a piece of two bytes under agh_mw_slot of
+                             // the pair, a longer one under agh_mw_slot3 of its first three bytes
+    const uint4 *fmask;      // per agh_mw_slot of a pair, bit (byte & 31): x the byte behind the pair (t[j+2]), y t[j+3], z t[j-1],
+                             // w t[j-2] that some entry starting with the pair can accept at all
     uint32_t n_ent;
 };
 struct agh_mwalk_args {
@@ -243,11 +242,8 @@ struct agh_mwalk_args {
     agh_marks mk;            // hash set + counters
     uint32_t *ticket;
     uint32_t n_cu;
-    uint32_t ch;             // text bytes per lane (0: 1024)
+    uint32_t ch;             // tiles a wave holds at a time (1, 2, 4; 0: 2); bits 8..: measurement switches
 };
-bool agh_launch_mwalk(const agh_mwalk_args &a, hipStream_t st);
-// ... the same scan as candidate / delimiter bits per tile and a walk over the candidate bits (agh_mtile.hip); a.ch: tiles
-// a wave holds at a time (1, 2, 4)
 bool agh_launch_mtile(const agh_mwalk_args &a, hipStream_t st);
 // forces the load of the core library's code object (first launch: ~7 ms) -- for a thread that has time for it
 void agh_warm_core_module();

@@ -4,9 +4,10 @@
 // monkey1(); what carries over from the reference is its early exit: after a record's first verified entry it goes on
 // behind the record's end, newmgrep.c:858-905.)
 //
-// Round 5's record walk (k_mwalk, one lane per 1..4 KiB) had the early exit but the wrong layout: every lane streamed
-// its own cache lines (EA reads 2.3-2.8 x the text, 43 % of wave time on memory) and walked its slot's entries while
-// its 63 neighbours waited (124 lane-instructions per byte): 207 GB/s.  Here the two kinds of work are separated:
+// Round 5's record walk (k_mwalk, one lane per 1..4 KiB; removed after the A/B in profiles/r06_ab_mtile_v1.log) had the
+// early exit but the wrong layout: every lane streamed its own cache lines (EA reads 2.3-2.8 x the text, 43 % of wave
+// time on memory) and walked its slot's entries while its 63 neighbours waited (124 lane-instructions per byte):
+// 207 GB/s.  Here the two kinds of work are separated:
 //
 //   phase A  position-parallel, the sweeps' chunk-per-lane layout (a wave loads 1 KiB strips with one coalesced
 //            dwordx4 per lane): for each of a chunk's 16 positions the pair t[j], t[j+1] selects a directory slot
@@ -33,7 +34,9 @@
 
 #define MT_WAVES 16u                // waves per workgroup = per CU (one copy of the tables)
 #define MT_TILE 4096u               // 64 lanes x 64 positions
-#define MT_RANGE_TILES 64u          // tiles per ticket (256 KiB)
+#define MT_RANGE_TILES 64u          // tiles per ticket (256 KiB) on large texts; fewer on small ones: the launcher
+#define MT_LIST 512u                // entries of a wave's list of left-over candidates
+#define MT_SHARE_AT 32u             // ... shared out once so few lanes still have a candidate of their own
 
 typedef uint64_t u64_a1 __attribute__((aligned(1)));
 
@@ -66,8 +69,9 @@ struct mt_shared {
     uint4 fmask[AGH_MW_DIR];                    // 64 KiB
     uint32_t dir[AGH_MW_DIR];                   // 16 KiB
     uint4 ent[AGH_MW_MAX_ENT];                  // 48 KiB
-    uint16_t cbits[MT_WAVES][256];              // 8 KiB: a tile's candidate bits, 16 per lane and strip
-    uint16_t dbits[MT_WAVES][256];              // 8 KiB: ... and its delimiter bits
+    uint16_t scratch[MT_WAVES][MT_LIST];        // 16 KiB, per wave: phase A: a tile's candidate bits (16 per lane and
+                                                // strip) and, behind them, its delimiter bits; phase B: the list of the
+                                                // candidates the wave shares out at the end
 };
 
 // NW: tiles a wave holds at a time (a lane walks the candidate words of NW tiles in the same rounds: the more words,
@@ -75,9 +79,11 @@ struct mt_shared {
 template <bool FOLD, int NW>
 __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restrict__ text, uint64_t n, uint32_t delim,
                                                          agh_mwalk_dev mw, agh_marks mk, uint32_t *__restrict__ ticket,
-                                                         uint32_t n_ranges, uint32_t dbg)
+                                                         uint32_t n_ranges, uint32_t range_tiles, uint32_t dbg)
 {
-    // dbg (AGH_MTILE_DBG, measurements only): 1 no walk over the candidate bits, 2 the walk without its text loads
+    // dbg (AGH_MTILE_DBG, measurements only): 1 no walk over the candidate bits, 2 the walk without its text loads,
+    // 4 AGH_C_CAND counts the rounds of the walk (per wave and tile group) instead of the candidates examined;
+    // bits 8..: 1 + the number of lanes with candidates at which the rest is shared out (0: MT_SHARE_AT)
     __shared__ __attribute__((aligned(16))) mt_shared sh;
     for (uint32_t i = threadIdx.x; i < AGH_MW_DIR; i += MT_WAVES * 64) {
         sh.fmask[i] = mw.fmask[i];
@@ -93,9 +99,11 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
     const uint64_t n_pad = (n + 15) & ~(uint64_t)15;      // readable bytes
     const uint64_t n_tiles = (n + MT_TILE - 1) / MT_TILE;
     const uint8_t *fmask8 = reinterpret_cast<const uint8_t *>(sh.fmask);
-    uint16_t *cb16 = sh.cbits[wib], *db16 = sh.dbits[wib];
+    uint16_t *cb16 = sh.scratch[wib], *db16 = cb16 + 256, *list = cb16;
     const uint64_t *cb64 = reinterpret_cast<const uint64_t *>(cb16), *db64 = reinterpret_cast<const uint64_t *>(db16);
     uint32_t local = 0;                                   // matched records that lie inside one tile (per lane)
+    uint32_t n_exam = 0;                                  // candidates examined by this wave (dbg & 4: rounds)
+    const uint32_t share_at = (dbg >> 8) ? (dbg >> 8) - 1u : MT_SHARE_AT;     // (A/B: AGH_MTILE_SHARE + 1 in bits 8..)
 
     auto load_strip = [&](uint64_t off) -> uint4 {        // 16 bytes at off + 16 lane; behind the text: delimiters
         const uint64_t o = off + (uint64_t)lane * 16u;
@@ -140,11 +148,12 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
         cand16 = (acc >> 16) & ~delim16;                                    // (no entry holds the delimiter byte)
     };
 
-    // ---- phase B, one candidate: does some entry of the slot of t[j], t[j+1] match at j? ---------------------------
+    // ---- phase B, one candidate: does some entry match at j?  Two lists: the pieces of two bytes under the pair at j,
+    // the longer ones under the three bytes at j (agh_mw_slot / agh_mw_slot3) -----------------------------------------
     auto examine = [&](bool cand, uint64_t j) -> bool {
         bool matched = false;
         uint64_t P = 0, F0 = 0, F1 = 0;
-        uint32_t first = 0, cnt = 0;
+        uint32_t first2 = 0, cnt2 = 0, first3 = 0, cnt = 0;
         if (cand && !(dbg & 2u)) {
             P = *reinterpret_cast<const u64_a1 *>(text + j - 8);
             F0 = *reinterpret_cast<const u64_a1 *>(text + j);
@@ -156,11 +165,12 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
             }
         }
         if (cand) {
-            const uint32_t dr = sh.dir[agh_mw_slot((uint32_t)F0 & 0xffffu)];
-            first = dr >> 16;
-            cnt = dr & 0xffffu;
+            const uint32_t d2 = sh.dir[agh_mw_slot((uint32_t)F0 & 0xffffu)], d3 = sh.dir[agh_mw_slot3((uint32_t)F0 & 0xffffffu)];
+            first2 = d2 >> 16;
+            cnt2 = d2 & 0xffffu;
+            first3 = (d3 >> 16) - cnt2;                                     // (entry i >= cnt2 of the walk: first3 + i)
+            cnt = cnt2 + (d3 & 0xffffu);
         }
-        const uint32_t lo = (uint32_t)F0, hi = (uint32_t)(F0 >> 32);
         const uint64_t Ph = __builtin_bswap64(P);                           // the bytes in front of j, nearest first
         uint32_t i = 0;
         while (__ballot(i < cnt)) {
@@ -169,12 +179,12 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
             uint64_t S = 0, B = 0;
             uint32_t L = 0;
             while (i < cnt && !pend) {
-                const uint4 e = sh.ent[first + i];
+                const uint4 e = sh.ent[(i < cnt2 ? first2 : first3) + i];
                 ++i;
                 const uint32_t pl = e.y >> 24;                              // piece length 2..7
-                uint32_t diff = (lo ^ e.x) & (pl >= 4u ? 0xffffffffu : ((1u << (8u * pl)) - 1u));
-                if (pl > 4u) diff |= (hi ^ e.y) & ((1u << (8u * (pl - 4u))) - 1u);
-                if (diff) continue;
+                // the piece's pl bytes against t[j ..): what differs above them is shifted out
+                const uint64_t E = (uint64_t)e.x | ((uint64_t)(e.y & 0xffffffu) << 32);
+                if ((F0 ^ E) << (64u - 8u * pl)) continue;
                 const uint32_t meta = e.w >> 24;
                 L = meta & 7u;
                 B = (uint64_t)e.z | ((uint64_t)(e.w & 0xffffffu) << 32);
@@ -194,8 +204,8 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
 
     uint32_t r = blockIdx.x * MT_WAVES + wib;
     while (r < n_ranges) {
-        const uint64_t t0 = (uint64_t)r * MT_RANGE_TILES;
-        uint64_t t1 = t0 + MT_RANGE_TILES;
+        const uint64_t t0 = (uint64_t)r * range_tiles;
+        uint64_t t1 = t0 + range_tiles;
         if (t1 > n_tiles) t1 = n_tiles;
         // the first tile of the range is in flight before the loop, every further one before the walk of the tiles
         // in front of it
@@ -267,6 +277,8 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
             }
 
             // ---- phase B: rounds over the candidate bits ---------------------------------------------------------
+            // (a lane takes its words one after the other and a word's candidates lowest first: below a candidate
+            // nothing of its record's run is left to clear)
             for (;;) {
                 int kk = -1;
                 uint64_t Ck = 0, Dk = 0;
@@ -274,24 +286,79 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
                 for (int k = NW - 1; k >= 0; --k)
                     if (C[k]) { kk = k; Ck = C[k]; Dk = D[k]; }
                 const bool cand = kk >= 0;
-                if (!__ballot(cand)) break;
+                const uint64_t cb = __ballot(cand);
+                if (!cb) break;
+                if ((uint32_t)__popcll(cb) <= share_at) {
+                    // Few lanes are left with candidates of their own -- those whose records do not match walk every
+                    // one of them (a record that matches is done after ~4), and the wave would wait for the longest
+                    // of them with most of its lanes idle (first version: 11.4 rounds per tile at 40 % of the lanes,
+                    // profiles/r06_ab_mtile_v3.log).  The rest is shared out: every candidate that is left goes
+                    // into a list, the lanes take 64 at a time, the owners read the hits back.  (No early exit among
+                    // those: a hit bit next to another one of the same record costs a test, not the count.)
+                    for (;;) {
+                        uint32_t mine = 0;
+#pragma unroll
+                        for (int k = 0; k < NW; ++k) mine += (uint32_t)__popcll(C[k]);
+                        if (!__ballot(mine != 0u)) break;
+                        const uint32_t incl = wave_sum_to_lane63(mine);
+                        const uint32_t total = mt_uni((uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
+                        const uint32_t my_first = incl - mine;
+                        uint32_t at = my_first;
+#pragma unroll
+                        for (int k = 0; k < NW; ++k) {
+                            uint64_t c = C[k];
+                            while (c && at < MT_LIST) {
+                                const uint32_t bb = (uint32_t)__builtin_ctzll(c);
+                                c &= c - 1ull;
+                                list[at++] = (uint16_t)((uint32_t)k << 12 | lane << 6 | bb);
+                            }
+                            C[k] = c;                                       // (what found no room: the next pass)
+                        }
+                        const uint32_t my_n = at - my_first;
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        const uint32_t listed = total < MT_LIST ? total : MT_LIST;
+                        for (uint32_t i0 = 0; i0 < listed; i0 = mt_uni(i0 + 64u)) {
+                            const uint32_t idx = i0 + lane;
+                            const bool has = idx < listed;
+                            const uint32_t e = has ? list[idx] : 0u;
+                            const uint64_t jj = (tg + (uint64_t)((e >> 12) & 3u)) * MT_TILE + (uint64_t)(e & 0xfffu);
+                            n_exam = mt_uni(n_exam + ((dbg & 4u) ? 1u : (uint32_t)__popcll(__ballot(has))));
+                            if (examine(has, jj) && has) list[idx] = (uint16_t)(e | 0x8000u);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        for (uint32_t i = 0; i < my_n; ++i) {
+                            const uint32_t e = list[my_first + i];
+                            if (e & 0x8000u) {
+#pragma unroll
+                                for (int k = 0; k < NW; ++k)
+                                    if ((int)((e >> 12) & 3u) == k) M[k] |= 1ull << (e & 63u);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the next pass writes the list again)
+                    }
+                    break;
+                }
+                n_exam = mt_uni(n_exam + ((dbg & 4u) ? 1u : (uint32_t)__popcll(cb)));
                 const uint32_t b = cand ? (uint32_t)__builtin_ctzll(Ck) : 0u;
                 const uint64_t j = (tg + (uint64_t)(cand ? kk : 0)) * MT_TILE + (uint64_t)lane * 64u + b;
                 const bool hit = examine(cand, j);
                 if (cand) {
-                    uint64_t clr = 1ull << b;
+                    const uint64_t bit = 1ull << b;
+                    uint64_t clr = bit;
                     if (hit) {
-                        // every candidate of this record's part of my word: the run between the delimiter bits around b
-                        const uint64_t below = Dk & (clr - 1ull), above = Dk & ~(clr - 1ull);
-                        const uint32_t from = below ? 64u - (uint32_t)__builtin_clzll(below) : 0u;
-                        const uint32_t to = above ? (uint32_t)__builtin_ctzll(above) : 64u;
-                        clr = mt_bits(from, to);
+                        // every candidate of this record from b to the next delimiter: + bit carries through the run of
+                        // non-delimiter bits above b and stops in the delimiter's zero
+                        const uint64_t S = ~Dk;
+                        clr = ((S + bit) ^ S) & S;
                     }
 #pragma unroll
                     for (int k = 0; k < NW; ++k)
                         if (k == kk) {
                             C[k] &= ~clr;
-                            if (hit) M[k] |= 1ull << b;
+                            if (hit) M[k] |= bit;
                         }
                 }
             }
@@ -357,6 +424,7 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
         atomicAdd(&mk.counters[AGH_C_MATCHED], local);
         mk.counters[AGH_C_ANYHIT] = 1u;
     }
+    if (lane == 0 && n_exam) atomicAdd(&mk.counters[AGH_C_CAND], n_exam);
 }
 
 // The positions k_mtile leaves out: fewer than 8 bytes in front of them or fewer than 24 behind.  Their records
@@ -373,32 +441,40 @@ __global__ __launch_bounds__(64) void k_mtile_edges(const uint8_t *__restrict__ 
 }
 
 template <int NW>
-static void launch_mtile(const agh_mwalk_args &a, uint32_t blocks, uint32_t n_ranges, hipStream_t st)
+static void launch_mtile(const agh_mwalk_args &a, uint32_t blocks, uint32_t n_ranges, uint32_t range_tiles, hipStream_t st)
 {
     if (a.q.fold)
         hipLaunchKernelGGL((k_mtile<true, NW>), dim3(blocks), dim3(MT_WAVES * 64), 0, st, (const uint8_t *)a.text, a.n, a.q.delim,
-                           a.mw, a.mk, a.ticket, n_ranges, a.ch >> 8);
+                           a.mw, a.mk, a.ticket, n_ranges, range_tiles, a.ch >> 8);
     else
         hipLaunchKernelGGL((k_mtile<false, NW>), dim3(blocks), dim3(MT_WAVES * 64), 0, st, (const uint8_t *)a.text, a.n, a.q.delim,
-                           a.mw, a.mk, a.ticket, n_ranges, a.ch >> 8);
+                           a.mw, a.mk, a.ticket, n_ranges, range_tiles, a.ch >> 8);
 }
 
 // false: no instance for this query / text -- the caller takes the general multi-pattern kernels.
-// a.ch: candidate words a lane walks at a time (1, 2 or 4 tiles per wave; 0: the default)
+// a.ch: tiles a wave holds at a time (1, 2 or 4; 0: the default); bits 8..: measurement switches
 bool agh_launch_mtile(const agh_mwalk_args &a, hipStream_t st)
 {
     if (a.q.k != 1 || a.q.mb || !a.n || !a.mw.n_ent || a.mw.n_ent > AGH_MW_MAX_ENT) return false;
     if (a.n >= 32u) {
+        const uint32_t nw = (a.ch & 0xffu) == 1u ? 1u : ((a.ch & 0xffu) == 2u ? 2u : 4u);
+        const uint32_t cus = a.n_cu ? a.n_cu : 256u;
         const uint64_t n_tiles = (a.n + MT_TILE - 1u) / MT_TILE;
-        const uint64_t n_ranges = (n_tiles + MT_RANGE_TILES - 1u) / MT_RANGE_TILES;
+        // tiles per ticket: 64 where that still leaves every wave of the chip eight tickets, else fewer (a multiple of
+        // the tiles a wave holds at a time) -- 64 MiB are 16 384 tiles for 4096 waves
+        uint64_t range_tiles = n_tiles / ((uint64_t)cus * MT_WAVES * 8u);
+        range_tiles = range_tiles / nw * nw;
+        if (range_tiles < nw) range_tiles = nw;
+        if (range_tiles > MT_RANGE_TILES) range_tiles = MT_RANGE_TILES;
+        const uint64_t n_ranges = (n_tiles + range_tiles - 1u) / range_tiles;
         if (n_ranges > 0xffffffffull - 65536ull) return false;
-        uint32_t blocks = a.n_cu ? a.n_cu : 256u;
+        uint32_t blocks = cus;
         const uint32_t need = (uint32_t)((n_ranges + MT_WAVES - 1u) / MT_WAVES);
         if (blocks > need) blocks = need;
-        switch (a.ch & 0xffu) {
-        case 1: launch_mtile<1>(a, blocks, (uint32_t)n_ranges, st); break;
-        case 4: launch_mtile<4>(a, blocks, (uint32_t)n_ranges, st); break;
-        default: launch_mtile<2>(a, blocks, (uint32_t)n_ranges, st); break;
+        switch (nw) {
+        case 1: launch_mtile<1>(a, blocks, (uint32_t)n_ranges, (uint32_t)range_tiles, st); break;
+        case 2: launch_mtile<2>(a, blocks, (uint32_t)n_ranges, (uint32_t)range_tiles, st); break;
+        default: launch_mtile<4>(a, blocks, (uint32_t)n_ranges, (uint32_t)range_tiles, st); break;
         }
     }
     hipLaunchKernelGGL(k_mtile_edges, dim3(1), dim3(64), 0, st, (const uint8_t *)a.text, a.n, a.q, a.mt, a.mk);

@@ -802,18 +802,18 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
             q->ms_dbg = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u;
         }
     }
-    // ---- tables of the record walk (agh_mwalk.hip): one error, patterns of 4..14 bytes some of which are too short
+    // ---- tables of the tile kernel for dense sets (agh_mtile.hip): one error, patterns of 4..14 bytes some of which are too short
     // for the one-pass kernel's 4-byte grams (pieces of 2..3 bytes: every position is a candidate) ---------------
     q->mw_ok = false;
     // (sets whose pieces all have >= 4 bytes are selective: the filter kernels are several times faster there)
     bool mw = D == 1 && q->multi && q->dlen == 1 && !q->delim_fold && !q->guard && !q->ms_ok && minlen >= 2 && minlen < 4;
     {
-        const char *e = getenv("AGH_MWALK");
+        const char *e = getenv("AGH_MTILE");      // 0: such sets stay on k_dense_multi (A/B; read when the query is built)
         if (e && e[0] == '0') mw = false;
     }
     for (int p = 0; p < npat && mw; ++p) mw = lens[p] >= 4 && lens[p] <= 14;
     if (mw) {
-        struct mw_entry { uint32_t slot; uint32_t w[4]; };
+        struct mw_entry { uint32_t slot; uint32_t w[4]; };    // slot: of the entry directory
         std::vector<mw_entry> es;
         for (int i = 0; i < npc; ++i) {
             if (!usable[i]) continue;
@@ -833,7 +833,8 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
             e.w[1] = pb(4) | pb(5) << 8 | pb(6) << 16 | (uint32_t)len << 24;
             e.w[2] = B[0] | B[1] << 8 | B[2] << 16 | (uint32_t)B[3] << 24;
             e.w[3] = B[4] | B[5] << 8 | B[6] << 16 | ((uint32_t)L | (before ? 8u : 0u)) << 24;
-            e.slot = agh_mw_slot(e.w[0] & 0xffffu);
+            // the directory's slot: a longer piece under its first three bytes, a piece of two under the pair
+            e.slot = len >= 3 ? agh_mw_slot3(e.w[0] & 0xffffffu) : agh_mw_slot(e.w[0] & 0xffffu);
             es.push_back(e);
         }
         if (es.empty() || es.size() > AGH_MW_MAX_ENT) mw = false;
@@ -854,7 +855,7 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
                 // byte there -- side_within_one_edit: the first mismatch is the missing, the replaced or the extra byte
                 const uint32_t *w = es[i].w;
                 const uint32_t pl = w[1] >> 24, meta = w[3] >> 24, L = meta & 7u;
-                uint32_t *fm = &fmask[(size_t)es[i].slot * 4];
+                uint32_t *fm = &fmask[(size_t)agh_mw_slot(w[0] & 0xffffu) * 4];     // (the mask table goes by the pair)
                 if (pl >= 3u) {
                     fm[0] |= 1u << ((w[0] >> 16) & 31u);
                 } else {

@@ -513,7 +513,8 @@ def config_blocks(A, torch, steps):
         "roofline": roofline_block("k_mscan (one pass: pair-table probes, exact gram table, k=1 side check)" if one_pass
                                    else "k_sweep_multi (+ k_verify_multi)", n, steps, sweep, launches)}
     # C5 as SURVEY 8d words the set: 1024 patterns of 4..12 bytes, k = 1 -- pieces of two bytes, every position a
-    # candidate, four records in five match: the record walk with exit at a record's first hit (agh_mwalk.hip)
+    # candidate, four records in five match: candidate / delimiter bits per tile, then a walk over the candidate bits with
+    # exit at a record's first hit (agh_mtile.hip)
     n = 4 << 30
     rng = random.Random(1024)
     pw = set()
@@ -535,8 +536,9 @@ def config_blocks(A, torch, steps):
                     "scans (tests/test_gpu_fullsize.py: 64 MiB slice)",
         "value": round(n / 1e9 / sec, 2), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4), "steps": nsw,
         "matched_records": int(r.n_matched), "one_pass": bool(r.fused_segments), "lean_reruns": int(r.lean_reruns),
+        "candidates_examined_per_step": int(r.n_candidates),
         "count_only_equals_numbered_on_256mib": bool(lean2.n_matched == numb2.n_matched),
-        "roofline": roofline_block("k_mwalk (record walk: stops at a record's first hit)" if r.fused_segments else "k_dense_multi",
+        "roofline": roofline_block("k_mtile (candidate bits per 4 KiB tile + walk with exit at a record's first hit)" if r.fused_segments else "k_dense_multi",
                                    n, nsw, sweep, launches)}
     del buf
     torch.cuda.empty_cache()

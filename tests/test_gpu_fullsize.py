@@ -285,8 +285,8 @@ def test_c5_1024_patterns_k1_8gib():
 
 def test_c5_as_worded_4_to_12_bytes_k1_dense():
     """The same set as SURVEY 8d words it (lengths 4..12, k = 1): four records in five match and every text position
-    is a candidate.  Count-only scans walk the records and stop at a record's first hit (agh_mwalk.hip; the role of
-    newmgrep.c:858-905) -- 4 GiB resident; the count equals the numbered multi-pattern pipeline on 256 MiB and, on a
+    is a candidate.  Count-only scans take candidate / delimiter bits per tile and walk the candidate bits with exit at a
+    record's first hit (agh_mtile.hip; the role of newmgrep.c:858-905) -- 4 GiB resident; the count equals the numbered multi-pattern pipeline on 256 MiB and, on a
     64 MiB slice, the union of 1024 single-pattern oracle scans (*unpinned config*: the reference ignores -# with -f)."""
     import torch
     import agrep_amd as A
@@ -319,4 +319,4 @@ def test_c5_as_worded_4_to_12_bytes_k1_dense():
     cut = host[:small].tobytes()
     orc_small = sorted(s for s in orc if s < small)
     assert [s for s, _, _ in rs[1]][:len(orc_small) - 2] == orc_small[:len(orc_small) - 2]
-    assert ms < 40.0, ms          # (round 5: 23.4 ms = 183 GB/s; round 4 ran this set at 28.7 GB/s)
+    assert ms < 12.0, ms          # (round 6: 6.7 ms = 640 GB/s; round 5: 20.8 ms; round 4 ran this set at 28.7 GB/s)

@@ -411,7 +411,7 @@ def test_one_pass_scan_fuzz(agh):
             assert got == want, (it, k, alpha, n)
 
 
-# ---- record walk over dense sets with one error (agh_mwalk.hip: BASELINE config 5 as SURVEY 8d words it) ----------
+# ---- dense sets with one error (agh_mtile.hip: BASELINE config 5 as SURVEY 8d words it) ----------
 def test_record_walk_takes_dense_one_error_sets(agh):
     """1024 patterns of 4..12 bytes, k = 1: pieces of two bytes, every position a candidate, most records match.
     Count-only scans walk the records lane by lane and stop at a record's first hit; the count equals the numbered
@@ -434,10 +434,10 @@ def test_record_walk_takes_dense_one_error_sets(agh):
             assert c.fused_segments == 0 and c.n_matched == q.scan_buffer(small, flags=agh.COUNT | agh.FORCE_NUMBERED)[0].n_matched
 
 
-@pytest.mark.parametrize("mtile", ["2", "1", "4", "0"])
+@pytest.mark.parametrize("mtile", ["2", "1", "4"])
 def test_record_walk_boundaries(agh, monkeypatch, mtile):
-    """Records and occurrences around the seams of the dense-set kernels (AGH_MTILE: k_mtile with 1 / 2 / 4 tiles per
-    wave; 0: the round-5 record walk): a lane's 64-position word and kilobyte, a 4 KiB tile, a wave's 256 KiB range,
+    """Records and occurrences around the seams of the dense-set kernel (AGH_MTILE: k_mtile with 1 / 2 / 4 tiles per
+    wave): a lane's 64-position word, a strip's kilobyte, a 4 KiB tile, a wave's 256 KiB range,
     the first 8 and last 24 positions (the edges kernel), records that cross several tiles with hits in each of them
     (counted once: the set of record starts), empty records, no trailing delimiter, a 2 MiB record in front of a hit
     (the give-up list), texts below 32 bytes."""
@@ -477,7 +477,7 @@ def test_record_walk_boundaries(agh, monkeypatch, mtile):
     assert _one_pass_count(agh, pats, 1, long) == 2
 
 
-@pytest.mark.parametrize("mtile", ["2", "1", "4", "0"])
+@pytest.mark.parametrize("mtile", ["2", "1", "4"])
 def test_record_walk_fuzz(agh, monkeypatch, mtile):
     """Random sets of 4..14-byte patterns over small and large alphabets (everything is a near miss, several
     entries per two-byte key, -i), random record lengths: count-only == numbered, and == the oracle's union on the
