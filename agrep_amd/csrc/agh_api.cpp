@@ -117,6 +117,7 @@ struct seg_result {
     float ms = 0.f, sweep_ms = 0.f;
 };
 
+static uint32_t device_cus();
 static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_t st,
                         unsigned flags, uint32_t head_byte, int tail_virtual,
                         const agh_list_out *list, seg_result *out, const uint64_t *pre_dbm)
@@ -380,6 +381,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
     // slices: the filter is not selective on this text; bitmap: more records than guessed)
     // does it run the affected stage again.
     bool use_filter = want_filter;
+    // numbered scans of a dense -f set with one error: the tile kernel marks records by number (round 5: k_dense_multi)
+    const bool tile_numbered = multi && q->mw_ok && !d_dbm && q->k == 1 && q->tune.mtile_numbered;
     uint64_t bits_hint = std::max<uint64_t>(q->bitmap_bits_hint, n / 64 + 1024);
     bool swept = false;
     float total_ms = 0.f;
@@ -426,7 +429,34 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
             sa.lean = 0;
             sa.ev_begin = (flags & AGH_TIME_SWEEP) ? q->ev2 : nullptr;
             sa.ev_end = (flags & AGH_TIME_SWEEP) ? q->ev3 : nullptr;
-            if (multi && q->multi_dense) {
+            if (tile_numbered) {
+                // dense one-error sets (agh_mtile.hip): the census, then candidate bits per tile and the walk over
+                // them, matched records marked by number -- no candidate slices, no second kernel
+                agh_launch_sweep(sa, 0, st);
+                agh_mwalk_args w;
+                w.text = d_text;
+                w.n = n;
+                w.q = dq;
+                w.mw.ent = (const uint4 *)q->d_mw_ent;
+                w.mw.dir = (const uint32_t *)q->d_mw_dir;
+                w.mw.fmask = (const uint4 *)q->d_mw_fmask;
+                w.mw.n_ent = q->mw_nent;
+                w.mt = multi_dev(q, nullptr);
+                memset(&w.mk, 0, sizeof(w.mk));
+                w.mk.bitmap = (uint32_t *)q->bitmap.p;
+                w.mk.bitmap_bits = (uint32_t)std::min<uint64_t>(bm_words * 32, 0xffffffffu);
+                w.mk.counters = q->d_counters;
+                w.mk.rec_pos = (d_match_pos && !invert_list) ? (uint64_t *)q->rec_pos.p : nullptr;
+                if (q->tickets.ensure(256u)) return -1;
+                HIP_TRY(hipMemsetAsync(q->tickets.p, 0, 256u, st));
+                w.ticket = (uint32_t *)q->tickets.p;
+                w.n_cu = device_cus();
+                w.ch = q->tune.mtile | q->tune.mtile_dbg << 8;
+                w.wave_totals = (const uint32_t *)q->wave_totals.p;
+                w.strip_prefix = (const uint32_t *)q->strip_prefix.p;
+                sa.ev_begin = sa.ev_end = nullptr;
+                if (!agh_launch_mtile(w, st)) return fail("internal error: no tile walk for this pattern set");
+            } else if (multi && q->multi_dense) {
                 // census first (plain H=0 sweep + prefix scan), then the inline multi sweep
                 // numbers records from that prefix and marks them directly
                 agh_launch_sweep(sa, 0, st);
@@ -476,7 +506,8 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         va.gram_spread = q->gram_spread;
         if (!multi && !use_filter && fs_fast_setup(q, n, &va)) return -1;
         const bool fs_fast = va.fs_fast != 0;
-        if (multi) agh_launch_verify_multi(va, multi_dev(q, d_dbm), false, st);
+        if (tile_numbered) { /* marked by k_mtile */ }
+        else if (multi) agh_launch_verify_multi(va, multi_dev(q, d_dbm), false, st);
         else if (use_filter) agh_launch_verify(va, st);
         else if (q->table) agh_launch_tablescan(va, st);
         else agh_launch_fullscan(va, st);
@@ -543,7 +574,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
         }
         if (slice_overflow || bm_overflow) {
             bits_hint = (uint64_t)n_delims + 1024;
-            if (multi && q->multi_dense) swept = false;     // the inline sweep does the marking
+            if ((multi && q->multi_dense) || tile_numbered) swept = false;     // the inline sweep / the tile kernel does the marking
             continue;
         }
         out->records = (uint64_t)n_delims +
@@ -682,6 +713,7 @@ void agh_read_tuning(agh_tuning *t)
         t->mtile = (mtl == 1 || mtl == 2 || mtl == 4) ? (uint32_t)mtl : 4u;
         // (measurements: AGH_MTILE_DBG bits, AGH_MTILE_SHARE = lanes with candidates at which the rest is shared out)
         t->mtile_dbg = (uint32_t)(env_u64("AGH_MTILE_DBG", 0) & 0xff);
+        t->mtile_numbered = env_on("AGH_MTILE_NUMBERED", true);
         if (getenv("AGH_MTILE_SHARE")) t->mtile_dbg |= (uint32_t)((env_u64("AGH_MTILE_SHARE", 32) & 0x7f) + 1) << 8;
     }
     t->fused = env_on("AGH_FUSED", AGH_FUSED_DEFAULT != 0);

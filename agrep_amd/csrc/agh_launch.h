@@ -17,6 +17,7 @@ struct agh_tuning {
     uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 / 2048 / 4096), 0 = by size
     uint32_t tr_group = 8;          // AGH_TR_GROUP: tiles whose replay lists one wave of k_table_replay takes (1, 2, 4, 8, 16)
     uint32_t mtile = 4;             // AGH_MTILE: dense -f sets with one error: tiles a wave of k_mtile holds at a time (1, 2, 4)
+    bool mtile_numbered = true;     // AGH_MTILE_NUMBERED: 0: numbered scans of such sets stay on k_dense_multi (A/B, tests)
     uint32_t mtile_dbg = 0;         // AGH_MTILE_DBG | (AGH_MTILE_SHARE + 1) << 8: measurement switches of k_mtile
     bool fused = true;              // AGH_FUSED
     bool debug = false;             // AGH_DEBUG
@@ -243,6 +244,7 @@ struct agh_mwalk_args {
     uint32_t *ticket;
     uint32_t n_cu;
     uint32_t ch;             // tiles a wave holds at a time (1, 2, 4; 0: 2); bits 8..: measurement switches
+    const uint32_t *wave_totals = nullptr, *strip_prefix = nullptr;     // numbered scans: the census in front of every strip
 };
 bool agh_launch_mtile(const agh_mwalk_args &a, hipStream_t st);
 // forces the load of the core library's code object (first launch: ~7 ms) -- for a thread that has time for it

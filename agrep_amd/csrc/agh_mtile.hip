@@ -76,10 +76,15 @@ struct mt_shared {
 
 // NW: tiles a wave holds at a time (a lane walks the candidate words of NW tiles in the same rounds: the more words,
 // the less a wave waits for its unluckiest lane)
-template <bool FOLD, int NW>
+// NUM: numbered scans (record lists, -n): the census of the numbered pipeline ran in front (wave_totals / strip_prefix:
+// delimiters in front of every 1 KiB strip), a record's number is the number of delimiters in front of it, and matched
+// records are marked in the record bitmap -- first and last parts of a tile like every other record, no hash set.
+template <bool FOLD, int NW, bool NUM>
 __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restrict__ text, uint64_t n, uint32_t delim,
                                                          agh_mwalk_dev mw, agh_marks mk, uint32_t *__restrict__ ticket,
-                                                         uint32_t n_ranges, uint32_t range_tiles, uint32_t dbg)
+                                                         uint32_t n_ranges, uint32_t range_tiles, uint32_t dbg,
+                                                         const uint32_t *__restrict__ wave_totals,
+                                                         const uint32_t *__restrict__ strip_prefix)
 {
     // dbg (AGH_MTILE_DBG, measurements only): 1 no walk over the candidate bits, 2 the walk without its text loads,
     // 4 AGH_C_CAND counts the rounds of the walk (per wave and tile group) instead of the candidates examined;
@@ -271,7 +276,9 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 const uint64_t wbase = tb + (uint64_t)lane * 64u;
                 C[k] = (dbg & 1u) ? 0ull : cb64[lane] & mt_valid(wbase, lo_lim, hi_lim);
-                D[k] = db64[lane] & mt_valid(wbase, lo_lim - 1u, hi_lim);
+                // (count-only: a record is counted in a register only between delimiters the walk can see on both
+                // sides; numbered: every delimiter of the text numbers a record)
+                D[k] = db64[lane] & (NUM ? mt_valid(wbase, 0, n) : mt_valid(wbase, lo_lim - 1u, hi_lim));
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (the next tile writes the same scratch)
             }
@@ -381,37 +388,58 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
                 const uint64_t lowD = Dk & (0ull - Dk);
                 if (((carry_into >> lane) & 1ull) && Dk) R |= lowD;
                 const bool any_delim = ND != 0ull;
-                const uint32_t f = any_delim ? (uint32_t)__builtin_ctzll(ND) : 64u;      // first / last lane with a delimiter
-                const uint32_t l = any_delim ? 63u - (uint32_t)__builtin_clzll(ND) : 64u;
-                // the record that ends at the tile's first delimiter began in front of the tile unless the tile starts
-                // a record: not mine to count
-                bool head_hit = false;
-                if (!s0[k] && lane == f) {
-                    head_hit = (R & lowD) != 0ull;
-                    R &= ~lowD;
-                }
-                local += (uint32_t)__popcll(R);
-                // the tile's first and last record parts, if they matched: into the set of record starts (by a look back
-                // from one matched position -- the last part's start lies inside the tile, a few bytes away)
-                const uint64_t head_any = __ballot(head_hit);
-                uint64_t Mh = 0, Mt = 0;                                    // my matched bits in the first / the last part
-                if (!s0[k]) Mh = lane < f ? Mk : (lane == f ? Mk & (lowD - 1ull) : 0ull);
+                const uint32_t l = any_delim ? 63u - (uint32_t)__builtin_clzll(ND) : 64u;      // last lane with a delimiter
+                // my matched bits in the tile's last part (behind its last delimiter)
+                uint64_t Mt = 0;
                 if (any_delim) {
                     const uint32_t top = Dk ? 63u - (uint32_t)__builtin_clzll(Dk) : 0u;
                     Mt = lane > l ? Mk : (lane == l ? (top == 63u ? 0ull : Mk & ~((2ull << top) - 1ull)) : 0ull);
-                } else if (s0[k]) {
-                    Mt = Mk;                                                // one record from the tile's first byte on
                 }
-                const bool want_head = !s0[k] && (any_delim ? head_any != 0ull : cout);
-                const bool want_tail = (any_delim || s0[k]) && cout;
-                const uint64_t hb = __ballot(Mh != 0ull), tbm = __ballot(Mt != 0ull);
-                if (want_head && hb && lane == (uint32_t)__builtin_ctzll(hb)) {
-                    const uint64_t st = lean_record_start(text, tb + (uint64_t)lane * 64u + (uint32_t)__builtin_ctzll(Mh), delim, mk);
-                    if (st != ~0ull) lean_insert(mk, st);
-                }
-                if (want_tail && tbm && lane == (uint32_t)__builtin_ctzll(tbm)) {
-                    const uint64_t st = lean_record_start(text, tb + (uint64_t)lane * 64u + (uint32_t)__builtin_ctzll(Mt), delim, mk);
-                    if (st != ~0ull) lean_insert(mk, st);
+                if constexpr (NUM) {
+                    // record number = delimiters in front: the census up to the tile's first strip, the lanes below me,
+                    // the bits below the delimiter in my word
+                    const uint64_t strip0 = tb >> AGH_STRIP_SHIFT;
+                    const uint32_t base = wave_totals[strip0 / AGH_WAVE_STRIPS] + strip_prefix[strip0];
+                    const uint32_t mine = (uint32_t)__popcll(Dk);
+                    const uint32_t incl = wave_sum_to_lane63(mine);
+                    const uint32_t total = mt_uni((uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
+                    const uint32_t rec0 = base + incl - mine;
+                    while (R) {
+                        const uint32_t d = (uint32_t)__builtin_ctzll(R);
+                        R &= R - 1ull;
+                        mark_record(mk, rec0 + (uint32_t)__popcll(Dk & ((1ull << d) - 1ull)), tb + (uint64_t)lane * 64u + d);
+                    }
+                    if (!any_delim) Mt = Mk;                                // (no delimiter in the tile: one record part)
+                    const uint64_t tbm = __ballot(Mt != 0ull);
+                    if (cout && tbm && lane == (uint32_t)__builtin_ctzll(tbm))
+                        mark_record(mk, base + total, tb + (uint64_t)lane * 64u + (uint32_t)__builtin_ctzll(Mt));
+                } else {
+                    const uint32_t f = any_delim ? (uint32_t)__builtin_ctzll(ND) : 64u;  // first lane with a delimiter
+                    // the record that ends at the tile's first delimiter began in front of the tile unless the tile
+                    // starts a record: not mine to count
+                    bool head_hit = false;
+                    if (!s0[k] && lane == f) {
+                        head_hit = (R & lowD) != 0ull;
+                        R &= ~lowD;
+                    }
+                    local += (uint32_t)__popcll(R);
+                    // the tile's first and last record parts, if they matched: into the set of record starts (by a look
+                    // back from one matched position -- the last part's start lies inside the tile, a few bytes away)
+                    const uint64_t head_any = __ballot(head_hit);
+                    uint64_t Mh = 0;                                        // my matched bits in the first part
+                    if (!s0[k]) Mh = lane < f ? Mk : (lane == f ? Mk & (lowD - 1ull) : 0ull);
+                    if (!any_delim && s0[k]) Mt = Mk;                       // one record from the tile's first byte on
+                    const bool want_head = !s0[k] && (any_delim ? head_any != 0ull : cout);
+                    const bool want_tail = (any_delim || s0[k]) && cout;
+                    const uint64_t hb = __ballot(Mh != 0ull), tbm = __ballot(Mt != 0ull);
+                    if (want_head && hb && lane == (uint32_t)__builtin_ctzll(hb)) {
+                        const uint64_t st = lean_record_start(text, tb + (uint64_t)lane * 64u + (uint32_t)__builtin_ctzll(Mh), delim, mk);
+                        if (st != ~0ull) lean_insert(mk, st);
+                    }
+                    if (want_tail && tbm && lane == (uint32_t)__builtin_ctzll(tbm)) {
+                        const uint64_t st = lean_record_start(text, tb + (uint64_t)lane * 64u + (uint32_t)__builtin_ctzll(Mt), delim, mk);
+                        if (st != ~0ull) lean_insert(mk, st);
+                    }
                 }
             }
         }
@@ -419,8 +447,8 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
         if (lane == 0) tk = atomicAdd(ticket, 1u);
         r = total_waves + mt_uni(tk);
     }
-    local = wave_sum_to_lane63(local);
-    if (lane == 63 && local) {
+    if (!NUM) local = wave_sum_to_lane63(local);
+    if (!NUM && lane == 63 && local) {
         atomicAdd(&mk.counters[AGH_C_MATCHED], local);
         mk.counters[AGH_C_ANYHIT] = 1u;
     }
@@ -440,19 +468,40 @@ __global__ __launch_bounds__(64) void k_mtile_edges(const uint8_t *__restrict__ 
     if (j < n) mp_verify_at<true, 1>(text8, n, q, mt, j, 0u, mk);
 }
 
+// ... numbered: the record count in front of a position's 16-byte chunk comes from the census (the strip's prefix) and
+// the delimiters between the strip's first byte and the chunk
+__global__ __launch_bounds__(64) void k_mtile_edges_numbered(const uint8_t *__restrict__ text8, uint64_t n, agh_dev_query q,
+                                                             agh_multi_dev mt, agh_marks mk,
+                                                             const uint32_t *__restrict__ wave_totals,
+                                                             const uint32_t *__restrict__ strip_prefix)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    uint64_t j = ~0ull;
+    if (lane < 8u) j = lane;
+    else if (lane < 32u && n >= 24u + 8u) j = n - 24u + (lane - 8u);
+    else if (lane < 32u && lane < n) j = lane;
+    if (j >= n) return;
+    const uint64_t chunk = j & ~(uint64_t)15, strip = chunk >> AGH_STRIP_SHIFT;
+    uint32_t rc = wave_totals[strip / AGH_WAVE_STRIPS] + strip_prefix[strip];
+    for (uint64_t i = strip << AGH_STRIP_SHIFT; i < chunk; ++i) rc += text8[i] == q.delim;
+    mp_verify_at<false, 1>(text8, n, q, mt, j, rc, mk);
+}
+
 template <int NW>
 static void launch_mtile(const agh_mwalk_args &a, uint32_t blocks, uint32_t n_ranges, uint32_t range_tiles, hipStream_t st)
 {
-    if (a.q.fold)
-        hipLaunchKernelGGL((k_mtile<true, NW>), dim3(blocks), dim3(MT_WAVES * 64), 0, st, (const uint8_t *)a.text, a.n, a.q.delim,
-                           a.mw, a.mk, a.ticket, n_ranges, range_tiles, a.ch >> 8);
-    else
-        hipLaunchKernelGGL((k_mtile<false, NW>), dim3(blocks), dim3(MT_WAVES * 64), 0, st, (const uint8_t *)a.text, a.n, a.q.delim,
-                           a.mw, a.mk, a.ticket, n_ranges, range_tiles, a.ch >> 8);
+#define AGH_MT_LAUNCH(F, NUMB)                                                                                        \
+    hipLaunchKernelGGL((k_mtile<F, NW, NUMB>), dim3(blocks), dim3(MT_WAVES * 64), 0, st, (const uint8_t *)a.text, a.n, \
+                       a.q.delim, a.mw, a.mk, a.ticket, n_ranges, range_tiles, a.ch >> 8, a.wave_totals, a.strip_prefix)
+    if (a.wave_totals) { if (a.q.fold) AGH_MT_LAUNCH(true, true); else AGH_MT_LAUNCH(false, true); }
+    else { if (a.q.fold) AGH_MT_LAUNCH(true, false); else AGH_MT_LAUNCH(false, false); }
+#undef AGH_MT_LAUNCH
 }
 
 // false: no instance for this query / text -- the caller takes the general multi-pattern kernels.
-// a.ch: tiles a wave holds at a time (1, 2 or 4; 0: the default); bits 8..: measurement switches
+// a.ch: tiles a wave holds at a time (1, 2 or 4; 0: the default); bits 8..: measurement switches.
+// a.wave_totals / a.strip_prefix (the census of the numbered pipeline): matched records go into the record bitmap by
+// number instead of being counted
 bool agh_launch_mtile(const agh_mwalk_args &a, hipStream_t st)
 {
     if (a.q.k != 1 || a.q.mb || !a.n || !a.mw.n_ent || a.mw.n_ent > AGH_MW_MAX_ENT) return false;
@@ -477,6 +526,10 @@ bool agh_launch_mtile(const agh_mwalk_args &a, hipStream_t st)
         default: launch_mtile<4>(a, blocks, (uint32_t)n_ranges, (uint32_t)range_tiles, st); break;
         }
     }
-    hipLaunchKernelGGL(k_mtile_edges, dim3(1), dim3(64), 0, st, (const uint8_t *)a.text, a.n, a.q, a.mt, a.mk);
+    if (a.wave_totals)
+        hipLaunchKernelGGL(k_mtile_edges_numbered, dim3(1), dim3(64), 0, st, (const uint8_t *)a.text, a.n, a.q, a.mt, a.mk,
+                           a.wave_totals, a.strip_prefix);
+    else
+        hipLaunchKernelGGL(k_mtile_edges, dim3(1), dim3(64), 0, st, (const uint8_t *)a.text, a.n, a.q, a.mt, a.mk);
     return true;
 }

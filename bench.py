@@ -527,6 +527,8 @@ def config_blocks(A, torch, steps):
         sec, r, sweep, launches, dev = timed_steps(torch, lambda: q.scan_device(buf.data_ptr(), n, flags=A.COUNT | F), max(steps // 2, 3))
         lean2 = q.scan_device(buf.data_ptr(), 256 << 20, flags=A.COUNT)
         numb2 = q.scan_device(buf.data_ptr(), 256 << 20, flags=A.COUNT | A.FORCE_NUMBERED)
+        # record-returning scans of the same set: record numbers from the census, matched records marked in the bitmap
+        secn, rn, _, _, devn = timed_steps(torch, lambda: q.scan_device(buf.data_ptr(), 1 << 30, flags=A.COUNT | A.FORCE_NUMBERED | F), 3, warmup=1)
     finally:
         q.close()
     nsw = max(steps // 2, 3)
@@ -538,6 +540,9 @@ def config_blocks(A, torch, steps):
         "matched_records": int(r.n_matched), "one_pass": bool(r.fused_segments), "lean_reruns": int(r.lean_reruns),
         "candidates_examined_per_step": int(r.n_candidates),
         "count_only_equals_numbered_on_256mib": bool(lean2.n_matched == numb2.n_matched),
+        "numbered_1gib": {"value": round((1 << 30) / 1e9 / secn, 2), "unit": "GB/s", "ms_per_step": round(secn * 1e3, 4),
+                          "device_ms": round(devn / 3, 4), "matched_records": int(rn.n_matched),
+                          "what": "census + k_mtile marking record numbers + bitmap count (round 5: k_dense_multi, 28 GB/s)"},
         "roofline": roofline_block("k_mtile (candidate bits per 4 KiB tile + walk with exit at a record's first hit)" if r.fused_segments else "k_dense_multi",
                                    n, nsw, sweep, launches)}
     del buf

@@ -58,3 +58,15 @@ for mt in ("2", "4"):
         print("c5 as worded %.0f GiB AGH_MTILE=%s AGH_MTILE_SHARE=%s: device %.3f ms (%.0f GB/s) matched %d examined %d"
               % (gib, mt, share, xs[1], n / 1e6 / xs[1], r.n_matched, r.n_candidates), flush=True)
 os.environ.pop("AGH_MTILE_SHARE")
+# record-returning (numbered) scans of the same set: the tile kernel's numbered form against round 5's k_dense_multi
+os.environ["AGH_MTILE"] = "4"
+nn = 1 << 30
+for numbered in ("1", "0"):
+    os.environ["AGH_MTILE_NUMBERED"] = numbered
+    xs = []
+    for _ in range(3):
+        r = q.scan_device(t.data_ptr(), nn, flags=A.COUNT | A.FORCE_NUMBERED | A.TIME_SCAN)
+        xs.append(r.device_ms)
+    print("c5 as worded 1 GiB numbered (record numbers, bitmap) AGH_MTILE_NUMBERED=%s: device %.3f ms (%.0f GB/s) matched %d"
+          % (numbered, min(xs), nn / 1e6 / min(xs), r.n_matched), flush=True)
+os.environ.pop("AGH_MTILE_NUMBERED")

@@ -300,11 +300,22 @@ def test_multi_pattern_nocase_letter_delimiter(agh):
 
 # ---- the one-pass count-only scan (agh_mscan.hip): sets it takes, every boundary it has ----------
 def _one_pass_count(agh, pats, k, text, nocase=False, expect=True):
-    """COUNT scan (the one-pass kernel where the set qualifies) == numbered two-kernel pipeline."""
+    """COUNT scan (the one-pass kernel where the set qualifies) == numbered pipeline -- for the dense one-error sets
+    both on the tile kernel's numbered form (marks by record number) and on round 5's k_dense_multi
+    (AGH_MTILE_NUMBERED=0: another kernel, another verifier)."""
     with agh.Query.multi(pats, nocase=nocase, k=k) as q:
         c, _ = q.scan_buffer(text, flags=agh.COUNT)
         n, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
-    assert c.n_matched == n.n_matched, (len(text), k, nocase)
+        saved = os.environ.get("AGH_MTILE_NUMBERED")
+        os.environ["AGH_MTILE_NUMBERED"] = "0"
+        try:
+            n0, _ = q.scan_buffer(text, flags=agh.COUNT | agh.FORCE_NUMBERED)
+        finally:
+            if saved is None:
+                del os.environ["AGH_MTILE_NUMBERED"]
+            else:
+                os.environ["AGH_MTILE_NUMBERED"] = saved
+    assert c.n_matched == n.n_matched == n0.n_matched, (len(text), k, nocase, c.n_matched, n.n_matched, n0.n_matched)
     if len(text):
         assert (c.fused_segments == 1) == expect, "one-pass kernel %s" % ("did not run" if expect else "ran")
         assert c.lean_reruns == 0
@@ -447,7 +458,10 @@ def test_record_walk_boundaries(agh, monkeypatch, mtile):
     for t in (b"", b"n", b"wxyz", b"wxyz\n", b"\nwxyz", b"xwxz", b"needle" * 3, b"needl", b"x" * 7 + b"needle" + b"y" * 23,
               b"x" * 8 + b"needle" + b"y" * 24, b"\n" * 100, b"wxz\n" * 10 + b"wx"):
         got = _one_pass_count(agh, pats, 1, t)
-        assert got == len(_approx_want(pats, 1, t)), t[:40]
+        want = _approx_want(pats, 1, t)
+        assert got == len(want), t[:40]
+        with agh.Query.multi(pats, k=1) as q:                   # the record LIST (numbered form: marks by record number)
+            assert [(s_, e_) for s_, e_, _ in q.scan_buffer(t, cap=1000)[1]] == want, t[:40]
     for boundary in (64, 1024, 2048, 4096, 8192, 16384, 65536, 65536 + 1024, 131072, 262144):
         for tail in (0, 7, 24, 900):
             base = bytearray(b"q" * (boundary + 64 + tail))
@@ -469,6 +483,9 @@ def test_record_walk_boundaries(agh, monkeypatch, mtile):
     rec = (b"r" * 500 + b"needle" + b"r" * 518) * 5
     t = b"wxyz one\n" + rec + b"\n" + b"haystack two\n" + rec[:3000] + b"\n" + b"s" * 3000 + b"\nwxz"
     assert _one_pass_count(agh, pats, 1, t) == len(_approx_want(pats, 1, t)) == 5
+    with agh.Query.multi(pats, k=1) as q:                       # ... and as a list: records across several tiles, by number
+        res, ms = q.scan_buffer(t, cap=100)
+        assert [(s_, e_) for s_, e_, _ in ms] == _approx_want(pats, 1, t) and [i_ for _, _, i_ in ms] == [0, 1, 2, 3, 5]
     # hits in every record of a long run of short records; empty records in between
     dense = (b"a needl b\n\n" + b"xx haystac yy\n") * 30000
     assert _one_pass_count(agh, pats, 1, dense) == 60000
@@ -504,5 +521,8 @@ def test_record_walk_fuzz(agh, monkeypatch, mtile):
         ran += 1
         got = _one_pass_count(agh, pats, 1, text, nocase=nocase)
         if n <= 70000 and len(pats) <= 30:
-            assert got == len(_approx_want(pats, 1, text, nocase)), (it, alpha, n, lo, hi)
+            want = _approx_want(pats, 1, text, nocase)
+            assert got == len(want), (it, alpha, n, lo, hi)
+            with agh.Query.multi(pats, nocase=nocase, k=1) as q:
+                assert [(s_, e_) for s_, e_, _ in q.scan_buffer(text, cap=len(want) + 16)[1]] == want, (it, alpha, n, lo, hi)
     assert ran >= 30
