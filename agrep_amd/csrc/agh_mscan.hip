@@ -359,34 +359,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
         // full strips, a multiple of four (every range but the last one of the text): straight loads;
         // else bytes behind the text become filler.  The next supertile is in flight either way.
         const bool plain = s1 <= n_full && ((s1 - s0) & 3u) == 0u;
-        uint4 c0, c1, c2, c3;
-        if (plain) {
-            const uint4 *p = text + s0 * 64 + lane;
-            // Plain loads, not the non-temporal ones of the other sweeps: level 3 reads the text around ~10 M
-            // candidates per 4 GiB again a few microseconds later, and lines that came in non-temporally are
-            // gone by then (HBM traffic 1.30 x the text, 1.31 vs 1.15 ms per 4 GiB: profiles/r04_perf_c5_dbg_a.log)
-            if (!(dbg & 16u)) { c0 = p[0]; c1 = p[64]; c2 = p[128]; c3 = p[192]; }
-            else { c0 = ld_stream(p); c1 = ld_stream(p + 64); c2 = ld_stream(p + 128); c3 = ld_stream(p + 192); }
-        } else {
-            c0 = load_strip(s0); c1 = load_strip(s0 + 1); c2 = load_strip(s0 + 2); c3 = load_strip(s0 + 3);
-        }
-        for (uint64_t s = s0; s < s1; s += 4) {
-            uint4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
-            uint32_t nx3;
-            if (s + 4 < s1) {
-                if (plain) {
-                    const uint4 *pn = text + (s + 4) * 64 + lane;
-                    if (!(dbg & 16u)) { n0 = pn[0]; n1 = pn[64]; n2 = pn[128]; n3 = pn[192]; }
-                    else { n0 = ld_stream(pn); n1 = ld_stream(pn + 64); n2 = ld_stream(pn + 128); n3 = ld_stream(pn + 192); }
-                } else {
-                    n0 = load_strip(s + 4); n1 = load_strip(s + 5); n2 = load_strip(s + 6); n3 = load_strip(s + 7);
-                }
-                nx3 = (uint32_t)__builtin_amdgcn_readlane((int)n0.x, 0);
+        // TWO supertiles in flight (round 6): level 1 of supertile s needs the first dword of supertile s + 4 (lane 63's
+        // last positions reach into it).  With one supertile ahead that dword came out of loads issued a few
+        // instructions earlier -- s_waitcnt vmcnt(3) right behind them, a full memory latency per supertile with the
+        // wave's own stream stalled (the ISA of round 5's kernel: profiles/r06_mscan_prefetch.log).  Now it was
+        // loaded a whole supertile ago.
+        auto load4 = [&](uint64_t st, uint4 &a0, uint4 &a1, uint4 &a2, uint4 &a3) {
+            if (plain) {
+                const uint4 *p = text + st * 64 + lane;
+                // Plain loads, not the non-temporal ones of the other sweeps: level 3 reads the text around ~10 M
+                // candidates per 4 GiB again a few microseconds later, and lines that came in non-temporally are
+                // gone by then (HBM traffic 1.30 x the text, 1.31 vs 1.15 ms per 4 GiB: profiles/r04_perf_c5_dbg_a.log)
+                if (!(dbg & 16u)) { a0 = p[0]; a1 = p[64]; a2 = p[128]; a3 = p[192]; }
+                else { a0 = ld_stream(p); a1 = ld_stream(p + 64); a2 = ld_stream(p + 128); a3 = ld_stream(p + 192); }
             } else {
-                nx3 = first_dword_of(s + 4);
+                a0 = load_strip(st); a1 = load_strip(st + 1); a2 = load_strip(st + 2); a3 = load_strip(st + 3);
             }
+        };
+        uint4 c0, c1, c2, c3, n0, n1, n2, n3;
+        load4(s0, c0, c1, c2, c3);
+        n0 = c0; n1 = c1; n2 = c2; n3 = c3;
+        if (s0 + 4 < s1) load4(s0 + 4, n0, n1, n2, n3);
+        for (uint64_t s = s0; s < s1; s += 4) {
+            uint4 m0 = n0, m1 = n1, m2 = n2, m3 = n3;
+            if (s + 8 < s1) load4(s + 8, m0, m1, m2, m3);
+            const uint32_t nx3 = s + 4 < s1 ? (uint32_t)__builtin_amdgcn_readlane((int)n0.x, 0) : first_dword_of(s + 4);
             supertile(c0, c1, c2, c3, nx3, (uint32_t)((s - s0) >> 2), s + 4 >= s1);
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            n0 = m0; n1 = m1; n2 = m2; n3 = m3;
         }
         // (queues A and B are empty here: their positions are relative to the range)
         uint32_t t = 0;
