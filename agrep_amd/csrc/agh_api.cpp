@@ -1118,7 +1118,6 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
         a.q = dq;
         a.ms.ptab = (const uint2 *)q->d_ms_ptab;
         a.ms.gtab = (const uint32_t *)q->d_ms_gtab;
-        a.ms.mdir = (const uint32_t *)q->d_ms_mdir;
         a.ms.ment = (const uint4 *)q->d_ms_ment;
         a.ms.rb = q->ms_rb;
         a.mt = multi_dev(q, nullptr);

@@ -150,7 +150,7 @@ struct agh_query {
     // one-pass count-only -f scan (agh_mscan.hip): pair table, exact gram table, entry directory
     bool ms_ok = false;
     uint32_t ms_rb = 0, ms_dbg = 0;
-    void *d_ms_ptab = nullptr, *d_ms_gtab = nullptr, *d_ms_mdir = nullptr, *d_ms_ment = nullptr;
+    void *d_ms_ptab = nullptr, *d_ms_gtab = nullptr, *d_ms_ment = nullptr;
     // record walk over dense -f sets with one error (agh_mwalk.hip)
     bool mw_ok = false;
     uint32_t mw_nent = 0;

@@ -207,8 +207,9 @@ void agh_launch_census_scan(const agh_sweep_args &a, bool with_cand, hipStream_t
 struct agh_mscan_dev {
     const uint2 *ptab;       // pair table, 1 << rb rows (agh_device.h)
     const uint32_t *gtab;    // AGH_MS_GSLOTS key grams (0 = empty), buckets of 4
-    const uint32_t *mdir;    // per gram slot: (first entry << 8) | number of entries with that gram
-    const uint4 *ment;       // entries: a whole pattern (k = 0) or a piece + the other side of its pattern (k = 1)
+    const uint4 *ment;       // entries: a whole pattern (k = 0) or a piece + the other side of its pattern (k = 1).  [slot]: the
+                             // first entry with the gram of gtab[slot], its gram word = (index of the further ones << 8) | their
+                             // number; [AGH_MS_GSLOTS + i]: the further ones
     uint32_t rb;             // log2 rows of ptab: 12 or 13
 };
 struct agh_mscan_args {

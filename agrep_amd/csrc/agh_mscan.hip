@@ -203,7 +203,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
             const uint32_t e = qb[(hB + (uint32_t)lane) & (MS_RING_B - 1u)];
             j = range_base + (e >> 12);
             if (j >= 8u && j + 24u <= n && !(dbg & 1u)) {
-                const uint32_t dir = ms.mdir[e & (AGH_MS_GSLOTS - 1u)];
+                // the gram's first entry sits at the gram's own slot (its gram word says where further entries with
+                // the same gram lie and how many): ONE load decides most candidates -- round 5 read a directory word
+                // first and the entry behind it, two dependent trips to the L2 with the wave's stream waiting
+                uint4 ent = ms.ment[e & (AGH_MS_GSLOTS - 1u)];
                 u32x4_a1 t0 = {0u, 0u, 0u, 0u}, t1 = {0u, 0u, 0u, 0u};
                 if (!(dbg & 2u)) {
                     t0 = *reinterpret_cast<const u32x4_a1 *>(text8 + j - 8);
@@ -214,10 +217,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_mscan(const uint4 *__restrict__ 
 #pragma unroll
                     for (int d = 0; d < 8; ++d) T[d] = swar_lower(T[d]);
                 }
-                const uint32_t first = dir >> 8, cnt = dir & 0xffu;
+                const uint32_t more = ent.x;                            // (further entries << 8) | how many
+                ent.x = T[2];                                           // (level 2 found the gram itself)
+                matched = K == 0 ? ms_match_k0(ent, T) : ms_match_k1(ent, T, delim);
+                const uint32_t first = AGH_MS_GSLOTS + (more >> 8), cnt = more & 0xffu;
                 for (uint32_t i = 0; i < cnt && !matched; ++i) {
-                    const uint4 ent = ms.ment[first + i];
-                    matched = K == 0 ? ms_match_k0(ent, T) : ms_match_k1(ent, T, delim);
+                    const uint4 en = ms.ment[first + i];
+                    matched = K == 0 ? ms_match_k0(en, T) : ms_match_k1(en, T, delim);
                 }
             }
         }

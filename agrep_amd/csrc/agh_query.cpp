@@ -770,8 +770,11 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
             const char *e = getenv("AGH_MSCAN_RB");
             if (e && e[0] == '1' && e[1] == '2') rb = 12;
         }
-        std::vector<uint32_t> ptab((size_t)2 << rb, 0), gtab(AGH_MS_GSLOTS, 0), mdir(AGH_MS_GSLOTS, 0);
-        std::vector<uint32_t> ment(es.size() * 4 + 4, 0);
+        // entries: one per gram slot (the gram's first entry, its gram word replaced by (index of the further entries with
+        // that gram << 8) | their number), then the further entries in the old 16-byte form
+        std::vector<uint32_t> ptab((size_t)2 << rb, 0), gtab(AGH_MS_GSLOTS, 0);
+        std::vector<uint32_t> ment((AGH_MS_GSLOTS + es.size()) * 4 + 4, 0);
+        size_t n_more = 0;
         size_t n_grams = 0;
         for (size_t a = 0; a < es.size() && ms;) {
             size_t b = a;
@@ -787,14 +790,15 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
             if (l1 >= 4 && l2 >= 4) { ms = false; break; }     // (both buckets full: the set stays on the two-kernel form)
             const uint32_t sl = l1 <= l2 ? 4 * b1 + (uint32_t)l1 : 4 * b2 + (uint32_t)l2;
             gtab[sl] = g;
-            mdir[sl] = (uint32_t)a << 8 | (uint32_t)(b - a);
+            memcpy(&ment[4 * (size_t)sl], es[a].w, 16);
+            ment[4 * (size_t)sl] = (uint32_t)n_more << 8 | (uint32_t)(b - a - 1);
+            for (size_t i = a + 1; i < b; ++i, ++n_more) memcpy(&ment[4 * (AGH_MS_GSLOTS + n_more)], es[i].w, 16);
             a = b;
         }
         if (es.size() >= (1u << 24)) ms = false;
-        for (size_t i = 0; i < es.size(); ++i) memcpy(&ment[4 * i], es[i].w, 16);
         if (ms) {
             if (up(&q->d_ms_ptab, ptab.data(), ptab.size() * 4) || up(&q->d_ms_gtab, gtab.data(), gtab.size() * 4) ||
-                up(&q->d_ms_mdir, mdir.data(), mdir.size() * 4) || up(&q->d_ms_ment, ment.data(), ment.size() * 4))
+                up(&q->d_ms_ment, ment.data(), ment.size() * 4))
                 return -1;
             q->ms_ok = true;
             q->ms_rb = rb;
@@ -992,7 +996,6 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_mw_fmask) (void)hipFree(q->d_mw_fmask);
     if (q->d_ms_ptab) (void)hipFree(q->d_ms_ptab);
     if (q->d_ms_gtab) (void)hipFree(q->d_ms_gtab);
-    if (q->d_ms_mdir) (void)hipFree(q->d_ms_mdir);
     if (q->d_ms_ment) (void)hipFree(q->d_ms_ment);
     if (q->d_acc) (void)hipFree(q->d_acc);
     if (q->h_acc) (void)hipHostFree(q->h_acc);
