@@ -38,6 +38,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     va->fs_fast = 0;
     va->tf_chunk = 0;
     va->tr_group = 0;
+    va->fs_streams = 0;
     if (!fs_fast_ok(q)) return 0;
     if (q->table && n < (q->tune.tf_fast_min_mb << 20)) return 0;
     // (64 KiB tiles with 256 entries each; the table engine's 256 KiB tiles with 1024 entries need the same)
@@ -47,6 +48,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     va->fs_fast = 1;
     va->tf_chunk = q->tune.tf_chunk;
     va->tr_group = q->tune.tr_group;
+    va->fs_streams = q->tune.fs_streams;
     // table engine, M <= 15: two streams per lane (k_tablescan_fast2) -- the always-one bit M must be there
     if (q->table && q->tune.tf_pack2) {
         const unsigned M = (unsigned)q->m + (unsigned)q->dlen + 1u;
@@ -702,6 +704,7 @@ void agh_read_tuning(agh_tuning *t)
     t->live = env_on("AGH_ENV_LIVE", false);
     t->tight_verify = env_on("AGH_TIGHT_VERIFY", true);
     t->fs_fast = env_on("AGH_FS_FAST", true);
+    t->fs_streams = (uint32_t)std::min<uint64_t>(env_u64("AGH_FS_STREAMS", 0), 4);
     t->tf_pack2 = env_on("AGH_TF_PACK2", true);
     t->tf_fast_min_mb = env_u64("AGH_TF_FAST_MIN_MB", AGH_TF_FAST_MIN_MB_DEFAULT);
     {

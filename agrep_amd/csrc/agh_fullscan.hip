@@ -381,22 +381,82 @@ __device__ __forceinline__ uint32_t ff_piece2(uint4 va, uint4 vb, const uint32_t
     return any;
 }
 
+// ... and of THREE streams in the 10-bit fields of a 32-bit word (m <= 10; round 6: the shape of agrep's everyday
+// query -- a word with two or three errors -- lands here: `matching` -2 has pieces of two bytes and no filter).  The
+// left shift carries a field's top bit into the next field's position 1, which the `| ones` of every shift sets
+// anyway; what stands above position m in a field only ever moves upward.  One table per stream, its entries already
+// in the stream's field: x = the byte's position mask, y = the field's ones unless the byte is the delimiter -- two
+// v_or3 put the three entries together (a perm cannot: the fields are not bytes).
+// Measured and dropped (profiles/r06_ab_fullscan_streams.log): four streams in the bytes (m <= 8) -- their ring
+// leaves six waves per CU and they lose to three streams at every k (k = 2: 1.40 vs 1.26 ms per 4 GiB); rounds of 32
+// instead of 64 bytes to shrink the ring -- the gather then reads half sectors, 2.4 ms whatever k.
+template <int K, int NS>
+__device__ __forceinline__ uint32_t ff_pieceN(const uint4 (&v)[NS], const uint2 *tab, Automaton<uint32_t, K> &A)
+{
+    static_assert(NS == 3, "three streams in 10-bit fields");
+    constexpr uint32_t ones = 0x00100401u;
+    uint32_t any = 0;
+    // the table entries of four steps at a time, the next four in flight while these are walked (left to itself the
+    // compiler reads a step's entries and waits for them: sixteen LDS round trips per piece)
+    auto fetch = [&](int g, uint2 (&t)[4][NS]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = 4 * g + i;
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const uint32_t d = b >> 2 == 0 ? v[st].x : (b >> 2 == 1 ? v[st].y : (b >> 2 == 2 ? v[st].z : v[st].w));
+                t[i][st] = tab[st * 256 + ((d >> (8 * (b & 3))) & 0xffu)];
+            }
+        }
+    };
+    auto walk = [&](const uint2 (&t)[4][NS]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t cm = t[i][0].x | t[i][1].x | t[i][2].x, kb = t[i][0].y | t[i][1].y | t[i][2].y;
+            any |= ff_step<uint32_t, K>(A, cm, kb, ones);
+        }
+    };
+    uint2 ta[4][NS], tb[4][NS];
+    fetch(0, ta);
+    fetch(1, tb);
+    __builtin_amdgcn_sched_barrier(0);
+    walk(ta);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(2, ta);
+    __builtin_amdgcn_sched_barrier(0);
+    walk(tb);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(3, tb);
+    __builtin_amdgcn_sched_barrier(0);
+    walk(ta);
+    __builtin_amdgcn_sched_barrier(0);
+    walk(tb);
+    return any;
+}
+
 #define AGH_FF_THREADS 128u     // two waves per workgroup: 2 x 10 KiB of ring for the two-stream form
 
-template <typename WT, int K, bool PACK>
+// NS: text streams per lane -- 1 (m <= 32 / 64), 2 (m <= 16, 16-bit halves), 3 (m <= 10, 10-bit fields)
+template <typename WT, int K, int NS>
 __global__ __launch_bounds__(AGH_FF_THREADS) void k_fullscan_fast(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, const WT *__restrict__ mask_g,
     uint64_t *__restrict__ replay, uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters)
 {
-    constexpr int NS = PACK ? 2 : 1;                    // text streams per lane
-    __shared__ MaskKill<WT> tabA[PACK ? 1 : 256];
-    __shared__ uint32_t tab2[PACK ? 256 : 1];
-    __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FF_THREADS / WAVE) * NS * WAVE * AGH_FS_ROW];
+    constexpr uint32_t ROUND = AGH_FS_ROUND, ROW = ROUND + 16u, PARTS = ROUND / 16u;
+    constexpr uint32_t FW = 32u / (NS >= 2 ? NS : 1), FMASK = NS >= 2 ? (1u << FW) - 1u : 0xffffffffu;
+    __shared__ MaskKill<WT> tabA[NS == 1 ? 256 : 1];
+    __shared__ uint32_t tab2[NS == 2 ? 256 : 1];
+    __shared__ uint2 tabN[NS >= 3 ? NS * 256 : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FF_THREADS / WAVE) * NS * WAVE * ROW];
     for (uint32_t c = threadIdx.x; c < 256u; c += AGH_FF_THREADS) {
         const WT cm = mask_g[c];
         const bool isd = c == q.delim;
-        if (PACK) {
+        if constexpr (NS == 2) {
             tab2[c] = ((uint32_t)cm & 0xffffu) | (isd ? 0u : 0xffff0000u);
+        } else if constexpr (NS >= 3) {
+#pragma unroll
+            for (int st = 0; st < NS; ++st)
+                tabN[st * 256 + c] = make_uint2(((uint32_t)cm & FMASK) << (FW * st), isd ? 0u : FMASK << (FW * st));
         } else {
             tabA[c].cm = cm;
             tabA[c].kb = isd ? (WT)0 : ~(WT)0;
@@ -404,22 +464,23 @@ __global__ __launch_bounds__(AGH_FF_THREADS) void k_fullscan_fast(
     }
     __syncthreads();
     const WT finalA = (WT)1 << (q.m - 1);
-    const WT finalB = PACK ? (WT)(finalA << 16) : (WT)0;
     const int lane = lane_id();
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    uint8_t *ring = ring_all + wib * (NS * WAVE * AGH_FS_ROW);
+    uint8_t *ring = ring_all + wib * (NS * WAVE * ROW);
     const uint64_t tile_bytes = (uint64_t)WAVE * AGH_FS_CHUNK;
     const uint64_t n_tiles = (n + tile_bytes - 1) / tile_bytes;
-    const uint64_t n_units = (n_tiles + NS - 1) / NS;   // tiles, or pairs of tiles
+    const uint64_t n_units = (n_tiles + NS - 1) / NS;   // tiles, or groups of NS tiles
     const uint32_t fill4 = (~q.delim & 0xffu) * 0x01010101u;
     const uint64_t n16 = (n + 15) & ~(uint64_t)15;
     const uint32_t warm = ((uint32_t)(q.m + q.k + 1) + 15u) & ~15u;   // <= 80 bytes
-    const uint32_t seg_lo = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
-    uint8_t *ring_w = ring + seg_lo * AGH_FS_ROW + part * 16u;
-    const uint8_t *ring_r = ring + (uint32_t)lane * AGH_FS_ROW;
-    auto piece = [&](uint4 va, uint4 vb, Automaton<WT, K> &A) -> WT {
-        if constexpr (PACK) return ff_piece2<K>(va, vb, tab2, A);
-        else return ff_piece<WT, K>(va, tabA, A);
+    // a round's bytes of a chunk are loaded by PARTS neighbouring lanes, 16 bytes each: 64 / PARTS chunks per load
+    const uint32_t seg_lo = (uint32_t)lane / PARTS, part = (uint32_t)lane % PARTS;
+    uint8_t *ring_w = ring + seg_lo * ROW + part * 16u;
+    const uint8_t *ring_r = ring + (uint32_t)lane * ROW;
+    auto piece = [&](const uint4 (&v)[NS], Automaton<WT, K> &A) -> WT {
+        if constexpr (NS == 2) return ff_piece2<K>(v[0], v[1], tab2, A);
+        else if constexpr (NS >= 3) return ff_pieceN<K, NS>(v, tabN, A);
+        else return ff_piece<WT, K>(v[0], tabA, A);
     };
 
     for (uint64_t unit = (uint64_t)blockIdx.x * (AGH_FF_THREADS / WAVE) + wib; unit < n_units;
@@ -433,17 +494,17 @@ __global__ __launch_bounds__(AGH_FF_THREADS) void k_fullscan_fast(
             len[st] = cs[st] < n ? (uint32_t)(n - cs[st] < AGH_FS_CHUNK ? n - cs[st] : AGH_FS_CHUNK) : 0u;
             cnt[st] = 0;
         }
-        auto gather = [&](uint32_t r, uint4 (&g)[NS][4]) {
+        auto gather = [&](uint32_t r, uint4 (&g)[NS][PARTS]) {
 #pragma unroll
             for (int st = 0; st < NS; ++st)
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
-                    const uint64_t a = t0[st] + (uint64_t)(seg_lo + 16u * i) * AGH_FS_CHUNK + r * AGH_FS_ROUND + part * 16u;
+                for (uint32_t i = 0; i < PARTS; ++i) {
+                    const uint64_t a = t0[st] + (uint64_t)(seg_lo + (64u / PARTS) * i) * AGH_FS_CHUNK + r * ROUND + part * 16u;
                     g[st][i] = a < n16 ? fs_load(reinterpret_cast<const uint4 *>(text + a))
                                        : make_uint4(fill4, fill4, fill4, fill4);
                 }
         };
-        uint4 g[NS][4];
+        uint4 g[NS][PARTS];
         gather(0, g);
 
         // state at the chunk starts: the m+k+1 (rounded to 16) bytes in front of them, or the
@@ -453,47 +514,50 @@ __global__ __launch_bounds__(AGH_FF_THREADS) void k_fullscan_fast(
         {
             const uint4 fillv = make_uint4(fill4, fill4, fill4, fill4);
             for (uint32_t t = 0; t < warm / 16; ++t) {
-                uint4 wa = fillv, wb = fillv;
-                if (len[0] && cs[0] >= warm) wa = *reinterpret_cast<const uint4 *>(text + cs[0] - warm + 16u * t);
-                if (PACK && len[NS - 1] && cs[NS - 1] >= warm) wb = *reinterpret_cast<const uint4 *>(text + cs[NS - 1] - warm + 16u * t);
-                (void)piece(wa, wb, A);
+                uint4 wv[NS];
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    wv[st] = fillv;
+                    if (len[st] && cs[st] >= warm) wv[st] = *reinterpret_cast<const uint4 *>(text + cs[st] - warm + 16u * t);
+                }
+                (void)piece(wv, A);
             }
-            if (cs[0] == 0) {                   // (only stream A of the first unit starts the text)
+            if (cs[0] == 0) {                   // (only stream 0 of the first unit starts the text)
                 Automaton<WT, K> H;
                 H.reset();
                 const uint32_t hb = q.head_byte & 0xffu;
                 const WT hcm = mask_g[hb];
-                (void)ff_step<WT, K>(H, PACK ? (WT)(hcm & (WT)0xffffu) : hcm, hb == q.delim ? (WT)0 : ~(WT)0, (WT)1);
+                (void)ff_step<WT, K>(H, NS >= 2 ? (WT)(hcm & (WT)FMASK) : hcm, hb == q.delim ? (WT)0 : ~(WT)0, (WT)1);
 #pragma unroll
                 for (int l = 0; l <= K; ++l)
-                    A.R[l] = PACK ? (WT)((A.R[l] & (WT)0xffff0000u) | (H.R[l] & (WT)0xffffu)) : H.R[l];
+                    A.R[l] = NS >= 2 ? (WT)((A.R[l] & ~(WT)FMASK) | (H.R[l] & (WT)FMASK)) : H.R[l];
             }
         }
-        for (uint32_t r = 0; r < AGH_FS_CHUNK / AGH_FS_ROUND; ++r) {
+        for (uint32_t r = 0; r < AGH_FS_CHUNK / ROUND; ++r) {
 #pragma unroll
             for (int st = 0; st < NS; ++st)
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i)
-                    *reinterpret_cast<uint4 *>(ring_w + st * (WAVE * AGH_FS_ROW) + 16u * i * AGH_FS_ROW) = g[st][i];
+                for (uint32_t i = 0; i < PARTS; ++i)
+                    *reinterpret_cast<uint4 *>(ring_w + st * (WAVE * ROW) + (64u / PARTS) * i * ROW) = g[st][i];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the whole wave's rows are in
             __builtin_amdgcn_wave_barrier();
-            if (r + 1 < AGH_FS_CHUNK / AGH_FS_ROUND) gather(r + 1, g);   // in flight during the walk
+            if (r + 1 < AGH_FS_CHUNK / ROUND) gather(r + 1, g);   // in flight during the walk
             uint32_t flags = 0;                 // bit 4*st + p: piece p of stream st goes to the replay list
             // (not unrolled: across four pieces the scheduler hoists table reads until the two-stream
             // instances need 134-138 VGPRs -- one wave per SIMD less -- and a register cap spills)
 #pragma unroll 1
-            for (uint32_t p = 0; p < 4; ++p) {
-                const uint32_t off = r * AGH_FS_ROUND + 16u * p;
+            for (uint32_t p = 0; p < PARTS; ++p) {
+                const uint32_t off = r * ROUND + 16u * p;
                 // the lane's own 16 bytes of every stream, read when they are needed (the ring is not
                 // written again before the next round: eight VGPRs of text instead of thirty-two)
                 uint4 v[NS];
 #pragma unroll
                 for (int st = 0; st < NS; ++st)
-                    v[st] = *reinterpret_cast<const uint4 *>(ring_r + st * (WAVE * AGH_FS_ROW) + 16u * p);
-                const WT any = piece(v[0], v[NS - 1], A);
+                    v[st] = *reinterpret_cast<const uint4 *>(ring_r + st * (WAVE * ROW) + 16u * p);
+                const WT any = piece(v, A);
 #pragma unroll
                 for (int st = 0; st < NS; ++st) {
-                    const WT fb = st == 0 ? finalA : finalB;
+                    const WT fb = NS >= 2 ? (WT)(finalA << (FW * st)) : finalA;
                     // a match may end in the piece, or the piece holds the last byte of the text
                     // (partial pieces and the appended delimiter, asearch.c:87-91, are the replay's)
                     const bool in_text = off < len[st];
@@ -505,7 +569,7 @@ __global__ __launch_bounds__(AGH_FF_THREADS) void k_fullscan_fast(
 #pragma unroll
                 for (int st = 0; st < NS; ++st)
 #pragma unroll
-                    for (uint32_t p = 0; p < 4; ++p) {
+                    for (uint32_t p = 0; p < PARTS; ++p) {
                         const bool f = (flags >> (4 * st + p)) & 1u;
                         const uint64_t fm = __ballot(f);
                         if (!fm) continue;
@@ -513,7 +577,7 @@ __global__ __launch_bounds__(AGH_FF_THREADS) void k_fullscan_fast(
                         const uint64_t tile = unit * NS + (uint64_t)st;
                         if (f) {
                             const uint32_t at = cnt[st] + rank;
-                            if (at < AGH_FF_SLICE) replay[tile * AGH_FF_SLICE + at] = cs[st] + r * AGH_FS_ROUND + 16u * p;
+                            if (at < AGH_FF_SLICE) replay[tile * AGH_FF_SLICE + at] = cs[st] + r * ROUND + 16u * p;
                             else counters[AGH_C_OVERFLOW] = 1u;
                         }
                         cnt[st] += (uint32_t)__popcll(fm);
@@ -610,20 +674,23 @@ static void launch_fullscan_t(const agh_scan_args &a, hipStream_t st)
         // unit costs, one-byte delimiter outside every pattern class (the host checked): the lean hot
         // kernel + the exact replay of the pieces it listed
         const bool leanv = a.mk.hashset != nullptr;
-        const bool pack = sizeof(WT) == 4 && a.q.m <= 16;
-        const uint64_t units = pack ? (n_tiles + 1) / 2 : n_tiles;
+        // text streams per lane by the pattern's length (32-bit words): three for m <= 10, two for m <= 16
+        // (a.fs_streams: 0 = by length; 1..3 caps it -- A/B, tests)
+        int ns = 1;
+        if (sizeof(WT) == 4) ns = a.q.m <= 10 ? 3 : (a.q.m <= 16 ? 2 : 1);
+        if (a.fs_streams && (int)a.fs_streams < ns) ns = (int)a.fs_streams;
+        const uint64_t units = (n_tiles + (uint64_t)ns - 1) / (uint64_t)ns;
         const uint64_t wantf = (units + (AGH_FF_THREADS / WAVE) - 1) / (AGH_FF_THREADS / WAVE);
         const uint32_t blocksf = wantf > 32768 ? 32768u : (uint32_t)wantf;
+#define AGH_FF_LAUNCH(WTT, NSV)                                                                                      \
+    hipLaunchKernelGGL((k_fullscan_fast<WTT, K, NSV>), dim3(blocksf), dim3(AGH_FF_THREADS), 0, st, (const uint8_t *)a.text, \
+                       a.n, a.q, (const WTT *)a.mask, a.fs_replay, a.fs_tile_cnt, a.mk.counters)
         if constexpr (sizeof(WT) == 4) {
-            if (pack)
-                hipLaunchKernelGGL((k_fullscan_fast<uint32_t, K, true>), dim3(blocksf), dim3(AGH_FF_THREADS), 0, st,
-                                   (const uint8_t *)a.text, a.n, a.q, (const uint32_t *)a.mask, a.fs_replay,
-                                   a.fs_tile_cnt, a.mk.counters);
+            if (ns == 3) AGH_FF_LAUNCH(uint32_t, 3);
+            else if (ns == 2) AGH_FF_LAUNCH(uint32_t, 2);
         }
-        if (!pack)
-            hipLaunchKernelGGL((k_fullscan_fast<WT, K, false>), dim3(blocksf), dim3(AGH_FF_THREADS), 0, st,
-                               (const uint8_t *)a.text, a.n, a.q, (const WT *)a.mask, a.fs_replay,
-                               a.fs_tile_cnt, a.mk.counters);
+        if (ns == 1) AGH_FF_LAUNCH(WT, 1);
+#undef AGH_FF_LAUNCH
         const uint32_t nt = (uint32_t)n_tiles;
         const uint32_t rblocks = (nt + 3u) / 4u > 16384u ? 16384u : (nt + 3u) / 4u;
         if (leanv)

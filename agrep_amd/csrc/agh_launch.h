@@ -12,6 +12,7 @@ struct agh_tuning {
     bool live = false;              // AGH_ENV_LIVE
     bool tight_verify = true;       // AGH_TIGHT_VERIFY
     bool fs_fast = true;            // AGH_FS_FAST
+    uint32_t fs_streams = 0;        // AGH_FS_STREAMS: full scan, fast form: at most 1..3 text streams per lane (0: by length; A/B)
     bool tf_pack2 = true;           // AGH_TF_PACK2: table engine, two streams per lane where M <= 15
     uint64_t tf_fast_min_mb = 0;    // AGH_TF_FAST_MIN_MB: table engine, fast form from this segment size on
     uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 / 2048 / 4096), 0 = by size
@@ -99,6 +100,7 @@ struct agh_scan_args {
     int fs_fast;
     uint32_t tf_chunk;              // table engine, fast form: bytes per lane (1024 / 2048 / 4096), 0 = by size
     uint32_t tr_group;              // tiles per wave of k_table_replay (0: 8)
+    uint32_t fs_streams;            // full scan, fast form: at most this many text streams per lane (0: by the pattern's length)
     uint64_t *fs_replay;
     uint32_t *fs_tile_cnt;
     long verify_blocks;      // AGH_VERIFY_BLOCKS: grid cap of k_verify (-1: the default)

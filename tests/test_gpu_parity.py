@@ -1346,6 +1346,40 @@ def test_fullscan_fast_form_equals_exact_kernel(agh, monkeypatch):
                 assert r2.n_matched == r3.n_matched == want[0], (pat, k, fast, len(t))
 
 
+@pytest.mark.parametrize("streams", ["0", "1", "2"])
+def test_fullscan_fast_streams_per_lane(agh, monkeypatch, streams):
+    """Round 6: k_fullscan_fast keeps THREE text streams per lane in the 10-bit fields of a 32-bit word for m <= 10
+    (two 16-bit halves for m <= 16 since round 3).  Every stream count (AGH_FS_STREAMS caps it; 0: by the pattern's
+    length) against asearch.c's restatement: patterns of 2..11 bytes, every k below the length
+    up to 4 (and 5..7 on m = 8), texts whose tiles end inside occurrences, a text of one byte more than a group of
+    tiles, the record list and both count-only forms."""
+    monkeypatch.setenv("AGH_FS_STREAMS", streams)
+    rng = random.Random(77)
+    base, _ = O.corpus(400, seed=77, variants=(b"matching", b"matchng", b"maXching", b"mmatching", b"approxima", b"aproxima",
+                                                  b"wordlength", b"wrdlength"), plant_period=9)
+    tb = base.tobytes()
+    tile = 64 * 1024
+    texts = [tb, tb[:4 * tile + 1], tb[:3 * tile - 3] + b"matchin", tb[:tile] + b"\n" * 70000 + tb[:9000], b"matching", b"x"]
+    pats = [b"matching", b"approxima", b"wordlength", b"match", b"at", b"the", b"tching", b"lengthwords", b"e tao ns"]
+    n = 0
+    for pat in pats:
+        for k in (1, 2, 3, 4, 5, 7):
+            if k >= len(pat) or (k > 4 and len(pat) != 8):
+                continue
+            for ti, t in enumerate(texts):
+                if k > 2 and ti not in (0, 2):
+                    continue
+                want = O.asearch(pat, k, t, cap=600000)
+                with agh.Query(pat, k) as q:
+                    r1, ms = q.scan_buffer(t, flags=agh.FORCE_FULLSCAN, cap=600000)
+                    r2, _ = q.scan_buffer(t, flags=agh.FORCE_FULLSCAN | agh.COUNT)
+                assert r1.engine == agh.ENGINE_FULLSCAN
+                assert (r1.n_matched, [(s_, e_) for s_, e_, _ in ms]) == want, (pat, k, streams, ti)
+                assert r2.n_matched == want[0], (pat, k, streams, ti)
+                n += 1
+    assert n > 60
+
+
 def test_table_engine_with_edit_costs(agh):
     """'#' / ';' / ',' together with -I -S -D: asearch1.c:88-97 runs on the same Init1 / endposition
     tables; the table engine's feed_costs against the oracle's restatement of asearch1.c on the
