@@ -169,3 +169,49 @@ def test_c_abi_shard_cuts_multi_byte_delimiter(world, tmp_path):
             agrep_amd.shard_cuts_fd(fd, 2, delim=b"\n\n")
     finally:
         os.close(fd)
+
+
+def _files_worker(rank, world, port, n_files, q):
+    """configs[4] as bench.py runs it at N > 1 (c5_file_hits_job): the files are dealt in blocks to the first G ranks,
+    every rank of the group takes part in the MAX reduction of the hit vector, the ones without files with zeros"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        G = min(world, 2)                       # (bench.py: min(N, 4); here: one rank of three has no files)
+        per = n_files // G
+        mine = list(range(rank * per, (rank + 1) * per)) if rank < G else []
+        pats = [b"needle", b"haystack", b"zebra"]
+        hits = [False] * n_files
+        for f in mine:
+            text, _ = O.corpus(2, first_page=2 * f, seed=55, variants=(b"a needle b", b"one haystack"),
+                               plant_period=40 if f % 3 == 0 else 1 << 30)
+            hits[f] = O.multi_exact_count(pats, text)[0] > 0
+        q.put((rank, shard.reduce_file_hits(hits), mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_ranks_file_hit_vector_with_an_idle_rank():
+    world, n_files = 3, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_files_worker, args=(r, world, port, n_files, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pats = [b"needle", b"haystack", b"zebra"]
+    want = []
+    for f in range(n_files):
+        text, _ = O.corpus(2, first_page=2 * f, seed=55, variants=(b"a needle b", b"one haystack"),
+                           plant_period=40 if f % 3 == 0 else 1 << 30)
+        want.append(O.multi_exact_count(pats, text)[0] > 0)
+    assert any(want) and not all(want)
+    assert [m for _, _, m in outs] == [[0, 1, 2, 3], [4, 5, 6, 7], []]
+    for _, vec, _ in outs:
+        assert vec == want
