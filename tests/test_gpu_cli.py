@@ -192,7 +192,7 @@ def test_cli_multi_gpu_equals_single(files, args):
 
 
 @pytest.mark.parametrize("args", [["-V0", "-2"], ["-V0", "-n", "-i", "-2"], ["-V0", "-2", "-c"], ["-V0", "-v", "-n", "-2"],
-                                  ["-V0", "-d", "e ", "-n", "-i", "-1"], ["-V0", "-h", "-1"]])
+                                  ["-V0", "-d", "e ", "-n", "-1"], ["-V0", "-d", "q", "-n", "-i", "-1"], ["-V0", "-h", "-1"]])
 def test_cli_shards_print_in_file_order_while_scanning(files, args, tmp_path):
     """--gpus N record output: every shard streams through agh_scan_fd_range_emit on a thread of its own; the shard
     whose turn it is prints straight from its emit() calls, the ones behind it hold their records back until the
