@@ -11,7 +11,7 @@ gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 mode = sys.argv[3] if len(sys.argv) > 3 else "lean"
 flags = {"full": A.FORCE_FULLSCAN, "fullc": A.FORCE_FULLSCAN | A.COUNT, "numbered": 0, "lean": A.COUNT, "multi": A.COUNT,
-         "multik": A.COUNT, "table": A.COUNT}[mode]
+         "multik": A.COUNT, "table": A.COUNT, "word": A.FORCE_FULLSCAN | A.COUNT}[mode]
 n = int(gib * (1 << 30))
 t = torch.empty(n, dtype=torch.uint8, device='cuda')
 A.corpus_fill_device(t.data_ptr(), n // 4096, seed=12345, variants=O.VARIANTS_C2, plant_period=500)
@@ -29,6 +29,8 @@ elif mode == "multik":                   # config 5 with errors: 1024 patterns o
     while len(pats) < 1024:
         pats.add(bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(8, 12))))
     q = A.Query.multi(sorted(pats), k=k)
+elif mode == "word":                     # `matching` (m = 8) with k errors on the fast full scan (three streams per lane)
+    q = A.Query(b"matching", k)
 elif mode == "table":                    # 'approx#match' on the reference's own tables (table engine)
     import json
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "pattern_language.json")))["cases"]
