@@ -442,6 +442,7 @@ static int scan_segment(agh_query *q, const void *d_text, uint64_t n, hipStream_
                 w.mw.ent = (const uint4 *)q->d_mw_ent;
                 w.mw.dir = (const uint32_t *)q->d_mw_dir;
                 w.mw.fmask = (const uint4 *)q->d_mw_fmask;
+                w.mw.g4 = (const uint32_t *)q->d_mw_g4;
                 w.mw.n_ent = q->mw_nent;
                 w.mt = multi_dev(q, nullptr);
                 memset(&w.mk, 0, sizeof(w.mk));
@@ -712,8 +713,8 @@ void agh_read_tuning(agh_tuning *t)
         t->tf_chunk = (c == 1024 || c == 2048 || c == 4096 || c == 8192 || c == 16384 || c == 32768) ? (uint32_t)c : 0u;
         const uint64_t g = env_u64("AGH_TR_GROUP", 8);
         t->tr_group = (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ? (uint32_t)g : 8u;
-        const uint64_t mtl = env_u64("AGH_MTILE", 4);
-        t->mtile = (mtl == 1 || mtl == 2 || mtl == 4) ? (uint32_t)mtl : 4u;
+        const uint64_t mtl = env_u64("AGH_MTILE", 2);
+        t->mtile = (mtl == 1 || mtl == 2 || mtl == 4) ? (uint32_t)mtl : 2u;
         // (measurements: AGH_MTILE_DBG bits, AGH_MTILE_SHARE = lanes with candidates at which the rest is shared out)
         t->mtile_dbg = (uint32_t)(env_u64("AGH_MTILE_DBG", 0) & 0xff);
         t->mtile_numbered = env_on("AGH_MTILE_NUMBERED", true);
@@ -1141,6 +1142,7 @@ static int mscan_run(agh_query *q, const unsigned char *base, const std::vector<
             w.mw.ent = (const uint4 *)q->d_mw_ent;
             w.mw.dir = (const uint32_t *)q->d_mw_dir;
             w.mw.fmask = (const uint4 *)q->d_mw_fmask;
+            w.mw.g4 = (const uint32_t *)q->d_mw_g4;
             w.mw.n_ent = q->mw_nent;
             w.mt = a.mt;
             w.mk = a.mk;

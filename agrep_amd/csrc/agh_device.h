@@ -205,7 +205,9 @@ AGH_HD uint32_t agh_ms_ghash(uint32_t g)
 #define AGH_MS_GB2(h) (((h) >> 12) & (AGH_MS_GBUCKETS - 1u))
 // ---- dense -f sets with one error (agh_mtile.hip): pieces of 2..7 bytes --------------------------------------------
 #define AGH_MW_DIR 4096u                    // slots of the mask table (by the pair) and of the entry directory
-#define AGH_MW_MAX_ENT 3072u                // entries (16 bytes each) next to the directory and the masks: 144 KiB of LDS, one
+#define AGH_MW_G4_WORDS 2048u               // 2^16 bits: the first four bytes of the pieces of >= 4 bytes (word: bits 2..12 of
+                                            // agh_sample_prod_q4, bit: bits 13..17)
+#define AGH_MW_MAX_ENT 3072u                // entries (16 bytes each) next to the directory, the masks and the bit table: 152 KiB of LDS, one
                                             // workgroup per CU
 // the mask table's slot: the first two bytes of a piece
 AGH_HD uint32_t agh_mw_slot(uint32_t bigram)

@@ -154,7 +154,7 @@ struct agh_query {
     // record walk over dense -f sets with one error (agh_mwalk.hip)
     bool mw_ok = false;
     uint32_t mw_nent = 0;
-    void *d_mw_ent = nullptr, *d_mw_dir = nullptr, *d_mw_fmask = nullptr;
+    void *d_mw_ent = nullptr, *d_mw_dir = nullptr, *d_mw_fmask = nullptr, *d_mw_g4 = nullptr;
 };
 
 // delimiter ends come from the delimiter bitmap: several bytes, or one letter under -i

@@ -17,7 +17,7 @@ struct agh_tuning {
     uint64_t tf_fast_min_mb = 0;    // AGH_TF_FAST_MIN_MB: table engine, fast form from this segment size on
     uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 / 2048 / 4096), 0 = by size
     uint32_t tr_group = 8;          // AGH_TR_GROUP: tiles whose replay lists one wave of k_table_replay takes (1, 2, 4, 8, 16)
-    uint32_t mtile = 4;             // AGH_MTILE: dense -f sets with one error: tiles a wave of k_mtile holds at a time (1, 2, 4)
+    uint32_t mtile = 2;             // AGH_MTILE: dense -f sets with one error: tiles a wave of k_mtile holds at a time (1, 2, 4)
     bool mtile_numbered = true;     // AGH_MTILE_NUMBERED: 0: numbered scans of such sets stay on k_dense_multi (A/B, tests)
     uint32_t mtile_dbg = 0;         // AGH_MTILE_DBG | (AGH_MTILE_SHARE + 1) << 8: measurement switches of k_mtile
     bool fused = true;              // AGH_FUSED
@@ -234,7 +234,8 @@ struct agh_mwalk_dev {
     const uint32_t *dir;     // AGH_MW_DIR slots, (first entry << 16) | entries: a piece of two bytes under agh_mw_slot of
                              // the pair, a longer one under agh_mw_slot3 of its first three bytes
     const uint4 *fmask;      // per agh_mw_slot of a pair, bit (byte & 31): x the byte behind the pair (t[j+2]), y t[j+3], z t[j-1],
-                             // w t[j-2] that some entry starting with the pair can accept at all
+                             // w t[j-2] that some entry of two or three bytes starting with the pair can accept at all
+    const uint32_t *g4;      // AGH_MW_G4_WORDS: one bit per piece of >= 4 bytes, by its first four bytes
     uint32_t n_ent;
 };
 struct agh_mwalk_args {

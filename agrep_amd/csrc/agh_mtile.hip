@@ -11,8 +11,9 @@
 //
 //   phase A  position-parallel, the sweeps' chunk-per-lane layout (a wave loads 1 KiB strips with one coalesced
 //            dwordx4 per lane): for each of a chunk's 16 positions the pair t[j], t[j+1] selects a directory slot
-//            whose four 32-bit masks say which bytes next to the pair some entry could accept at all (the walk's
-//            lossless necessary condition, unchanged: fill_multi_tables) -- a CANDIDATE bit; and a DELIMITER bit per
+//            whose four 32-bit masks say which bytes next to the pair some entry of two or three bytes could accept at
+//            all (round 5's lossless necessary condition), the four bytes at j select a bit that says whether a piece of
+//            >= 4 bytes starts with them (fill_multi_tables) -- a CANDIDATE bit; and a DELIMITER bit per
 //            byte.  Both go through 1 KiB of LDS per wave into natural bit order: lane l then holds the 64 candidate
 //            and the 64 delimiter bits of positions [64 l, 64 l + 64) of the tile.
 //   phase B  every lane walks the candidate bits of its own word(s) in rounds, lowest first: the entries of the
@@ -69,6 +70,7 @@ struct mt_shared {
     uint4 fmask[AGH_MW_DIR];                    // 64 KiB
     uint32_t dir[AGH_MW_DIR];                   // 16 KiB
     uint4 ent[AGH_MW_MAX_ENT];                  // 48 KiB
+    uint32_t g4[AGH_MW_G4_WORDS];               // 8 KiB: the first four bytes of the pieces of >= 4 bytes, one bit each
     uint16_t scratch[MT_WAVES][MT_LIST];        // 16 KiB, per wave: phase A: a tile's candidate bits (16 per lane and
                                                 // strip) and, behind them, its delimiter bits; phase B: the list of the
                                                 // candidates the wave shares out at the end
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
         sh.dir[i] = mw.dir[i];
     }
     for (uint32_t i = threadIdx.x; i < mw.n_ent; i += MT_WAVES * 64) sh.ent[i] = mw.ent[i];
+    for (uint32_t i = threadIdx.x; i < AGH_MW_G4_WORDS; i += MT_WAVES * 64) sh.g4[i] = mw.g4[i];
     __syncthreads();
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t wib = mt_uni(threadIdx.x / WAVE);
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
     const uint64_t lo_lim = 8, hi_lim = n - 24;           // (n >= 32: the launcher checks)
     const uint64_t n_pad = (n + 15) & ~(uint64_t)15;      // readable bytes
     const uint64_t n_tiles = (n + MT_TILE - 1) / MT_TILE;
-    const uint8_t *fmask8 = reinterpret_cast<const uint8_t *>(sh.fmask);
+    const uint8_t *fmask8 = reinterpret_cast<const uint8_t *>(sh.fmask), *g4b = reinterpret_cast<const uint8_t *>(sh.g4);
     uint16_t *cb16 = sh.scratch[wib], *db16 = cb16 + 256, *list = cb16;
     const uint64_t *cb64 = reinterpret_cast<const uint64_t *>(cb16), *db64 = reinterpret_cast<const uint64_t *>(db16);
     uint32_t local = 0;                                   // matched records that lie inside one tile (per lane)
@@ -127,29 +130,53 @@ __global__ __launch_bounds__(MT_WAVES * 64) void k_mtile(const uint8_t *__restri
                   mt_delim_nibble(W[4], dd) << 12;
         auto byte_at = [&](int idx) -> uint32_t { return (W[idx >> 2] >> (8 * (idx & 3))) & 0xffu; };   // idx: offset in W
         uint32_t acc = 0;
-        // four positions at a time: their table reads are issued together
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint4 fm[4];
+        // four positions at a time; the table reads of the next four are in flight while these are tested (left alone
+        // the scheduler issues all sixteen reads of the chunk first: 64 result registers, spills in the hot loop)
+        // per position two reads: the pair's masks (pieces of two and three bytes) and the bit of the four bytes at j
+        // (pieces of >= 4 bytes: with the third byte alone -- round 6's first version -- 7 % of all positions were
+        // candidates of such a piece and 96 % of those failed on the fourth byte in the walk)
+        auto fetch = [&](int g, uint4 (&fm)[4], uint32_t (&gw)[4], uint32_t (&gs)[4]) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int o = 4 + 4 * g + p;                                // offset of t[j] in W
-                uint32_t pair;
-                if ((o & 3) == 3) pair = __builtin_amdgcn_alignbyte(W[(o >> 2) + 1], W[o >> 2], 3) & 0xffffu;
-                else pair = (W[o >> 2] >> (8 * (o & 3))) & 0xffffu;
-                if (FOLD) pair = swar_lower(pair);
+                uint32_t gram = (o & 3) ? __builtin_amdgcn_alignbyte(W[(o >> 2) + 1], W[o >> 2], o & 3) : W[o >> 2];
+                if (FOLD) gram = swar_lower(gram);
                 // slot * 16 = the byte offset of the slot's masks: (pair * 40503 >> 4 & 4095) << 4
-                const uint32_t a = (pair * 40503u) & ((AGH_MW_DIR - 1u) << 4);
+                const uint32_t a = ((gram & 0xffffu) * 40503u) & ((AGH_MW_DIR - 1u) << 4);
                 fm[p] = *reinterpret_cast<const uint4 *>(fmask8 + a);
+                const uint32_t h = agh_sample_prod_q4(gram);                // word: bits 2..12, bit: bits 13..17
+                gw[p] = *reinterpret_cast<const uint32_t *>(g4b + (h & ((AGH_MW_G4_WORDS - 1u) << 2)));
+                gs[p] = h >> 13;
             }
+        };
+        auto test = [&](int g, const uint4 (&fm)[4], const uint32_t (&gw)[4], const uint32_t (&gs)[4]) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int o = 4 + 4 * g + p;
                 const uint32_t hit = (fm[p].x >> (byte_at(o + 2) & 31u)) | (fm[p].y >> (byte_at(o + 3) & 31u)) |
-                                     (fm[p].z >> (byte_at(o - 1) & 31u)) | (fm[p].w >> (byte_at(o - 2) & 31u));
+                                     (fm[p].z >> (byte_at(o - 1) & 31u)) | (fm[p].w >> (byte_at(o - 2) & 31u)) |
+                                     (gw[p] >> (gs[p] & 31u));
                 acc = __builtin_amdgcn_alignbit(hit, acc, 1);               // bit 0 of hit -> bit 31, the rest moves down
             }
-        }
+            asm volatile("" : "+v"(acc));
+        };
+        uint4 fa[4], fb[4];
+        uint32_t ga[4], gb[4], sa[4], sb[4];
+        fetch(0, fa, ga, sa);
+        fetch(1, fb, gb, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        test(0, fa, ga, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2, fa, ga, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        test(1, fb, gb, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(3, fb, gb, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        test(2, fa, ga, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        test(3, fb, gb, sb);
+        __builtin_amdgcn_sched_barrier(0);
         cand16 = (acc >> 16) & ~delim16;                                    // (no entry holds the delimiter byte)
     };
 
@@ -506,7 +533,7 @@ bool agh_launch_mtile(const agh_mwalk_args &a, hipStream_t st)
 {
     if (a.q.k != 1 || a.q.mb || !a.n || !a.mw.n_ent || a.mw.n_ent > AGH_MW_MAX_ENT) return false;
     if (a.n >= 32u) {
-        const uint32_t nw = (a.ch & 0xffu) == 1u ? 1u : ((a.ch & 0xffu) == 2u ? 2u : 4u);
+        const uint32_t nw = (a.ch & 0xffu) == 1u ? 1u : ((a.ch & 0xffu) == 4u ? 4u : 2u);
         const uint32_t cus = a.n_cu ? a.n_cu : 256u;
         const uint64_t n_tiles = (a.n + MT_TILE - 1u) / MT_TILE;
         // tiles per ticket: 64 where that still leaves every wave of the chip eight tickets, else fewer (a multiple of
@@ -522,8 +549,8 @@ bool agh_launch_mtile(const agh_mwalk_args &a, hipStream_t st)
         if (blocks > need) blocks = need;
         switch (nw) {
         case 1: launch_mtile<1>(a, blocks, (uint32_t)n_ranges, (uint32_t)range_tiles, st); break;
-        case 2: launch_mtile<2>(a, blocks, (uint32_t)n_ranges, (uint32_t)range_tiles, st); break;
-        default: launch_mtile<4>(a, blocks, (uint32_t)n_ranges, (uint32_t)range_tiles, st); break;
+        case 4: launch_mtile<4>(a, blocks, (uint32_t)n_ranges, (uint32_t)range_tiles, st); break;
+        default: launch_mtile<2>(a, blocks, (uint32_t)n_ranges, (uint32_t)range_tiles, st); break;
         }
     }
     if (a.wave_totals)

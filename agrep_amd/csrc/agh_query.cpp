@@ -844,7 +844,7 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
         if (es.empty() || es.size() > AGH_MW_MAX_ENT) mw = false;
         if (mw) {
             std::stable_sort(es.begin(), es.end(), [](const mw_entry &a, const mw_entry &b) { return a.slot < b.slot; });
-            std::vector<uint32_t> dir(AGH_MW_DIR, 0), ent(es.size() * 4), fmask((size_t)AGH_MW_DIR * 4, 0);
+            std::vector<uint32_t> dir(AGH_MW_DIR, 0), ent(es.size() * 4), fmask((size_t)AGH_MW_DIR * 4, 0), g4(AGH_MW_G4_WORDS, 0);
             for (size_t a = 0; a < es.size();) {
                 size_t b = a;
                 while (b < es.size() && es[b].slot == es[a].slot) ++b;
@@ -860,7 +860,10 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
                 const uint32_t *w = es[i].w;
                 const uint32_t pl = w[1] >> 24, meta = w[3] >> 24, L = meta & 7u;
                 uint32_t *fm = &fmask[(size_t)agh_mw_slot(w[0] & 0xffffu) * 4];     // (the mask table goes by the pair)
-                if (pl >= 3u) {
+                if (pl >= 4u) {                     // its first four bytes (the pool holds folded bytes under -i)
+                    const uint32_t h = agh_sample_prod_q4(w[0]);
+                    g4[(h >> 2) & (AGH_MW_G4_WORDS - 1u)] |= 1u << ((h >> 13) & 31u);
+                } else if (pl == 3u) {
                     fm[0] |= 1u << ((w[0] >> 16) & 31u);
                 } else {
                     const uint32_t near2 = L >= 2u ? (1u << (w[2] & 31u)) | (1u << ((w[2] >> 8) & 31u)) : ~0u;
@@ -869,7 +872,7 @@ static int fill_multi_tables(agh_query *q, const unsigned char *const *pats, con
                 }
             }
             if (up(&q->d_mw_ent, ent.data(), ent.size() * 4) || up(&q->d_mw_dir, dir.data(), dir.size() * 4) ||
-                up(&q->d_mw_fmask, fmask.data(), fmask.size() * 4))
+                up(&q->d_mw_fmask, fmask.data(), fmask.size() * 4) || up(&q->d_mw_g4, g4.data(), g4.size() * 4))
                 return -1;
             q->mw_nent = (uint32_t)es.size();
             q->mw_ok = true;
@@ -994,6 +997,7 @@ extern "C" void agh_query_free(agh_query *q)
     if (q->d_mw_ent) (void)hipFree(q->d_mw_ent);
     if (q->d_mw_dir) (void)hipFree(q->d_mw_dir);
     if (q->d_mw_fmask) (void)hipFree(q->d_mw_fmask);
+    if (q->d_mw_g4) (void)hipFree(q->d_mw_g4);
     if (q->d_ms_ptab) (void)hipFree(q->d_ms_ptab);
     if (q->d_ms_gtab) (void)hipFree(q->d_ms_gtab);
     if (q->d_ms_ment) (void)hipFree(q->d_ms_ment);
