@@ -562,17 +562,35 @@ def c5_file_hits_job(A, torch, dist, comm, rank, world, backend, fence, args, n_
     fbytes = (args.c5_file_mib << 20) // 4096 * 4096
     pats, variants = c5_patterns_and_variants()
     mine = list(range(rank * per, (rank + 1) * per)) if rank < G else []
-    buf = torch.empty(max(len(mine), 1) * fbytes, dtype=torch.uint8, device="cuda")
     pages = fbytes // 4096
     planted_files = []
-    for i, f in enumerate(mine):
-        # (one file in four holds planted patterns; with one error allowed the other files have chance
-        # matches of their own -- about 4 per MiB -- so on this corpus -l lists every file of a GiB)
-        pl = A.corpus_fill_device(buf.data_ptr() + i * fbytes, pages, first_page=f * pages, seed=55, variants=variants,
-                                  plant_period=500 if f % 4 == 0 else 1 << 30)
-        planted_files.append(int(sum(pl[:5])))
-    torch.cuda.synchronize()
-    q = A.Query.multi(pats, k=1)
+    buf = q = None
+    ok, why = 1, ""
+    try:                                        # everything a rank does alone: no collective in here
+        buf = torch.empty(max(len(mine), 1) * fbytes, dtype=torch.uint8, device="cuda")
+        for i, f in enumerate(mine):
+            # (one file in four holds planted patterns; with one error allowed the other files have chance
+            # matches of their own -- about 4 per MiB -- so on this corpus -l lists every file of a GiB)
+            pl = A.corpus_fill_device(buf.data_ptr() + i * fbytes, pages, first_page=f * pages, seed=55, variants=variants,
+                                      plant_period=500 if f % 4 == 0 else 1 << 30)
+            planted_files.append(int(sum(pl[:5])))
+        torch.cuda.synchronize()
+        q = A.Query.multi(pats, k=1)
+        for i, f in enumerate(mine[:1]):        # (one scan of each kind before anybody waits in a collective)
+            q.scan_device(buf.data_ptr(), fbytes, flags=A.COUNT, time_sweep=False, time_scan=False)
+            q.scan_device(buf.data_ptr(), fbytes, flags=A.FILENAMEONLY, time_sweep=False, time_scan=False)
+    except Exception as e:
+        ok, why = 0, str(e)[:200]
+    # the ranks agree to run the job or to skip it TOGETHER: a rank that failed above must not leave the others waiting
+    # in the collectives below
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if q is not None:
+            q.close()
+        del buf
+        torch.cuda.empty_cache()
+        return {"skipped": "a rank could not set the job up" + (": " + why if why else "")}
     res = {}
     try:
         for name, fl in (("every_byte", A.COUNT), ("dash_l", A.FILENAMEONLY)):
