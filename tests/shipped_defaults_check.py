@@ -55,6 +55,22 @@ with A.Query.multi(pats) as q:
     res_m, _ = q.scan_buffer(text, flags=A.COUNT)
 assert res_m.n_matched == O.multi_exact_count(pats, tb)[0]
 n_cases += 3
+# ... -f with one error: a selective set (k_mscan), a dense one (k_mtile, count-only and by record number) and a short word
+# with errors on the fast full scan (three text streams per lane), each against the union of single-pattern oracle scans
+for pats, k in (([b"approxim", b"atematch", b"zzzzqqqq"], 1), ([b"appr", b"match", b"atema", b"zqzq"], 1)):
+    want_u = set()
+    for p_ in pats:
+        want_u.update(O.asearch(p_, k, tb, cap=400000)[1])
+    with A.Query.multi(pats, k=k) as q:
+        rc, _ = q.scan_buffer(text, flags=A.COUNT)
+        rl, ms = q.scan_buffer(text, cap=400000)
+    assert rc.fused_segments == 1 and rc.n_matched == len(want_u), (pats, rc.n_matched, len(want_u))
+    assert [(s_, e_) for s_, e_, _ in ms] == sorted(want_u), pats
+    n_cases += 2
+with A.Query(b"matching", 2) as q:
+    rw, msw = q.scan_buffer(text, cap=400000)
+    assert rw.engine == A.ENGINE_FULLSCAN and (rw.n_matched, [(s_, e_) for s_, e_, _ in msw]) == O.asearch(b"matching", 2, tb, cap=400000)
+n_cases += 1
 # 4. 4 GiB resident: the fused kernel (the shipped form from 4 GiB on) against two kernels and the planted records
 n = 4 << 30
 buf = torch.empty(n, dtype=torch.uint8, device="cuda")
