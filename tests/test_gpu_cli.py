@@ -211,11 +211,23 @@ def test_cli_shards_print_in_file_order_while_scanning(files, args, tmp_path):
 def test_cli_multi_gpu_pattern_file(files, tmp_path):
     pf = tmp_path / "pats.txt"
     pf.write_bytes(b"approximatematch\naproximatematch\nzzzzqqqq\n")
-    for mode in (["-c"], ["-l"], []):
+    for mode in (["-c"], ["-l"], [], ["-n"]):
         a = ["-V0"] + mode + ["-f", str(pf)] + files
         rc_1, out_1, _ = _run(CLI, a)
         rc_g, out_g, err_g = _run(CLI, ["--gpus", "1"] + a)
         assert err_g == b"" and out_g == out_1 and rc_g == rc_1, (mode, out_g[:200], out_1[:200])
+        # ... and over three shards per file on the one GPU (records: printed shard after shard while the others scan)
+        rc_3, out_3, err_3 = _run(CLI, ["--gpus", "3"] + a, env={"AGH_CLI_SHARE_DEVICES": "1", "AGH_STREAM_SEG_MB": "1"})
+        assert err_3 == b"" and out_3 == out_1 and rc_3 == rc_1, (mode, out_3[:200], out_1[:200])
+    # -f with one error (--approx-f) on a dense set: the tile kernel's numbered form behind every shard's record list
+    pd = tmp_path / "dense.txt"
+    pd.write_bytes(b"appr\nmatch\natema\nzqzq\n")
+    for mode in (["-c"], [], ["-n"]):
+        a = ["-V0", "--approx-f", "-1"] + mode + ["-f", str(pd)] + files[:2]
+        rc_1, out_1, err_1 = _run(CLI, a)
+        assert err_1 == b"" and out_1
+        rc_3, out_3, err_3 = _run(CLI, ["--gpus", "3"] + a, env={"AGH_CLI_SHARE_DEVICES": "1", "AGH_STREAM_SEG_MB": "1"})
+        assert err_3 == b"" and out_3 == out_1 and rc_3 == rc_1, (mode, out_3[:200], out_1[:200])
 
 
 def test_cli_q6_divergence_is_deliberate(tmp_path):
