@@ -334,19 +334,25 @@ __device__ uint64_t delim_bitmap_serial(const uint8_t *__restrict__ text, uint64
     return out;
 }
 
+#ifndef AGH_DBM_ITER
+#define AGH_DBM_ITER 8u
+#endif
 __global__ __launch_bounds__(256) void k_delim_bitmap(const uint8_t *__restrict__ text,
                                                       uint64_t n, agh_dev_query q,
                                                       uint64_t *__restrict__ dbm,
                                                       uint64_t n_words,
                                                       uint32_t *__restrict__ counters)
 {
-    const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (AGH_DBM_ITER words per lane, 256 apart: one word per lane made a 4 GiB text 262144 workgroups that lived for
+    // a few microseconds each)
+    for (uint32_t it = 0; it < AGH_DBM_ITER; ++it) {
+    const uint64_t wi = ((uint64_t)blockIdx.x * AGH_DBM_ITER + it) * blockDim.x + threadIdx.x;
     if (wi >= n_words) return;
     const uint64_t b = wi * 64;
-    if (b >= n) { dbm[wi] = 0; return; }
+    if (b >= n) { dbm[wi] = 0; continue; }
     if (wi == 0) {                              // (the virtual head byte in front)
         dbm[0] = delim_bitmap_serial(text, n, q, 0, counters);
-        return;
+        continue;
     }
     // bytes b - 16 .. b + 63 as 20 dwords (pieces at or behind the end of the text: none; the piece that holds the
     // last byte is readable to its end, its bytes behind the text are masked below)
@@ -399,6 +405,7 @@ __global__ __launch_bounds__(256) void k_delim_bitmap(const uint8_t *__restrict_
     const uint64_t out = (e_lo >> 16) | ((uint64_t)e_hi << 48);
     const uint64_t ov = ((e_lo & a_lo) >> 16) | ((uint64_t)(e_hi & a_hi) << 48);
     dbm[wi] = ov ? delim_bitmap_serial(text, n, q, b, counters) : out;
+    }
 }
 
 void agh_warm_core_module()
@@ -411,7 +418,7 @@ void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &
                              uint64_t n_words, uint32_t *counters, hipStream_t st)
 {
     if (!n_words) return;
-    hipLaunchKernelGGL(k_delim_bitmap, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_delim_bitmap, dim3((uint32_t)((n_words + 256 * AGH_DBM_ITER - 1) / (256 * AGH_DBM_ITER))), dim3(256), 0, st,
                        (const uint8_t *)text, n, q, dbm, n_words, counters);
 }
 

@@ -487,7 +487,8 @@ def test_scan_fd_emit_multi_byte_delimiters(agh, tmp_path, monkeypatch, delim):
     assert len(batches) >= 3
 
 
-@pytest.mark.parametrize("delim", [b"FROM ", b"\n\n", b"#%", b"@@@", b"ab", b"aa", b"\n.\n"])
+@pytest.mark.parametrize("delim", [b"FROM ", b"\n\n", b"#%", b"@@@", b"ab", b"aa", b"\n.\n", b"<record>", b"ENDREC\n", b"abcabc",
+                                   b"aaaaaaaa"])
 def test_multi_byte_delimiters(agh, delim):
     """-d with 2..8 byte delimiters (-d 'From ', -d '$$'): leftmost non-overlapping delimiter
     occurrences, reset after the delimiter's last byte -- bit-exact with asearch.c, including
