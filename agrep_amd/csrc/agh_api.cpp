@@ -38,6 +38,10 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     va->fs_fast = 0;
     va->tf_chunk = 0;
     va->tr_group = 0;
+    va->tf_direct = 0;
+    va->tf_cont = nullptr;
+    va->tf_cont_cap = 0;
+    va->tf_cont_at = 0;
     va->fs_streams = 0;
     if (!fs_fast_ok(q)) return 0;
     if (q->table && n < (q->tune.tf_fast_min_mb << 20)) return 0;
@@ -48,6 +52,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     va->fs_fast = 1;
     va->tf_chunk = q->tune.tf_chunk;
     va->tr_group = q->tune.tr_group;
+    va->tf_direct = q->tune.tf_direct ? 1u : 0u;
     va->fs_streams = q->tune.fs_streams;
     // table engine, M <= 15: two streams per lane (k_tablescan_fast2) -- the always-one bit M must be there
     if (q->table && q->tune.tf_pack2) {
@@ -56,6 +61,19 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
     }
     va->fs_replay = (uint64_t *)q->cand.p;
     va->fs_tile_cnt = (uint32_t *)q->wave_cand.p;
+    if (q->table && q->tune.tf_cont) {
+        // at most tf_cont lanes x (one or two streams) of every 64-chunk tile hand a record over, and two streams per
+        // lane come with two tiles per wave; the chunk is agh_launch_tablescan's choice (48 B per entry: 0.9 % of a
+        // text of 1 GiB or more at the default of 48 lanes)
+        const uint64_t chunk = q->tune.tf_chunk ? q->tune.tf_chunk
+                                                : (n >= ((uint64_t)1 << 30) ? 4096u : (n >= ((uint64_t)512 << 20) ? 2048u : 1024u));
+        const uint64_t cap = ((n + 64 * chunk - 1) / (64 * chunk) + 8) * q->tune.tf_cont;
+        if (cap < ((uint64_t)1 << 31) && q->tf_cont.ensure(cap * 48u) == 0) {
+            va->tf_cont = (uint4 *)q->tf_cont.p;
+            va->tf_cont_cap = (uint32_t)cap;
+            va->tf_cont_at = q->tune.tf_cont;
+        }
+    }
     return 0;
 }
 
@@ -707,6 +725,8 @@ void agh_read_tuning(agh_tuning *t)
     t->fs_fast = env_on("AGH_FS_FAST", true);
     t->fs_streams = (uint32_t)std::min<uint64_t>(env_u64("AGH_FS_STREAMS", 0), 4);
     t->tf_pack2 = env_on("AGH_TF_PACK2", true);
+    t->tf_direct = env_on("AGH_TF_DIRECT", true);
+    t->tf_cont = (uint32_t)std::min<uint64_t>(env_u64("AGH_TF_CONT", 48), 64);
     t->tf_fast_min_mb = env_u64("AGH_TF_FAST_MIN_MB", AGH_TF_FAST_MIN_MB_DEFAULT);
     {
         const uint64_t c = env_u64("AGH_TF_CHUNK", AGH_TF_CHUNK_DEFAULT);

@@ -53,7 +53,9 @@ enum agh_counter {
     AGH_C_RECBYTES_LO = 12, // record output: bytes of the listed records (one 64-bit sum: k_match_bounds)
     AGH_C_RECBYTES_HI = 13,
     AGH_C_NREC = 14,     // -v record lists: records k_unmatched walked over (the compaction inverts below this)
-    AGH_C_COUNT = 16
+    AGH_C_CONT_N = 15,   // table engine, fast form: open records handed to k_table_cont
+    AGH_C_CONT_NEXT = 16, // ... and the ticket its lanes take them with
+    AGH_C_COUNT = 20
 };
 
 // The reference's own query tables for the table engine (agh_table.hip), maskgen.c layout.

@@ -86,6 +86,7 @@ struct agh_query {
     // per-query workspace (grown lazily, reused across scans)
     dev_buf strip_prefix, wave_totals, cand, wave_cand, bitmap, hashset, dbm, staging, match_pos,
         match_rec, match_start, match_end, match_off, gather;
+    dev_buf tf_cont;                    // table engine, fast form: open records handed from the scan to k_table_cont (48 B each)
     dev_buf rec_pos;                    // record lists: one byte offset per record number (8 B per bitmap bit)
     dev_buf bm_blocks;                  // ... scratch of the ordered compaction of the bitmap
     dev_buf match_out;                  // ... agh_match entries of the piece being emitted

@@ -16,6 +16,8 @@ struct agh_tuning {
     bool tf_pack2 = true;           // AGH_TF_PACK2: table engine, two streams per lane where M <= 15
     uint64_t tf_fast_min_mb = 0;    // AGH_TF_FAST_MIN_MB: table engine, fast form from this segment size on
     uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 / 2048 / 4096), 0 = by size
+    bool tf_direct = true;          // AGH_TF_DIRECT: table engine, count-only: the fast kernel counts pieces with one record end itself (0: every flagged piece is replayed; A/B)
+    uint32_t tf_cont = 48;          // AGH_TF_CONT: table engine, fast form: the walk past a chunk's end hands its open records to k_table_cont once this few lanes still have one (0: every wave walks to its longest record's end)
     uint32_t tr_group = 8;          // AGH_TR_GROUP: tiles whose replay lists one wave of k_table_replay takes (1, 2, 4, 8, 16)
     uint32_t mtile = 2;             // AGH_MTILE: dense -f sets with one error: tiles a wave of k_mtile holds at a time (1, 2, 4)
     bool mtile_numbered = true;     // AGH_MTILE_NUMBERED: 0: numbered scans of such sets stay on k_dense_multi (A/B, tests)
@@ -100,6 +102,10 @@ struct agh_scan_args {
     int fs_fast;
     uint32_t tf_chunk;              // table engine, fast form: bytes per lane (1024 / 2048 / 4096), 0 = by size
     uint32_t tr_group;              // tiles per wave of k_table_replay (0: 8)
+    uint4 *tf_cont;                 // table engine, fast form: entries of the open records handed over (3 x uint4 each), or null
+    uint32_t tf_cont_cap;           // ... entries the buffer holds
+    uint32_t tf_cont_at;            // ... lanes with an open record at which a wave hands over (0: never)
+    uint32_t tf_direct;             // table engine, fast form, count-only: 1 = count pieces with one record end in the fast kernel
     uint32_t fs_streams;            // full scan, fast form: at most this many text streams per lane (0: by the pattern's length)
     uint64_t *fs_replay;
     uint32_t *fs_tile_cnt;

@@ -1036,6 +1036,7 @@ extern "C" void agh_query_free(agh_query *q)
     q->match_off.release();
     q->gather.release();
     q->rec_pos.release();
+    q->tf_cont.release();
     q->bm_blocks.release();
     q->match_out.release();
     if (q->h_emit) (void)hipHostFree(q->h_emit);

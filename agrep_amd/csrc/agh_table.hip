@@ -358,14 +358,78 @@ __device__ __forceinline__ void table_reset_state(const agh_dev_tables &T, uint3
 // the byte's table entry; what a boundary does to the state (RF: every level Init[0], the delimiter's last byte
 // consumed again, level 0 masked) is the one-byte case's.  A lane that starts inside a delimiter needs no special
 // case here: its state is untrusted until the first bitmap bit anyway.
+// Count-only scans of patterns without ';' (round 6): a flagged piece in which exactly ONE record ends needs no
+// replay -- the fast recurrence is asearch.c's from the first delimiter a stream has seen (the reset leaves a state
+// that does not depend on what came before), so "an end bit on the top level at a trusted record end" IS that
+// record's verdict (asearch.c:119-128 without AND), and a record ends in one piece only: it is counted in a
+// register here.  Pieces with several record ends and the piece at the text's end still go to the replay, which
+// walks every record that ends in a listed piece -- a piece is either counted here or listed, never both.
+// (With 1.7 KB records the replay -- one lane per record, from its first byte -- was 2.3 of 11 ms.)
+template <bool MB>
+__device__ __forceinline__ bool tf_one_end(uint4 v, uint32_t nb, uint32_t d16, uint32_t delim)
+{
+    if (MB) return __popc(d16 & ((1u << nb) - 1u)) == 1;
+    return delims_in(mask_tail(v, (int)nb, (~delim & 0xffu) * 0x01010101u), (delim & 0xffu) * 0x01010101u) == 1u;
+}
+__device__ __forceinline__ void tf_add_direct(uint32_t ndirect, uint32_t *__restrict__ counters)
+{
+    if (!__ballot(ndirect != 0u)) return;
+    const uint32_t t = wave_sum_to_lane63(ndirect);
+    if (lane_id() == 63) {
+        atomicAdd(&counters[AGH_C_MATCHED], t);
+        counters[AGH_C_ANYHIT] = 1u;
+    }
+}
+
+// The walk past a chunk's end costs a wave the LONGEST of its lanes' walks: ~5 x the mean record with records of
+// random length (1.7 KB records: 9 KB behind every 4 KiB chunk, 8.1 of 11 ms -- profiles/r06_table_delims.log).  Once
+// only `at` lanes still have an open record the wave hands those over -- position, tile and the K + 1 state words of
+// the stream -- and goes on to its next tile; k_table_cont walks them to their delimiters one lane per record, every
+// lane taking the next entry as soon as its record has closed.
+// (Not before the walk is AGH_TF_CONT_MIN bytes long: with 80-byte lines the longest of 128 walks ends at ~400 bytes,
+// the hand-over and the second kernel cost more than those last rounds.)
+#ifndef AGH_TF_CONT_MIN
+#define AGH_TF_CONT_MIN 512u
+#endif
+struct tf_cont_args {
+    uint4 *ent;
+    uint32_t cap, at;
+};
+template <int K>
+__device__ __forceinline__ void tf_cont_push(const tf_cont_args &c, uint32_t *__restrict__ counters, bool open,
+                                             uint64_t pos, uint32_t tile, const uint32_t (&S)[K + 1])
+{
+    const uint64_t m = __ballot(open);
+    if (!open) return;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint32_t base = 0;
+    if (rank == 0) base = atomicAdd(&counters[AGH_C_CONT_N], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);         // (the first active lane is the one of rank 0)
+    const uint32_t at = base + rank;
+    if (at >= c.cap) {
+        counters[AGH_C_OVERFLOW] = 1u;
+        return;
+    }
+    uint32_t w[12];
+    w[0] = (uint32_t)pos;
+    w[1] = (uint32_t)(pos >> 32);
+    w[2] = tile;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) w[3 + e] = e <= K ? S[e <= K ? e : 0] : 0u;
+    c.ent[3u * at] = make_uint4(w[0], w[1], w[2], w[3]);
+    c.ent[3u * at + 1u] = make_uint4(w[4], w[5], w[6], w[7]);
+    c.ent[3u * at + 2u] = make_uint4(w[8], w[9], w[10], w[11]);
+}
+
 template <int K, bool COSTS, bool MB>
 __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
     uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters, uint32_t tf_chunk,
-    const uint16_t *__restrict__ dbm16)
+    const uint16_t *__restrict__ dbm16, uint32_t direct, tf_cont_args cont)
 {
     const uint32_t tf_slice = AGH_TF_SLICE_OF(tf_chunk);
+    uint32_t ndirect = 0;                       // (direct) records counted here: see tf_one_end
     struct MK { uint32_t cm, kb; };
     __shared__ MK tab[256];
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * WAVE * AGH_FS_ROW];
@@ -468,9 +532,15 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
                 const uint32_t off = r * AGH_FS_ROUND + 16u * p;
                 const uint4 v = *reinterpret_cast<const uint4 *>(ring_r + 16u * p);
                 const uint32_t nb = off + 16u <= len ? 16u : (off < len ? len - off : 0u);
-                uint32_t flag = nb ? piece(v, nb, (uint32_t)(dcur >> (16u * p)) & 0xffffu) : 0u;
+                const uint32_t d16 = (uint32_t)(dcur >> (16u * p)) & 0xffffu;
+                uint32_t flag = nb ? piece(v, nb, d16) : 0u;
+                const bool last = cs + off + 16u >= n;
+                if (direct && __ballot(flag != 0u) && flag && !last && tf_one_end<MB>(v, nb, d16, q.delim)) {
+                    ++ndirect;
+                    flag = 0u;
+                }
                 // the piece that holds the last byte of the text: the appended delimiter is the replay's
-                if (nb && cs + off + 16u >= n && trusted) flag = 1u;
+                if (nb && last && trusted) flag = 1u;
                 emit(flag != 0u, cs + off);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all reads done before the next round's writes
@@ -488,7 +558,13 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
             vw = *reinterpret_cast<const uint4 *>(text + ce);
             dw16 = MB ? (uint32_t)dbm16[ce >> 4] : 0u;
         }
-        for (uint64_t p0 = ce; __ballot(open); p0 += 16) {
+        for (uint64_t p0 = ce;; p0 += 16) {
+            const uint64_t om = __ballot(open);
+            if (!om) break;
+            if (cont.at && p0 - ce >= AGH_TF_CONT_MIN && (uint32_t)__popcll(om) <= cont.at) {   // the stragglers: k_table_cont's
+                tf_cont_push<K>(cont, counters, open, p0, (uint32_t)tile, A.B);
+                break;
+            }
             // whole 16-byte pieces until one holds a delimiter: what it flags behind that delimiter
             // belongs to the next lane, which flags it as well -- the replay does not mind
             uint32_t flag = 0;
@@ -502,6 +578,10 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
                 }
                 const uint32_t nb = p0 + 16 <= n ? 16u : (uint32_t)(n - p0);
                 flag = piece(v, nb, d16);
+                if (direct && flag && p0 + 16 < n && tf_one_end<MB>(v, nb, d16, q.delim)) {
+                    ++ndirect;
+                    flag = 0u;
+                }
                 if (dseen) open = false;
                 else if (p0 + 16 >= n) {         // the text ends inside my record: the last piece
                     flag = 1u;
@@ -513,6 +593,7 @@ __global__ __launch_bounds__(AGH_FS_THREADS) void k_tablescan_fast(
         }
         if (lane == 0) tile_cnt[tile] = cnt < tf_slice ? cnt : tf_slice;
     }
+    tf_add_direct(ndirect, counters);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -549,9 +630,10 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
     const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
     const uint32_t *__restrict__ mask_g, uint64_t *__restrict__ replay,
     uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters, uint32_t M, uint32_t n_tiles1,
-    uint32_t tf_chunk, const uint16_t *__restrict__ dbm16)
+    uint32_t tf_chunk, const uint16_t *__restrict__ dbm16, uint32_t direct, tf_cont_args cont)
 {
     const uint32_t tf_slice = AGH_TF_SLICE_OF(tf_chunk);
+    uint32_t ndirect = 0;                       // (direct) records counted here: tf_one_end
     __shared__ uint32_t tab[256];               // mask (bits 0..M-1) | kill << 16 (0 for the delimiter, else 0xffff)
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[(AGH_FS_THREADS / WAVE) * 2 * WAVE * AGH_TF2_ROW];
     const uint32_t keep = (2u << M) - 1u;       // bits 0..M
@@ -700,10 +782,15 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
                 const uint32_t flag = settled ? piece(va, vb, nba, nbb, posa, posb, std::integral_constant<int, 2>{})
                                       : full  ? piece(va, vb, nba, nbb, posa, posb, std::integral_constant<int, 1>{})
                                               : piece(va, vb, nba, nbb, posa, posb, std::integral_constant<int, 0>{});
-                // the piece that holds the last byte of the text: the appended delimiter is the replay's
                 bool fa = nba && (flag & 0xffffu), fb = nbb && (flag >> 16);
-                if (nba && cs[0] + off + 16u >= n && (trusted & 0xffffu)) fa = true;
-                if (nbb && cs[1] + off + 16u >= n && (trusted >> 16)) fb = true;
+                const bool lasta = cs[0] + off + 16u >= n, lastb = cs[1] + off + 16u >= n;
+                if (direct && __ballot(fa || fb)) {
+                    if (fa && !lasta && tf_one_end<MB>(va, nba, posa, q.delim)) { ++ndirect; fa = false; }
+                    if (fb && !lastb && tf_one_end<MB>(vb, nbb, posb, q.delim)) { ++ndirect; fb = false; }
+                }
+                // the piece that holds the last byte of the text: the appended delimiter is the replay's
+                if (nba && lasta && (trusted & 0xffffu)) fa = true;
+                if (nbb && lastb && (trusted >> 16)) fb = true;
                 emit(fa, cs[0] + off, tile2 * 2, cnt0);
                 emit(fb, cs[1] + off, tile2 * 2 + 1, cnt1);
             }
@@ -726,7 +813,19 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
             wb = *reinterpret_cast<const uint4 *>(text + ce[1]);
             wdb = MB ? (uint32_t)dbm16[ce[1] >> 4] : 0u;
         }
-        for (uint64_t step = 0; __ballot(opa || opb); step += 16) {
+        for (uint64_t step = 0;; step += 16) {
+            const uint64_t om = __ballot(opa || opb);
+            if (!om) break;
+            if (cont.at && step >= AGH_TF_CONT_MIN && (uint32_t)__popcll(om) <= cont.at) {       // the stragglers: k_table_cont's
+                uint32_t S[K + 1];
+#pragma unroll
+                for (int e = 0; e <= K; ++e) S[e] = A.B[e] & 0xffffu;
+                tf_cont_push<K>(cont, counters, opa, ce[0] + step, (uint32_t)(tile2 * 2), S);
+#pragma unroll
+                for (int e = 0; e <= K; ++e) S[e] = A.B[e] >> 16;
+                tf_cont_push<K>(cont, counters, opb, ce[1] + step, (uint32_t)(tile2 * 2 + 1), S);
+                break;
+            }
             const uint64_t pa = ce[0] + step, pb = ce[1] + step;
             const bool ma = opa, mb = opb;
             uint4 va = vfill, vb = vfill;
@@ -751,6 +850,10 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
             }
             const uint32_t flag = piece(va, vb, nba, nbb, da16, db16, std::integral_constant<int, 0>{});
             bool fa = ma && (flag & 0xffffu), fb = mb && (flag >> 16);
+            if (direct && __ballot(fa || fb)) {
+                if (fa && pa + 16 < n && tf_one_end<MB>(va, nba, da16, q.delim)) { ++ndirect; fa = false; }
+                if (fb && pb + 16 < n && tf_one_end<MB>(vb, nbb, db16, q.delim)) { ++ndirect; fb = false; }
+            }
             if (opa) {
                 if (dseen & 0xffffu) opa = false;
                 else if (pa + 16 >= n) { fa = true; opa = false; }      // the text ends inside my record
@@ -767,6 +870,142 @@ __global__ __launch_bounds__(AGH_FS_THREADS) AGH_TF2_ATTR void k_tablescan_fast2
             if (tile2 * 2 + 1 < n_tiles1) tile_cnt[tile2 * 2 + 1] = cnt1 < tf_slice ? cnt1 : tf_slice;
         }
     }
+    tf_add_direct(ndirect, counters);
+}
+
+#ifndef AGH_TF_CONT_PER_LANE
+#define AGH_TF_CONT_PER_LANE 4u
+#endif
+// The open records the fast kernels handed over (tf_cont_push): one lane per record, 16 bytes at a time up to the
+// delimiter that closes it, the walk's rules at that piece -- flagged and the only record end of its piece (count-only,
+// no ';'): counted here; flagged otherwise, or the piece at the text's end: onto the replay list of the tile the record
+// came from.  A lane whose record has closed takes the next entry (one ticket per wave and refill).
+template <int K, bool COSTS, bool MB>
+__global__ __launch_bounds__(256) void k_table_cont(
+    const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q, agh_dev_tables T,
+    const uint32_t *__restrict__ mask_g, const uint4 *__restrict__ ent, uint32_t cap,
+    uint64_t *__restrict__ replay, uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ counters,
+    uint32_t tf_slice, const uint16_t *__restrict__ dbm16, uint32_t direct, uint32_t M)
+{
+    __shared__ uint32_t lmask[256];
+    lmask[threadIdx.x] = mask_g[threadIdx.x];
+    __syncthreads();
+    uint32_t total = counters[AGH_C_CONT_N];
+    if (total > cap) total = cap;
+    // four entries per lane or so: a lane that takes the next entry when its record closes evens out the records'
+    // lengths, a lane per entry would leave every wave waiting for its longest one
+    if (((uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u)) * AGH_TF_CONT_PER_LANE >= total && (blockIdx.x | (threadIdx.x >> 6))) return;
+    const uint32_t keep = M >= 31u ? ~0u : (2u << M) - 1u;      // (a half of a two-stream word: nothing above bit M)
+    const uint32_t ci = q.ci, cs_ = q.cs, cd = q.cd;
+    uint32_t RF[K + 1];                                           // (unused: no byte resets the state here)
+#pragma unroll
+    for (int e = 0; e <= K; ++e) RF[e] = 0u;
+    const uint32_t dd = (q.delim & 0xffu) * 0x01010101u;
+    uint32_t ndirect = 0;
+    bool have = false, dry = false;
+    uint64_t pos = 0;
+    uint32_t tile = 0;
+    TableFast<K> A;
+#pragma unroll
+    for (int e = 0; e <= K; ++e) A.B[e] = 0u;
+    uint4 vcur = make_uint4(0, 0, 0, 0);
+    uint32_t dcur = 0;
+    uint32_t wnext = 0, wend = 0;                 // (uniform) the wave's block of entries: 64 per ticket
+    for (;;) {
+        // (a ticket per lane and record made every round of every wave wait for an L2 atomic: 1.7 ms for 260 000 records)
+        const uint64_t need = __ballot(!have);
+        if (need) {
+            if (wnext == wend && !dry) {
+                uint32_t b = 0;
+                if (lane_id() == 0) b = atomicAdd(&counters[AGH_C_CONT_NEXT], 64u);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= total) {
+                    dry = true;
+                } else {
+                    wnext = b;
+                    wend = b + 64u < total ? b + 64u : total;
+                }
+            }
+            if (wnext < wend) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const uint32_t idx = wnext + rank;
+                if (!have && idx < wend) {
+                    const uint4 e0 = ent[3u * idx], e1 = ent[3u * idx + 1u], e2 = ent[3u * idx + 2u];
+                    const uint32_t w[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
+                    pos = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+                    tile = w[2];
+#pragma unroll
+                    for (int e = 0; e <= K; ++e) A.B[e] = w[3 + e] & keep;
+                    have = true;
+                    vcur = *reinterpret_cast<const uint4 *>(text + pos);
+                    dcur = MB ? (uint32_t)dbm16[pos >> 4] : 0u;
+                }
+                const uint32_t took = (uint32_t)__popcll(need);
+                wnext = wnext + took < wend ? wnext + took : wend;
+            }
+        }
+        if (!__ballot(have)) {
+            if (dry) break;
+            continue;                           // (the block ran out in this round: the next one brings a new ticket)
+        }
+        if (have) {
+            const uint4 v = vcur;
+            uint32_t m16 = dcur;
+            if (pos + 16 < n) {                 // the next piece is on its way while this one runs
+                vcur = *reinterpret_cast<const uint4 *>(text + pos + 16);
+                dcur = MB ? (uint32_t)dbm16[(pos + 16) >> 4] : 0u;
+            }
+            const uint32_t nb = pos + 16 <= n ? 16u : (uint32_t)(n - pos);
+            const uint32_t dws[4] = {v.x, v.y, v.z, v.w};
+            if (!MB) {
+                m16 = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t x = dws[d] ^ dd;
+                    const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+                    m16 |= ((((z >> 7) & 0x01010101u) * 0x10204080u) >> 28) << (4 * d);
+                }
+            }
+            m16 &= (1u << nb) - 1u;
+            const uint32_t first = m16 ? (uint32_t)__builtin_ctz(m16) : 16u;
+            // all sixteen bytes, whatever closes in between: behind the delimiter (and behind the text's end) the
+            // state is not used again, and a lane that stops early saves the wave nothing -- sixteen table reads in
+            // flight and no branch instead (a branch per byte made a piece 1.6 us: profiles/r06_ab_table_cont.log)
+            uint32_t cm[16];
+#pragma unroll
+            for (uint32_t b = 0; b < 16; ++b) cm[b] = lmask[(dws[b >> 2] >> (8u * (b & 3u))) & 0xffu];
+            uint32_t vtop = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 16; ++b) {
+                const uint32_t top = A.template feed<COSTS>(cm[b], ~0u, T, RF, ci, cs_, cd);
+                vtop = b == first ? top : vtop;
+            }
+            const bool last = pos + 16 >= n;
+            bool list = false;
+            if (first < 16u) {                  // my record closes here
+                if (vtop & T.endposition) {
+                    if (direct && !last && __popc(m16) == 1) ++ndirect;
+                    else list = true;
+                }
+                have = false;
+            } else if (last) {                  // the text ends inside my record: the replay's (the appended delimiter)
+                list = true;
+                have = false;
+            } else {
+                pos += 16;
+            }
+            if (list) {
+                const uint32_t slot = atomicAdd(&tile_cnt[tile], 1u);
+                if (slot < tf_slice) {
+                    replay[(uint64_t)tile * tf_slice + slot] = pos;
+                } else {
+                    counters[AGH_C_OVERFLOW] = 1u;
+                    atomicMin(&tile_cnt[tile], tf_slice);
+                }
+            }
+        }
+    }
+    tf_add_direct(ndirect, counters);
 }
 
 // Exact: for every listed piece, every record that ENDS in it (a delimiter inside the piece, or the
@@ -923,6 +1162,18 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
         const uint32_t nt2 = (nt + 1u) / 2u;
         const uint32_t fblocks2 = (nt2 + 3u) / 4u > 16384u ? 16384u : (nt2 + 3u) / 4u;
         const uint32_t M = (uint32_t)a.q.m + a.q.dlen + 1u;                  // maskgen's M (agh_query_from_maskgen)
+        // count-only, no ';': pieces in which one record ends are counted by the fast kernel itself (tf_one_end)
+        const uint32_t direct = (lean && !a.tab.AND && a.tf_direct) ? 1u : 0u;
+        tf_cont_args cont;
+        cont.ent = a.tf_cont;
+        cont.cap = a.tf_cont_cap;
+        cont.at = a.tf_cont ? a.tf_cont_at : 0u;
+        // (k_table_cont: a lane per handed-over record, refilled; at most `at` lanes of every tile hand one or two over)
+        // (the hand-over count and its ticket start at zero for every launch: a scan that is repeated -- a bigger record
+        // bitmap -- does not zero the scan's counters again)
+        if (cont.at) (void)hipMemsetAsync(a.mk.counters + AGH_C_CONT_N, 0, 2 * sizeof(uint32_t), st);
+        const uint64_t cwant = ((uint64_t)nt * (cont.at ? cont.at : 1u) + 255u) / 256u;
+        const uint32_t cblocks = cwant > 2048u ? 2048u : (cwant ? (uint32_t)cwant : 1u);
 #define AGH_TF_REPLAY(KK, LEANV, COSTV)                                                       \
             hipLaunchKernelGGL((k_table_replay<KK, LEANV, COSTV>), dim3(rblocks), dim3(256), 0, st, \
                                (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
@@ -932,11 +1183,16 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
             if (a.fs_fast == 2)                                                               \
                 hipLaunchKernelGGL((k_tablescan_fast2<KK, COSTV, MBV>), dim3(fblocks2), dim3(AGH_FS_THREADS), 0, st, \
                                    (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                                   a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt, tf_chunk, (const uint16_t *)a.dbm); \
+                                   a.fs_replay, a.fs_tile_cnt, a.mk.counters, M, nt, tf_chunk, (const uint16_t *)a.dbm, direct, cont); \
             else                                                                              \
                 hipLaunchKernelGGL((k_tablescan_fast<KK, COSTV, MBV>), dim3(fblocks), dim3(AGH_FS_THREADS), 0, st, \
                                    (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
-                                   a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_chunk, (const uint16_t *)a.dbm)
+                                   a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_chunk, (const uint16_t *)a.dbm, direct, cont); \
+            if (cont.at)                                                                      \
+                hipLaunchKernelGGL((k_table_cont<KK, COSTV, MBV>), dim3(cblocks), dim3(256), 0, st, \
+                                   (const uint8_t *)a.text, a.n, a.q, a.tab, (const uint32_t *)a.mask, \
+                                   (const uint4 *)cont.ent, cont.cap, a.fs_replay, a.fs_tile_cnt, a.mk.counters, tf_slice, \
+                                   (const uint16_t *)a.dbm, direct, M)
 #define AGH_TF_TAIL(KK, COSTV)                                                                \
             if (lean) AGH_TF_REPLAY(KK, true, COSTV); else AGH_TF_REPLAY(KK, false, COSTV);   \
             break

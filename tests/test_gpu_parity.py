@@ -828,6 +828,53 @@ def test_table_engine_with_multi_byte_delimiters(agh):
         q.close()
 
 
+@pytest.mark.parametrize("delim", [b"s\n", b"\n", b"q"])
+def test_table_engine_hands_long_records_over(agh, monkeypatch, delim):
+    """Round 6: the fast table kernels walk past a chunk's end only until few lanes still have an open record and
+    hand those to k_table_cont (AGH_TF_CONT lanes; 0: the old walk), and count-only scans of patterns without ';'
+    count a flagged piece with one record end in the fast kernel (AGH_TF_DIRECT).  Records of ~1.7 KB with lengths
+    all over the place ('s' + newline as the delimiter of the corpus), lines, and records of ~100 KB ('q'): every
+    threshold, one and two streams per lane, the three chunk sizes, with costs, ';' and ',' -- always the oracle's
+    count and record list."""
+    text, _ = O.corpus(2048, seed=66, variants=(b"approxQmatch", b"approx--match", b"approximatematch", b"apprXmatZch",
+                                                  b"match approx", b"aproxQmatch", b"approxmatch"), plant_period=7)
+    tb_text = text.tobytes()                                        # 8 MiB
+    cases = [(b"approx#match", 0), (b"approx#match", 1), (b"appr#mat#ch", 2), (b"match,approx", 1), (b"approx;match", 1)]
+    for pat, k in cases:
+        tb = agh.compile_pattern(pat, delim=delim)
+        ot = O.tables_from_golden({"Mask": list(tb.Mask), "Init0": tb.Init0, "Init1": tb.Init1, "NO_ERR_MASK": tb.NO_ERR_MASK,
+                                   "endposition": tb.endposition, "D_endpos": tb.D_endpos, "wildmask": tb.wildmask,
+                                   "AND": tb.AND}, tb.M, dlen=len(delim))
+        want = O.asearch_tables(ot, k, tb_text, delim=delim, cap=400000)
+        assert want[0] > 20
+        want_costs = O.asearch_tables_costs(ot, k, (2, 1, 1), tb_text, delim=delim, cap=400000) if k and not tb.AND else None
+        with agh.Query.pattern(pat, k, delim=delim) as q:
+            for env in ({"AGH_TF_CONT": "0"}, {"AGH_TF_CONT": "1"}, {"AGH_TF_CONT": "48"}, {"AGH_TF_CONT": "64"},
+                        {"AGH_TF_CONT": "64", "AGH_TF_CHUNK": "1024"}, {"AGH_TF_CONT": "16", "AGH_TF_CHUNK": "4096"},
+                        {"AGH_TF_CONT": "48", "AGH_TF_PACK2": "0"}, {"AGH_TF_CONT": "48", "AGH_TF_DIRECT": "0"},
+                        {"AGH_TF_CONT": "0", "AGH_TF_DIRECT": "0"}):
+                for key in ("AGH_TF_CONT", "AGH_TF_CHUNK", "AGH_TF_PACK2", "AGH_TF_DIRECT"):
+                    monkeypatch.delenv(key, raising=False)
+                for key, v in env.items():
+                    monkeypatch.setenv(key, v)
+                res, ms = q.scan_buffer(tb_text, cap=400000)
+                assert (res.n_matched, [(s, e) for s, e, _ in ms]) == want, (delim, pat, k, env)
+                assert int(res.engine) == agh.ENGINE_FULLSCAN
+                res_c, _ = q.scan_buffer(tb_text, flags=agh.COUNT)
+                assert res_c.n_matched == want[0], (delim, pat, k, env, "count-only")
+                if want_costs is not None and env.get("AGH_TF_CONT") in ("0", "48"):
+                    q.set_costs(2, 1, 1)
+                    try:
+                        res_k, ms_k = q.scan_buffer(tb_text, cap=400000)
+                        res_kc, _ = q.scan_buffer(tb_text, flags=agh.COUNT)
+                    finally:
+                        q.set_costs(1, 1, 1)
+                    assert (res_k.n_matched, [(s, e) for s, e, _ in ms_k]) == want_costs, (delim, pat, k, env, "costs")
+                    assert res_kc.n_matched == want_costs[0], (delim, pat, k, env, "costs, count-only")
+    for key in ("AGH_TF_CONT", "AGH_TF_CHUNK", "AGH_TF_PACK2", "AGH_TF_DIRECT"):
+        monkeypatch.delenv(key, raising=False)
+
+
 def test_table_engine_multi_byte_delimiters_above_one_segment(agh, monkeypatch):
     """The table engine's fast form under a delimiter of several bytes on a text of several kernel segments
     (AGH_SEG_MAX_MB=1): the delimiter-end bitmap of the whole text, every segment on its part of it (16-byte loads at
