@@ -65,8 +65,7 @@ static int fs_fast_setup(agh_query *q, uint64_t n, agh_scan_args *va)
         // at most tf_cont lanes x (one or two streams) of every 64-chunk tile hand a record over, and two streams per
         // lane come with two tiles per wave; the chunk is agh_launch_tablescan's choice (48 B per entry: 0.9 % of a
         // text of 1 GiB or more at the default of 48 lanes)
-        const uint64_t chunk = q->tune.tf_chunk ? q->tune.tf_chunk
-                                                : (n >= ((uint64_t)1 << 30) ? 4096u : (n >= ((uint64_t)512 << 20) ? 2048u : 1024u));
+        const uint64_t chunk = agh_tf_chunk_for(n, q->tune.tf_chunk);
         const uint64_t cap = ((n + 64 * chunk - 1) / (64 * chunk) + 8) * q->tune.tf_cont;
         if (cap < ((uint64_t)1 << 31) && q->tf_cont.ensure(cap * 48u) == 0) {
             va->tf_cont = (uint4 *)q->tf_cont.p;

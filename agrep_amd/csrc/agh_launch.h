@@ -15,7 +15,7 @@ struct agh_tuning {
     uint32_t fs_streams = 0;        // AGH_FS_STREAMS: full scan, fast form: at most 1..3 text streams per lane (0: by length; A/B)
     bool tf_pack2 = true;           // AGH_TF_PACK2: table engine, two streams per lane where M <= 15
     uint64_t tf_fast_min_mb = 0;    // AGH_TF_FAST_MIN_MB: table engine, fast form from this segment size on
-    uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 / 2048 / 4096), 0 = by size
+    uint32_t tf_chunk = 0;          // AGH_TF_CHUNK: bytes per lane of the fast form (1024 .. 32768), 0 = by size (agh_tf_chunk_for)
     bool tf_direct = true;          // AGH_TF_DIRECT: table engine, count-only: the fast kernel counts pieces with one record end itself (0: every flagged piece is replayed; A/B)
     uint32_t tf_cont = 48;          // AGH_TF_CONT: table engine, fast form: the walk past a chunk's end hands its open records to k_table_cont once this few lanes still have one (0: every wave walks to its longest record's end)
     uint32_t tr_group = 8;          // AGH_TR_GROUP: tiles whose replay lists one wave of k_table_replay takes (1, 2, 4, 8, 16)
@@ -76,6 +76,18 @@ struct agh_sweep_args {
     uint32_t w_begin = 0, w_end = 0;
     int tail_only = 0;       // 1: only the partial last strip (the fused kernel swept the rest)
 };
+
+// Bytes per lane of the fast table kernels (a tile is 64 such chunks): the walk past a chunk's end and the start-up of
+// a stream cost the same whatever the chunk, but a wave walks its chunk serially, so small texts take small chunks
+// (profiles/r06_ab_table_chunk.log: 8 KiB is worth 28 % at 8 GiB with 1.7 KB records and costs lines nothing there;
+// at 4 GiB 16 % against 2 % of the lines' rate, at 2 GiB 14 % against 4 % -- lines decide).  forced: AGH_TF_CHUNK.
+static inline uint32_t agh_tf_chunk_for(uint64_t n, uint32_t forced)
+{
+    if (forced) return forced;
+    if (n >= ((uint64_t)8 << 30)) return 8192u;
+    if (n >= ((uint64_t)1 << 30)) return 4096u;
+    return n >= ((uint64_t)512 << 20) ? 2048u : 1024u;
+}
 
 struct agh_scan_args {
     const void *text;

@@ -347,10 +347,9 @@ __device__ __forceinline__ void table_reset_state(const agh_dev_tables &T, uint3
 // LONGEST of its 64 lanes' walks (~300 bytes with 80-byte records), a third of a 1 KiB chunk's work
 // but a twelfth of this one's.  Record numbers do not depend on it (the replay takes them from the
 // census strips).
-// Round 4: the chunk is a launch parameter (1, 2 or 4 KiB: agh_launch_tablescan picks it by the size of the
-// text -- a wave walks its chunk serially, 0.28 ms at 4 KiB, so small texts take small chunks); a tile is 64
-// chunks and its replay slice holds one entry per 256 bytes of text whatever the chunk.
-#define AGH_TF_CHUNK_MAX 4096u
+// Round 4: the chunk is a launch parameter (1, 2, 4 or -- round 6, from 8 GiB on -- 8 KiB: agh_tf_chunk_for picks it
+// by the size of the text -- a wave walks its chunk serially, 0.28 ms at 4 KiB, so small texts take small chunks); a
+// tile is 64 chunks and its replay slice holds one entry per 256 bytes of text whatever the chunk.
 #define AGH_TF_SLICE_OF(chunk) ((chunk) / 4u)      // replay entries per tile (64 chunks)
 
 // MB (round 5): delimiters of several bytes / a folded letter -- WHERE a record ends is read from the delimiter-end
@@ -1150,9 +1149,8 @@ void agh_launch_tablescan(const agh_scan_args &a, hipStream_t st)
     const bool lean = a.mk.hashset != nullptr;  // count-only: hash set of record starts, no census
     const bool costs = a.q.ci != 1u || a.q.cs != 1u || a.q.cd != 1u;     // asearch1.c instead of asearch.c
     if (a.fs_fast) {                            // branch-free hot kernel + exact replay (the host checked)
-        // chunk per lane: 4 KiB from 1 GiB on, 2 KiB from 512 MiB, else 1 KiB (a.tf_chunk forces one)
-        const uint32_t tf_chunk = a.tf_chunk ? a.tf_chunk
-                                      : (a.n >= ((uint64_t)1 << 30) ? 4096u : (a.n >= ((uint64_t)512 << 20) ? 2048u : 1024u));
+        // chunk per lane: 8 KiB from 8 GiB on, 4 KiB from 1 GiB, 2 KiB from 512 MiB, else 1 KiB (a.tf_chunk forces one)
+        const uint32_t tf_chunk = agh_tf_chunk_for(a.n, a.tf_chunk);
         const uint32_t tf_slice = AGH_TF_SLICE_OF(tf_chunk);
         const uint64_t tf_tile = (uint64_t)WAVE * tf_chunk;             // 64 / 128 / 256 KiB tiles
         const uint32_t nt = (uint32_t)((a.n + tf_tile - 1) / tf_tile);

@@ -851,6 +851,7 @@ def test_table_engine_hands_long_records_over(agh, monkeypatch, delim):
         with agh.Query.pattern(pat, k, delim=delim) as q:
             for env in ({"AGH_TF_CONT": "0"}, {"AGH_TF_CONT": "1"}, {"AGH_TF_CONT": "48"}, {"AGH_TF_CONT": "64"},
                         {"AGH_TF_CONT": "64", "AGH_TF_CHUNK": "1024"}, {"AGH_TF_CONT": "16", "AGH_TF_CHUNK": "4096"},
+                        {"AGH_TF_CHUNK": "8192"}, {"AGH_TF_CHUNK": "16384", "AGH_TF_PACK2": "0"},
                         {"AGH_TF_CONT": "48", "AGH_TF_PACK2": "0"}, {"AGH_TF_CONT": "48", "AGH_TF_DIRECT": "0"},
                         {"AGH_TF_CONT": "0", "AGH_TF_DIRECT": "0"}):
                 for key in ("AGH_TF_CONT", "AGH_TF_CHUNK", "AGH_TF_PACK2", "AGH_TF_DIRECT"):
