@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cstdlib>
 #include "agh_device_inl.h"
 
 
@@ -408,6 +409,133 @@ __global__ __launch_bounds__(256) void k_delim_bitmap(const uint8_t *__restrict_
     }
 }
 
+// Round 6: the same selection with the sweeps' layout -- a wave takes 1 KiB strips with one coalesced 16-byte load per
+// lane (the kernel above: five loads per lane, 64 bytes apart, every wave-instruction touching 32 cache lines), the 8
+// bytes in front of a lane's chunk come from the lane before it (DPP; lane 0: the strip before, carried in scalars),
+// and "an occurrence ends here" costs one zero-byte test per dword whatever the delimiter's length: the byte s in
+// front of an end must be delimiter byte dlen - 1 - s, so y = OR over s of (the dword moved back by s bytes) ^ that
+// byte is zero exactly in the bytes where an occurrence ends.  A lane writes the 16 bits of its chunk; four lanes make
+// a word of the bitmap, and a word in which two occurrences overlap (and word 0: the virtual head byte) is selected by
+// the serial automaton of the group's first lane as before.  A wave walks AGH_DBM_STRIPS consecutive strips; the one
+// in front of them is computed for its carries only.
+#ifndef AGH_DBM_STRIPS
+#define AGH_DBM_STRIPS 16u
+#endif
+template <uint32_t DLEN>                        // (the delimiter's length at compile time: no branch per shifted compare)
+__global__ __launch_bounds__(256) void k_delim_bitmap_strips(const uint8_t *__restrict__ text, uint64_t n, agh_dev_query q,
+                                                             uint64_t *__restrict__ dbm, uint64_t n_words,
+                                                             uint32_t *__restrict__ counters)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint64_t n_strips = (n_words * 64u + 1023u) / 1024u;
+    const uint64_t s0 = ((uint64_t)blockIdx.x * 4u + threadIdx.x / WAVE) * AGH_DBM_STRIPS;
+    if (s0 >= n_strips) return;
+    const uint64_t s1 = s0 + AGH_DBM_STRIPS < n_strips ? s0 + AGH_DBM_STRIPS : n_strips;
+    uint16_t *out = reinterpret_cast<uint16_t *>(dbm);
+    constexpr uint32_t dlen = DLEN;
+    uint64_t dall = 0;                          // the delimiter's bytes as one scalar
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) dall |= (uint64_t)q.dbytes[j] << (8u * j);
+    uint32_t dds[8];                            // delimiter byte dlen - 1 - s in all four bytes of a dword
+#pragma unroll
+    for (uint32_t sft = 0; sft < 8; ++sft)
+        dds[sft] = sft < dlen ? ((uint32_t)(dall >> (8u * (dlen - 1u - sft))) & 0xffu) * 0x01010101u : 0u;
+    auto load = [&](uint64_t s) -> uint4 {
+        const uint64_t a = s * 1024u + (uint64_t)lane * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (a < n) v = *reinterpret_cast<const uint4 *>(text + a);      // (the piece that holds the last byte is readable to its end)
+        return v;
+    };
+    uint32_t c_e = 0, c_z = 0, c_w = 0;         // lane 63 of the strip before: its ends and its last two dwords
+    const uint64_t first = s0 ? s0 - 1u : 0u;
+    __shared__ uint16_t lists[4][64];
+    uint16_t *list = lists[threadIdx.x / WAVE];
+    uint32_t n_list = 0;                        // (uniform)
+    auto strip = [&](uint64_t s, uint4 v, uint32_t slot) {
+        const uint64_t a = s * 1024u + (uint64_t)lane * 16u;
+        if (q.dfold) {
+            v.x = fold4(v.x); v.y = fold4(v.y); v.z = fold4(v.z); v.w = fold4(v.w);
+        }
+        const uint32_t pz = (uint32_t)__builtin_amdgcn_update_dpp((int)c_z, (int)v.z, 0x138, 0xf, 0xf, false);   // wave_shr:1
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp((int)c_w, (int)v.w, 0x138, 0xf, 0xf, false);
+        const uint32_t W[6] = {pz, pw, v.x, v.y, v.z, v.w};
+        uint32_t zb[4];
+#pragma unroll
+        for (uint32_t d = 0; d < 4; ++d) {
+            uint32_t y = 0;
+#pragma unroll
+            for (uint32_t sft = 0; sft < 8; ++sft) {
+                if (sft < dlen) {               // (compile time)
+                    const uint32_t hi = d + 2u - (sft >> 2);
+                    const uint32_t src = (sft & 3u) ? __builtin_amdgcn_alignbyte(W[hi], W[hi - 1u], 4u - (sft & 3u)) : W[hi];
+                    y |= src ^ dds[sft];
+                }
+            }
+            zb[d] = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);      // bit 7 of every byte where an occurrence ends
+        }
+        // two dwords' bits 7, 15, 23, 31 -> eight bits in text order
+        auto pack8 = [](uint32_t z0, uint32_t z1) -> uint32_t {
+            const uint32_t u = (z0 >> 7) | (z1 >> 3);
+            return (u | (u >> 7) | (u >> 14) | (u >> 21)) & 0xffu;
+        };
+        uint32_t e16 = pack8(zb[0], zb[1]) | (pack8(zb[2], zb[3]) << 8);
+        const uint64_t left = a < n ? n - a : 0u;                        // (an end at i < n has all its bytes inside the text)
+        if (left < 16u) e16 &= (1u << left) - 1u;
+        // two occurrences whose ends are less than dlen apart overlap: the serial selection decides
+        const uint32_t pe = (uint32_t)__builtin_amdgcn_update_dpp((int)c_e, (int)e16, 0x138, 0xf, 0xf, false);
+        uint32_t near = 0;
+#pragma unroll
+        for (uint32_t p = 1; p < dlen; ++p) near |= (e16 << p) | (pe >> (16u - p));
+        const bool ov = (e16 & near & 0xffffu) != 0u;
+        c_e = (uint32_t)__builtin_amdgcn_readlane((int)e16, 63);
+        c_z = (uint32_t)__builtin_amdgcn_readlane((int)v.z, 63);
+        c_w = (uint32_t)__builtin_amdgcn_readlane((int)v.w, 63);
+        if (s < s0) return;                     // (uniform) the strip in front: carries only
+        // a word (four lanes) in which two occurrences overlap, and word 0 (the virtual head byte in front), is left to
+        // the serial selection: listed here, and walked one word per lane after the wave's four strips (one lane of
+        // every four walking while the wave waits made a text full of '   ' runs 6.7 ms against round 5's 4.8)
+        const uint64_t nm = __ballot(ov || (s == 0 && lane < 4u));
+        bool grp = false;
+        if (nm) {
+            grp = ((uint32_t)(nm >> (lane & ~3u)) & 0xfu) != 0u;
+            const bool lead = grp && (lane & 3u) == 0u;
+            const uint64_t lm = __ballot(lead);
+            if (lead)
+                list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u))] =
+                    (uint16_t)((slot << 4) | (lane >> 2));
+            n_list += (uint32_t)__popcll(lm);
+        }
+        if (!grp && a < n_words * 64u) out[a >> 4] = (uint16_t)e16;
+    };
+    // four strips of a wave in flight while the four before are worked on (one strip ahead left the chip with 64 KiB
+    // per CU under way: 1.4 ms per 4 GiB)
+    uint4 buf[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) buf[i] = first + i < s1 ? load(first + i) : make_uint4(0, 0, 0, 0);
+    for (uint64_t base = first; base < s1; base += 4) {
+        uint4 nbuf[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) nbuf[i] = base + 4u + i < s1 ? load(base + 4u + i) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i)
+            if (base + i < s1) strip(base + i, buf[i], i);
+        if (n_list) {                           // (uniform) at most 4 x 16 words: one per lane
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < n_list) {
+                const uint32_t e = list[lane];
+                const uint64_t word = (base + (e >> 4)) * 16u + (e & 15u);
+                if (word < n_words) dbm[word] = word * 64u < n ? delim_bitmap_serial(text, n, q, word * 64u, counters) : 0ull;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            n_list = 0;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) buf[i] = nbuf[i];
+    }
+}
+
 void agh_warm_core_module()
 {
     hipFuncAttributes attr;
@@ -418,8 +546,27 @@ void agh_launch_delim_bitmap(const void *text, uint64_t n, const agh_dev_query &
                              uint64_t n_words, uint32_t *counters, hipStream_t st)
 {
     if (!n_words) return;
-    hipLaunchKernelGGL(k_delim_bitmap, dim3((uint32_t)((n_words + 256 * AGH_DBM_ITER - 1) / (256 * AGH_DBM_ITER))), dim3(256), 0, st,
-                       (const uint8_t *)text, n, q, dbm, n_words, counters);
+    static const bool by_words = [] { const char *e = getenv("AGH_DBM_WORDS"); return e && e[0] == '1'; }();    // (A/B: round 5's kernel)
+    if (by_words) {
+        hipLaunchKernelGGL(k_delim_bitmap, dim3((uint32_t)((n_words + 256 * AGH_DBM_ITER - 1) / (256 * AGH_DBM_ITER))), dim3(256), 0, st,
+                           (const uint8_t *)text, n, q, dbm, n_words, counters);
+        return;
+    }
+    const uint64_t n_strips = (n_words * 64u + 1023u) / 1024u;
+    const uint64_t waves = (n_strips + AGH_DBM_STRIPS - 1u) / AGH_DBM_STRIPS;
+    const dim3 grid((uint32_t)((waves + 3u) / 4u));
+#define AGH_DBM_CASE(L)                                                                       \
+    case L:                                                                                   \
+        hipLaunchKernelGGL(k_delim_bitmap_strips<L>, grid, dim3(256), 0, st, (const uint8_t *)text, n, q, dbm, n_words, counters); \
+        break;
+    switch (q.dlen) {
+        AGH_DBM_CASE(1) AGH_DBM_CASE(2) AGH_DBM_CASE(3) AGH_DBM_CASE(4) AGH_DBM_CASE(5) AGH_DBM_CASE(6) AGH_DBM_CASE(7)
+        AGH_DBM_CASE(8)
+    default:                                    // (no such query: dbytes holds eight)
+        hipLaunchKernelGGL(k_delim_bitmap, dim3((uint32_t)((n_words + 256 * AGH_DBM_ITER - 1) / (256 * AGH_DBM_ITER))), dim3(256), 0, st,
+                           (const uint8_t *)text, n, q, dbm, n_words, counters);
+    }
+#undef AGH_DBM_CASE
 }
 
 // Exclusive scan of the per-wave delimiter totals, two small multi-block kernels:
