@@ -479,8 +479,11 @@ __global__ __launch_bounds__(256) void k_delim_bitmap_strips(const uint8_t *__re
             return (u | (u >> 7) | (u >> 14) | (u >> 21)) & 0xffu;
         };
         uint32_t e16 = pack8(zb[0], zb[1]) | (pack8(zb[2], zb[3]) << 8);
-        const uint64_t left = a < n ? n - a : 0u;                        // (an end at i < n has all its bytes inside the text)
-        if (left < 16u) e16 &= (1u << left) - 1u;
+        const bool inside = s * 1024u + 1024u <= n;                      // (uniform) the whole strip lies in the text
+        if (!inside) {
+            const uint64_t left = a < n ? n - a : 0u;                    // (an end at i < n has all its bytes inside the text)
+            if (left < 16u) e16 &= (1u << left) - 1u;
+        }
         // two occurrences whose ends are less than dlen apart overlap: the serial selection decides
         const uint32_t pe = (uint32_t)__builtin_amdgcn_update_dpp((int)c_e, (int)e16, 0x138, 0xf, 0xf, false);
         uint32_t near = 0;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256) void k_delim_bitmap_strips(const uint8_t *__re
                     (uint16_t)((slot << 4) | (lane >> 2));
             n_list += (uint32_t)__popcll(lm);
         }
-        if (!grp && a < n_words * 64u) out[a >> 4] = (uint16_t)e16;
+        if (!grp && (inside || a < n_words * 64u)) out[a >> 4] = (uint16_t)e16;
     };
     // four strips of a wave in flight while the four before are worked on (one strip ahead left the chip with 64 KiB
     // per CU under way: 1.4 ms per 4 GiB)
