@@ -71,6 +71,20 @@ with A.Query(b"matching", 2) as q:
     rw, msw = q.scan_buffer(text, cap=400000)
     assert rw.engine == A.ENGINE_FULLSCAN and (rw.n_matched, [(s_, e_) for s_, e_, _ in msw]) == O.asearch(b"matching", 2, tb, cap=400000)
 n_cases += 1
+# ... the table engine on records of ~1.7 KB (delimiter 's' + newline) and on a delimiter of two bytes: the fast kernels count
+# pieces with one record end themselves and hand the stragglers of the walk to k_table_cont -- count, list and 4 GiB against
+# the same scan with both switched off
+for delim in (b"s\n", b"e "):
+    tbl = A.compile_pattern(b"approx#match", delim=delim)
+    ot = O.tables_from_golden({"Mask": list(tbl.Mask), "Init0": tbl.Init0, "Init1": tbl.Init1, "NO_ERR_MASK": tbl.NO_ERR_MASK,
+                               "endposition": tbl.endposition, "D_endpos": tbl.D_endpos, "wildmask": tbl.wildmask,
+                               "AND": tbl.AND}, tbl.M, dlen=len(delim))
+    want_t = O.asearch_tables(ot, 1, tb, delim=delim, cap=400000)
+    with A.Query.pattern(b"approx#match", 1, delim=delim) as q:
+        rt, mst = q.scan_buffer(text, cap=400000)
+        rtc, _ = q.scan_buffer(text, flags=A.COUNT)
+    assert want_t[0] > 0 and (rt.n_matched, [(s_, e_) for s_, e_, _ in mst]) == want_t and rtc.n_matched == want_t[0], delim
+    n_cases += 2
 # 4. 4 GiB resident: the fused kernel (the shipped form from 4 GiB on) against two kernels and the planted records
 n = 4 << 30
 buf = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -84,4 +98,13 @@ with A.Query(O.PATTERN_C2, 2) as q:
 del os.environ["AGH_FUSED"]
 assert r_fused.fused_segments == 1 and r_two.fused_segments == 0
 assert r_fused.n_matched == r_two.n_matched == want, (r_fused.n_matched, r_two.n_matched, want)
-print("shipped defaults ok: %d cases, 4 GiB fused == two kernels == planted == %d" % (n_cases, want))
+with A.Query.pattern(b"approx#match", 1, delim=b"s\n") as q:
+    r_cont = q.scan_device(buf.data_ptr(), n, flags=A.COUNT)
+os.environ["AGH_TF_CONT"] = "0"
+os.environ["AGH_TF_DIRECT"] = "0"
+with A.Query.pattern(b"approx#match", 1, delim=b"s\n") as q:
+    r_walk = q.scan_device(buf.data_ptr(), n, flags=A.COUNT)
+del os.environ["AGH_TF_CONT"], os.environ["AGH_TF_DIRECT"]
+assert r_cont.n_matched == r_walk.n_matched > 1000, (r_cont.n_matched, r_walk.n_matched)
+print("shipped defaults ok: %d cases, 4 GiB fused == two kernels == planted == %d; table engine, 1.7 KB records, 4 GiB: %d == %d"
+      % (n_cases, want, r_cont.n_matched, r_walk.n_matched))
